@@ -1,0 +1,173 @@
+/*
+ * vitsmi.h — C ABI of libvitsmi.so, the MI355X-native (gfx950) VITS inference engine
+ * that replaces the onnxruntime session on phoonnx's hot path.
+ *
+ * Reference interface replaced (paths relative to the phoonnx checkout):
+ *   - session construction      phoonnx/voice.py:167-171  -> vits_open()
+ *   - session.get_inputs()      phoonnx/voice.py:347      -> vits_num_inputs()/vits_input_name()
+ *   - session.run(None, feed)   phoonnx/voice.py:374-377  -> vits_run()
+ * The computation is the graph phoonnx_train/export_onnx.py:250-327 traces from
+ * SynthesizerTrn.infer (phoonnx_train/vits/models.py:681-722); weights are read from
+ * the same .onnx file onnxruntime would load.
+ *
+ * Conventions: plain pointers and sizes, no C++ or torch types.  All functions
+ * returning int return 0 on success and a negative VITS_E_* code on failure; the
+ * message is available from vits_last_error().  A handle owns one HIP stream, the
+ * device weight arena and a growable activation workspace; calls on one handle are
+ * serialised by an internal mutex, different handles (one per GPU) run concurrently.
+ */
+#ifndef VITSMI_H
+#define VITSMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vits_handle vits_handle;
+
+enum {
+    VITS_OK = 0,
+    VITS_E_IO = -1,        /* cannot open / read the .onnx file */
+    VITS_E_FORMAT = -2,    /* not a VITS graph this engine understands */
+    VITS_E_ARG = -3,       /* invalid argument (shape, id out of range, missing sid, ...) */
+    VITS_E_DEVICE = -4,    /* HIP error / no gfx950 device */
+    VITS_E_NOMEM = -5
+};
+
+/* Stage taps for parity tests ("x","m_p","logs_p","logw","w_ceil","z_p","z"). */
+#define VITS_MAX_DIMS 4
+
+/* ---- lifetime ------------------------------------------------------------------- */
+
+/* Parse `onnx_path`, derive the model description, pack the weights into one
+ * contiguous device arena on GPU `device_id` (replaces InferenceSession(path, ...),
+ * voice.py:167-171). */
+int vits_open(const char *onnx_path, int device_id, vits_handle **out);
+
+/* Same, but the packed weight arena is supplied by the caller (already resident on the
+ * device, e.g. received by an RCCL broadcast from the rank that read the file).
+ * `arena_dev` must stay valid for the life of the handle.  See vits_arena_* below. */
+int vits_open_with_arena(const char *onnx_path, int device_id, void *arena_dev, size_t arena_bytes,
+                         vits_handle **out);
+
+/* Host-only open: parses and packs but touches no GPU (device_id ignored).  Only the
+ * metadata / arena / hparam calls work on such a handle.  Used by CPU-side tests and
+ * by non-root ranks that only need the arena size. */
+int vits_open_host(const char *onnx_path, vits_handle **out);
+
+void vits_close(vits_handle *h);
+
+/* Last error message for this handle (or, with h == NULL, of the last failed open on
+ * this thread).  Never NULL. */
+const char *vits_last_error(vits_handle *h);
+
+/* ---- model description (session.get_inputs(), metadata_props) ---------------------- */
+
+int vits_num_inputs(vits_handle *h);                 /* 3, or 4 with "sid" */
+const char *vits_input_name(vits_handle *h, int i);  /* "input","input_lengths","scales"[,"sid"] */
+
+/* metadata_props written by export_onnx.py:335-350 (sample_rate, n_speakers, ...).
+ * Returns the value length, or VITS_E_ARG if the key is absent. */
+int vits_meta(vits_handle *h, const char *key, char *buf, size_t n);
+
+/* Derived hyper-parameters: "hidden","inter","filter","n_heads","n_layers","n_vocab",
+ * "n_speakers","gin","use_sdp","hop" (= product of upsample rates),"n_ups","resblock". */
+int vits_hparam(vits_handle *h, const char *key, int64_t *out);
+
+/* ---- weight arena (multi-GPU: one rank reads + packs, RCCL broadcasts the bytes) ---- */
+
+size_t vits_arena_bytes(vits_handle *h);
+/* Host copy of the packed arena (valid until vits_close). */
+const void *vits_arena_host(vits_handle *h);
+/* Device copy (NULL for a host-only handle). */
+void *vits_arena_device(vits_handle *h);
+
+/* ---- the hot call ------------------------------------------------------------------ */
+
+typedef struct {
+    /* Optional injected noise for parity with the reference graph's two RandomNormalLike
+     * nodes (models.py:111 and :718).  NULL -> generated on the device (Philox) from
+     * `seed`.  With scales[2]==0 / scales[0]==0 the respective noise is not used. */
+    const float *noise_dp;   /* [B, 2, T] host (vits_run) or device (vits_run_device) */
+    const float *noise_z;    /* [B, inter, noise_z_stride] */
+    int64_t noise_z_stride;  /* frames per row in noise_z; must be >= max frames */
+    uint64_t seed;
+} vits_noise;
+
+typedef struct {
+    float *data;             /* [B,1,1,S] float32, C-contiguous */
+    int64_t dims[4];
+    int64_t *y_lengths;      /* [B] frames per utterance (valid samples = y_lengths*hop) */
+} vits_output;
+
+/* Host buffers in, host buffers out (what session.run does, voice.py:374).
+ *   ids   int64 [B,T]   "input"          (voice.py:350)
+ *   lens  int64 [B]     "input_lengths"  (voice.py:351)
+ *   scales float32 [3]  [noise_scale, length_scale, noise_w]  (voice.py:364-367)
+ *   sid   int64 [B] or NULL              (voice.py:370)
+ * `out->data` / `out->y_lengths` are allocated by the library (pinned host memory);
+ * release with vits_free_output(). */
+int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
+             const int64_t *sid, const vits_noise *noise, vits_output *out);
+void vits_free_output(vits_handle *h, vits_output *out);
+
+/* Device-resident variant: every pointer (ids, lens, sid, noise arrays) is a device
+ * pointer on the handle's GPU; `out->data` and `out->y_lengths` are device pointers into
+ * the handle's workspace, valid until the next call on this handle.  Returns after the
+ * work has been enqueued on the handle's stream and the one mid-pipeline readback
+ * (max frame count) has completed; call vits_sync() before reading `out`. */
+int vits_run_device(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T,
+                    const float scales[3], const int64_t *sid, const vits_noise *noise, vits_output *out);
+int vits_sync(vits_handle *h);
+
+/* Vocoder only (BASELINE config 2, and teacher-forced parity): z is [B, inter, F] host
+ * float32, already masked; output as vits_run. */
+int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t *sid, vits_output *out);
+
+/* Copy a stage tensor of the LAST run to host: name in {"x","m_p","logs_p","logw",
+ * "w_ceil","z_p","z"}.  dims receives the shape (rank returned). buf may be NULL to
+ * query the shape only. */
+int vits_tap(vits_handle *h, const char *name, float *buf, size_t buf_elems, int64_t dims[VITS_MAX_DIMS]);
+
+/* ---- measurement ------------------------------------------------------------------- */
+
+typedef struct {
+    double conv_flops;      /* algorithmic FLOPs issued through the conv engine in the last run */
+    double conv_bytes;      /* layer-granular bytes (each conv reads input once, writes output once) */
+    double dec_flops, dec_bytes;   /* same, HiFi-GAN generator only */
+    double flow_flops, enc_flops, dp_flops;
+    float conv_ms;          /* HIP-event time of all conv-engine launches (needs timing enabled) */
+    float dec_ms, flow_ms, enc_ms, dp_ms, total_ms;
+    int conv_launches, total_launches;
+} vits_stats;
+
+/* Enable per-stage HIP-event timing (adds event records on the handle's stream). */
+int vits_set_timing(vits_handle *h, int enable);
+int vits_get_stats(vits_handle *h, vits_stats *out);
+
+/* The HIP stream the handle launches on (hipStream_t as void*), for callers that want
+ * to order their own work or events against it. */
+void *vits_stream(vits_handle *h);
+
+/* ---- kernel-level test hooks (used by tests/ to localise parity failures) ------------ */
+
+/* out[B,Cout,T] = conv1d(x[B,Cin,T], w[Cout,Cin,K], bias) through the MFMA conv engine,
+ * same padding pad_l/pad_r with pad_l + pad_r == dil*(K-1); flags: bit0 leaky-relu(slope)
+ * on the input, bit1 relu on the output.  Host pointers. */
+int vits_test_conv1d(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
+                     int Cout, int K, int dil, int pad_l, int flags, float slope, float *out);
+/* out[B,Cout,T*stride] = conv_transpose1d(x, w[Cin,Cout,K], bias, stride, pad=(K-stride)/2). */
+int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, int T, const float *w,
+                               const float *bias, int Cout, int K, int stride, float *out);
+/* Relative-position multi-head self-attention core (attentions.py:225-272): q,k,v
+ * [B,C,T] host, emb_rel_k/v [2w+1, dk], lens int64[B]; out [B,C,T]. */
+int vits_test_attention(int device_id, const float *qkv, int B, int C, int T, int n_heads, const float *rel_k,
+                        const float *rel_v, int window, const int64_t *lens, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITSMI_H */

@@ -297,20 +297,10 @@ static float *conv_named(vo_model *m, const char *prefix, const float *x, int B,
  *   scores[i][j] += q_i . E_k[j-i+w]      for |j-i| <= w
  *   out_i        += sum_{|j-i|<=w} p[i][j] * E_v[j-i+w]
  * (verified against the module incl. T < w+1 where the reference slices, :295-297). */
-static float *mha(vo_model *m, const char *pfx, const float *x, int B, int C, int T, const int64_t *len) {
-    const vo_tensor *ek = T_req(m, "%s.emb_rel_k", pfx);
-    const vo_tensor *ev = T_req(m, "%s.emb_rel_v", pfx);
-    if (g_missing) return NULL;
-    int win = ((int)ek->d[1] - 1) / 2, dk = (int)ek->d[2], H = C / dk;
-    char nm[200];
-    snprintf(nm, sizeof nm, "%s.conv_q", pfx);
-    float *q = conv_named(m, nm, x, B, T, 1, 0, 0, 1, NULL);
-    snprintf(nm, sizeof nm, "%s.conv_k", pfx);
-    float *k = conv_named(m, nm, x, B, T, 1, 0, 0, 1, NULL);
-    snprintf(nm, sizeof nm, "%s.conv_v", pfx);
-    float *v = conv_named(m, nm, x, B, T, 1, 0, 0, 1, NULL);
-    if (g_missing) return NULL;
-    float *o = falloc((int64_t)B * C * T);
+/* core of attentions.py:225-272 on already-projected q,k,v [B,C,T]; o [B,C,T] */
+void vo_attention_core(const float *q, const float *k, const float *v, const float *ek, const float *ev, int B,
+                       int C, int T, int dk, int win, const int64_t *len, float *o) {
+    int H = C / dk;
     float scale = sqrtf((float)dk);
 #pragma omp parallel for collapse(2) schedule(dynamic)
     for (int b = 0; b < B; b++)
@@ -328,7 +318,7 @@ static float *mha(vo_model *m, const char *pfx, const float *x, int B, int C, in
                     int r = j - i + win;
                     if (r >= 0 && r <= 2 * win) { /* :237-242 */
                         float rl = 0.f;
-                        for (int d = 0; d < dk; d++) rl += (qh[(int64_t)d * T + i] / scale) * ek->data[(int64_t)r * dk + d];
+                        for (int d = 0; d < dk; d++) rl += (qh[(int64_t)d * T + i] / scale) * ek[(int64_t)r * dk + d];
                         s += rl;
                     }
                     /* attn_mask = x_mask[i]*x_mask[j]; masked_fill(mask==0, -1e4) (:247, :61) */
@@ -349,13 +339,30 @@ static float *mha(vo_model *m, const char *pfx, const float *x, int B, int C, in
                     float rel = 0.f;
                     for (int r = 0; r <= 2 * win; r++) { /* :261-268 */
                         int j = i + r - win;
-                        if (j >= 0 && j < T) rel += sc[j] * ev->data[(int64_t)r * dk + d];
+                        if (j >= 0 && j < T) rel += sc[j] * ev[(int64_t)r * dk + d];
                     }
                     oh[(int64_t)d * T + i] = acc + rel;
                 }
             }
             free(sc);
         }
+}
+
+static float *mha(vo_model *m, const char *pfx, const float *x, int B, int C, int T, const int64_t *len) {
+    const vo_tensor *ek = T_req(m, "%s.emb_rel_k", pfx);
+    const vo_tensor *ev = T_req(m, "%s.emb_rel_v", pfx);
+    if (g_missing) return NULL;
+    int win = ((int)ek->d[1] - 1) / 2, dk = (int)ek->d[2];
+    char nm[200];
+    snprintf(nm, sizeof nm, "%s.conv_q", pfx);
+    float *q = conv_named(m, nm, x, B, T, 1, 0, 0, 1, NULL);
+    snprintf(nm, sizeof nm, "%s.conv_k", pfx);
+    float *k = conv_named(m, nm, x, B, T, 1, 0, 0, 1, NULL);
+    snprintf(nm, sizeof nm, "%s.conv_v", pfx);
+    float *v = conv_named(m, nm, x, B, T, 1, 0, 0, 1, NULL);
+    if (g_missing) return NULL;
+    float *o = falloc((int64_t)B * C * T);
+    vo_attention_core(q, k, v, ek->data, ev->data, B, C, T, dk, win, len, o);
     free(q);
     free(k);
     free(v);

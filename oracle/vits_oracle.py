@@ -50,6 +50,7 @@ def load_lib(native=False):
     lib.vo_conv_transpose1d.argtypes = [c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_void_p, c.c_int,
                                         c.c_int, c.c_int, c.c_int, c.c_void_p]
     lib.vo_num_threads.restype = c.c_int
+    lib.vo_attention_core.argtypes = [c.c_void_p] * 5 + [c.c_int] * 5 + [c.c_void_p, c.c_void_p]
     _LIBS[native] = lib
     return lib
 
@@ -198,4 +199,19 @@ def conv_transpose1d(x, w, bias, stride, pad, native=False):
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     lib.vo_conv_transpose1d(x.ctypes.data, B, Cin, T, w.ctypes.data, None if b is None else b.ctypes.data, Cout, K,
                             stride, pad, out.ctypes.data)
+    return out
+
+
+def attention_core(qkv, n_heads, rel_k, rel_v, lens, native=False):
+    """qkv [B,3C,T] -> [B,C,T] (attentions.py:225-272 on projected q,k,v)."""
+    lib = load_lib(native)
+    qkv = np.ascontiguousarray(qkv, np.float32)
+    B, C3, T = qkv.shape
+    C = C3 // 3
+    q = np.ascontiguousarray(qkv[:, :C]); k = np.ascontiguousarray(qkv[:, C:2 * C]); v = np.ascontiguousarray(qkv[:, 2 * C:])
+    rel_k = np.ascontiguousarray(rel_k, np.float32); rel_v = np.ascontiguousarray(rel_v, np.float32)
+    lens = np.ascontiguousarray(lens, np.int64)
+    out = np.empty((B, C, T), np.float32)
+    lib.vo_attention_core(q.ctypes.data, k.ctypes.data, v.ctypes.data, rel_k.ctypes.data, rel_v.ctypes.data, B, C, T,
+                          C // n_heads, (rel_k.shape[0] - 1) // 2, lens.ctypes.data, out.ctypes.data)
     return out

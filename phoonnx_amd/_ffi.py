@@ -1,0 +1,98 @@
+"""ctypes binding of libvitsmi.so (include/vitsmi.h).  Fails loudly if the library is missing
+or cannot be built: there is no CPU fallback on the product path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+VITS_MAX_DIMS = 4
+
+
+class VitsNoise(C.Structure):
+    _fields_ = [("noise_dp", C.c_void_p), ("noise_z", C.c_void_p), ("noise_z_stride", C.c_int64),
+                ("seed", C.c_uint64)]
+
+
+class VitsOutput(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_float)), ("dims", C.c_int64 * 4), ("y_lengths", C.POINTER(C.c_int64))]
+
+
+class VitsStats(C.Structure):
+    _fields_ = [("conv_flops", C.c_double), ("conv_bytes", C.c_double), ("dec_flops", C.c_double),
+                ("dec_bytes", C.c_double), ("flow_flops", C.c_double), ("enc_flops", C.c_double),
+                ("dp_flops", C.c_double), ("conv_ms", C.c_float), ("dec_ms", C.c_float), ("flow_ms", C.c_float),
+                ("enc_ms", C.c_float), ("dp_ms", C.c_float), ("total_ms", C.c_float), ("conv_launches", C.c_int),
+                ("total_launches", C.c_int)]
+
+
+EXPORTS = [
+    "vits_open", "vits_open_with_arena", "vits_open_host", "vits_close", "vits_last_error", "vits_num_inputs",
+    "vits_input_name", "vits_meta", "vits_hparam", "vits_arena_bytes", "vits_arena_host", "vits_arena_device",
+    "vits_run", "vits_free_output", "vits_run_device", "vits_sync", "vits_run_vocoder", "vits_tap",
+    "vits_set_timing", "vits_get_stats", "vits_stream", "vits_test_conv1d", "vits_test_conv_transpose1d",
+    "vits_test_attention",
+]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libvitsmi.so")
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        from . import build as _build
+        _build.build()
+    lib = C.CDLL(path)
+    vp, i64p, f32p = C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_float)
+    lib.vits_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.vits_open_with_arena.argtypes = [C.c_char_p, C.c_int, vp, C.c_size_t, C.POINTER(vp)]
+    lib.vits_open_host.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.vits_close.argtypes = [vp]
+    lib.vits_close.restype = None
+    lib.vits_last_error.argtypes = [vp]
+    lib.vits_last_error.restype = C.c_char_p
+    lib.vits_num_inputs.argtypes = [vp]
+    lib.vits_input_name.argtypes = [vp, C.c_int]
+    lib.vits_input_name.restype = C.c_char_p
+    lib.vits_meta.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_size_t]
+    lib.vits_hparam.argtypes = [vp, C.c_char_p, i64p]
+    lib.vits_arena_bytes.argtypes = [vp]
+    lib.vits_arena_bytes.restype = C.c_size_t
+    lib.vits_arena_host.argtypes = [vp]
+    lib.vits_arena_host.restype = vp
+    lib.vits_arena_device.argtypes = [vp]
+    lib.vits_arena_device.restype = vp
+    run_args = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(VitsNoise), C.POINTER(VitsOutput)]
+    lib.vits_run.argtypes = run_args
+    lib.vits_run_device.argtypes = run_args
+    lib.vits_free_output.argtypes = [vp, C.POINTER(VitsOutput)]
+    lib.vits_free_output.restype = None
+    lib.vits_sync.argtypes = [vp]
+    lib.vits_run_vocoder.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(VitsOutput)]
+    lib.vits_tap.argtypes = [vp, C.c_char_p, vp, C.c_size_t, i64p]
+    lib.vits_set_timing.argtypes = [vp, C.c_int]
+    lib.vits_get_stats.argtypes = [vp, C.POINTER(VitsStats)]
+    lib.vits_stream.argtypes = [vp]
+    lib.vits_stream.restype = vp
+    lib.vits_test_conv1d.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_float, vp]
+    lib.vits_test_conv_transpose1d.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int,
+                                               C.c_int, vp]
+    lib.vits_test_attention.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]
+    _LIB = lib
+    return lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def last_error(h=None):
+    return load().vits_last_error(h).decode("utf-8", "replace")

@@ -1,0 +1,596 @@
+// kernels.hip.hpp — the non-conv kernels of the VITS pipeline (gfx950, wave64).
+// Activations are [B, C, T] fp32 with time contiguous, so one lane per time step gives
+// coalesced rows; channel reductions (LayerNorm) loop over C per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "conv_engine.hip.hpp"
+
+namespace vitsmi {
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float softplus_f(float v) { return v > 20.0f ? v : log1pf(expf(v)); }
+
+// ---- lengths: int64 -> int32 (clamped to [0,T]) ---------------------------------------------
+__global__ void lens_to_i32(const int64_t *in, int *out, int B, int T) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        int64_t v = in[b];
+        out[b] = v < 0 ? 0 : (v > T ? T : (int)v);
+    }
+}
+
+// ---- a1: embedding gather * sqrt(H), transposed to [B,H,T], masked (models.py:199-205) -------
+__global__ void embed_kernel(const int64_t *ids, const int *len, const float *emb, float *x, int H, int T,
+                             int n_vocab, float scale) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    int64_t id = ids[(int64_t)b * T + t];
+    bool ok = t < len[b] && id >= 0 && id < n_vocab;
+    const float *row = emb + id * H;
+    float *o = x + (int64_t)b * H * T + t;
+    for (int c = 0; c < H; c++) o[(int64_t)c * T] = ok ? row[c] * scale : 0.f;
+}
+
+// ---- LayerNorm over channels (modules.py:14-26), options: GELU, accumulate, mask ------------
+enum : int { LN_GELU = 1, LN_ACCUM = 2, LN_MASK = 4, LN_RELU_IN = 8 };
+__global__ void layernorm_c_kernel(const float *in, float *out, const float *gamma, const float *beta,
+                                   const int *len, int C, int T, int flags) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    const float *p = in + (int64_t)b * C * T + t;
+    float *o = out + (int64_t)b * C * T + t;
+    const bool relu_in = flags & LN_RELU_IN;
+    float mean = 0.f;
+    for (int c = 0; c < C; c++) {
+        float v = p[(int64_t)c * T];
+        if (relu_in) v = v > 0.f ? v : 0.f;
+        mean += v;
+    }
+    mean /= (float)C;
+    float var = 0.f;
+    for (int c = 0; c < C; c++) {
+        float v = p[(int64_t)c * T];
+        if (relu_in) v = v > 0.f ? v : 0.f;
+        float d = v - mean;
+        var += d * d;
+    }
+    var /= (float)C;
+    float rs = 1.0f / sqrtf(var + 1e-5f);
+    float mk = (!(flags & LN_MASK) || t < len[b]) ? 1.f : 0.f;
+    for (int c = 0; c < C; c++) {
+        float v = p[(int64_t)c * T];
+        if (relu_in) v = v > 0.f ? v : 0.f;
+        float y = (v - mean) * rs * gamma[c] + beta[c];
+        if (flags & LN_GELU) y = gelu_erf(y);
+        if (flags & LN_ACCUM) y += o[(int64_t)c * T];
+        o[(int64_t)c * T] = y * mk;
+    }
+}
+
+// ---- a6: depthwise conv (groups=C) on x*mask -> LayerNorm -> GELU (modules.py:121-123) --------
+__global__ void dds_dw_ln_gelu_kernel(const float *x, float *y, const float *w, const float *bias,
+                                      const float *gamma, const float *beta, const int *len, int C, int T, int K,
+                                      int dil) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    const int L = len[b];
+    const float *p = x + (int64_t)b * C * T;
+    float *o = y + (int64_t)b * C * T + t;
+    const int pad = (K * dil - dil) / 2;
+    auto conv = [&](int c) {
+        float s = bias[c];
+        for (int k = 0; k < K; k++) {
+            int tt = t + k * dil - pad;
+            float v = (tt >= 0 && tt < T && tt < L) ? p[(int64_t)c * T + tt] : 0.f;
+            s += w[c * K + k] * v;
+        }
+        return s;
+    };
+    float mean = 0.f;
+    for (int c = 0; c < C; c++) mean += conv(c);
+    mean /= (float)C;
+    float var = 0.f;
+    for (int c = 0; c < C; c++) {
+        float d = conv(c) - mean;
+        var += d * d;
+    }
+    var /= (float)C;
+    float rs = 1.0f / sqrtf(var + 1e-5f);
+    for (int c = 0; c < C; c++) o[(int64_t)c * T] = gelu_erf((conv(c) - mean) * rs * gamma[c] + beta[c]);
+}
+
+// ---- a7: ConvFlow pre (1 -> C) + conditioning add: h = w*z[ch] + b + cond (modules.py:498-499,119)
+__global__ void cf_pre_kernel(const float *z, int ch, const float *w, const float *bias, const float *cond,
+                              float *h, int C, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    float z0 = z[((int64_t)b * 2 + ch) * T + t];
+    for (int c = 0; c < C; c++) {
+        int64_t o = ((int64_t)b * C + c) * T + t;
+        h[o] = w[c] * z0 + bias[c] + cond[o];
+    }
+}
+
+// ---- a7: inverse rational-quadratic spline with linear tails (transforms.py:50-98,101-191) ----
+// pr: [B, 3*nb-1, T] (already masked); z: [B,2,T]; logical x0 = z[ch0], x1 = z[ch1].
+template <int NBMAX>
+__global__ void rqs_inverse_kernel(const float *pr, float *z, const int *len, int ch0, int ch1, int nb, int T,
+                                   float inv_sqrt_c_div) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    const int P = 3 * nb - 1;
+    const float *q = pr + (int64_t)b * P * T + t;
+    float mk = t < len[b] ? 1.f : 0.f;
+    float *px0 = z + ((int64_t)b * 2 + ch0) * T + t, *px1 = z + ((int64_t)b * 2 + ch1) * T + t;
+    float x = *px1;
+    const float tb = 5.0f, minw = 1e-3f, minh = 1e-3f, mind = 1e-3f;
+    float y = x;
+    if (x >= -tb && x <= tb) {
+        float w[NBMAX], h[NBMAX], cw[NBMAX + 1], ch[NBMAX + 1], d[NBMAX + 1];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NBMAX; i++)
+            if (i < nb) {
+                w[i] = q[(int64_t)i * T] / inv_sqrt_c_div;
+                mx = fmaxf(mx, w[i]);
+            }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBMAX; i++)
+            if (i < nb) {
+                w[i] = expf(w[i] - mx);
+                s += w[i];
+            }
+        cw[0] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBMAX; i++)
+            if (i < nb) {
+                w[i] = minw + (1.0f - minw * nb) * (w[i] / s);
+                cw[i + 1] = cw[i] + w[i];
+            }
+#pragma unroll
+        for (int i = 0; i <= NBMAX; i++)
+            if (i <= nb) cw[i] = (tb - (-tb)) * cw[i] + (-tb);
+        cw[0] = -tb;
+#pragma unroll
+        for (int i = 0; i <= NBMAX; i++)
+            if (i == nb) cw[i] = tb;
+#pragma unroll
+        for (int i = 0; i < NBMAX; i++)
+            if (i < nb) w[i] = cw[i + 1] - cw[i];
+
+        mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NBMAX; i++)
+            if (i < nb) {
+                h[i] = q[(int64_t)(nb + i) * T] / inv_sqrt_c_div;
+                mx = fmaxf(mx, h[i]);
+            }
+        s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBMAX; i++)
+            if (i < nb) {
+                h[i] = expf(h[i] - mx);
+                s += h[i];
+            }
+        ch[0] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBMAX; i++)
+            if (i < nb) {
+                h[i] = minh + (1.0f - minh * nb) * (h[i] / s);
+                ch[i + 1] = ch[i] + h[i];
+            }
+#pragma unroll
+        for (int i = 0; i <= NBMAX; i++)
+            if (i <= nb) ch[i] = (tb - (-tb)) * ch[i] + (-tb);
+        ch[0] = -tb;
+#pragma unroll
+        for (int i = 0; i <= NBMAX; i++)
+            if (i == nb) ch[i] = tb;
+#pragma unroll
+        for (int i = 0; i < NBMAX; i++)
+            if (i < nb) h[i] = ch[i + 1] - ch[i];
+
+        const float cst = 0.5397424172369522f;  // log(exp(1 - 1e-3) - 1), transforms.py:70
+        const float dedge = mind + softplus_f(cst);
+#pragma unroll
+        for (int i = 0; i <= NBMAX; i++)
+            if (i <= nb) d[i] = (i == 0 || i == nb) ? dedge : mind + softplus_f(q[(int64_t)(2 * nb + i - 1) * T]);
+
+        // searchsorted on cumheights (last knot + 1e-6), then gather by select (registers only)
+        int bin = -1;
+#pragma unroll
+        for (int i = 0; i <= NBMAX; i++)
+            if (i <= nb) {
+                float loc = ch[i] + (i == nb ? 1e-6f : 0.f);
+                if (x >= loc) bin++;
+            }
+        bin = bin < 0 ? 0 : (bin > nb - 1 ? nb - 1 : bin);
+        float icw = 0.f, ibw = 1.f, ich = 0.f, ih = 1.f, dd = 1.f, dp1 = 1.f;
+#pragma unroll
+        for (int i = 0; i < NBMAX; i++)
+            if (i == bin) {
+                icw = cw[i];
+                ibw = w[i];
+                ich = ch[i];
+                ih = h[i];
+                dd = d[i];
+                dp1 = d[i + 1];
+            }
+        float delta = ih / ibw;
+        float a = (x - ich) * (dd + dp1 - 2.0f * delta) + ih * (delta - dd);
+        float bq = ih * dd - (x - ich) * (dd + dp1 - 2.0f * delta);
+        float c = -delta * (x - ich);
+        float disc = bq * bq - 4.0f * a * c;
+        float root = (2.0f * c) / (-bq - sqrtf(disc));
+        y = root * ibw + icw;
+    }
+    *px0 = *px0 * mk;  // cat([x0, x1]) * x_mask (modules.py:521)
+    *px1 = y * mk;
+}
+
+// ---- SDP tail: ElementwiseAffine reverse on channel ch -> logw (modules.py:407-409) -------------
+__global__ void ea_logw_kernel(const float *z, int ch, float m0, float logs0, const int *len, float *logw, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= T) return;
+    float mk = t < len[b] ? 1.f : 0.f;
+    logw[(int64_t)b * T + t] = (z[((int64_t)b * 2 + ch) * T + t] - m0) * expf(-logs0) * mk;
+}
+
+__global__ void scale_kernel(const float *in, float *out, float s, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * s;
+}
+
+// x[b,c,t] = (x[b,c,t] + bias_b[b,c]) (DurationPredictor cond, models.py:153-155)
+__global__ void add_bias_b_kernel(const float *in, float *out, const float *bias_b, int stride, int C, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    int64_t o = ((int64_t)b * C + c) * T + t;
+    out[o] = in[o] + bias_b[(int64_t)b * stride + c];
+}
+
+// ---- a9: durations (models.py:702-704): one block per utterance ----------------------------------
+// w = exp(logw)*mask*length_scale; w_ceil = ceil(w); cum = inclusive scan (ints); y_len = max(sum,1)
+__global__ void duration_kernel(const float *logw, const int *len, float length_scale, float *w_ceil, int *cum,
+                                int *y_len, int T) {
+    __shared__ int sh[256];
+    __shared__ int carry_s;
+    int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    const int L = len[b];
+    for (int base = 0; base < T; base += 256) {
+        int t = base + tid;
+        int v = 0;
+        if (t < T) {
+            float mk = t < L ? 1.f : 0.f;
+            float w = expf(logw[(int64_t)b * T + t]) * mk * length_scale;
+            float c = ceilf(w);
+            w_ceil[(int64_t)b * T + t] = c;
+            v = (int)c;
+        }
+        sh[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int add = tid >= off ? sh[tid - off] : 0;
+            __syncthreads();
+            sh[tid] += add;
+            __syncthreads();
+        }
+        int carry = carry_s;
+        if (t < T) cum[(int64_t)b * T + t] = carry + sh[tid];
+        __syncthreads();
+        if (tid == 255) carry_s = carry + sh[255];
+        __syncthreads();
+    }
+    if (tid == 0) y_len[b] = carry_s < 1 ? 1 : carry_s;
+}
+
+// ---- a9: expand prior by durations + sample (commons.py:116-129, models.py:711-718) --------------
+// z_p[b,c,f] = m_p[b,c,i(f)] + noise[b,c,f] * exp(logs_p[b,c,i(f)]) * noise_scale ; frames with no
+// token (f >= y_len[b]) see m=0, logs=0 exactly as the reference's masked path matmul gives.
+// m_p / logs_p are strided views (batch stride `bstride`, channel stride T).
+__global__ void expand_prior_strided_kernel(const float *m_p, const float *logs_p, int64_t bstride, const int *cum,
+                                            const int *len, const int *y_len, const float *noise,
+                                            int64_t noise_stride, float noise_scale, float *z_p, int C, int T, int F) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (f >= F) return;
+    const int *cb = cum + (int64_t)b * T;
+    int tok = -1;
+    if (f < y_len[b]) {
+        int lo = 0, hi = T;  // smallest i with cum[i] > f
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (cb[mid] > f) hi = mid;
+            else lo = mid + 1;
+        }
+        if (lo < T && lo < len[b]) tok = lo;
+    }
+    const float *mb = m_p + (int64_t)b * bstride, *lb = logs_p + (int64_t)b * bstride;
+    for (int c = 0; c < C; c++) {
+        float mp = 0.f, lp = 0.f;
+        if (tok >= 0) {
+            mp = mb[(int64_t)c * T + tok];
+            lp = lb[(int64_t)c * T + tok];
+        }
+        float e = noise ? noise[((int64_t)b * C + c) * noise_stride + f] : 0.f;
+        z_p[((int64_t)b * C + c) * F + f] = mp + e * expf(lp) * noise_scale;
+    }
+}
+
+__global__ void mask_kernel(float *x, const int *len, int C, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    if (t >= len[b]) x[((int64_t)b * C + c) * T + t] = 0.f;
+}
+
+__global__ void ylen_to_i64(const int *in, int64_t *out, int B) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] = in[b];
+}
+
+// copy a strided [B][C][T] view (batch stride bstride) into a contiguous buffer
+__global__ void gather_view_kernel(const float *in, int64_t bstride, float *out, int C, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t < T) out[((int64_t)b * C + c) * T + t] = in[(int64_t)b * bstride + (int64_t)c * T + t];
+}
+
+// ---- speaker conditioning: out[b,r] = bias[r] + W[r,:] . emb_g[sid[b],:] (1x1 conv on g) -------
+__global__ void cond_matvec_kernel(const float *emb_g, const int64_t *sid, int n_speakers, const float *W,
+                                   const float *bias, float *out, int rows, int gin) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (r >= rows) return;
+    int64_t s = sid[b];
+    s = s < 0 ? 0 : (s >= n_speakers ? n_speakers - 1 : s);
+    const float *g = emb_g + s * gin;
+    const float *w = W + (int64_t)r * gin;
+    float acc = bias ? bias[r] : 0.f;
+    for (int k = 0; k < gin; k++) acc += w[k] * g[k];
+    out[(int64_t)b * rows + r] = acc;
+}
+
+// ---- a11: WN gate tanh(a[:H]) * sigmoid(a[H:]) (commons.py:99-106) --------------------------------
+__global__ void wn_gate_kernel(const float *a, float *acts, int H, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    float ta = a[((int64_t)b * 2 * H + c) * T + t], sa = a[((int64_t)b * 2 * H + H + c) * T + t];
+    acts[((int64_t)b * H + c) * T + t] = tanhf(ta) * sigmoid_f(sa);
+}
+
+// ---- a11: WN residual/skip update (modules.py:203-209) --------------------------------------------
+// not last: x = (x + rs[:, :H]) * mask; skip (+)= rs[:, H:]      last: skip = (skip + rs) * mask
+__global__ void wn_update_kernel(float *x, float *skip, const float *rs, const int *len, int H, int T, int first,
+                                 int last) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    float mk = t < len[b] ? 1.f : 0.f;
+    int64_t o = ((int64_t)b * H + c) * T + t;
+    if (!last) {
+        int64_t r0 = ((int64_t)b * 2 * H + c) * T + t, r1 = ((int64_t)b * 2 * H + H + c) * T + t;
+        x[o] = (x[o] + rs[r0]) * mk;
+        skip[o] = first ? rs[r1] : skip[o] + rs[r1];
+    } else {
+        float s = first ? rs[o] : skip[o] + rs[o];
+        skip[o] = s * mk;
+    }
+}
+
+// ---- a12 tail: leaky_relu(0.01) -> conv_post (C -> 1, k taps, no bias) -> tanh ---------------------
+// The one genuinely HBM-bound kernel: C*4 bytes read + 4 written per sample.
+__global__ __launch_bounds__(256) void post_conv_tanh_kernel(const float *x, const float *w, float *out, int C,
+                                                             int K, int T, float slope) {
+    extern __shared__ float sm[];  // [C][256 + K - 1] staged tile, then weights [C*K]
+    const int LW = 256 + K - 1;
+    float *ws = sm + (size_t)C * LW;
+    int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+    const float *xb = x + (int64_t)b * C * T;
+    for (int i = tid; i < C * K; i += 256) ws[i] = w[i];
+    const int pad = (K - 1) / 2;
+    for (int c = 0; c < C; c++)
+        for (int i = tid; i < LW; i += 256) {
+            int t = t0 - pad + i;
+            float v = (t >= 0 && t < T) ? xb[(int64_t)c * T + t] : 0.f;
+            sm[c * LW + i] = v > 0.f ? v : v * slope;
+        }
+    __syncthreads();
+    int t = t0 + tid;
+    if (t >= T) return;
+    float acc = 0.f;
+    for (int c = 0; c < C; c++)
+        for (int k = 0; k < K; k++) acc += ws[c * K + k] * sm[c * LW + tid + k];
+    out[(int64_t)b * T + t] = tanhf(acc);
+}
+
+// ---- noise: Philox4x32-10 counter RNG + Box-Muller (production path; parity uses injected noise) ---
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void fill_normal_kernel(float *out, int64_t n, uint64_t seed, uint64_t stream_id) {
+    int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= n) return;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)i4, (uint32_t)(i4 >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32),
+                  (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float k = 2.3283064365386963e-10f;  // 2^-32
+    float u0 = ((float)r[0] + 0.5f) * k, u1 = ((float)r[1] + 0.5f) * k;
+    float u2 = ((float)r[2] + 0.5f) * k, u3 = ((float)r[3] + 0.5f) * k;
+    u0 = fminf(fmaxf(u0, 1e-12f), 1.0f);
+    u2 = fminf(fmaxf(u2, 1e-12f), 1.0f);
+    float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float v[4] = {ra * cosf(6.283185307179586f * u1), ra * sinf(6.283185307179586f * u1),
+                  rb * cosf(6.283185307179586f * u3), rb * sinf(6.283185307179586f * u3)};
+    for (int j = 0; j < 4; j++)
+        if (i4 * 4 + j < n) out[i4 * 4 + j] = v[j];
+}
+
+// ---- a3: relative-position self-attention core on the f32 matrix cores ---------------------------
+// One wavefront per (32-query block, head, utterance); flash-style online softmax over 32-key blocks.
+//   S^T[j,i] = sum_d k[d,j] * (q[d,i]/sqrt(dk))        A = K rows (coalesced global), B = Q fragment
+//   + q_i . E_k[j-i+w] for |j-i| <= w ; masked keys -> -1e4 (attentions.py:232-247)
+//   O^T[d,i] = sum_j v[d,j] * P^T[j,i]                  B = the S^T accumulator registers, in place:
+//       register r of lane (c, h) holds row rho(r) + 4h of column c, so the k-pair of MFMA #r is
+//       (rho(r), rho(r)+4) and the A operand is V[d, j0 + rho(r) + 4h] (staged through LDS).
+//   + sum_{|j-i|<=w} p[i,j] * E_v[j-i+w] (attentions.py:261-268); everything divided by the row sum.
+// Query columns live on lanes (lane&31) in both products, so the softmax statistics are per-lane
+// scalars and the only cross-lane traffic is one lane^32 exchange per block.
+template <int DKB>  // ceil(dk/32)
+__global__ __launch_bounds__(64) void attention_relpos_kernel(const float *qkv, float *out, const float *relk,
+                                                              const float *relv, const int *len, int Hc, int T,
+                                                              int dk, int win) {
+    __shared__ float vs[DKB * 32 * 33];
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    const int L = len[b] < T ? len[b] : T;
+    const int i = i0 + l31;
+    const float *q = qkv + ((int64_t)b * 3 * Hc + (int64_t)h * dk) * T;
+    const float *k = q + (int64_t)Hc * T;
+    const float *v = k + (int64_t)Hc * T;
+    float *o = out + ((int64_t)b * Hc + (int64_t)h * dk) * T;
+    constexpr int STEPS = DKB * 16;
+    if (i0 >= L) {  // fully padded query block: defined zeros (never read by valid positions)
+        for (int d = hi; d < dk; d += 2)
+            if (i < T) o[(int64_t)d * T + i] = 0.f;
+        return;
+    }
+    const float sq = sqrtf((float)dk);
+    float qf[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+        int d = 2 * s + hi;
+        qf[s] = (d < dk && i < T) ? q[(int64_t)d * T + i] / sq : 0.f;
+    }
+    // relative-key logits of this lane's query: rq[m] = q_i . E_k[m]
+    float rq[9];
+    const int nrel = 2 * win + 1;
+#pragma unroll
+    for (int m = 0; m < 9; m++) {
+        float s = 0.f;
+        if (m < nrel) {
+#pragma unroll
+            for (int st = 0; st < STEPS; st++) {
+                int d = 2 * st + hi;
+                if (d < dk) s += qf[st] * relk[m * dk + d];
+            }
+        }
+        s += __shfl_xor(s, 32);
+        rq[m] = s;
+    }
+    float mrun = -INFINITY, lrun = 0.f;
+    float wrel[9];
+#pragma unroll
+    for (int m = 0; m < 9; m++) wrel[m] = 0.f;
+    f32x16 oacc[DKB];
+#pragma unroll
+    for (int db = 0; db < DKB; db++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[db][r] = 0.f;
+
+    const int nkb = (L + 31) / 32;
+    for (int kb = 0; kb < nkb; kb++) {
+        const int j0 = kb * 32;
+        __syncthreads();
+        // stage V block [dk][32] (coalesced rows) into LDS with stride 33
+        for (int d = hi; d < DKB * 32; d += 2) {
+            int j = j0 + l31;
+            vs[d * 33 + l31] = (d < dk && j < T) ? v[(int64_t)d * T + j] : 0.f;
+        }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = 0.f;
+#pragma unroll
+        for (int st = 0; st < STEPS; st++) {
+            int d = 2 * st + hi, j = j0 + l31;
+            float a = (d < dk && j < T) ? k[(int64_t)d * T + j] : 0.f;
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qf[st], s, 0, 0, 0);
+        }
+        const bool near = (j0 + 31 >= i0 - win) && (j0 <= i0 + 31 + win);
+        float bm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float sv = s[r];
+            if (near) {
+                int m = j - i + win;
+#pragma unroll
+                for (int mm = 0; mm < 9; mm++)
+                    if (mm == m && mm < nrel) sv += rq[mm];
+            }
+            if (j >= L) sv = -1e4f;
+            s[r] = sv;
+            bm = fmaxf(bm, sv);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32));
+        const float mnew = fmaxf(mrun, bm);
+        const float alpha = expf(mrun - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float p = expf(s[r] - mnew);
+            s[r] = p;
+            psum += p;
+        }
+        psum += __shfl_xor(psum, 32);
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int db = 0; db < DKB; db++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[db][r] *= alpha;
+#pragma unroll
+        for (int m = 0; m < 9; m++) wrel[m] *= alpha;
+        if (near) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                int m = j - i + win;
+#pragma unroll
+                for (int mm = 0; mm < 9; mm++)
+                    if (mm == m && mm < nrel) wrel[mm] += s[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < DKB; db++) {
+                float a = vs[(db * 32 + l31) * 33 + jj];
+                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[r], oacc[db], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 9; m++) wrel[m] += __shfl_xor(wrel[m], 32);
+    const bool qvalid = i < L;
+#pragma unroll
+    for (int db = 0; db < DKB; db++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (d < dk && i < T) {
+                float val = oacc[db][r];
+#pragma unroll
+                for (int m = 0; m < 9; m++)
+                    if (m < nrel) val += wrel[m] * relv[m * dk + d];
+                o[(int64_t)d * T + i] = qvalid ? val / lrun : 0.f;
+            }
+        }
+}
+
+}  // namespace vitsmi

@@ -1,0 +1,550 @@
+// model.cpp — resolve VITS parameters from the exported graph and pack them for gfx950.
+//
+// Parameters are found by FOLLOWING GRAPH NODES, not by trusting initializer names:
+// the exporter folds weight-normed flow convs into anonymous `onnx::Conv_N` tensors,
+// folds Neg(logs) of ElementwiseAffine into `onnx::Exp_N`, and de-duplicates identical
+// initializers.  Node names carry the module path
+// ("/flow/flows.6/enc/in_layers.0/Conv"), which is what we key on.
+#include "model.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+
+namespace vitsmi {
+namespace {
+
+struct TRef {
+    const float *p = nullptr;
+    std::vector<int64_t> dims;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto d : dims) n *= d;
+        return n;
+    }
+};
+
+struct Resolver {
+    std::map<std::string, TRef> t;
+    std::map<std::string, int64_t> ints;
+    std::vector<std::vector<float>> owned;
+
+    void put(const std::string &name, const OnnxTensor *ot) {
+        if (!ot || !ot->data() || t.count(name)) return;
+        TRef r;
+        r.p = ot->data();
+        r.dims = ot->dims;
+        t[name] = r;
+    }
+    const TRef *get(const std::string &name) const {
+        auto it = t.find(name);
+        return it == t.end() ? nullptr : &it->second;
+    }
+    const TRef &req(const std::string &name) const {
+        auto it = t.find(name);
+        if (it == t.end()) throw std::runtime_error("parameter not found in graph: " + name);
+        return it->second;
+    }
+    int64_t geti(const std::string &k, int64_t d) const {
+        auto it = ints.find(k);
+        return it == ints.end() ? d : it->second;
+    }
+};
+
+void split_path(const std::string &node_name, std::string &mod, std::string &leaf) {
+    std::vector<std::string> parts;
+    std::string cur;
+    for (char c : node_name) {
+        if (c == '/') {
+            if (!cur.empty()) parts.push_back(cur);
+            cur.clear();
+        } else
+            cur.push_back(c);
+    }
+    if (!cur.empty()) parts.push_back(cur);
+    mod.clear();
+    leaf = parts.empty() ? "" : parts.back();
+    for (size_t i = 0; i + 1 < parts.size(); i++) {
+        if (i) mod += ".";
+        mod += parts[i];
+    }
+}
+
+void resolve(const OnnxModel &om, Resolver &R) {
+    auto init = [&](const std::string &n) -> const OnnxTensor * {
+        auto it = om.init.find(n);
+        return it == om.init.end() ? nullptr : &it->second;
+    };
+    std::map<std::string, int> pad_seen;
+    for (const auto &n : om.nodes) {
+        if (n.name.empty()) continue;
+        std::string mod, leaf;
+        split_path(n.name, mod, leaf);
+        if (n.op == "Conv" || n.op == "ConvTranspose") {
+            if (n.inputs.size() > 1) R.put(mod + ".weight", init(n.inputs[1]));
+            if (n.inputs.size() > 2 && !n.inputs[2].empty()) R.put(mod + ".bias", init(n.inputs[2]));
+            auto a = n.ints.find("dilations");
+            if (a != n.ints.end() && !a->second.empty()) R.ints[mod + ".dilation"] = a->second[0];
+            a = n.ints.find("strides");
+            if (a != n.ints.end() && !a->second.empty()) R.ints[mod + ".stride"] = a->second[0];
+            a = n.ints.find("pads");
+            if (a != n.ints.end() && !a->second.empty()) R.ints[mod + ".pad"] = a->second[0];
+            a = n.ints.find("group");
+            R.ints[mod + ".group"] = (a != n.ints.end() && !a->second.empty()) ? a->second[0] : 1;
+        } else if (n.op == "Gather" && !n.inputs.empty()) {
+            const OnnxTensor *t = init(n.inputs[0]);
+            if (t && t->dtype == 1 && t->dims.size() == 2) R.put(mod + ".weight", t);
+        } else if ((n.op == "Mul" || n.op == "Add") && mod.find("norm") != std::string::npos) {
+            for (const auto &i : n.inputs) {
+                const OnnxTensor *t = init(i);
+                if (t && t->dtype == 1 && t->dims.size() == 1) R.put(mod + (n.op == "Mul" ? ".gamma" : ".beta"), t);
+            }
+        } else if (n.op == "Pad" && mod.find("attn_layers") != std::string::npos && !n.inputs.empty()) {
+            const OnnxTensor *t = init(n.inputs[0]);
+            if (t && t->dtype == 1 && t->dims.size() == 3) {
+                int k = pad_seen[mod]++;
+                R.put(mod + (k == 0 ? ".emb_rel_k" : ".emb_rel_v"), t);
+            }
+        } else if (mod == "dp.flows.0" && n.op == "Sub") {
+            for (const auto &i : n.inputs) R.put("dp.flows.0.m", init(i));
+        } else if (mod == "dp.flows.0" && n.op == "Exp") {
+            for (const auto &i : n.inputs) {
+                const OnnxTensor *t = init(i);
+                if (t && t->data() && !R.t.count("dp.flows.0.logs")) {
+                    // the exporter constant-folded Neg(logs): undo it
+                    R.owned.emplace_back(t->data(), t->data() + t->numel());
+                    for (auto &v : R.owned.back()) v = -v;
+                    TRef r;
+                    r.p = R.owned.back().data();
+                    r.dims = t->dims;
+                    R.t["dp.flows.0.logs"] = r;
+                }
+            }
+        }
+    }
+    // relative-position tables are also reachable by parameter name (they are never folded)
+    for (const auto &kv : om.init) {
+        const std::string &k = kv.first;
+        auto ends = [&](const char *s) {
+            size_t n = std::strlen(s);
+            return k.size() >= n && k.compare(k.size() - n, n, s) == 0;
+        };
+        if (ends("emb_rel_k") || ends("emb_rel_v")) R.put(k, &kv.second);
+    }
+}
+
+// ---------------------------------------------------------------------------------- packing
+
+struct Packer {
+    std::vector<float> &arena;
+    explicit Packer(std::vector<float> &a) : arena(a) {}
+    int64_t alloc(int64_t n) {
+        int64_t off = int64_t((arena.size() + 63) / 64 * 64);  // 256-byte alignment
+        arena.resize(size_t(off + n), 0.f);
+        return off;
+    }
+    int64_t put(const float *p, int64_t n) {
+        int64_t off = alloc(n);
+        std::memcpy(arena.data() + off, p, size_t(n) * 4);
+        return off;
+    }
+    int64_t put(const TRef &r) { return put(r.p, r.numel()); }
+};
+
+int pick_cfg(int Cout) { return (Cout % 128 == 0) ? 2 : (Cout <= 32 ? 0 : 1); }
+int tile_m(int cfg) { return cfg == 2 ? 128 : (cfg == 1 ? 64 : 32); }
+
+// W is addressed through a functor so that permutations / transposed-conv rewrites need no copies:
+// w(co, ci, tap) for co < Cout, ci < Cin, tap < K.
+template <class WF>
+ConvDesc pack_conv(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF w, const float *bias_virtual) {
+    ConvDesc d;
+    d.Cin = Cin;
+    d.Cout = Cout;
+    d.K = K;
+    d.dil = dil;
+    d.padL = padL;
+    d.cfg = pick_cfg(Cout);
+    int cap = d.cfg == 2 ? 32 : 16;
+    d.CK = Cin <= 8 ? 8 : (Cin <= 16 ? 16 : cap);
+    d.nchunks = (Cin + d.CK - 1) / d.CK;
+    int bm = tile_m(d.cfg);
+    d.mblocks = (Cout + bm - 1) / bm * (bm / 32);
+    d.steps4 = d.nchunks * K * d.CK / 8;
+    int64_t per_block = int64_t(d.steps4) * 64 * 4;
+    d.w_off = P.alloc(per_block * d.mblocks);
+    float *dst = P.arena.data() + d.w_off;
+    int half = d.CK / 2;
+    for (int mb = 0; mb < d.mblocks; mb++)
+        for (int chunk = 0; chunk < d.nchunks; chunk++)
+            for (int tap = 0; tap < K; tap++)
+                for (int pair = 0; pair < half; pair++) {
+                    int step = (chunk * K + tap) * half + pair;
+                    float *g = dst + (int64_t(mb) * d.steps4 + step / 4) * 256 + (step & 3);
+                    for (int lane = 0; lane < 64; lane++) {
+                        int co = mb * 32 + (lane & 31);
+                        int ci = chunk * d.CK + 2 * pair + (lane >> 5);
+                        g[lane * 4] = (co < Cout && ci < Cin) ? w(co, ci, tap) : 0.f;
+                    }
+                }
+    if (bias_virtual) d.b_off = P.put(bias_virtual, Cout);
+    d.macs_per_t = double(Cin) * Cout * K;
+    return d;
+}
+
+// plain Conv1d module "<name>": weight [Cout, Cin, K]
+ConvDesc pack_named(Packer &P, const Resolver &R, const std::string &name, int dil, int padL,
+                    const std::vector<int> *in_perm = nullptr, const std::vector<int> *out_perm = nullptr) {
+    const TRef &w = R.req(name + ".weight");
+    if (w.dims.size() != 3) throw std::runtime_error(name + ".weight is not rank 3");
+    int Cout = int(w.dims[0]), Cin = int(w.dims[1]), K = int(w.dims[2]);
+    if (R.geti(name + ".group", 1) != 1) throw std::runtime_error(name + ": grouped conv not expected here");
+    const TRef *b = R.get(name + ".bias");
+    const float *wp = w.p;
+    auto wf = [&](int co, int ci, int tap) {
+        int so = out_perm ? (*out_perm)[co] : co;
+        int si = in_perm ? (*in_perm)[ci] : ci;
+        return wp[(int64_t(so) * Cin + si) * K + tap];
+    };
+    std::vector<float> bperm;
+    const float *bp = b ? b->p : nullptr;
+    if (b && out_perm) {
+        bperm.resize(Cout);
+        for (int c = 0; c < Cout; c++) bperm[c] = b->p[(*out_perm)[c]];
+        bp = bperm.data();
+    }
+    return pack_conv(P, Cin, Cout, K, dil, padL, wf, bp);
+}
+
+// ConvTranspose1d [Cin, Cout, K], stride u, padding p  ->  dense conv with Cout*u virtual
+// channels (co' = co*u + r) over taps o_min..o_max and a pixel-shuffle store.
+ConvDesc pack_convT(Packer &P, const Resolver &R, const std::string &name) {
+    const TRef &w = R.req(name + ".weight");
+    int Cin = int(w.dims[0]), Cout = int(w.dims[1]), K = int(w.dims[2]);
+    int u = int(R.geti(name + ".stride", -1));
+    int p = int(R.geti(name + ".pad", -1));
+    if (u < 1 || p < 0) throw std::runtime_error(name + ": missing stride/pads attributes");
+    if (K - 2 * p != u) throw std::runtime_error(name + ": transposed conv with K-2*pad != stride is unsupported");
+    int o_max = -1000000, o_min = 1000000;
+    for (int r = 0; r < u; r++) {
+        int j0 = (r + p) % u, e = (r + p) / u;
+        int M = (K - j0 + u - 1) / u;
+        if (M <= 0) continue;
+        if (e > o_max) o_max = e;
+        if (e - (M - 1) < o_min) o_min = e - (M - 1);
+    }
+    int Kv = o_max - o_min + 1;
+    const float *wp = w.p;
+    auto wf = [&](int cov, int ci, int tapv) -> float {
+        int co = cov / u, r = cov % u;
+        int j0 = (r + p) % u, e = (r + p) / u;
+        int m = e - o_min - tapv;
+        int j = j0 + m * u;
+        if (m < 0 || j >= K) return 0.f;
+        return wp[(int64_t(ci) * Cout + co) * K + j];
+    };
+    std::vector<float> bv;
+    const TRef *b = R.get(name + ".bias");
+    if (b) {
+        bv.resize(size_t(Cout) * u);
+        for (int c = 0; c < Cout * u; c++) bv[c] = b->p[c / u];
+    }
+    ConvDesc d = pack_conv(P, Cin, Cout * u, Kv, 1, -o_min, wf, b ? bv.data() : nullptr);
+    d.ups = u;
+    d.macs_per_t = double(Cin) * Cout * K;  // per INPUT time step
+    return d;
+}
+
+int same_pad(int K, int dil) { return (K * dil - dil) / 2; }  // commons.py:17-18, modules.py:102,163
+
+DDSDesc pack_dds(Packer &P, const Resolver &R, const std::string &pfx) {
+    DDSDesc d;
+    for (int l = 0; l < 4; l++) {
+        std::string s = pfx + ".convs_sep." + std::to_string(l);
+        const TRef *w = R.get(s + ".weight");
+        if (!w) break;
+        d.n_layers = l + 1;
+        d.K = int(w->dims[2]);
+        auto &L = d.l[l];
+        L.dw_w = P.put(*w);
+        L.dw_b = P.put(R.req(s + ".bias"));
+        int dil = 1;
+        for (int i = 0; i < l; i++) dil *= d.K;  // modules.py:101
+        L.dil = int(R.geti(s + ".dilation", dil));
+        L.ln1_g = P.put(R.req(pfx + ".norms_1." + std::to_string(l) + ".gamma"));
+        L.ln1_b = P.put(R.req(pfx + ".norms_1." + std::to_string(l) + ".beta"));
+        L.ln2_g = P.put(R.req(pfx + ".norms_2." + std::to_string(l) + ".gamma"));
+        L.ln2_b = P.put(R.req(pfx + ".norms_2." + std::to_string(l) + ".beta"));
+        L.pw = pack_named(P, R, pfx + ".convs_1x1." + std::to_string(l), 1, 0);
+    }
+    if (!d.n_layers) throw std::runtime_error("no DDSConv layers under " + pfx);
+    return d;
+}
+
+}  // namespace
+
+std::string pack_test_conv(const float *w, const float *bias, int Cin, int Cout, int K, int dil, int pad_l, ConvDesc *d,
+                           std::vector<float> *arena) {
+    if (Cin < 1 || Cout < 1 || K < 1 || dil < 1 || pad_l < 0) return "bad conv shape";
+    Packer P(*arena);
+    auto wf = [&](int co, int ci, int tap) { return w[(int64_t(co) * Cin + ci) * K + tap]; };
+    *d = pack_conv(P, Cin, Cout, K, dil, pad_l, wf, bias);
+    return "";
+}
+
+std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout, int K, int stride, ConvDesc *d,
+                            std::vector<float> *arena) {
+    try {
+        Resolver R;
+        TRef t;
+        t.p = w;
+        t.dims = {Cin, Cout, K};
+        R.t["t.weight"] = t;
+        if (bias) {
+            TRef b;
+            b.p = bias;
+            b.dims = {Cout};
+            R.t["t.bias"] = b;
+        }
+        R.ints["t.stride"] = stride;
+        R.ints["t.pad"] = (K - stride) / 2;
+        Packer P(*arena);
+        *d = pack_convT(P, R, "t");
+    } catch (const std::exception &e) {
+        return e.what();
+    }
+    return "";
+}
+
+std::string Model::build(const OnnxModel &om) {
+    try {
+        Resolver R;
+        resolve(om, R);
+        Packer P(arena);
+        input_names = om.inputs;
+        meta = om.meta;
+
+        // ---------------- text encoder (models.py:168-209, attentions.py)
+        const TRef &embw = R.req("enc_p.emb.weight");
+        n_vocab = int(embw.dims[0]);
+        H = int(embw.dims[1]);
+        emb = P.put(embw);
+        for (int l = 0;; l++) {
+            std::string a = "enc_p.encoder.attn_layers." + std::to_string(l);
+            if (!R.get(a + ".conv_q.weight")) break;
+            EncLayerDesc L;
+            const TRef &wq = R.req(a + ".conv_q.weight"), &wk = R.req(a + ".conv_k.weight"),
+                       &wv = R.req(a + ".conv_v.weight");
+            const TRef &bq = R.req(a + ".conv_q.bias"), &bk = R.req(a + ".conv_k.bias"), &bv = R.req(a + ".conv_v.bias");
+            if (wq.dims[2] != 1) throw std::runtime_error("attention projections must be 1x1");
+            // fused q|k|v projection: one [3H, H, 1] conv
+            const float *ws[3] = {wq.p, wk.p, wv.p};
+            int Hh = H;
+            auto wf = [&](int co, int ci, int) { return ws[co / Hh][int64_t(co % Hh) * Hh + ci]; };
+            std::vector<float> b3(size_t(3) * H);
+            std::memcpy(b3.data(), bq.p, size_t(H) * 4);
+            std::memcpy(b3.data() + H, bk.p, size_t(H) * 4);
+            std::memcpy(b3.data() + 2 * H, bv.p, size_t(H) * 4);
+            L.qkv = pack_conv(P, H, 3 * H, 1, 1, 0, wf, b3.data());
+            L.o = pack_named(P, R, a + ".conv_o", 1, 0);
+            const TRef &rk = R.req(a + ".emb_rel_k"), &rv = R.req(a + ".emb_rel_v");
+            if (rk.dims[0] != 1) throw std::runtime_error("per-head relative embeddings are unsupported");
+            window = int(rk.dims[1] - 1) / 2;
+            dk = int(rk.dims[2]);
+            n_heads = H / dk;
+            L.rel_k = P.put(rk);
+            L.rel_v = P.put(rv);
+            L.ln1_g = P.put(R.req("enc_p.encoder.norm_layers_1." + std::to_string(l) + ".gamma"));
+            L.ln1_b = P.put(R.req("enc_p.encoder.norm_layers_1." + std::to_string(l) + ".beta"));
+            L.ln2_g = P.put(R.req("enc_p.encoder.norm_layers_2." + std::to_string(l) + ".gamma"));
+            L.ln2_b = P.put(R.req("enc_p.encoder.norm_layers_2." + std::to_string(l) + ".beta"));
+            std::string f = "enc_p.encoder.ffn_layers." + std::to_string(l);
+            const TRef &w1 = R.req(f + ".conv_1.weight");
+            int fk = int(w1.dims[2]);
+            FF = int(w1.dims[0]);
+            L.ffn1 = pack_named(P, R, f + ".conv_1", 1, (fk - 1) / 2);  // attentions.py:419-427
+            L.ffn2 = pack_named(P, R, f + ".conv_2", 1, (fk - 1) / 2);
+            enc.push_back(L);
+        }
+        n_layers = int(enc.size());
+        if (!n_layers) throw std::runtime_error("no encoder attention layers found");
+        enc_proj = pack_named(P, R, "enc_p.proj", 1, 0);
+        C = enc_proj.Cout / 2;
+
+        // ---------------- speaker embedding (models.py:614-615)
+        if (const TRef *eg = R.get("emb_g.weight")) {
+            n_speakers = int(eg->dims[0]);
+            gin = int(eg->dims[1]);
+            emb_g = P.put(*eg);
+        }
+
+        // ---------------- duration predictor
+        use_sdp = R.get("dp.flows.0.m") != nullptr;
+        if (use_sdp) {
+            dp_pre = pack_named(P, R, "dp.pre", 1, 0);
+            dp_proj = pack_named(P, R, "dp.proj", 1, 0);
+            dp_convs = pack_dds(P, R, "dp.convs");
+            int order[3] = {7, 5, 3};  // models.py:109-110
+            for (int i = 0; i < 3; i++) {
+                std::string s = "dp.flows." + std::to_string(order[i]);
+                cf[i].pre_w = P.put(R.req(s + ".pre.weight"));
+                cf[i].pre_b = P.put(R.req(s + ".pre.bias"));
+                cf[i].convs = pack_dds(P, R, s + ".convs");
+                cf[i].proj = pack_named(P, R, s + ".proj", 1, 0);
+                cf[i].nb = (cf[i].proj.Cout + 1) / 3;
+                if (cf[i].nb > 16) throw std::runtime_error("spline with more than 16 bins is unsupported");
+            }
+            ea_m0 = R.req("dp.flows.0.m").p[0];
+            ea_logs0 = R.req("dp.flows.0.logs").p[0];
+        } else {
+            const TRef &w1 = R.req("dp.conv_1.weight");
+            int k = int(w1.dims[2]);
+            dpp_F = int(w1.dims[0]);
+            dpp_conv1 = pack_named(P, R, "dp.conv_1", 1, k / 2);  // models.py:138-144
+            dpp_conv2 = pack_named(P, R, "dp.conv_2", 1, k / 2);
+            dpp_proj = pack_named(P, R, "dp.proj", 1, 0);
+            dpp_n1_g = P.put(R.req("dp.norm_1.gamma"));
+            dpp_n1_b = P.put(R.req("dp.norm_1.beta"));
+            dpp_n2_g = P.put(R.req("dp.norm_2.gamma"));
+            dpp_n2_b = P.put(R.req("dp.norm_2.beta"));
+        }
+        if (gin) {
+            const TRef &cw = R.req("dp.cond.weight");
+            dp_cond_rows = int(cw.dims[0]);
+            dp_cond_w = P.put(cw);
+            dp_cond_b = P.put(R.req("dp.cond.bias"));
+        }
+
+        // ---------------- flow (models.py:212-254), Flip folded into channel permutations
+        {
+            int nfl = 0;
+            while (R.get("flow.flows." + std::to_string(2 * nfl) + ".pre.weight")) nfl++;
+            if (!nfl) throw std::runtime_error("no coupling layers found");
+            int half = C / 2;
+            std::vector<int> rev(half);
+            for (int i = 0; i < half; i++) rev[i] = half - 1 - i;
+            for (int e = 0; e < nfl; e++) {
+                int idx = 2 * (nfl - 1 - e);
+                std::string s = "flow.flows." + std::to_string(idx);
+                CouplingDesc cd;
+                cd.swapped = ((e + 1) % 2) == 1;  // odd number of Flips so far
+                cd.pre = pack_named(P, R, s + ".pre", 1, 0, cd.swapped ? &rev : nullptr, nullptr);
+                cd.post = pack_named(P, R, s + ".post", 1, 0, nullptr, cd.swapped ? &rev : nullptr);
+                if (cd.post.Cout != half) throw std::runtime_error("only mean_only coupling layers are supported");
+                flow_H = cd.pre.Cout;
+                for (int i = 0; i < 8; i++) {
+                    std::string in = s + ".enc.in_layers." + std::to_string(i);
+                    const TRef *w = R.get(in + ".weight");
+                    if (!w) break;
+                    int k = int(w->dims[2]);
+                    int dil = int(R.geti(in + ".dilation", 1));
+                    cd.wn[i].in = pack_named(P, R, in, dil, same_pad(k, dil));
+                    cd.wn[i].rs = pack_named(P, R, s + ".enc.res_skip_layers." + std::to_string(i), 1, 0);
+                    cd.n_wn = i + 1;
+                }
+                if (gin) {
+                    cd.cond_w = P.put(R.req(s + ".enc.cond_layer.weight"));
+                    cd.cond_b = P.put(R.req(s + ".enc.cond_layer.bias"));
+                }
+                flow.push_back(cd);
+            }
+            if (nfl % 2) throw std::runtime_error("odd number of coupling layers is unsupported");
+        }
+
+        // ---------------- generator (models.py:299-368)
+        conv_pre = pack_named(P, R, "dec.conv_pre", 1, 3);
+        C0 = conv_pre.Cout;
+        if (gin) {
+            dec_cond_w = P.put(R.req("dec.cond.weight"));
+            dec_cond_b = P.put(R.req("dec.cond.bias"));
+        }
+        int nups = 0;
+        while (R.get("dec.ups." + std::to_string(nups) + ".weight")) nups++;
+        int nrb = 0;
+        while (R.get("dec.resblocks." + std::to_string(nrb) + ".convs1.0.weight") ||
+               R.get("dec.resblocks." + std::to_string(nrb) + ".convs.0.weight"))
+            nrb++;
+        if (!nups || nrb % nups) throw std::runtime_error("unexpected generator structure");
+        int nk = nrb / nups;
+        hop = 1;
+        for (int i = 0; i < nups; i++) {
+            UpStageDesc st;
+            st.up = pack_convT(P, R, "dec.ups." + std::to_string(i));
+            st.u = st.up.ups;
+            st.C = st.up.Cout / st.u;
+            hop *= st.u;
+            for (int j = 0; j < nk; j++) {
+                std::string rb = "dec.resblocks." + std::to_string(i * nk + j);
+                ResBlockDesc rd;
+                rd.type1 = R.get(rb + ".convs1.0.weight") != nullptr;
+                for (int q = 0; q < 4; q++) {
+                    std::string c1 = rb + (rd.type1 ? ".convs1." : ".convs.") + std::to_string(q);
+                    const TRef *w = R.get(c1 + ".weight");
+                    if (!w) break;
+                    int k = int(w->dims[2]);
+                    int dil = int(R.geti(c1 + ".dilation", 1));
+                    rd.c1[q] = pack_named(P, R, c1, dil, same_pad(k, dil));
+                    if (rd.type1) {
+                        std::string c2 = rb + ".convs2." + std::to_string(q);
+                        const TRef &w2 = R.req(c2 + ".weight");
+                        int k2 = int(w2.dims[2]);
+                        int d2 = int(R.geti(c2 + ".dilation", 1));
+                        rd.c2[q] = pack_named(P, R, c2, d2, same_pad(k2, d2));
+                    }
+                    rd.n = q + 1;
+                }
+                st.rbs.push_back(rd);
+            }
+            ups.push_back(st);
+        }
+        const TRef &pw = R.req("dec.conv_post.weight");
+        if (pw.dims[0] != 1) throw std::runtime_error("conv_post must have one output channel");
+        if (R.get("dec.conv_post.bias")) throw std::runtime_error("conv_post with bias is unsupported");
+        post_cin = int(pw.dims[1]);
+        post_k = int(pw.dims[2]);
+        post_w = P.put(pw);
+
+        // ---------------- reference-definition work counts
+        {
+            double t = 1, macs = conv_pre.macs_per_t, el = double(conv_pre.Cin) + conv_pre.Cout;
+            for (auto &st : ups) {
+                macs += t * st.up.macs_per_t;
+                el += t * st.up.Cin;
+                t *= st.u;
+                el += t * st.C;
+                for (auto &rb : st.rbs)
+                    for (int q = 0; q < rb.n; q++) {
+                        macs += t * rb.c1[q].macs_per_t;
+                        el += t * 2 * st.C;
+                        if (rb.type1) {
+                            macs += t * rb.c2[q].macs_per_t;
+                            el += t * 2 * st.C;
+                        }
+                    }
+            }
+            macs += t * post_cin * post_k;
+            el += t * (post_cin + 1);
+            dec_macs_per_frame = macs;
+            dec_elems_per_frame = el;
+            double fm = 0;
+            for (auto &cd : flow) {
+                fm += cd.pre.macs_per_t + cd.post.macs_per_t;
+                for (int i = 0; i < cd.n_wn; i++) fm += cd.wn[i].in.macs_per_t + cd.wn[i].rs.macs_per_t;
+            }
+            flow_macs_per_frame = fm;
+            double em = enc_proj.macs_per_t;
+            for (auto &L : enc) em += L.qkv.macs_per_t + L.o.macs_per_t + L.ffn1.macs_per_t + L.ffn2.macs_per_t;
+            enc_macs_per_token = em;  // attention contraction added at run time (depends on T)
+        }
+        if (input_names.empty()) {
+            input_names = {"input", "input_lengths", "scales"};
+            if (gin) input_names.push_back("sid");
+        }
+    } catch (const std::exception &e) {
+        return e.what();
+    }
+    return "";
+}
+
+}  // namespace vitsmi

@@ -1,0 +1,135 @@
+// model.hpp — VITS model description derived from the .onnx graph + packed weight arena.
+// Host-side C++17; no HIP types here so CPU-only tests can exercise it.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "onnx_reader.hpp"
+
+namespace vitsmi {
+
+// One dense conv as executed by the MFMA conv engine (conv_engine.hip).
+// Weights are packed as Wp[mblock][step/4][lane 0..63][4] with
+//   step = (chunk*K + tap)*(CK/2) + pair,
+//   value = W[co = mblock*32 + (lane&31)][ci = chunk*CK + 2*pair + (lane>>5)][tap]  (0 if out of range)
+// i.e. exactly the A-operand lane layout of v_mfma_f32_32x32x2_f32, four k-steps per 16-byte load.
+struct ConvDesc {
+    int64_t w_off = -1;   // arena offset (floats) of packed weights
+    int64_t b_off = -1;   // arena offset of bias [Cout] (virtual channels), -1 if none
+    int Cin = 0, Cout = 0;  // Cout = virtual output channels (real Cout * ups for transposed conv)
+    int K = 1, dil = 1, padL = 0;
+    int CK = 8, nchunks = 0;
+    int mblocks = 0;      // packed 32-row blocks (padded to the tile config)
+    int steps4 = 0;       // float4 groups per mblock = nchunks*K*CK/8
+    int ups = 1;          // pixel-shuffle factor (transposed conv), real Cout = Cout/ups
+    int cfg = 0;          // 0: 32x512 tile, 1: 64x256, 2: 128x128
+    double macs_per_t = 0;   // algorithmic MACs per input time step (reference definition)
+    bool valid() const { return w_off >= 0; }
+};
+
+struct DDSDesc {  // modules.py:81-129
+    int n_layers = 0, K = 3;
+    struct L {
+        int64_t dw_w = -1, dw_b = -1;  // depthwise [C,K], [C]
+        int dil = 1;
+        int64_t ln1_g = -1, ln1_b = -1, ln2_g = -1, ln2_b = -1;
+        ConvDesc pw;  // 1x1
+    } l[4];
+};
+
+struct ConvFlowDesc {  // modules.py:469-527
+    int64_t pre_w = -1, pre_b = -1;  // [C], [C]
+    DDSDesc convs;
+    ConvDesc proj;  // C -> 3*nb-1
+    int nb = 10;
+};
+
+struct EncLayerDesc {
+    ConvDesc qkv, o, ffn1, ffn2;
+    int64_t rel_k = -1, rel_v = -1;  // [2w+1, dk]
+    int64_t ln1_g = -1, ln1_b = -1, ln2_g = -1, ln2_b = -1;
+};
+
+struct CouplingDesc {  // one ResidualCouplingLayer with the preceding Flip folded in
+    ConvDesc pre, post;
+    int n_wn = 0;
+    struct {
+        ConvDesc in, rs;
+    } wn[8];
+    int64_t cond_w = -1, cond_b = -1;  // [2*H*n_wn, gin]
+    bool swapped = false;  // true: x0 is the physical upper half, x1 the lower
+};
+
+struct ResBlockDesc {
+    int n = 0;          // pairs (ResBlock1) or single convs (ResBlock2)
+    bool type1 = true;
+    ConvDesc c1[4], c2[4];
+};
+
+struct UpStageDesc {
+    ConvDesc up;
+    int u = 1, C = 0;
+    std::vector<ResBlockDesc> rbs;
+};
+
+struct Model {
+    // ---- hyper-parameters recovered from the graph
+    int n_vocab = 0, H = 0, C = 0, FF = 0, n_heads = 0, dk = 0, n_layers = 0, window = 0;
+    int n_speakers = 1, gin = 0;
+    bool use_sdp = true;
+    int hop = 1;  // product of upsample rates
+    std::vector<std::string> input_names;
+    std::map<std::string, std::string> meta;
+
+    // ---- text encoder
+    int64_t emb = -1;
+    std::vector<EncLayerDesc> enc;
+    ConvDesc enc_proj;
+
+    // ---- speaker conditioning
+    int64_t emb_g = -1;
+    int64_t dp_cond_w = -1, dp_cond_b = -1;    // [Cdp_in, gin]
+    int dp_cond_rows = 0;
+    int64_t dec_cond_w = -1, dec_cond_b = -1;  // [C0, gin]
+
+    // ---- stochastic duration predictor (reverse)
+    ConvDesc dp_pre, dp_proj;
+    DDSDesc dp_convs;
+    ConvFlowDesc cf[3];  // execution order: flows.7, flows.5, flows.3
+    float ea_m0 = 0.f, ea_logs0 = 0.f;
+    // ---- plain duration predictor
+    ConvDesc dpp_conv1, dpp_conv2, dpp_proj;
+    int64_t dpp_n1_g = -1, dpp_n1_b = -1, dpp_n2_g = -1, dpp_n2_b = -1;
+    int dpp_F = 0;
+
+    // ---- flow (execution order: flows.6, .4, .2, .0)
+    std::vector<CouplingDesc> flow;
+    int flow_H = 0;
+
+    // ---- generator
+    ConvDesc conv_pre;
+    int C0 = 0;
+    std::vector<UpStageDesc> ups;
+    int64_t post_w = -1;  // [Cin, K] conv_post weight (Cout = 1, no bias)
+    int post_cin = 0, post_k = 7;
+
+    // ---- packed arena (host copy)
+    std::vector<float> arena;
+
+    // Build from a parsed file.  Returns "" or an error message.
+    std::string build(const OnnxModel &om);
+
+    // reference-definition work per unit: MACs per frame / per token
+    double dec_macs_per_frame = 0, flow_macs_per_frame = 0, enc_macs_per_token = 0, dp_macs_per_token = 0;
+    double dec_elems_per_frame = 0;  // conv input + output elements per frame (layer-granular bytes / 4)
+};
+
+// kernel-level test hooks: pack one conv / transposed conv into a private arena
+std::string pack_test_conv(const float *w, const float *bias, int Cin, int Cout, int K, int dil, int pad_l, ConvDesc *d,
+                           std::vector<float> *arena);
+std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout, int K, int stride, ConvDesc *d,
+                            std::vector<float> *arena);
+
+}  // namespace vitsmi

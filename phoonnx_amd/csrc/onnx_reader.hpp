@@ -1,0 +1,49 @@
+// onnx_reader.hpp — dependency-free reader for the subset of ONNX protobuf the PyTorch
+// exporter writes (phoonnx_train/export_onnx.py:318-327).  Host-side C++17.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace vitsmi {
+
+struct OnnxTensor {
+    std::string name;
+    int dtype = 0;                 // onnx TensorProto.DataType (1 = float32, 7 = int64)
+    std::vector<int64_t> dims;
+    const uint8_t *raw = nullptr;  // raw_data span inside the file buffer (may be null)
+    size_t raw_bytes = 0;
+    std::vector<float> f32;        // float_data (when raw is absent)
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto d : dims) n *= d;
+        return n;
+    }
+    // float view (nullptr if not float32)
+    const float *data() const {
+        if (dtype != 1) return nullptr;
+        if (raw) return reinterpret_cast<const float *>(raw);
+        return f32.empty() ? nullptr : f32.data();
+    }
+};
+
+struct OnnxNode {
+    std::string name, op;
+    std::vector<std::string> inputs, outputs;
+    std::map<std::string, std::vector<int64_t>> ints;  // attribute ints / single i
+};
+
+struct OnnxModel {
+    std::vector<uint8_t> buf;  // whole file
+    std::vector<OnnxNode> nodes;
+    std::map<std::string, OnnxTensor> init;
+    std::vector<std::string> inputs;  // graph inputs that are not initializers
+    std::vector<std::string> outputs;
+    std::map<std::string, std::string> meta;
+    int64_t opset = 0;
+    // returns empty string on success, else the error
+    std::string load(const std::string &path);
+};
+
+}  // namespace vitsmi

@@ -1,0 +1,1002 @@
+// vitsmi.hip — host side of libvitsmi.so: handle, workspace, the VITS pipeline as a sequence of
+// kernel launches on one HIP stream, and the C ABI declared in include/vitsmi.h.
+//
+// Pipeline = SynthesizerTrn.infer (phoonnx_train/vits/models.py:681-722):
+//   text encoder -> (stochastic) duration predictor -> length regulator -> inverse coupling flow
+//   -> HiFi-GAN generator.  The only host synchronisation inside a run is the readback of the frame
+//   counts (data-dependent output length).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vitsmi.h"
+#include "kernels.hip.hpp"
+#include "model.hpp"
+
+using namespace vitsmi;
+
+namespace {
+
+thread_local std::string g_open_error;
+
+struct Slab {
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+};
+
+struct StageTimer {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+}  // namespace
+
+struct vits_handle {
+    Model model;
+    int device = -1;
+    bool host_only = false;
+    hipStream_t stream = nullptr;
+    float *arena_dev = nullptr;
+    bool arena_owned = false;
+    Slab tok, frm;  // token-domain and frame-domain workspaces
+    std::mutex mu;
+    std::string err;
+    // last-run state (for taps / outputs)
+    int B = 0, T = 0, F = 0, S = 0;
+    float *d_x = nullptr, *d_mp = nullptr, *d_logs = nullptr, *d_logw = nullptr, *d_wceil = nullptr;
+    float *d_zp = nullptr, *d_z = nullptr, *d_out = nullptr;
+    int *d_len = nullptr, *d_ylen = nullptr, *d_cum = nullptr;
+    int64_t *d_ylen64 = nullptr;
+    std::vector<int> h_ylen;
+    // stats
+    bool timing = false;
+    vits_stats stats{};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;
+    size_t conv_events_used = 0;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int cur_stage = 0;  // 0 enc, 1 dp, 2 flow, 3 dec
+    uint64_t run_counter = 0;
+};
+
+namespace {
+
+int fail(vits_handle *h, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_open_error = buf;
+    return code;
+}
+
+#define HIPCHECK(h, expr)                                                                       \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail(h, VITS_E_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+int slab_reserve(vits_handle *h, Slab &s, size_t bytes) {
+    if (bytes <= s.cap) return 0;
+    if (s.base) {
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        HIPCHECK(h, hipFree(s.base));
+        s.base = nullptr;
+        s.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + (1 << 20);
+    hipError_t e = hipMalloc((void **)&s.base, want);
+    if (e != hipSuccess) return fail(h, VITS_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    s.cap = want;
+    return 0;
+}
+
+template <class Tp>
+Tp *slab_take(Slab &s, size_t n) {
+    size_t off = (s.used + 255) & ~size_t(255);
+    s.used = off + n * sizeof(Tp);
+    return reinterpret_cast<Tp *>(s.base + off);
+}
+
+inline size_t al(size_t nfloats) { return ((nfloats * 4 + 255) & ~size_t(255)) + 256; }
+
+struct Ctx {
+    vits_handle *h;
+    const Model &m;
+    hipStream_t st;
+    const float *A;  // device arena
+    int B;
+    hipError_t err = hipSuccess;
+    const float *P(int64_t off) const { return off >= 0 ? A + off : nullptr; }
+    void note(hipError_t e) {
+        if (err == hipSuccess && e != hipSuccess) err = e;
+    }
+};
+
+// Launch one conv through the engine; accounts algorithmic FLOPs/bytes per stage.
+void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, float *out, int64_t out_bstride,
+          int flags, const int *len = nullptr, const float *res = nullptr, int64_t res_bstride = 0,
+          const float *bias_b = nullptr, int bias_b_stride = 0, float slope = 0.1f, float div = 1.f) {
+    ConvArgs a{};
+    a.x = x;
+    a.x_bstride = x_bstride;
+    a.T = T;
+    a.len = len;
+    a.wp = c.P(d.w_off);
+    a.bias = c.P(d.b_off);
+    a.bias_b = bias_b;
+    a.bias_b_stride = bias_b_stride;
+    a.out = out;
+    a.out_bstride = out_bstride;
+    a.res = res;
+    a.res_bstride = res_bstride;
+    a.Cin = d.Cin;
+    a.Cout = d.Cout;
+    a.K = d.K;
+    a.dil = d.dil;
+    a.padL = d.padL;
+    a.CK = d.CK;
+    a.nchunks = d.nchunks;
+    a.steps4 = d.steps4;
+    a.ups = d.ups;
+    a.flags = flags;
+    a.slope = slope;
+    a.div = div;
+    vits_handle *h = c.h;
+    bool ev = h->timing;
+    if (ev) {
+        if (h->conv_events_used == h->conv_events.size()) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            h->conv_events.push_back({e0, e1});
+        }
+        hipEventRecord(h->conv_events[h->conv_events_used].first, c.st);
+    }
+    c.note(launch_conv(a, d.cfg, c.B, c.st));
+    if (ev) hipEventRecord(h->conv_events[h->conv_events_used++].second, c.st);
+    double fl = 2.0 * d.macs_per_t * (double)T * c.B;
+    double by = 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T);
+    h->stats.conv_flops += fl;
+    h->stats.conv_bytes += by;
+    h->stats.conv_launches++;
+    h->stats.total_launches++;
+    switch (h->cur_stage) {
+        case 0: h->stats.enc_flops += fl; break;
+        case 1: h->stats.dp_flops += fl; break;
+        case 2: h->stats.flow_flops += fl; break;
+        default:
+            h->stats.dec_flops += fl;
+            h->stats.dec_bytes += by;
+            break;
+    }
+}
+
+inline dim3 grid_t(int T, int y, int z = 1) { return dim3((T + 255) / 256, y, z); }
+
+void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const int *len, int C, int T, int flags) {
+    layernorm_c_kernel<<<dim3((T + 63) / 64, c.B), 64, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags);
+    c.note(hipGetLastError());
+    c.h->stats.total_launches++;
+}
+
+// DDSConv (modules.py:117-129) in place on h [B,C,T]; y,y2 are scratch of the same size.
+void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const int *len, int C, int T) {
+    for (int l = 0; l < d.n_layers; l++) {
+        const auto &L = d.l[l];
+        dds_dw_ln_gelu_kernel<<<dim3((T + 63) / 64, c.B), 64, 0, c.st>>>(hbuf, y, c.P(L.dw_w), c.P(L.dw_b),
+                                                                         c.P(L.ln1_g), c.P(L.ln1_b), len, C, T, d.K,
+                                                                         L.dil);
+        c.note(hipGetLastError());
+        c.h->stats.total_launches++;
+        conv(c, L.pw, y, (int64_t)C * T, T, y2, (int64_t)C * T, 0);
+        int fl = LN_GELU | LN_ACCUM | (l == d.n_layers - 1 ? LN_MASK : 0);
+        layernorm(c, y2, hbuf, L.ln2_g, L.ln2_b, len, C, T, fl);
+    }
+}
+
+void stage_mark(vits_handle *h, int idx) {
+    if (h->timing) hipEventRecord(h->ev[idx], h->stream);
+}
+
+// ---- token-domain part: encoder + duration predictor + durations.  Leaves y_len on the host.
+int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int B, int T, const float *scales,
+               const int64_t *d_sid, const float *d_noise_dp, uint64_t seed) {
+    const Model &m = h->model;
+    const int H = m.H, C = m.C;
+    // workspace plan (floats)
+    const size_t nHT = (size_t)B * H * T;
+    const int Cdp = m.use_sdp ? m.dp_pre.Cout : m.dpp_F;
+    size_t need = 0;
+    need += al(nHT) * 3;                                   // x, attn out, spare
+    need += al((size_t)B * 3 * H * T);                     // qkv
+    need += al((size_t)B * m.FF * T);                      // ffn hidden
+    need += al((size_t)B * 2 * C * T) + 2 * al((size_t)B * C * T);  // stats, m_p, logs_p
+    need += al((size_t)B * Cdp * T) * 5;                   // dp buffers
+    need += al((size_t)B * 32 * T) + al((size_t)B * 2 * T) * 2 + al((size_t)B * T) * 4;
+    need += al((size_t)B * (m.gin + m.dp_cond_rows + m.C0 + 16)) + (1 << 16);
+    for (auto &cd : m.flow) need += al((size_t)B * 2 * m.flow_H * cd.n_wn);
+    if (int rc = slab_reserve(h, h->tok, need)) return rc;
+    Slab &s = h->tok;
+    s.used = 0;
+    Ctx c{h, m, h->stream, h->arena_dev, B};
+    hipStream_t st = h->stream;
+
+    h->d_len = slab_take<int>(s, B);
+    h->d_ylen = slab_take<int>(s, B);
+    h->d_ylen64 = slab_take<int64_t>(s, B);
+    h->d_cum = slab_take<int>(s, (size_t)B * T);
+    float *x = slab_take<float>(s, nHT), *att = slab_take<float>(s, nHT);
+    float *qkv = slab_take<float>(s, (size_t)B * 3 * H * T);
+    float *ffh = slab_take<float>(s, (size_t)B * m.FF * T);
+    float *stats = slab_take<float>(s, (size_t)B * 2 * C * T);
+    h->d_x = x;
+    h->d_logw = slab_take<float>(s, (size_t)B * T);
+    h->d_wceil = slab_take<float>(s, (size_t)B * T);
+
+    lens_to_i32<<<(B + 63) / 64, 64, 0, st>>>(d_lens, h->d_len, B, T);
+    const int *len = h->d_len;
+    h->cur_stage = 0;
+    stage_mark(h, 0);
+    embed_kernel<<<dim3((T + 63) / 64, B), 64, 0, st>>>(d_ids, len, c.P(m.emb), x, H, T, m.n_vocab,
+                                                        (float)std::sqrt((double)H));
+    h->stats.total_launches += 2;
+    const int64_t sHT = (int64_t)H * T;
+    for (auto &L : m.enc) {
+        // q|k|v = 1x1 convs (attentions.py:216-218), fused into one [3H,H] GEMM
+        conv(c, L.qkv, x, sHT, T, qkv, 3 * sHT, 0);
+        dim3 ag((T + 31) / 32, m.n_heads, B);
+        int dkb = (m.dk + 31) / 32;
+        switch (dkb) {
+            case 1: attention_relpos_kernel<1><<<ag, 64, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
+            case 2: attention_relpos_kernel<2><<<ag, 64, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
+            case 3: attention_relpos_kernel<3><<<ag, 64, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
+            default: attention_relpos_kernel<4><<<ag, 64, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
+        }
+        c.note(hipGetLastError());
+        h->stats.total_launches++;
+        h->stats.enc_flops += 2.0 * B * m.n_heads * (2.0 * m.dk * T * (double)T);
+        // x = LN(x + conv_o(att))  (attentions.py:66-68)
+        conv(c, L.o, att, sHT, T, x, sHT, EPI_RES, nullptr, x, sHT);
+        layernorm(c, x, x, L.ln1_g, L.ln1_b, len, H, T, 0);
+        // FFN (attentions.py:386-407): conv(x*mask) -> relu -> conv(h*mask) -> *mask ; x = LN(x + y)
+        conv(c, L.ffn1, x, sHT, T, ffh, (int64_t)m.FF * T, PRO_MASK | EPI_RELU, len);
+        conv(c, L.ffn2, ffh, (int64_t)m.FF * T, T, x, sHT, PRO_MASK | EPI_MASK | EPI_RES, len, x, sHT);
+        layernorm(c, x, x, L.ln2_g, L.ln2_b, len, H, T, 0);
+    }
+    // x = x * mask ; stats = proj(x) * mask (models.py:205-208)
+    mask_kernel<<<dim3((T + 255) / 256, H, B), 256, 0, st>>>(x, len, H, T);
+    h->stats.total_launches++;
+    conv(c, m.enc_proj, x, sHT, T, stats, (int64_t)2 * C * T, EPI_MASK, len);
+    h->d_mp = stats;                       // [B, 2C, T] : m_p = rows [0,C), logs_p = rows [C,2C)
+    h->d_logs = stats + (int64_t)C * T;    // batch stride 2*C*T for both
+
+    // ---- speaker conditioning vectors
+    float *dp_cond = nullptr;
+    if (m.gin) {
+        if (!d_sid) return fail(h, VITS_E_ARG, "Missing speaker id");
+        dp_cond = slab_take<float>(s, (size_t)B * m.dp_cond_rows);
+        cond_matvec_kernel<<<dim3((m.dp_cond_rows + 63) / 64, B), 64, 0, st>>>(
+            c.P(m.emb_g), d_sid, m.n_speakers, c.P(m.dp_cond_w), c.P(m.dp_cond_b), dp_cond, m.dp_cond_rows, m.gin);
+        h->stats.total_launches++;
+    }
+
+    // ---- duration predictor
+    h->cur_stage = 1;
+    stage_mark(h, 1);
+    const float noise_w = scales[2];
+    if (m.use_sdp) {
+        const int Cd = m.dp_pre.Cout;
+        const int64_t sC = (int64_t)Cd * T;
+        float *hb = slab_take<float>(s, (size_t)B * Cd * T), *y = slab_take<float>(s, (size_t)B * Cd * T);
+        float *y2 = slab_take<float>(s, (size_t)B * Cd * T), *cond = slab_take<float>(s, (size_t)B * Cd * T);
+        float *h2 = slab_take<float>(s, (size_t)B * Cd * T);
+        float *pr = slab_take<float>(s, (size_t)B * 32 * T);
+        float *z = slab_take<float>(s, (size_t)B * 2 * T);
+        // h = pre(x) [+ cond(g)] ; DDSConv ; cond = proj(h)*mask (models.py:65-70)
+        conv(c, m.dp_pre, x, sHT, T, hb, sC, 0, nullptr, nullptr, 0, dp_cond, m.dp_cond_rows);
+        ddsconv(c, m.dp_convs, hb, y, y2, len, Cd, T);
+        conv(c, m.dp_proj, hb, sC, T, cond, sC, EPI_MASK, len);
+        // z = randn * noise_scale_w (models.py:111)
+        int64_t nz = (int64_t)B * 2 * T;
+        if (noise_w == 0.f) {
+            c.note(hipMemsetAsync(z, 0, nz * 4, st));
+        } else if (d_noise_dp) {
+            scale_kernel<<<(unsigned)((nz + 255) / 256), 256, 0, st>>>(d_noise_dp, z, noise_w, nz);
+        } else {
+            fill_normal_kernel<<<(unsigned)((nz / 4 + 256) / 256), 256, 0, st>>>(z, nz, seed, 1);
+            scale_kernel<<<(unsigned)((nz + 255) / 256), 256, 0, st>>>(z, z, noise_w, nz);
+        }
+        h->stats.total_launches += 2;
+        int swapped = 0;  // logical channel 0 lives in physical channel `swapped`
+        for (int f = 0; f < 3; f++) {
+            swapped ^= 1;  // Flip (modules.py:384-391)
+            const auto &cf = m.cf[f];
+            int ch0 = swapped, ch1 = swapped ^ 1;
+            cf_pre_kernel<<<dim3((T + 63) / 64, B), 64, 0, st>>>(z, ch0, c.P(cf.pre_w), c.P(cf.pre_b), cond, h2, Cd, T);
+            h->stats.total_launches++;
+            ddsconv(c, cf.convs, h2, y, y2, len, Cd, T);
+            conv(c, cf.proj, h2, sC, T, pr, (int64_t)cf.proj.Cout * T, EPI_MASK, len);
+            float sqc = std::sqrt((float)Cd);
+            if (cf.nb <= 10)
+                rqs_inverse_kernel<10><<<dim3((T + 63) / 64, B), 64, 0, st>>>(pr, z, len, ch0, ch1, cf.nb, T, sqc);
+            else
+                rqs_inverse_kernel<16><<<dim3((T + 63) / 64, B), 64, 0, st>>>(pr, z, len, ch0, ch1, cf.nb, T, sqc);
+            c.note(hipGetLastError());
+            h->stats.total_launches++;
+        }
+        swapped ^= 1;
+        ea_logw_kernel<<<dim3((T + 63) / 64, B), 64, 0, st>>>(z, swapped, m.ea_m0, m.ea_logs0, len, h->d_logw, T);
+        h->stats.total_launches++;
+    } else {
+        const int Fd = m.dpp_F;
+        float *xi = x;
+        if (dp_cond) {  // x = x + cond(g) (models.py:153-155)
+            xi = slab_take<float>(s, nHT);
+            add_bias_b_kernel<<<dim3((T + 255) / 256, H, B), 256, 0, st>>>(x, xi, dp_cond, m.dp_cond_rows, H, T);
+            h->stats.total_launches++;
+        }
+        float *h1 = slab_take<float>(s, (size_t)B * Fd * T), *h2 = slab_take<float>(s, (size_t)B * Fd * T);
+        const int64_t sF = (int64_t)Fd * T;
+        conv(c, m.dpp_conv1, xi, sHT, T, h1, sF, PRO_MASK | EPI_RELU, len);
+        layernorm(c, h1, h1, m.dpp_n1_g, m.dpp_n1_b, len, Fd, T, 0);
+        conv(c, m.dpp_conv2, h1, sF, T, h2, sF, PRO_MASK | EPI_RELU, len);
+        layernorm(c, h2, h2, m.dpp_n2_g, m.dpp_n2_b, len, Fd, T, 0);
+        conv(c, m.dpp_proj, h2, sF, T, h->d_logw, T, PRO_MASK | EPI_MASK, len);
+    }
+    // ---- durations (models.py:702-704)
+    duration_kernel<<<B, 256, 0, st>>>(h->d_logw, len, scales[1], h->d_wceil, h->d_cum, h->d_ylen, T);
+    h->stats.total_launches++;
+    c.note(hipGetLastError());
+    if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
+    h->h_ylen.resize(B);
+    HIPCHECK(h, hipMemcpyAsync(h->h_ylen.data(), h->d_ylen, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    HIPCHECK(h, hipStreamSynchronize(st));  // the one data-dependent readback: output length
+    int F = 1;
+    for (int b = 0; b < B; b++) F = h->h_ylen[b] > F ? h->h_ylen[b] : F;
+    h->F = F;
+    return 0;
+}
+
+// frame-domain layout: flow buffers + generator ping-pong regions
+size_t gen_region_floats(const Model &m, int B, int F) {
+    size_t mx = (size_t)B * m.C0 * F;
+    int64_t t = F;
+    for (auto &st : m.ups) {
+        t *= st.u;
+        size_t n = (size_t)B * st.C * t;
+        mx = n > mx ? n : mx;
+    }
+    return mx;
+}
+
+int run_generator(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, const int *ylen, int B, int F,
+                  const float *dec_cond, Slab &s) {
+    const Model &m = h->model;
+    hipStream_t st = h->stream;
+    const size_t R = gen_region_floats(m, B, F);
+    float *reg[7];
+    for (int i = 0; i < 7; i++) reg[i] = slab_take<float>(s, R);
+    h->cur_stage = 3;
+    stage_mark(h, 3);
+    // x = conv_pre(z * y_mask) [+ cond(g)] (models.py:349-351)
+    float *x = reg[0];
+    conv(c, m.conv_pre, z, z_bstride, F, x, (int64_t)m.C0 * F, ylen ? PRO_MASK : 0, ylen, nullptr, 0, dec_cond, m.C0);
+    int T = F, Cc = m.C0, xs_idx = 0;
+    for (auto &stg : m.ups) {
+        // x = leaky_relu(x, 0.1); x = up(x) (models.py:354-355): transposed conv as a pixel-shuffled dense conv
+        float *y = reg[2];
+        const int To = T * stg.u;
+        conv(c, stg.up, x, (int64_t)Cc * T, T, y, (int64_t)stg.C * To, PRO_LRELU, nullptr, nullptr, 0, nullptr, 0, 0.1f);
+        T = To;
+        Cc = stg.C;
+        const int64_t sCT = (int64_t)Cc * T;
+        xs_idx ^= 1;
+        float *xs = reg[xs_idx], *ra = reg[3], *rb = reg[4], *tmp = reg[5];
+        const int nk = (int)stg.rbs.size();
+        for (int j = 0; j < nk; j++) {
+            const auto &rbk = stg.rbs[j];
+            const float *cur = y;
+            // MRF accumulation (models.py:356-363): xs = rb0(x); xs += rb1(x); ... ; x = xs / nk
+            int last_flags = (j == 0 ? 0 : EPI_ACC) | (j == nk - 1 && nk > 1 ? EPI_DIV : 0);
+            if (nk == 1) last_flags = 0;
+            for (int q = 0; q < rbk.n; q++) {
+                const bool last = q == rbk.n - 1;
+                float *dst = last ? xs : (q % 2 == 0 ? ra : rb);
+                if (rbk.type1) {  // modules.py:301-314
+                    conv(c, rbk.c1[q], cur, sCT, T, tmp, sCT, PRO_LRELU, nullptr, nullptr, 0, nullptr, 0, 0.1f);
+                    conv(c, rbk.c2[q], tmp, sCT, T, dst, sCT, PRO_LRELU | EPI_RES | (last ? last_flags : 0), nullptr, cur,
+                         sCT, nullptr, 0, 0.1f, (float)nk);
+                } else {  // modules.py:355-364
+                    conv(c, rbk.c1[q], cur, sCT, T, dst, sCT, PRO_LRELU | EPI_RES | (last ? last_flags : 0), nullptr, cur,
+                         sCT, nullptr, 0, 0.1f, (float)nk);
+                }
+                cur = dst;
+            }
+        }
+        x = xs;
+    }
+    // x = leaky_relu(x) [slope 0.01]; conv_post; tanh (models.py:364-366)
+    h->S = T;
+    h->d_out = reg[6];
+    size_t lds = ((size_t)m.post_cin * (256 + m.post_k - 1) + (size_t)m.post_cin * m.post_k) * sizeof(float);
+    post_conv_tanh_kernel<<<dim3((T + 255) / 256, B), 256, lds, st>>>(x, c.P(m.post_w), h->d_out, m.post_cin, m.post_k,
+                                                                      T, 0.01f);
+    c.note(hipGetLastError());
+    h->stats.total_launches++;
+    {
+        double fl = 2.0 * m.post_cin * m.post_k * (double)T * B, by = 4.0 * B * ((double)m.post_cin * T + T);
+        h->stats.dec_flops += fl;
+        h->stats.dec_bytes += by;
+    }
+    stage_mark(h, 4);
+    return 0;
+}
+
+int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t *d_sid, const float *d_noise_z,
+               int64_t noise_z_stride, uint64_t seed) {
+    const Model &m = h->model;
+    const int C = m.C, F = h->F, Hf = m.flow_H;
+    if (d_noise_z && noise_z_stride < F)
+        return fail(h, VITS_E_ARG, "noise_z has %lld frames per row but %d are needed", (long long)noise_z_stride, F);
+    const size_t nCF = (size_t)B * C * F, nHF = (size_t)B * Hf * F;
+    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + 7 * al(gen_region_floats(m, B, F)) + (1 << 16);
+    for (auto &cd : m.flow) need += al((size_t)B * 2 * Hf * cd.n_wn);
+    need += al((size_t)B * m.C0);
+    if (int rc = slab_reserve(h, h->frm, need)) return rc;
+    Slab &s = h->frm;
+    s.used = 0;
+    Ctx c{h, m, h->stream, h->arena_dev, B};
+    hipStream_t st = h->stream;
+    const int *len = h->d_len, *ylen = h->d_ylen;
+    float *zp = slab_take<float>(s, nCF), *z = slab_take<float>(s, nCF);
+    h->d_zp = zp;
+    h->d_z = z;
+    h->cur_stage = 2;
+    stage_mark(h, 2);
+    const float noise_scale = scales[0];
+    const float *nz = nullptr;
+    int64_t nzs = F;
+    if (noise_scale != 0.f) {
+        if (d_noise_z) {
+            nz = d_noise_z;
+            nzs = noise_z_stride;
+        } else {
+            float *g = slab_take<float>(s, nCF);
+            fill_normal_kernel<<<(unsigned)((nCF / 4 + 256) / 256), 256, 0, st>>>(g, (int64_t)nCF, seed, 2);
+            h->stats.total_launches++;
+            nz = g;
+        }
+    }
+    // m_p / logs_p are the two halves of the proj output: channel stride T, batch stride 2*C*T
+    expand_prior_strided_kernel<<<dim3((F + 63) / 64, B), 64, 0, st>>>(h->d_mp, h->d_logs, (int64_t)2 * C * T, h->d_cum,
+                                                                       len, ylen, nz, nzs, noise_scale, zp, C, T, F);
+    h->stats.total_launches++;
+    HIPCHECK(h, hipMemcpyAsync(z, zp, nCF * 4, hipMemcpyDeviceToDevice, st));
+
+    // ---- inverse coupling flow (models.py:247-254, modules.py:447-466); Flips folded at pack time
+    float *hx = slab_take<float>(s, nHF), *skip = slab_take<float>(s, nHF), *acts = slab_take<float>(s, nHF);
+    float *a2 = slab_take<float>(s, nHF * 2), *rs = slab_take<float>(s, nHF * 2);
+    const int half = C / 2;
+    const int64_t sCF = (int64_t)C * F, sHF = (int64_t)Hf * F;
+    for (auto &cd : m.flow) {
+        float *gc = nullptr;
+        const int gc_rows = 2 * Hf * cd.n_wn;
+        if (m.gin) {
+            gc = slab_take<float>(s, (size_t)B * gc_rows);
+            cond_matvec_kernel<<<dim3((gc_rows + 63) / 64, B), 64, 0, st>>>(c.P(m.emb_g), d_sid, m.n_speakers, c.P(cd.cond_w),
+                                                                           c.P(cd.cond_b), gc, gc_rows, m.gin);
+            h->stats.total_launches++;
+        }
+        const float *x0 = z + (cd.swapped ? (int64_t)half * F : 0);
+        float *x1 = z + (cd.swapped ? 0 : (int64_t)half * F);
+        // h = pre(x0) * mask
+        conv(c, cd.pre, x0, sCF, F, hx, sHF, EPI_MASK, ylen);
+        for (int i = 0; i < cd.n_wn; i++) {
+            const bool last = i == cd.n_wn - 1;
+            // x_in = in_layer(h) + g_l ; acts = tanh * sigmoid ; rs = res_skip(acts)
+            conv(c, cd.wn[i].in, hx, sHF, F, a2, 2 * sHF, 0, nullptr, nullptr, 0, gc ? gc + (int64_t)i * 2 * Hf : nullptr,
+                 gc_rows);
+            wn_gate_kernel<<<dim3((F + 255) / 256, Hf, B), 256, 0, st>>>(a2, acts, Hf, F);
+            conv(c, cd.wn[i].rs, acts, sHF, F, rs, (int64_t)cd.wn[i].rs.Cout * F, 0);
+            wn_update_kernel<<<dim3((F + 255) / 256, Hf, B), 256, 0, st>>>(hx, skip, rs, ylen, Hf, F, i == 0, last);
+            h->stats.total_launches += 2;
+        }
+        // x1 = (x1 - post(skip)*mask) * mask
+        conv(c, cd.post, skip, sHF, F, x1, sCF, EPI_COUPLING, ylen);
+    }
+    c.note(hipGetLastError());
+
+    float *dec_cond = nullptr;
+    if (m.gin) {
+        dec_cond = slab_take<float>(s, (size_t)B * m.C0);
+        cond_matvec_kernel<<<dim3((m.C0 + 63) / 64, B), 64, 0, st>>>(c.P(m.emb_g), d_sid, m.n_speakers, c.P(m.dec_cond_w),
+                                                                    c.P(m.dec_cond_b), dec_cond, m.C0, m.gin);
+        h->stats.total_launches++;
+    }
+    if (int rc = run_generator(h, c, z, sCF, ylen, B, F, dec_cond, s)) return rc;
+    if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+
+static int open_common(const char *path, vits_handle **out, bool host_only, int device, void *ext_arena,
+                       size_t ext_bytes) {
+    if (!out || !path) return fail(nullptr, VITS_E_ARG, "null argument");
+    *out = nullptr;
+    OnnxModel om;
+    std::string e = om.load(path);
+    if (!e.empty()) return fail(nullptr, e.rfind("cannot open", 0) == 0 ? VITS_E_IO : VITS_E_FORMAT, "%s", e.c_str());
+    vits_handle *h = new vits_handle();
+    e = h->model.build(om);
+    if (!e.empty()) {
+        delete h;
+        return fail(nullptr, VITS_E_FORMAT, "%s: %s", path, e.c_str());
+    }
+    if (h->model.window > 4) {
+        delete h;
+        return fail(nullptr, VITS_E_FORMAT, "attention window %d > 4 is unsupported", h->model.window);
+    }
+    h->host_only = host_only;
+    if (!host_only) {
+        int n = 0;
+        hipError_t er = hipGetDeviceCount(&n);
+        if (er != hipSuccess || device < 0 || device >= n) {
+            delete h;
+            return fail(nullptr, VITS_E_DEVICE, "no usable HIP device %d (count %d): %s", device, n,
+                        er == hipSuccess ? "index out of range" : hipGetErrorString(er));
+        }
+        h->device = device;
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete h;
+            return fail(nullptr, VITS_E_DEVICE, "cannot create stream on device %d", device);
+        }
+        size_t bytes = h->model.arena.size() * 4;
+        if (ext_arena) {
+            if (ext_bytes != bytes) {
+                delete h;
+                return fail(nullptr, VITS_E_ARG, "arena size mismatch: got %zu, model needs %zu", ext_bytes, bytes);
+            }
+            h->arena_dev = (float *)ext_arena;
+        } else {
+            if (hipMalloc((void **)&h->arena_dev, bytes) != hipSuccess ||
+                hipMemcpy(h->arena_dev, h->model.arena.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+                delete h;
+                return fail(nullptr, VITS_E_NOMEM, "cannot place %zu-byte weight arena on device %d", bytes, device);
+            }
+            h->arena_owned = true;
+        }
+        for (auto &e2 : h->ev) hipEventCreate(&e2);
+    }
+    *out = h;
+    return VITS_OK;
+}
+
+extern "C" {
+
+int vits_open(const char *p, int dev, vits_handle **out) { return open_common(p, out, false, dev, nullptr, 0); }
+int vits_open_with_arena(const char *p, int dev, void *arena, size_t bytes, vits_handle **out) {
+    if (!arena) return fail(nullptr, VITS_E_ARG, "null arena");
+    return open_common(p, out, false, dev, arena, bytes);
+}
+int vits_open_host(const char *p, vits_handle **out) { return open_common(p, out, true, -1, nullptr, 0); }
+
+void vits_close(vits_handle *h) {
+    if (!h) return;
+    if (!h->host_only) {
+        hipSetDevice(h->device);
+        if (h->stream) hipStreamSynchronize(h->stream);
+        if (h->arena_owned && h->arena_dev) hipFree(h->arena_dev);
+        if (h->tok.base) hipFree(h->tok.base);
+        if (h->frm.base) hipFree(h->frm.base);
+        for (auto &p : h->conv_events) {
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+        for (auto &e : h->ev)
+            if (e) hipEventDestroy(e);
+        if (h->stream) hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+const char *vits_last_error(vits_handle *h) { return h ? h->err.c_str() : g_open_error.c_str(); }
+
+int vits_num_inputs(vits_handle *h) { return h ? (int)h->model.input_names.size() : 0; }
+const char *vits_input_name(vits_handle *h, int i) {
+    if (!h || i < 0 || i >= (int)h->model.input_names.size()) return nullptr;
+    return h->model.input_names[i].c_str();
+}
+
+int vits_meta(vits_handle *h, const char *key, char *buf, size_t n) {
+    if (!h || !key) return VITS_E_ARG;
+    auto it = h->model.meta.find(key);
+    if (it == h->model.meta.end()) return fail(h, VITS_E_ARG, "no metadata key %s", key);
+    if (buf && n) {
+        size_t k = it->second.size() < n - 1 ? it->second.size() : n - 1;
+        std::memcpy(buf, it->second.data(), k);
+        buf[k] = 0;
+    }
+    return (int)it->second.size();
+}
+
+int vits_hparam(vits_handle *h, const char *key, int64_t *out) {
+    if (!h || !key || !out) return VITS_E_ARG;
+    const Model &m = h->model;
+    std::string k = key;
+    if (k == "hidden") *out = m.H;
+    else if (k == "inter") *out = m.C;
+    else if (k == "filter") *out = m.FF;
+    else if (k == "n_heads") *out = m.n_heads;
+    else if (k == "n_layers") *out = m.n_layers;
+    else if (k == "n_vocab") *out = m.n_vocab;
+    else if (k == "n_speakers") *out = m.n_speakers;
+    else if (k == "gin") *out = m.gin;
+    else if (k == "use_sdp") *out = m.use_sdp;
+    else if (k == "hop") *out = m.hop;
+    else if (k == "n_ups") *out = (int64_t)m.ups.size();
+    else if (k == "resblock") *out = m.ups.empty() || m.ups[0].rbs.empty() ? 0 : (m.ups[0].rbs[0].type1 ? 1 : 2);
+    else if (k == "window") *out = m.window;
+    else if (k == "upsample_initial_channel") *out = m.C0;
+    else if (k == "dec_macs_per_frame") *out = (int64_t)m.dec_macs_per_frame;
+    else if (k == "flow_macs_per_frame") *out = (int64_t)m.flow_macs_per_frame;
+    else if (k == "enc_macs_per_token") *out = (int64_t)m.enc_macs_per_token;
+    else if (k == "dec_bytes_per_frame") *out = (int64_t)(m.dec_elems_per_frame * 4);
+    else return fail(h, VITS_E_ARG, "unknown hparam %s", key);
+    return VITS_OK;
+}
+
+size_t vits_arena_bytes(vits_handle *h) { return h ? h->model.arena.size() * 4 : 0; }
+const void *vits_arena_host(vits_handle *h) { return h ? h->model.arena.data() : nullptr; }
+void *vits_arena_device(vits_handle *h) { return h ? h->arena_dev : nullptr; }
+void *vits_stream(vits_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+int vits_set_timing(vits_handle *h, int enable) {
+    if (!h) return VITS_E_ARG;
+    h->timing = enable != 0;
+    return VITS_OK;
+}
+
+static int check_dev(vits_handle *h) {
+    if (!h) return VITS_E_ARG;
+    if (h->host_only) return fail(h, VITS_E_DEVICE, "handle was opened host-only");
+    if (hipSetDevice(h->device) != hipSuccess) return fail(h, VITS_E_DEVICE, "hipSetDevice(%d) failed", h->device);
+    return 0;
+}
+
+static int run_device_locked(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T,
+                             const float scales[3], const int64_t *sid, const vits_noise *noise, vits_output *out) {
+    if (B <= 0 || T <= 0) return fail(h, VITS_E_ARG, "empty batch or sequence (B=%d, T=%d)", B, T);
+    if (!ids || !lens || !scales || !out) return fail(h, VITS_E_ARG, "null argument");
+    if (h->model.gin && !sid) return fail(h, VITS_E_ARG, "Missing speaker id");
+    std::memset(&h->stats, 0, sizeof h->stats);
+    h->conv_events_used = 0;
+    h->B = B;
+    h->T = T;
+    uint64_t seed = noise ? noise->seed : 0;
+    seed = seed * 0x9E3779B97F4A7C15ull + (++h->run_counter);
+    if (int rc = run_tokens(h, ids, lens, B, T, scales, sid, noise ? noise->noise_dp : nullptr, seed)) return rc;
+    if (int rc = run_frames(h, B, T, scales, sid, noise ? noise->noise_z : nullptr, noise ? noise->noise_z_stride : 0,
+                            seed))
+        return rc;
+    ylen_to_i64<<<(B + 63) / 64, 64, 0, h->stream>>>(h->d_ylen, h->d_ylen64, B);
+    out->data = h->d_out;
+    out->dims[0] = B;
+    out->dims[1] = 1;
+    out->dims[2] = 1;
+    out->dims[3] = h->S;
+    out->y_lengths = h->d_ylen64;
+    return VITS_OK;
+}
+
+int vits_run_device(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
+                    const int64_t *sid, const vits_noise *noise, vits_output *out) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    return run_device_locked(h, ids, lens, B, T, scales, sid, noise, out);
+}
+
+int vits_sync(vits_handle *h) {
+    if (int rc = check_dev(h)) return rc;
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    return VITS_OK;
+}
+
+int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
+             const int64_t *sid, const vits_noise *noise, vits_output *out) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (B <= 0 || T <= 0) return fail(h, VITS_E_ARG, "empty batch or sequence (B=%d, T=%d)", B, T);
+    if (!ids || !lens || !scales || !out) return fail(h, VITS_E_ARG, "null argument");
+    const Model &m = h->model;
+    for (int b = 0; b < B; b++) {
+        if (lens[b] < 0 || lens[b] > T)
+            return fail(h, VITS_E_ARG, "input_lengths[%d]=%lld outside [0,%d]", b, (long long)lens[b], T);
+        for (int t = 0; t < T; t++) {
+            int64_t id = ids[(int64_t)b * T + t];
+            if (id < 0 || id >= m.n_vocab)
+                return fail(h, VITS_E_ARG, "phoneme id %lld at [%d,%d] is out of range [0,%d)", (long long)id, b, t,
+                            m.n_vocab);
+        }
+        if (sid && m.gin && (sid[b] < 0 || sid[b] >= m.n_speakers))
+            return fail(h, VITS_E_ARG, "sid[%d]=%lld is out of range [0,%d)", b, (long long)sid[b], m.n_speakers);
+    }
+    if (m.gin && !sid) return fail(h, VITS_E_ARG, "Missing speaker id");
+    // stage host inputs on the device
+    size_t nb = (size_t)B * T * 8 + (size_t)B * 16 + 1024;
+    size_t ndp = noise && noise->noise_dp ? (size_t)B * 2 * T * 4 : 0;
+    size_t nz = noise && noise->noise_z ? (size_t)B * m.C * (size_t)noise->noise_z_stride * 4 : 0;
+    char *stage = nullptr;
+    HIPCHECK(h, hipMalloc((void **)&stage, nb + ndp + nz + 1024));
+    int64_t *d_ids = (int64_t *)stage, *d_lens = d_ids + (size_t)B * T, *d_sid = d_lens + B;
+    float *d_ndp = (float *)(stage + ((nb + 255) & ~size_t(255)));
+    float *d_nz = (float *)((char *)d_ndp + ((ndp + 255) & ~size_t(255)));
+    hipStream_t st = h->stream;
+    int rc = VITS_OK;
+    auto cp = [&](void *d, const void *s, size_t n) {
+        if (rc == VITS_OK && hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st) != hipSuccess)
+            rc = fail(h, VITS_E_DEVICE, "host-to-device copy failed");
+    };
+    cp(d_ids, ids, (size_t)B * T * 8);
+    cp(d_lens, lens, (size_t)B * 8);
+    if (sid) cp(d_sid, sid, (size_t)B * 8);
+    vits_noise dn{};
+    if (noise) {
+        dn = *noise;
+        if (noise->noise_dp) {
+            cp(d_ndp, noise->noise_dp, ndp);
+            dn.noise_dp = d_ndp;
+        }
+        if (noise->noise_z) {
+            cp(d_nz, noise->noise_z, nz);
+            dn.noise_z = d_nz;
+        }
+    }
+    vits_output dev{};
+    if (rc == VITS_OK) rc = run_device_locked(h, d_ids, d_lens, B, T, scales, sid ? d_sid : nullptr, noise ? &dn : nullptr, &dev);
+    if (rc == VITS_OK) {
+        size_t n = (size_t)B * h->S;
+        float *host = nullptr;
+        int64_t *hy = nullptr;
+        if (hipHostMalloc((void **)&host, n * 4 + 64) != hipSuccess || hipHostMalloc((void **)&hy, (size_t)B * 8 + 64) != hipSuccess)
+            rc = fail(h, VITS_E_NOMEM, "cannot allocate pinned output (%zu bytes)", n * 4);
+        else if (hipMemcpyAsync(host, dev.data, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                 hipStreamSynchronize(st) != hipSuccess)
+            rc = fail(h, VITS_E_DEVICE, "device-to-host copy failed: %s", hipGetErrorString(hipGetLastError()));
+        else {
+            for (int b = 0; b < B; b++) hy[b] = h->h_ylen[b];
+            out->data = host;
+            std::memcpy(out->dims, dev.dims, sizeof dev.dims);
+            out->y_lengths = hy;
+        }
+    }
+    hipStreamSynchronize(st);
+    hipFree(stage);
+    return rc;
+}
+
+void vits_free_output(vits_handle *h, vits_output *out) {
+    (void)h;
+    if (!out) return;
+    if (out->data) hipHostFree(out->data);
+    if (out->y_lengths) hipHostFree(out->y_lengths);
+    out->data = nullptr;
+    out->y_lengths = nullptr;
+}
+
+int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t *sid, vits_output *out) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const Model &m = h->model;
+    if (!z || !out || B <= 0 || F <= 0) return fail(h, VITS_E_ARG, "bad vocoder arguments");
+    if (m.gin && !sid) return fail(h, VITS_E_ARG, "Missing speaker id");
+    std::memset(&h->stats, 0, sizeof h->stats);
+    h->conv_events_used = 0;
+    const size_t nCF = (size_t)B * m.C * F;
+    size_t need = al(nCF) + 7 * al(gen_region_floats(m, B, F)) + al((size_t)B * m.C0) + (1 << 16);
+    if (int rc = slab_reserve(h, h->frm, need)) return rc;
+    Slab &s = h->frm;
+    s.used = 0;
+    hipStream_t st = h->stream;
+    float *dz = slab_take<float>(s, nCF);
+    HIPCHECK(h, hipMemcpyAsync(dz, z, nCF * 4, hipMemcpyHostToDevice, st));
+    Ctx c{h, m, st, h->arena_dev, B};
+    float *dec_cond = nullptr;
+    int64_t *d_sid = nullptr;
+    if (m.gin) {
+        d_sid = slab_take<int64_t>(s, B);
+        HIPCHECK(h, hipMemcpyAsync(d_sid, sid, (size_t)B * 8, hipMemcpyHostToDevice, st));
+        dec_cond = slab_take<float>(s, (size_t)B * m.C0);
+        cond_matvec_kernel<<<dim3((m.C0 + 63) / 64, B), 64, 0, st>>>(c.P(m.emb_g), d_sid, m.n_speakers, c.P(m.dec_cond_w),
+                                                                    c.P(m.dec_cond_b), dec_cond, m.C0, m.gin);
+    }
+    h->B = B;
+    h->F = F;
+    if (int rc = run_generator(h, c, dz, (int64_t)m.C * F, nullptr, B, F, dec_cond, s)) return rc;
+    if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
+    size_t n = (size_t)B * h->S;
+    float *host = nullptr;
+    if (hipHostMalloc((void **)&host, n * 4 + 64) != hipSuccess) return fail(h, VITS_E_NOMEM, "pinned alloc failed");
+    HIPCHECK(h, hipMemcpyAsync(host, h->d_out, n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHECK(h, hipStreamSynchronize(st));
+    out->data = host;
+    out->dims[0] = B;
+    out->dims[1] = 1;
+    out->dims[2] = 1;
+    out->dims[3] = h->S;
+    out->y_lengths = nullptr;
+    return VITS_OK;
+}
+
+int vits_tap(vits_handle *h, const char *name, float *buf, size_t buf_elems, int64_t dims[VITS_MAX_DIMS]) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!name || !dims) return fail(h, VITS_E_ARG, "null argument");
+    const Model &m = h->model;
+    const int B = h->B, T = h->T, F = h->F;
+    std::string k = name;
+    const float *src = nullptr;
+    int64_t bstride = 0;
+    int nd = 3, C = 0, L = 0;
+    if (k == "x") { src = h->d_x; C = m.H; L = T; bstride = (int64_t)C * L; }
+    else if (k == "m_p") { src = h->d_mp; C = m.C; L = T; bstride = (int64_t)2 * C * L; }
+    else if (k == "logs_p") { src = h->d_logs; C = m.C; L = T; bstride = (int64_t)2 * C * L; }
+    else if (k == "logw") { src = h->d_logw; C = 1; L = T; bstride = L; }
+    else if (k == "w_ceil") { src = h->d_wceil; C = 1; L = T; bstride = L; nd = 2; }
+    else if (k == "z_p") { src = h->d_zp; C = m.C; L = F; bstride = (int64_t)C * L; }
+    else if (k == "z") { src = h->d_z; C = m.C; L = F; bstride = (int64_t)C * L; }
+    else return fail(h, VITS_E_ARG, "unknown tap %s", name);
+    if (!src || B == 0) return fail(h, VITS_E_ARG, "no completed run to tap");
+    if (nd == 2) { dims[0] = B; dims[1] = L; }
+    else { dims[0] = B; dims[1] = C; dims[2] = L; }
+    size_t n = (size_t)B * C * L;
+    if (!buf) return nd;
+    if (buf_elems < n) return fail(h, VITS_E_ARG, "tap buffer too small: %zu < %zu", buf_elems, n);
+    float *tmp = nullptr;
+    HIPCHECK(h, hipMalloc((void **)&tmp, n * 4 + 16));
+    gather_view_kernel<<<dim3((L + 255) / 256, C, B), 256, 0, h->stream>>>(src, bstride, tmp, C, L);
+    hipError_t e = hipMemcpyAsync(buf, tmp, n * 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(h, VITS_E_DEVICE, "tap copy failed: %s", hipGetErrorString(e));
+    return nd;
+}
+
+int vits_get_stats(vits_handle *h, vits_stats *out) {
+    if (!h || !out) return VITS_E_ARG;
+    if (!h->host_only) {
+        hipSetDevice(h->device);
+        hipStreamSynchronize(h->stream);
+        if (h->timing) {
+            float ms = 0.f, tot = 0.f;
+            for (size_t i = 0; i < h->conv_events_used; i++) {
+                if (hipEventElapsedTime(&ms, h->conv_events[i].first, h->conv_events[i].second) == hipSuccess) tot += ms;
+            }
+            h->stats.conv_ms = tot;
+            auto el = [&](int a, int b) {
+                float v = 0.f;
+                if (hipEventElapsedTime(&v, h->ev[a], h->ev[b]) != hipSuccess) v = 0.f;
+                return v;
+            };
+            h->stats.enc_ms = el(0, 1);
+            h->stats.dp_ms = el(1, 2);
+            h->stats.flow_ms = el(2, 3);
+            h->stats.dec_ms = el(3, 4);
+            h->stats.total_ms = el(0, 4);
+        }
+    }
+    *out = h->stats;
+    return VITS_OK;
+}
+
+// ---------------------------------------------------------------- kernel-level test hooks
+
+static int test_dev(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n)
+        return fail(nullptr, VITS_E_DEVICE, "no usable HIP device %d", device_id);
+    if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, VITS_E_DEVICE, "hipSetDevice failed");
+    return 0;
+}
+
+#define TCHECK(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) return fail(nullptr, VITS_E_DEVICE, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+static int run_test_conv(const ConvDesc &d, const std::vector<float> &arena, const float *x, int B, int T,
+                         int flags, float slope, float *out, size_t out_elems, int64_t out_bstride) {
+    float *dA = nullptr, *dx = nullptr, *dout = nullptr;
+    size_t nx = (size_t)B * d.Cin * T;
+    TCHECK(hipMalloc((void **)&dA, arena.size() * 4));
+    TCHECK(hipMalloc((void **)&dx, nx * 4 + 16));
+    TCHECK(hipMalloc((void **)&dout, out_elems * 4 + 16));
+    TCHECK(hipMemcpy(dA, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemset(dout, 0, out_elems * 4));
+    ConvArgs a{};
+    a.x = dx;
+    a.x_bstride = (int64_t)d.Cin * T;
+    a.T = T;
+    a.wp = dA + d.w_off;
+    a.bias = d.b_off >= 0 ? dA + d.b_off : nullptr;
+    a.out = dout;
+    a.out_bstride = out_bstride;
+    a.Cin = d.Cin; a.Cout = d.Cout; a.K = d.K; a.dil = d.dil; a.padL = d.padL; a.CK = d.CK;
+    a.nchunks = d.nchunks; a.steps4 = d.steps4; a.ups = d.ups;
+    a.flags = ((flags & 1) ? PRO_LRELU : 0) | ((flags & 2) ? EPI_RELU : 0);
+    a.slope = slope;
+    a.div = 1.f;
+    TCHECK(launch_conv(a, d.cfg, B, nullptr));
+    TCHECK(hipDeviceSynchronize());
+    TCHECK(hipMemcpy(out, dout, out_elems * 4, hipMemcpyDeviceToHost));
+    hipFree(dA);
+    hipFree(dx);
+    hipFree(dout);
+    return VITS_OK;
+}
+
+int vits_test_conv1d(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias, int Cout,
+                     int K, int dil, int pad_l, int flags, float slope, float *out) {
+    if (int rc = test_dev(device_id)) return rc;
+    ConvDesc d;
+    std::vector<float> arena;
+    { std::string e = pack_test_conv(w, bias, Cin, Cout, K, dil, pad_l, &d, &arena); if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str()); }
+    return run_test_conv(d, arena, x, B, T, flags, slope, out, (size_t)B * Cout * T, (int64_t)Cout * T);
+}
+
+int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
+                               int Cout, int K, int stride, float *out) {
+    if (int rc = test_dev(device_id)) return rc;
+    ConvDesc d;
+    std::vector<float> arena;
+    { std::string e = pack_test_convT(w, bias, Cin, Cout, K, stride, &d, &arena); if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str()); }
+    return run_test_conv(d, arena, x, B, T, 0, 0.f, out, (size_t)B * Cout * T * stride, (int64_t)Cout * T * stride);
+}
+
+int vits_test_attention(int device_id, const float *qkv, int B, int C, int T, int n_heads, const float *rel_k,
+                        const float *rel_v, int window, const int64_t *lens, float *out) {
+    if (int rc = test_dev(device_id)) return rc;
+    if (window > 4 || C % n_heads) return fail(nullptr, VITS_E_ARG, "bad attention test arguments");
+    int dk = C / n_heads;
+    float *dq = nullptr, *dout = nullptr, *drk = nullptr, *drv = nullptr;
+    int *dlen = nullptr;
+    size_t nq = (size_t)B * 3 * C * T, no = (size_t)B * C * T, nr = (size_t)(2 * window + 1) * dk;
+    std::vector<int> l32(B);
+    for (int b = 0; b < B; b++) l32[b] = (int)lens[b];
+    TCHECK(hipMalloc((void **)&dq, nq * 4));
+    TCHECK(hipMalloc((void **)&dout, no * 4));
+    TCHECK(hipMalloc((void **)&drk, nr * 4));
+    TCHECK(hipMalloc((void **)&drv, nr * 4));
+    TCHECK(hipMalloc((void **)&dlen, B * 4));
+    TCHECK(hipMemcpy(dq, qkv, nq * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(drk, rel_k, nr * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(drv, rel_v, nr * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dlen, l32.data(), B * 4, hipMemcpyHostToDevice));
+    dim3 ag((T + 31) / 32, n_heads, B);
+    switch ((dk + 31) / 32) {
+        case 1: attention_relpos_kernel<1><<<ag, 64>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
+        case 2: attention_relpos_kernel<2><<<ag, 64>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
+        case 3: attention_relpos_kernel<3><<<ag, 64>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
+        default: attention_relpos_kernel<4><<<ag, 64>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
+    }
+    TCHECK(hipGetLastError());
+    TCHECK(hipDeviceSynchronize());
+    TCHECK(hipMemcpy(out, dout, no * 4, hipMemcpyDeviceToHost));
+    hipFree(dq); hipFree(dout); hipFree(drk); hipFree(drv); hipFree(dlen);
+    return VITS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,304 @@
+"""MiSession — the object that stands where `onnxruntime.InferenceSession` stands in
+phoonnx (`phoonnx/voice.py:107,167-171,347,374-377`).
+
+It duck-types exactly the three calls the reference makes:
+    MiSession(path, sess_options=..., providers=...)      voice.py:167-171
+    session.get_inputs() -> objects with .name            voice.py:347
+    session.run(None, feed)[0] -> float32 [B,1,1,S]       voice.py:374-377
+and forwards them over the C ABI (include/vitsmi.h) to the gfx950 engine.  There is no CPU
+fallback: without libvitsmi.so + an MI355X this raises.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+
+
+class SessionError(RuntimeError):
+    """Raised for every failure of the engine (onnxruntime raises its own
+    InvalidArgument/RuntimeException at voice.py:374; callers there do not catch either)."""
+
+
+@dataclass
+class NodeArg:
+    name: str
+    type: str
+    shape: list
+
+
+_INPUT_SPECS = {
+    "input": ("tensor(int64)", ["batch_size", "phonemes"]),
+    "input_lengths": ("tensor(int64)", ["batch_size"]),
+    "scales": ("tensor(float)", [3]),
+    "sid": ("tensor(int64)", ["batch_size"]),
+}
+
+
+class ModelMeta:
+    def __init__(self, custom):
+        self.custom_metadata_map = custom
+        self.producer_name = "pytorch"
+        self.graph_name = "vits"
+
+
+class MiSession:
+    def __init__(self, path_or_bytes, sess_options=None, providers=None, provider_options=None, device_id: int = 0,
+                 arena_device_ptr: Optional[int] = None, arena_bytes: int = 0, host_only: bool = False, **kwargs):
+        if not isinstance(path_or_bytes, (str, bytes)) or isinstance(path_or_bytes, bytes):
+            if isinstance(path_or_bytes, bytes):
+                raise SessionError("MiSession loads a model from a file path, not from serialized bytes")
+            path_or_bytes = str(path_or_bytes)
+        self._lib = _ffi.load()
+        self._h = C.c_void_p()
+        self.path = path_or_bytes
+        self.device_id = device_id
+        self.host_only = host_only
+        p = path_or_bytes.encode()
+        if host_only:
+            rc = self._lib.vits_open_host(p, C.byref(self._h))
+        elif arena_device_ptr is not None:
+            rc = self._lib.vits_open_with_arena(p, device_id, C.c_void_p(arena_device_ptr), arena_bytes,
+                                                C.byref(self._h))
+        else:
+            rc = self._lib.vits_open(p, device_id, C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise SessionError(f"vits_open({path_or_bytes!r}) failed [{rc}]: {_ffi.last_error(None)}")
+        n = self._lib.vits_num_inputs(self._h)
+        self._input_names = [self._lib.vits_input_name(self._h, i).decode() for i in range(n)]
+        self._seed = 0
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.vits_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self):
+        return _ffi.last_error(self._h)
+
+    # ------------------------------------------------------------------ onnxruntime surface
+    def get_inputs(self) -> List[NodeArg]:
+        out = []
+        for n in self._input_names:
+            t, s = _INPUT_SPECS.get(n, ("tensor(int64)", ["batch_size"]))
+            out.append(NodeArg(n, t, list(s)))
+        return out
+
+    def get_outputs(self) -> List[NodeArg]:
+        return [NodeArg("output", "tensor(float)", ["batch_size", 1, 1, "time"])]
+
+    def get_providers(self):
+        return ["MI355XExecutionProvider"]
+
+    def get_modelmeta(self) -> ModelMeta:
+        keys = ("model_type", "n_speakers", "n_vocab", "sample_rate", "alphabet", "phoneme_type",
+                "phonemizer_model", "phoneme_id_map", "has_espeak", "comment")
+        return ModelMeta({k: v for k in keys if (v := self.meta(k)) is not None})
+
+    def run(self, output_names: Optional[Sequence[str]], input_feed: Dict[str, np.ndarray], run_options=None):
+        if output_names is not None and list(output_names) != ["output"]:
+            raise SessionError(f"unknown output names {output_names!r}; the graph has one output 'output'")
+        for k in input_feed:
+            if k not in self._input_names:
+                raise SessionError(f"Invalid input name: {k}")
+        for k in self._input_names:
+            if k not in input_feed:
+                raise SessionError(f"Required input {k} is missing")
+        out = self.synthesize_batch(input_feed["input"], input_feed["input_lengths"], input_feed["scales"],
+                                    input_feed.get("sid"))
+        return [out["output"]]
+
+    # ------------------------------------------------------------------ extensions
+    def set_seed(self, seed: int):
+        """Seed of the device-side Philox stream that replaces the graph's two unseeded
+        RandomNormalLike nodes (models.py:111, :718)."""
+        self._seed = int(seed)
+
+    def synthesize_batch(self, ids, lens, scales, sid=None, noise_dp=None, noise_z=None, taps=()):
+        """One batched run.  Returns {"output": [B,1,1,S] float32, "y_lengths": int64 [B], taps...}.
+        noise_dp [B,2,T] / noise_z [B,inter,>=F] inject the graph's noise for parity runs."""
+        ids = np.ascontiguousarray(ids)
+        lens = np.ascontiguousarray(lens)
+        scales = np.ascontiguousarray(scales)
+        if ids.dtype != np.int64 or lens.dtype != np.int64:
+            raise SessionError("Unexpected input data type: 'input'/'input_lengths' must be tensor(int64)")
+        if scales.dtype != np.float32 or scales.shape != (3,):
+            raise SessionError("Unexpected input: 'scales' must be float32 of shape [3]")
+        if ids.ndim != 2 or lens.ndim != 1 or lens.shape[0] != ids.shape[0]:
+            raise SessionError(f"Invalid rank/shape for input: {ids.shape} / input_lengths: {lens.shape}")
+        B, T = ids.shape
+        if sid is not None:
+            sid = np.ascontiguousarray(sid)
+            if sid.dtype != np.int64 or sid.shape != (B,):
+                raise SessionError("Unexpected input: 'sid' must be int64 of shape [batch_size]")
+        noise = _ffi.VitsNoise()
+        noise.seed = self._seed
+        if noise_dp is not None:
+            noise_dp = np.ascontiguousarray(noise_dp, np.float32)
+            if noise_dp.shape != (B, 2, T):
+                raise SessionError(f"noise_dp must be [B,2,T], got {noise_dp.shape}")
+            noise.noise_dp = noise_dp.ctypes.data
+        if noise_z is not None:
+            noise_z = np.ascontiguousarray(noise_z, np.float32)
+            if noise_z.ndim != 3 or noise_z.shape[0] != B or noise_z.shape[1] != self.hparam("inter"):
+                raise SessionError(f"noise_z must be [B,inter,F], got {noise_z.shape}")
+            noise.noise_z = noise_z.ctypes.data
+            noise.noise_z_stride = noise_z.shape[2]
+        out = _ffi.VitsOutput()
+        rc = self._lib.vits_run(self._h, _ffi.ptr(ids), _ffi.ptr(lens), B, T, _ffi.ptr(scales), _ffi.ptr(sid),
+                                C.byref(noise), C.byref(out))
+        if rc != 0:
+            raise SessionError(f"vits_run failed [{rc}]: {self._err()}")
+        try:
+            dims = tuple(out.dims[i] for i in range(4))
+            n = int(np.prod(dims))
+            audio = np.ctypeslib.as_array(out.data, shape=(n,)).reshape(dims).copy()
+            ylen = np.ctypeslib.as_array(out.y_lengths, shape=(B,)).copy()
+        finally:
+            self._lib.vits_free_output(self._h, C.byref(out))
+        res = {"output": audio, "y_lengths": ylen}
+        for t in taps:
+            res[t] = self.tap(t)
+        return res
+
+    def vocoder(self, z, sid=None):
+        z = np.ascontiguousarray(z, np.float32)
+        B, Cc, F = z.shape
+        if Cc != self.hparam("inter"):
+            raise SessionError(f"z must have {self.hparam('inter')} channels")
+        sid = None if sid is None else np.ascontiguousarray(sid, np.int64)
+        out = _ffi.VitsOutput()
+        rc = self._lib.vits_run_vocoder(self._h, _ffi.ptr(z), B, F, _ffi.ptr(sid), C.byref(out))
+        if rc != 0:
+            raise SessionError(f"vits_run_vocoder failed [{rc}]: {self._err()}")
+        try:
+            dims = tuple(out.dims[i] for i in range(4))
+            return np.ctypeslib.as_array(out.data, shape=(int(np.prod(dims)),)).reshape(dims).copy()
+        finally:
+            self._lib.vits_free_output(self._h, C.byref(out))
+
+    def tap(self, name):
+        dims = (C.c_int64 * 4)()
+        nd = self._lib.vits_tap(self._h, name.encode(), None, 0, dims)
+        if nd < 0:
+            raise SessionError(f"vits_tap({name}) failed: {self._err()}")
+        shape = tuple(dims[i] for i in range(nd))
+        buf = np.empty(shape, np.float32)
+        nd = self._lib.vits_tap(self._h, name.encode(), _ffi.ptr(buf), buf.size, dims)
+        if nd < 0:
+            raise SessionError(f"vits_tap({name}) failed: {self._err()}")
+        return buf
+
+    def meta(self, key):
+        buf = C.create_string_buffer(1 << 16)
+        n = self._lib.vits_meta(self._h, key.encode(), buf, len(buf))
+        return None if n < 0 else buf.value.decode()
+
+    def hparam(self, key) -> int:
+        v = C.c_int64()
+        if self._lib.vits_hparam(self._h, key.encode(), C.byref(v)) != 0:
+            raise SessionError(self._err())
+        return v.value
+
+    def set_timing(self, on=True):
+        self._lib.vits_set_timing(self._h, 1 if on else 0)
+
+    def stats(self):
+        s = _ffi.VitsStats()
+        self._lib.vits_get_stats(self._h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in _ffi.VitsStats._fields_}
+
+    def arena_bytes(self):
+        return self._lib.vits_arena_bytes(self._h)
+
+    def arena_host(self) -> np.ndarray:
+        n = self.arena_bytes()
+        p = self._lib.vits_arena_host(self._h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,))
+
+    def arena_device(self) -> int:
+        return self._lib.vits_arena_device(self._h) or 0
+
+    def stream(self) -> int:
+        return self._lib.vits_stream(self._h) or 0
+
+    # device-resident run for the benchmark / sharded path: arguments are device pointers (ints)
+    def run_device(self, ids_ptr, lens_ptr, B, T, scales, sid_ptr=None, noise_dp_ptr=None, noise_z_ptr=None,
+                   noise_z_stride=0):
+        scales = np.ascontiguousarray(scales, np.float32)
+        noise = _ffi.VitsNoise()
+        noise.seed = self._seed
+        noise.noise_dp = noise_dp_ptr
+        noise.noise_z = noise_z_ptr
+        noise.noise_z_stride = noise_z_stride
+        out = _ffi.VitsOutput()
+        rc = self._lib.vits_run_device(self._h, C.c_void_p(ids_ptr), C.c_void_p(lens_ptr), B, T, _ffi.ptr(scales),
+                                       C.c_void_p(sid_ptr) if sid_ptr else None, C.byref(noise), C.byref(out))
+        if rc != 0:
+            raise SessionError(f"vits_run_device failed [{rc}]: {self._err()}")
+        dims = tuple(out.dims[i] for i in range(4))
+        return {"data_ptr": C.cast(out.data, C.c_void_p).value, "dims": dims,
+                "y_lengths_ptr": C.cast(out.y_lengths, C.c_void_p).value}
+
+    def sync(self):
+        if self._lib.vits_sync(self._h) != 0:
+            raise SessionError(self._err())
+
+
+# kernel-level hooks (tests)
+def test_conv1d(x, w, bias=None, dil=1, pad_l=0, lrelu_slope=None, relu=False, device_id=0):
+    lib = _ffi.load()
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    B, Cin, T = x.shape
+    Cout, _, K = w.shape
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    out = np.empty((B, Cout, T), np.float32)
+    flags = (1 if lrelu_slope is not None else 0) | (2 if relu else 0)
+    rc = lib.vits_test_conv1d(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, dil, pad_l, flags,
+                              float(lrelu_slope or 0.0), _ffi.ptr(out))
+    if rc != 0:
+        raise SessionError(_ffi.last_error(None))
+    return out
+
+
+def test_conv_transpose1d(x, w, bias, stride, device_id=0):
+    lib = _ffi.load()
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    B, Cin, T = x.shape
+    _, Cout, K = w.shape
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    out = np.empty((B, Cout, T * stride), np.float32)
+    rc = lib.vits_test_conv_transpose1d(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, stride,
+                                        _ffi.ptr(out))
+    if rc != 0:
+        raise SessionError(_ffi.last_error(None))
+    return out
+
+
+def test_attention(qkv, n_heads, rel_k, rel_v, lens, device_id=0):
+    lib = _ffi.load()
+    qkv = np.ascontiguousarray(qkv, np.float32)
+    B, C3, T = qkv.shape
+    Cc = C3 // 3
+    rel_k = np.ascontiguousarray(rel_k, np.float32)
+    rel_v = np.ascontiguousarray(rel_v, np.float32)
+    window = (rel_k.shape[0] - 1) // 2
+    lens = np.ascontiguousarray(lens, np.int64)
+    out = np.empty((B, Cc, T), np.float32)
+    rc = lib.vits_test_attention(device_id, _ffi.ptr(qkv), B, Cc, T, n_heads, _ffi.ptr(rel_k), _ffi.ptr(rel_v), window,
+                                 _ffi.ptr(lens), _ffi.ptr(out))
+    if rc != 0:
+        raise SessionError(_ffi.last_error(None))
+    return out

@@ -1,0 +1,240 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(libvitsmi.so); the C oracle and the committed reference fixtures are the checkers.
+
+Tolerances: integer/index work (durations, frame counts, output shape) bit-exact; fp32
+intermediates 2e-4 max-abs; the waveform 1e-3 max-abs (north_star) — in practice ~1e-5.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, TINY_PRESETS, case_get, golden_cases
+
+pytestmark = pytest.mark.gpu
+
+WAVE_TOL = 1e-3   # BASELINE.json north_star: max-abs on the final fp32 waveform
+STAGE_TOL = 2e-4
+
+
+def _session(preset):
+    from phoonnx_amd import MiSession
+    return MiSession(os.path.join(GOLDEN, preset + ".onnx"))
+
+
+# ------------------------------------------------------------------ kernel level: conv engine
+
+CONV_CASES = [
+    # (B, Cin, Cout, T, K, dil)                      tile config exercised
+    (2, 32, 32, 300, 3, 1),     # cfg0 32x512
+    (1, 4, 4, 77, 7, 3),        # tiny channels, padded M and K
+    (2, 29, 16, 65, 1, 1),      # odd Cin
+    (1, 16, 1, 130, 7, 1),      # Cout = 1
+    (2, 64, 64, 513, 11, 5),    # cfg1 64x256, widest receptive field of the "high" preset
+    (1, 96, 192, 40, 1, 1),     # flow pre
+    (1, 192, 96, 33, 1, 1),     # flow post (Cout not multiple of 64)
+    (2, 192, 384, 200, 5, 1),   # cfg2 128x128, WN in_layer
+    (1, 128, 128, 700, 7, 12),  # medium preset's widest dilation
+    (1, 192, 576, 19, 1, 1),    # fused qkv
+    (3, 48, 200, 257, 3, 2),    # ragged everything
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,dil", CONV_CASES)
+def test_conv_engine_matches_oracle(B, Cin, Cout, T, K, dil):
+    from phoonnx_amd.session import test_conv1d
+    from vits_oracle import conv1d
+    rng = np.random.default_rng(B * 1000 + Cin + Cout + T)
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    pad = dil * (K - 1) // 2
+    got = test_conv1d(x, w, b, dil=dil, pad_l=pad)
+    ref = conv1d(x, w, b, dil=dil, pad_l=pad, pad_r=dil * (K - 1) - pad)
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
+    # fused leaky-relu prologue + relu epilogue
+    got = test_conv1d(x, w, None, dil=dil, pad_l=pad, lrelu_slope=0.1, relu=True)
+    xa = np.where(x > 0, x, x * np.float32(0.1)).astype(np.float32)
+    ref = np.maximum(conv1d(xa, w, None, dil=dil, pad_l=pad, pad_r=dil * (K - 1) - pad), 0)
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
+
+
+def test_conv_engine_identity_asymmetric():
+    # A = I check with an asymmetric operand (catches transposed C/D maps)
+    from phoonnx_amd.session import test_conv1d
+    C, T = 64, 96
+    w = np.zeros((C, C, 1), np.float32)
+    w[np.arange(C), np.arange(C), 0] = 1
+    x = (np.arange(C)[:, None] * 1000 + np.arange(T)[None, :]).astype(np.float32)[None]
+    got = test_conv1d(x, w)
+    assert np.array_equal(got, x)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,u", [(2, 32, 16, 50, 16, 8), (1, 64, 32, 37, 8, 4), (2, 16, 8, 129, 4, 2),
+                                              (1, 512, 256, 9, 16, 8), (1, 6, 3, 20, 6, 2)])
+def test_conv_transpose_matches_oracle(B, Cin, Cout, T, K, u):
+    from phoonnx_amd.session import test_conv_transpose1d
+    from vits_oracle import conv_transpose1d
+    rng = np.random.default_rng(K * 100 + u)
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(Cin * K / u)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    got = test_conv_transpose1d(x, w, b, u)
+    ref = conv_transpose1d(x, w, b, u, (K - u) // 2)
+    assert got.shape == ref.shape == (B, Cout, T * u)
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ kernel level: attention
+
+@pytest.mark.parametrize("B,heads,dk,T,lens", [(2, 2, 16, 40, [40, 17]), (1, 2, 96, 256, [256]), (3, 4, 8, 5, [5, 1, 3]),
+                                               (2, 2, 96, 70, [33, 70]), (1, 1, 64, 3, [3]), (2, 2, 48, 129, [129, 64])])
+def test_attention_matches_oracle(B, heads, dk, T, lens):
+    from phoonnx_amd.session import test_attention
+    from vits_oracle import attention_core
+    rng = np.random.default_rng(T * 7 + dk)
+    C = heads * dk
+    qkv = rng.standard_normal((B, 3 * C, T)).astype(np.float32)
+    rk = (rng.standard_normal((9, dk)) * dk ** -0.5).astype(np.float32)
+    rv = (rng.standard_normal((9, dk)) * dk ** -0.5).astype(np.float32)
+    lens = np.asarray(lens, np.int64)
+    got = test_attention(qkv, heads, rk, rv, lens)
+    ref = attention_core(qkv, heads, rk, rv, lens)
+    for b in range(B):  # padded query rows never reach valid outputs; compare valid ones
+        np.testing.assert_allclose(got[b, :, :lens[b]], ref[b, :, :lens[b]], atol=2e-5, rtol=1e-4)
+        assert np.all(got[b, :, lens[b]:] == 0)
+
+
+def test_attention_sharp_softmax():
+    # large logits force the online-softmax rescale branch across key blocks
+    from phoonnx_amd.session import test_attention
+    from vits_oracle import attention_core
+    rng = np.random.default_rng(5)
+    B, heads, dk, T = 1, 2, 32, 200
+    C = heads * dk
+    qkv = rng.standard_normal((B, 3 * C, T)).astype(np.float32)
+    qkv[:, :C] *= 6.0
+    qkv[:, C:2 * C, 150:] *= 5.0   # the maximum jumps late in the key sweep
+    rk = rng.standard_normal((9, dk)).astype(np.float32)
+    rv = rng.standard_normal((9, dk)).astype(np.float32)
+    lens = np.asarray([T], np.int64)
+    got = test_attention(qkv, heads, rk, rv, lens)
+    ref = attention_core(qkv, heads, rk, rv, lens)
+    np.testing.assert_allclose(got, ref, atol=1e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ whole path vs reference fixtures
+
+TAPS = ("x", "m_p", "logs_p", "logw", "w_ceil", "z_p", "z")
+
+
+@pytest.mark.parametrize("preset", TINY_PRESETS)
+def test_pipeline_matches_reference_goldens(preset):
+    s = _session(preset)
+    g = np.load(os.path.join(GOLDEN, preset + ".npz"))
+    for c in golden_cases(g):
+        r = s.synthesize_batch(case_get(g, c, "ids"), case_get(g, c, "lens"), case_get(g, c, "scales"),
+                               case_get(g, c, "sid"), case_get(g, c, "noise_dp"), case_get(g, c, "noise_z"), taps=TAPS)
+        lens = case_get(g, c, "lens")
+        ylen = case_get(g, c, "out_y_lengths")
+        # integer work first: durations and frame counts are exact
+        assert np.array_equal(r["w_ceil"], case_get(g, c, "out_w_ceil")), (preset, c)
+        assert np.array_equal(r["y_lengths"], ylen), (preset, c)
+        for k in ("x", "m_p", "logs_p", "logw", "z_p", "z"):
+            ref = case_get(g, c, "out_" + k)
+            assert r[k].shape == ref.shape, (preset, c, k, r[k].shape, ref.shape)
+            np.testing.assert_allclose(r[k], ref, atol=STAGE_TOL, rtol=0, err_msg=f"{preset}/{c}/{k}")
+        ref = case_get(g, c, "out_output")
+        assert r["output"].shape == ref.shape and r["output"].dtype == np.float32
+        np.testing.assert_allclose(r["output"], ref, atol=WAVE_TOL, rtol=0, err_msg=f"{preset}/{c}/output")
+        assert np.abs(r["output"] - ref).max() < 5e-5, "fp32 path should sit far inside the 1e-3 budget"
+    s.close()
+
+
+def test_session_run_duck_types_onnxruntime():
+    # the exact call sequence of phoonnx/voice.py:347-377
+    s = _session("tiny_rb1")
+    g = np.load(os.path.join(GOLDEN, "tiny_rb1.npz"))
+    expected_args = [i.name for i in s.get_inputs()]
+    assert expected_args == ["input", "input_lengths", "scales"]
+    ids = case_get(g, "b1_zero", "ids")
+    args = {"input": ids, "input_lengths": np.array([ids.shape[1]], dtype=np.int64),
+            "scales": np.array([0.0, 1.0, 0.0], dtype=np.float32),
+            "langid": np.array([0], dtype=np.int64), "sid": np.array([0], dtype=np.int64)}
+    args = {k: v for k, v in args.items() if k in expected_args}
+    out = s.run(None, args)
+    assert isinstance(out, list) and out[0].ndim == 4 and out[0].shape[:3] == (1, 1, 1)
+    audio = out[0].squeeze()
+    np.testing.assert_allclose(audio, case_get(g, "b1_zero", "out_output").squeeze(), atol=WAVE_TOL)
+    from phoonnx_amd import SessionError
+    with pytest.raises(SessionError):
+        s.run(None, dict(args, bogus=np.zeros(1)))
+    with pytest.raises(SessionError):
+        s.run(None, {"input": ids})
+    with pytest.raises(SessionError):  # id out of the embedding's range
+        s.run(None, dict(args, input=ids + 100000))
+    s.close()
+
+
+def test_multispeaker_requires_sid_and_uses_it():
+    s = _session("tiny_rb2_ms")
+    assert [i.name for i in s.get_inputs()] == ["input", "input_lengths", "scales", "sid"]
+    ids = np.arange(1, 13, dtype=np.int64)[None]
+    lens = np.array([12], np.int64)
+    sc = np.array([0, 1.2, 0], np.float32)
+    from phoonnx_amd import SessionError
+    with pytest.raises(SessionError):
+        s.synthesize_batch(ids, lens, sc)
+    a = s.synthesize_batch(ids, lens, sc, sid=np.array([0], np.int64))["output"]
+    b = s.synthesize_batch(ids, lens, sc, sid=np.array([3], np.int64))["output"]
+    assert a.shape != b.shape or np.abs(a - b).max() > 1e-3
+    s.close()
+
+
+def test_determinism_and_seeded_noise():
+    s = _session("tiny_rb1")
+    ids = np.arange(3, 33, dtype=np.int64)[None]
+    lens = np.array([30], np.int64)
+    z0 = s.synthesize_batch(ids, lens, np.array([0, 1, 0], np.float32))["output"]
+    z1 = s.synthesize_batch(ids, lens, np.array([0, 1, 0], np.float32))["output"]
+    assert np.array_equal(z0, z1)                      # zero noise: bit-identical run to run
+    s.set_seed(7)
+    n0 = s.synthesize_batch(ids, lens, np.array([0.667, 1, 0.8], np.float32))
+    n1 = s.synthesize_batch(ids, lens, np.array([0.667, 1, 0.8], np.float32))
+    # like the graph's unseeded RandomNormalLike nodes, successive calls draw fresh noise
+    assert n0["output"].shape != n1["output"].shape or not np.array_equal(n0["output"], n1["output"])
+    assert np.isfinite(n0["output"]).all() and np.abs(n0["output"]).max() <= 1.0
+    s.close()
+
+
+def test_padded_batch_interior_equals_single(tmp_path):
+    # inside a padded batch an item equals its batch-1 rendering except the tail
+    s = _session("tiny_rb1")
+    rng = np.random.default_rng(3)
+    ids = np.zeros((2, 30), np.int64)
+    ids[0] = rng.integers(1, 200, 30)
+    ids[1, :11] = rng.integers(1, 200, 11)
+    sc = np.array([0, 1.5, 0], np.float32)
+    both = s.synthesize_batch(ids, np.array([30, 11], np.int64), sc)
+    one = s.synthesize_batch(ids[1:2, :11].copy(), np.array([11], np.int64), sc)
+    assert both["y_lengths"][1] == one["y_lengths"][0]
+    hop = s.hparam("hop")
+    n = int(one["y_lengths"][0]) * hop
+    rf = 200  # receptive field margin of the tiny generator at the right edge
+    np.testing.assert_allclose(both["output"][1, 0, 0, :n - rf], one["output"][0, 0, 0, :n - rf], atol=1e-5)
+    s.close()
+
+
+def test_vocoder_only_matches_oracle():
+    from vits_oracle import VitsOracle
+    for preset in ("tiny_rb1", "tiny_rb2_ms"):
+        s = _session(preset)
+        o = VitsOracle(os.path.join(GOLDEN, preset + ".onnx"))
+        rng = np.random.default_rng(11)
+        z = rng.standard_normal((2, s.hparam("inter"), 37)).astype(np.float32)
+        sid = np.array([1, 2], np.int64) if s.hparam("n_speakers") > 1 else None
+        got = s.vocoder(z, sid)
+        ref = o.vocoder(z, sid)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, atol=1e-4)
+        s.close()
