@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — audio samples/s of the MI355X-native VITS path on synthetic fixed-length
+phoneme batches (BASELINE.json: batch-32, 256-phoneme utterances, 22.05 kHz).
+
+  python bench.py --gpus N --steps K --warmup W [--preset high|medium] [--batch 32] [--tokens 256]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU: rank 0 reads and packs the
+.onnx, the packed weight arena is broadcast over RCCL/xGMI, then every rank synthesises its
+own 32 utterances with no further communication ("scaling": "weak").
+A step = one pass of the whole path (encoder + duration predictor + flow + vocoder) over one
+batch whose inputs are already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
+LENGTH_SCALE = {"high": 1.5, "medium": 1.5, "small": 1.5}  # gives ~3 frames per phoneme id with synth weights
+
+
+def cpu_baseline(voice_path, preset, tokens, scales, seed):
+    """Oracle (C restatement, OpenMP, all host cores) timed on a bounded sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vits_oracle
+    try:
+        o = vits_oracle.VitsOracle(voice_path, native=True)
+    except Exception:
+        o = vits_oracle.VitsOracle(voice_path, native=False)
+    Bs = 2 if preset == "high" else 4
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(0, 256, size=(Bs, tokens)).astype(np.int64)
+    lens = np.full((Bs,), tokens, np.int64)
+    ndp = rng.standard_normal((Bs, 2, tokens)).astype(np.float32)
+    nz = rng.standard_normal((Bs, o.inter_channels, tokens * 12)).astype(np.float32)
+    t0 = time.perf_counter()
+    r = o.infer(ids, lens, scales, None, ndp, nz)
+    dt = time.perf_counter() - t0
+    hop = r["output"].shape[3] // int(r["y_lengths"].max())
+    samples = int(r["y_lengths"].sum()) * hop
+    return {"value": samples / dt, "unit": "samples/s", "cores": int(o.lib.vo_num_threads()), "kind": "port",
+            "sample": f"C/OpenMP restatement (oracle/vits_oracle.c), B={Bs} x {tokens} ids, {samples} samples in {dt:.1f}s",
+            "rtf": dt / (samples / 22050.0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preset", default="high", choices=["high", "medium", "small"])
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--tokens", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from phoonnx_amd import MiSession
+    from phoonnx_amd.sharding import open_sharded
+    from phoonnx_amd.synth import write_voice
+
+    cache = os.environ.get("VITSMI_BENCH_CACHE", "/tmp/vitsmi_bench")
+    voice = os.path.join(cache, f"synth_{a.preset}.onnx")
+    if rank == 0 and not os.path.exists(voice):
+        os.makedirs(cache, exist_ok=True)
+        write_voice(voice + ".tmp", a.preset, seed=1234)
+        os.replace(voice + ".tmp", voice)
+    if dist:
+        dist.barrier()
+
+    # weights: rank 0 reads + packs, RCCL broadcast of the arena, every rank opens on its GPU
+    sess, arena_keepalive = open_sharded(voice, local_rank, dist)
+    hop = sess.hparam("hop")
+    sess.set_seed(1234 + rank)
+
+    B, T = a.batch, a.tokens
+    scales = np.array([0.667, LENGTH_SCALE[a.preset], 0.8], np.float32)
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    ids = torch.randint(0, 256, (B, T), generator=g, dtype=torch.int64).cuda()
+    lens = torch.full((B,), T, dtype=torch.int64).cuda()
+    torch.cuda.synchronize()
+
+    def step():
+        sess.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+        return int(sess.last_y_lengths().sum()) * hop
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(a.steps):
+        samples += step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([dt, float(samples)], dtype=torch.float64, device="cuda")
+    if dist:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt_max, samples_all = float(mx[0]), float(sm[1])
+    else:
+        dt_max, samples_all = dt, float(samples)
+
+    roofline = None
+    stage = None
+    if rank == 0 and not a.no_roofline:
+        # per-kernel timing with HIP events on the engine's own stream (vits_set_timing)
+        sess.set_timing(True)
+        fl = ms = by = 0.0
+        launches = 0
+        agg = {}
+        n_t = max(3, min(a.steps, 5))
+        for _ in range(n_t):
+            step()
+            st = sess.stats()
+            fl += st["conv_flops"]
+            by += st["conv_bytes"]
+            ms += st["conv_ms"]
+            launches += st["conv_launches"]
+            for k in ("enc_ms", "dp_ms", "flow_ms", "dec_ms", "total_ms", "dec_flops", "dec_bytes", "flow_flops"):
+                agg[k] = agg.get(k, 0.0) + st[k]
+        sess.set_timing(False)
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "conv_engine_kernel (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)",
+                    "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+                    "traffic": None, "launches_per_step": launches // n_t,
+                    "avg_launch_ms": ms / max(launches, 1),
+                    "algorithmic_gflop_per_step": fl / n_t / 1e9,
+                    "algorithmic_gbytes_per_step": by / n_t / 1e9,
+                    "hbm_frac_of_8TBs": (by / (ms * 1e-3)) / 8.0e12 if ms > 0 else 0.0}
+        stage = {k: v / n_t for k, v in agg.items()}
+        if stage.get("dec_ms", 0) > 0:
+            stage["dec_tflops"] = stage["dec_flops"] / (stage["dec_ms"] * 1e-3) / 1e12
+            stage["dec_hbm_frac"] = stage["dec_bytes"] / (stage["dec_ms"] * 1e-3) / 8.0e12
+
+    cpu = None
+    if rank == 0 and not a.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(voice, a.preset, T, scales, 1234)
+        except Exception as e:  # the baseline is a report, never the product
+            cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+
+    if rank == 0:
+        value = samples_all / dt_max
+        line = {
+            "metric": "audio samples/sec (22.05 kHz), batch-32 256-phoneme utterances",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rtf": dt_max / (samples_all / world / 22050.0) if samples_all else None,
+            "config": {"workload": f"VITS full pipeline (encoder+duration+flow+HiFi-GAN), preset={a.preset}, "
+                                   f"batch={B}/GPU x {T} phoneme ids, scales=[0.667,{scales[1]:.2f},0.8], "
+                                   f"device Philox noise, seeded synthetic weights",
+                       "preset": a.preset, "batch_per_gpu": B, "tokens": T, "hop": hop,
+                       "samples_per_step": samples_all / a.steps,
+                       "frames_per_id": samples_all / a.steps / hop / (B * world * T),
+                       "weights": "RCCL broadcast of packed arena" if world > 1 else "local"},
+            "roofline": roofline, "cpu_baseline": cpu, "stages": stage,
+        }
+        if cpu and cpu.get("value"):
+            line["gpu_over_cpu"] = value / world / cpu["value"]
+        print(json.dumps(line), flush=True)
+    sess.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

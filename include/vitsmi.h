@@ -123,6 +123,10 @@ int vits_run_device(vits_handle *h, const int64_t *ids, const int64_t *lens, int
                     const float scales[3], const int64_t *sid, const vits_noise *noise, vits_output *out);
 int vits_sync(vits_handle *h);
 
+/* Frame counts of the last run, from the host copy made by the mid-pipeline readback
+ * (no synchronisation).  Writes min(n, B) values, returns B. */
+int vits_last_y_lengths(vits_handle *h, int64_t *buf, int n);
+
 /* Vocoder only (BASELINE config 2, and teacher-forced parity): z is [B, inter, F] host
  * float32, already masked; output as vits_run. */
 int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t *sid, vits_output *out);

@@ -707,6 +707,13 @@ int vits_run_device(vits_handle *h, const int64_t *ids, const int64_t *lens, int
     return run_device_locked(h, ids, lens, B, T, scales, sid, noise, out);
 }
 
+int vits_last_y_lengths(vits_handle *h, int64_t *buf, int n) {
+    if (!h) return VITS_E_ARG;
+    int B = (int)h->h_ylen.size();
+    for (int b = 0; b < B && b < n && buf; b++) buf[b] = h->h_ylen[b];
+    return B;
+}
+
 int vits_sync(vits_handle *h) {
     if (int rc = check_dev(h)) return rc;
     HIPCHECK(h, hipStreamSynchronize(h->stream));

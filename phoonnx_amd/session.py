@@ -250,6 +250,13 @@ class MiSession:
         return {"data_ptr": C.cast(out.data, C.c_void_p).value, "dims": dims,
                 "y_lengths_ptr": C.cast(out.y_lengths, C.c_void_p).value}
 
+    def last_y_lengths(self) -> np.ndarray:
+        n = self._lib.vits_last_y_lengths(self._h, None, 0)
+        buf = np.zeros(max(n, 0), np.int64)
+        if n > 0:
+            self._lib.vits_last_y_lengths(self._h, buf.ctypes.data_as(C.POINTER(C.c_int64)), n)
+        return buf
+
     def sync(self):
         if self._lib.vits_sync(self._h) != 0:
             raise SessionError(self._err())

@@ -1,0 +1,108 @@
+"""Multi-GPU path: independent utterances sharded across the GPUs of one node.
+
+VITS inference has no exchange step: utterances share nothing but the
+weights.  So the only collective is ONE broadcast of the packed weight arena (RCCL over
+xGMI when the backend is "nccl") at load time; in steady state every rank runs its own
+sub-batch on its own handle/stream with no inter-GPU dependence.
+
+One process per GPU (torch.distributed); torch is used here for device memory and the
+process group only.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .session import MiSession
+
+
+def partition(lengths: Sequence[int], world: int) -> Tuple[List[np.ndarray], np.ndarray]:
+    """Deal utterances to ranks: sort by length (longest first) so each rank's padded batch
+    wastes little, then give rank r the r-th contiguous block.  Returns (per-rank index arrays
+    into the original order, inverse permutation that restores the original order from the
+    concatenation of the per-rank results)."""
+    lengths = np.asarray(lengths)
+    n = len(lengths)
+    order = np.argsort(-lengths, kind="stable")
+    per = (n + world - 1) // world if world else n
+    shards = [order[r * per:(r + 1) * per] for r in range(world)]
+    inv = np.empty(n, dtype=np.int64)
+    inv[np.concatenate(shards) if n else np.zeros(0, np.int64)] = np.arange(n)
+    return shards, inv
+
+
+def pad_batch(utts: Sequence[Sequence[int]], pad_id: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    """ids int64 [B, Tmax] zero-padded + lengths int64 [B] (the feed layout of voice.py:350-351, batched)."""
+    lens = np.asarray([len(u) for u in utts], np.int64)
+    T = int(lens.max()) if len(utts) else 0
+    ids = np.full((len(utts), T), pad_id, np.int64)
+    for i, u in enumerate(utts):
+        ids[i, :len(u)] = np.asarray(u, np.int64)
+    return ids, lens
+
+
+def broadcast_arena(path: str, dist, device: Optional[int], src: int = 0):
+    """Rank `src` parses + packs the .onnx on the host; the packed arena is broadcast to every
+    rank (device tensors over RCCL when `device` is not None, host tensors otherwise, e.g. gloo).
+    Returns a uint8 torch tensor holding the arena on this rank."""
+    import torch
+    rank = dist.get_rank()
+    dev = torch.device("cuda", device) if device is not None else torch.device("cpu")
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    host = None
+    if rank == src:
+        host = MiSession(path, host_only=True)
+        n[0] = host.arena_bytes()
+    dist.broadcast(n, src)
+    nbytes = int(n.item())
+    if rank == src:
+        arena = torch.from_numpy(np.array(host.arena_host(), copy=True)).to(dev)
+        host.close()
+    else:
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dist.broadcast(arena, src)  # ~64-119 MB once; 7 xGMI links x ~153 GB/s -> sub-millisecond class
+    return arena
+
+
+def open_sharded(path: str, device_id: int, dist=None, src: int = 0):
+    """Open one engine handle per rank.  With a process group, weights arrive by broadcast and the
+    handle adopts the device arena (vits_open_with_arena); without one this is a plain open.
+    Returns (session, arena_tensor_or_None) — keep the tensor alive as long as the session."""
+    if dist is None or dist.get_world_size() == 1:
+        return MiSession(path, device_id=device_id), None
+    arena = broadcast_arena(path, dist, device_id, src)
+    sess = MiSession(path, device_id=device_id, arena_device_ptr=arena.data_ptr(), arena_bytes=arena.numel())
+    return sess, arena
+
+
+class ShardedSynthesizer:
+    """Batched-utterance front: `synthesize(utterances)` runs this rank's shard and (optionally)
+    gathers the waveforms of all ranks on the host in the original order."""
+
+    def __init__(self, path: str, device_id: int, dist=None):
+        self.dist = dist
+        self.rank = dist.get_rank() if dist else 0
+        self.world = dist.get_world_size() if dist else 1
+        self.session, self._arena = open_sharded(path, device_id, dist)
+        self.hop = self.session.hparam("hop")
+
+    def synthesize(self, utterances: Sequence[Sequence[int]], scales, sids: Optional[Sequence[int]] = None,
+                   gather: bool = False):
+        shards, inv = partition([len(u) for u in utterances], self.world)
+        mine = shards[self.rank]
+        local = []
+        if len(mine):
+            ids, lens = pad_batch([utterances[i] for i in mine])
+            sid = None if sids is None else np.asarray([sids[i] for i in mine], np.int64)
+            r = self.session.synthesize_batch(ids, lens, np.asarray(scales, np.float32), sid)
+            for b in range(len(mine)):
+                n = int(r["y_lengths"][b]) * self.hop
+                local.append(r["output"][b, 0, 0, :n].copy())
+        if not gather or self.dist is None:
+            return [(int(i), w) for i, w in zip(mine, local)]
+        allw = [None] * self.world
+        self.dist.all_gather_object(allw, local)  # host-side gather of results; not on the compute path
+        flat = [w for part in allw for w in part]
+        return [flat[int(inv[i])] for i in range(len(utterances))]
+
+    def close(self):
+        self.session.close()

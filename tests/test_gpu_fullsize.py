@@ -1,0 +1,76 @@
+"""Full-size parity on the GPU box: synthetic "medium" / "high" / multi-speaker voices
+(phoonnx_amd/synth.py writes .onnx files with the exporter's structure), HIP path vs the C
+oracle on identical inputs and injected noise, plus size-independent properties at the
+BASELINE batch size."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CACHE = os.environ.get("VITSMI_BENCH_CACHE", "/tmp/vitsmi_bench")
+
+
+def _voice(preset, **over):
+    from phoonnx_amd.synth import write_voice
+    tag = preset + "".join(f"_{k}{v}" for k, v in sorted(over.items()))
+    path = os.path.join(CACHE, f"synth_{tag}.onnx")
+    if not os.path.exists(path):
+        os.makedirs(CACHE, exist_ok=True)
+        write_voice(path + ".tmp", preset, seed=1234, **over)
+        os.replace(path + ".tmp", path)
+    return path
+
+
+@pytest.mark.parametrize("preset,over,B,T", [("medium", {}, 3, 96), ("high", {}, 2, 64),
+                                             ("medium", {"n_speakers": 4}, 2, 80)])
+def test_fullsize_pipeline_matches_oracle(preset, over, B, T):
+    from phoonnx_amd import MiSession
+    from vits_oracle import VitsOracle
+    path = _voice(preset, **over)
+    s, o = MiSession(path), VitsOracle(path)
+    rng = np.random.default_rng(99)
+    lens = np.array([T] + [int(x) for x in rng.integers(T // 3, T, B - 1)], np.int64)
+    ids = np.zeros((B, T), np.int64)
+    for b in range(B):
+        ids[b, :lens[b]] = rng.integers(0, 256, lens[b])
+    sid = rng.integers(0, 4, B).astype(np.int64) if over.get("n_speakers", 1) > 1 else None
+    scales = np.array([0.667, 1.4, 0.8], np.float32)
+    ndp = rng.standard_normal((B, 2, T)).astype(np.float32)
+    nz = rng.standard_normal((B, 192, T * 8)).astype(np.float32)
+    ref = o.infer(ids, lens, scales, sid, ndp, nz)
+    got = s.synthesize_batch(ids, lens, scales, sid, ndp, nz, taps=("x", "m_p", "logs_p", "logw", "w_ceil", "z_p", "z"))
+    assert np.array_equal(got["w_ceil"], ref["w_ceil"])          # integer durations: exact
+    assert np.array_equal(got["y_lengths"], ref["y_lengths"])
+    for k in ("x", "m_p", "logs_p", "logw", "z_p", "z"):
+        np.testing.assert_allclose(got[k], ref[k], atol=5e-4, rtol=0, err_msg=k)
+    assert got["output"].shape == ref["output"].shape
+    err = np.abs(got["output"] - ref["output"]).max()
+    assert err < 1e-3, err                                        # north_star tolerance
+    assert 0.02 < np.abs(ref["output"]).max() < 0.999             # the comparison is not vacuous
+    s.close()
+
+
+def test_baseline_batch_properties():
+    """B=32 x 256 ids (BASELINE config 3) is too slow for the CPU oracle inside a test, so check
+    size-independent properties: batch-composition invariance of durations, shape law
+    S = hop * max(y_len), finiteness, |audio| <= 1, and agreement of item 0 with its batch-1 run."""
+    from phoonnx_amd import MiSession
+    path = _voice("medium")
+    s = MiSession(path)
+    rng = np.random.default_rng(1234)
+    B, T = 32, 256
+    ids = rng.integers(0, 256, (B, T)).astype(np.int64)
+    lens = np.full(B, T, np.int64)
+    sc = np.array([0, 1.5, 0], np.float32)
+    r = s.synthesize_batch(ids, lens, sc, taps=("w_ceil",))
+    hop = s.hparam("hop")
+    assert r["output"].shape == (B, 1, 1, hop * int(r["y_lengths"].max()))
+    assert np.isfinite(r["output"]).all() and np.abs(r["output"]).max() <= 1.0
+    assert np.array_equal(r["w_ceil"].sum(1).astype(np.int64), r["y_lengths"])
+    one = s.synthesize_batch(ids[:1], lens[:1], sc, taps=("w_ceil",))
+    assert np.array_equal(one["w_ceil"][0], r["w_ceil"][0])
+    n = (int(one["y_lengths"][0]) - 64) * hop  # minus the generator's receptive field at the right edge
+    np.testing.assert_allclose(r["output"][0, 0, 0, :n], one["output"][0, 0, 0, :n], atol=2e-5)
+    s.close()
