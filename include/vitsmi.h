@@ -163,6 +163,10 @@ void *vits_stream(vits_handle *h);
  * on the input, bit1 relu on the output.  Host pointers. */
 int vits_test_conv1d(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
                      int Cout, int K, int dil, int pad_l, int flags, float slope, float *out);
+/* Kernel tuning: average launch time (ms) of one same-padded conv shape on random data through the
+ * engine; ms_out[0] = ms, [1] = tile config used, [2] = channel chunk.  cfg/ck_override < 0 = automatic. */
+int vits_bench_conv1d(int device_id, int B, int Cin, int Cout, int T, int K, int dil, int hint, int iters,
+                      int cfg_override, int ck_override, float *ms_out);
 /* out[B,Cout,T*stride] = conv_transpose1d(x, w[Cin,Cout,K], bias, stride, pad=(K-stride)/2). */
 int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, int T, const float *w,
                                const float *bias, int Cout, int K, int stride, float *out);

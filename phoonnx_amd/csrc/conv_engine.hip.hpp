@@ -2,19 +2,38 @@
 //
 //   out[b, co, t] = epi( bias[co] + sum_{ci,tap} W[co,ci,tap] * pro(x[b, ci, t + tap*dil - padL]) )
 //
-// GEMM view per batch item: M = Cout, N = T, K = Cin*taps.  v_mfma_f32_32x32x2_f32 computes a
+// GEMM view per utterance: M = Cout, N = T, K = Cin*taps.  v_mfma_f32_32x32x2_f32 computes a
 // 32(co) x 32(t) tile per instruction with two k-values (an input-channel pair) — exact fp32 FMA
-// chains, the same arithmetic the reference's fp32 convs perform (only the summation order differs).
-//   A operand (weights)  : pre-packed at load time in lane order (model.cpp pack_conv), streamed from
-//                          L2 with one 16-byte load per lane per four k-steps.
-//   B operand (activation): a [CK channels] x [BN + halo] tile staged once per channel chunk into LDS
-//                          (prologue activation / mask applied while staging, zero padding at the
-//                          sequence ends), then read as conflict-free 32-lane rows, shifted per tap.
-// One 256-thread workgroup = 4 wavefronts (64 lanes) arranged WM x WN; each wave owns MW x NW
-// accumulator tiles (64 accumulator VGPRs).  Three tile shapes cover the model's channel widths:
-//   cfg 2: 128(co) x 128(t)   Cout % 128 == 0      cfg 1: 64 x 256      cfg 0: 32 x 512 (Cout <= 32)
-// Epilogues fuse bias, per-utterance conditioning bias, sequence mask, ReLU, residual add, multi-
-// receptive-field accumulation (/3), the coupling update and the transposed-conv pixel shuffle.
+// chains, the arithmetic the reference's fp32 convs perform (only the summation order differs).
+//
+// Data movement: BOTH operands reach the matrix cores through LDS and are brought there by LDS-DMA
+// (`global_load_lds`, no VGPR round trip), double-buffered per input-channel chunk:
+//   A (weights)   : pre-packed at load time in MFMA lane order (model.cpp pack_conv); the
+//                   [BM/32 blocks] x [K*CK/8 groups] x 1 KiB slab of a chunk is copied with 16-byte
+//                   DMA pieces and read back with conflict-free lane-linear ds_read_b128.
+//   B (activation): a [CK channels] x [BN + halo] tile, zero padding / sequence masking realised by
+//                   redirecting out-of-range lanes to a zero page; read as 32-lane rows shifted per
+//                   tap.  16-byte DMA pieces when rows are 16-byte aligned (T % 4 == 0), else 4-byte.
+// Schedule per chunk: [wait own DMA] [barrier] [issue DMA for chunk+1] [MFMA over chunk from LDS].
+//
+// Measured facts this file is shaped by (tools/mfma_peak.hip, tools/conv_bench.py, MI355X):
+//   * v_mfma_f32_32x32x2_f32 sustains 155 TFLOP/s alone, but it shares the SIMD's fp32 datapath with
+//     VALU work: one ds_read2 + 6 VALU per 4 MFMAs already caps the loop at 130 TFLOP/s, whatever the
+//     occupancy.  So the k-loop carries NO activation math: producers store pre-activated tensors
+//     (epilogue `oslope`, optional second output), and the in-loop leaky-ReLU exists only as the ACT
+//     template variant for callers that cannot arrange that.
+//   * hipcc sinks LDS prefetches below the MFMA group and waits with lgkmcnt(0) -> LDS reads are
+//     inline asm with our own waits, order pinned by sched_barrier.
+//   * compiler-visible ds_reads are ordered against in-flight LDS-DMA by alias analysis; the two
+//     pipeline stages are distinct __shared__ objects and the reads are asm, so the prefetch of the
+//     next chunk is never drained early.
+//
+// One 256-thread workgroup = 4 wavefronts (64 lanes) arranged WM x WN, each owning MW x NW 32x32
+// accumulator tiles.  Tile shapes (BM x BN): 128x128, 64x256, 32x512 for long sequences and 64x64,
+// 32x128 for short ones (token-domain layers), chosen at pack time together with the chunk depth CK.
+// Epilogues fuse bias, per-utterance conditioning bias, sequence mask, ReLU / leaky-ReLU, residual
+// add, multi-receptive-field accumulation (/3), the coupling update, the transposed-conv pixel
+// shuffle and an optional second (pre-activated) output.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,16 +41,20 @@
 namespace vitsmi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 enum : int {
-    PRO_LRELU = 1,      // leaky-relu(slope) on the input while staging
+    PRO_LRELU = 1,      // leaky-relu(slope) on the input (in-loop; prefer pre-activated inputs)
     PRO_MASK = 2,       // input * (t < len[b])
     EPI_RELU = 4,
     EPI_MASK = 8,       // value * (t < len[b])   (before the residual is added)
     EPI_RES = 16,       // + res[b,co,t]
     EPI_ACC = 32,       // out = out + value
     EPI_DIV = 64,       // out = value / div      (after EPI_ACC)
-    EPI_COUPLING = 128  // out = (out - value*mask) * mask   (modules.py:464, mean_only)
+    EPI_COUPLING = 128,  // out = (out - value*mask) * mask   (modules.py:464, mean_only)
+    DBG_NO_DMA = 1 << 16,  // ablation (tools/conv_bench.py): stop prefetching after the second chunk
+    DBG_NO_EPI = 1 << 17   // ablation: skip the epilogue stores
 };
 
 struct ConvArgs {
@@ -45,17 +68,48 @@ struct ConvArgs {
     int bias_b_stride;
     float *out;
     int64_t out_bstride;  // channel stride of out is T*ups
+    float *out2;          // optional second output: leaky_relu(final value, oslope2); same layout as out
     const float *res;
     int64_t res_bstride;
-    int Cin, Cout, K, dil, padL, CK, nchunks, steps4, LW, ups;
+    const float *zeros;   // >= 256 zero floats, 16-byte aligned (padding source for the DMA)
+    int Cin, Cout, K, dil, padL, CK, nchunks, steps4, ups;
+    int LW, padLa, xs_floats;  // filled by launch_conv
+    unsigned magic;            // ceil(2^32 / LW)
     int flags;
     float slope, div;
+    float oslope, oslope2;  // leaky-relu slope applied to the value stored in out / out2 (1 = none)
 };
 
+template <int BYTES>
+__device__ __forceinline__ void lds_dma(const void *gsrc, float *ldst) {
+    // the size operand must be a literal (not template-dependent): dispatch with if constexpr
+    if constexpr (BYTES == 16)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                         (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
+    else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                         (__attribute__((address_space(3))) void *)ldst, 4, 0, 0);
+}
+
+__device__ __forceinline__ float lrelu_f(float v, float slope) {
+    // leaky_relu(v) == med3(v, v*slope, +inf) for 0 < slope <= 1 (slope == 1: identity)
+    return __builtin_amdgcn_fmed3f(v, v * slope, __builtin_inff());
+}
+
+// LDS floats per pipeline stage (x tile + A slab), per tile config.  The two stages are two DISTINCT
+// static __shared__ arrays: only distinct objects are provably disjoint for hipcc's LDS-DMA tracking.
 template <int MW, int NW, int WM, int WN>
+struct ConvTile {
+    static constexpr int BM = WM * MW * 32, BN = WN * NW * 32;
+    static constexpr int STAGE_FLOATS = (MW * NW >= 4) ? 9728 : 4864;  // 38 KiB / 19 KiB per stage
+};
+
+template <int MW, int NW, int WM, int WN, int VEC, int ACT>
 __global__ __launch_bounds__(256) void conv_engine_kernel(ConvArgs a) {
-    extern __shared__ float xs[];  // [CK][LW]
-    constexpr int BM = WM * MW * 32, BN = WN * NW * 32;
+    using Tile = ConvTile<MW, NW, WM, WN>;
+    constexpr int BM = Tile::BM, BN = Tile::BN, MB = BM / 32;
+    __shared__ __attribute__((aligned(16))) float stageP[Tile::STAGE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float stageQ[Tile::STAGE_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -65,6 +119,33 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(ConvArgs a) {
     const int T = a.T;
     const int len_b = a.len ? a.len[b] : T;
     const int in_lim = (a.flags & PRO_MASK) ? (len_b < T ? len_b : T) : T;
+    const int LW = a.LW, CK = a.CK, K = a.K;
+    const int spc = (K * CK) >> 3;  // float4 groups per 32-row block per chunk
+    const int XS = a.xs_floats;     // x tile floats (padded to the DMA piece); the A slab follows it
+    const float *xb = a.x + (int64_t)b * a.x_bstride;
+    const int mblk_base = blockIdx.y * MB;
+    const int nxs = XS / (256 * VEC);
+    // A slab of (m-tile, chunk): MB*spc KiB, CONTIGUOUS in the packed weights (model.cpp pack_conv)
+    const float4 *aslab0 = reinterpret_cast<const float4 *>(a.wp) + (int64_t)blockIdx.y * a.nchunks * (MB * spc * 64) + lane;
+    const int na = MB * spc;
+
+    auto issue = [&](int chunk, float *stage) {
+        const float4 *src = aslab0 + (int64_t)chunk * (na * 64);
+        float *ab = stage + XS;
+        for (int i = wave; i < na; i += 4) lds_dma<16>(src + i * 64, ab + i * 256);
+        // x tile: CK rows x LW columns, linear in LDS; out-of-range lanes read the zero page
+        const int rows_valid = (a.Cin - chunk * CK) < CK ? (a.Cin - chunk * CK) : CK;
+        const float *xc = xb + (int64_t)chunk * CK * T;
+        for (int s = 0; s < nxs; s++) {
+            const int e = (s * 256 + tid) * VEC;
+            const int r = (int)__umulhi((unsigned)e, a.magic);
+            const int c = e - r * LW;
+            const int t = t0 - a.padLa + c;
+            const bool ok = r < rows_valid && t >= 0 && t < in_lim;
+            const float *src_x = ok ? xc + (int64_t)r * T + t : a.zeros + lane * VEC;
+            lds_dma<VEC * 4>(src_x, stage + (s * 256 + wave * 64) * VEC);
+        }
+    };
 
     f32x16 acc[MW][NW];
 #pragma unroll
@@ -74,114 +155,263 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
-    const float *xb = a.x + (int64_t)b * a.x_bstride;
-    const float4 *wp4 = reinterpret_cast<const float4 *>(a.wp);
-    const int mblk0 = blockIdx.y * (BM / 32) + wm * MW;
-    const int LW = a.LW, CK = a.CK, K = a.K;
-    const int g_per_tap = CK >> 3;
-    const bool lrelu = a.flags & PRO_LRELU;
     const float slope = a.slope;
+    const int g_per_tap = CK >> 3;
+    const int col0 = (a.padLa - a.padL) + wn * (NW * 32) + l31;
 
-    for (int chunk = 0; chunk < a.nchunks; chunk++) {
-        __syncthreads();  // previous chunk fully consumed
-        for (int r = 0; r < CK; r++) {
-            const int ci = chunk * CK + r;
-            const float *row = xb + (int64_t)ci * T;
-            const bool rv = ci < a.Cin;
-            for (int c = tid; c < LW; c += 256) {
-                const int t = t0 - a.padL + c;
-                float v = 0.f;
-                if (rv && t >= 0 && t < in_lim) {
-                    v = row[t];
-                    if (lrelu) v = v > 0.f ? v : v * slope;
+    // ---- MFMA loop over one chunk, reading both operands from LDS with inline-asm ds_reads.
+    // Order per k-step (pinned with sched_barrier): [wait for step s] [issue prefetch of step s+1]
+    // [MW*NW MFMAs]; the prefetch latency hides behind the 256-cycle MFMA group.
+    const uint32_t a_byte0 = (uint32_t)(XS + ((wm * MW) * spc * 64 + lane) * 4) * 4u;
+    const int ngroups = K * g_per_tap;  // groups of 4 k-steps (8 input channels of one tap)
+    const uint32_t lw2b = (uint32_t)(2 * LW) * 4u;
+    auto compute = [&](const float *stage) {
+        const uint32_t sbase = (uint32_t)(uintptr_t)stage;  // LDS byte offset of this stage
+        auto read_a = [&](int m, int grp) {
+            f32x4 r;
+            const uint32_t ad = sbase + a_byte0 + (uint32_t)((m * spc + grp) * 1024);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(ad) : "memory");
+            return r;
+        };
+        auto read_b = [&](uint32_t ad, float *dst) {
+            if constexpr (NW == 1) {
+                float r;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(ad) : "memory");
+                dst[0] = r;
+            } else {
+                f32x2 r;
+                asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(r) : "v"(ad) : "memory");
+                dst[0] = r.x;
+                dst[1] = r.y;
+                if constexpr (NW == 4) {
+                    f32x2 q;
+                    asm volatile("ds_read2_b32 %0, %1 offset0:64 offset1:96" : "=v"(q) : "v"(ad) : "memory");
+                    dst[2] = q.x;
+                    dst[3] = q.y;
                 }
-                xs[r * LW + c] = v;
             }
+        };
+        int tap = 0, g = 0;
+        uint32_t bbyte = sbase + (uint32_t)(hi * LW + col0) * 4u;  // B(tap, g, j = 0, n = 0) of this lane
+        f32x4 av_n[MW];
+        float bv_n[NW];
+#pragma unroll
+        for (int m = 0; m < MW; m++) av_n[m] = read_a(m, 0);
+        read_b(bbyte, bv_n);
+        for (int gi = 0; gi < ngroups; gi++) {
+            // next group's coordinates; the last group prefetches itself again (no branch around a read)
+            int g2 = g + 1, tap2 = tap;
+            if (g2 == g_per_tap) { g2 = 0; tap2 = tap + 1; }
+            const bool more = gi + 1 < ngroups;
+            const uint32_t bbyte2 = more ? sbase + (uint32_t)((g2 * 8 + hi) * LW + tap2 * a.dil + col0) * 4u : bbyte;
+            const int gnext = more ? gi + 1 : gi;
+            f32x4 av[MW];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float bv[NW];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments of step j have landed
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) {
+#pragma unroll
+                    for (int m = 0; m < MW; m++) av[m] = av_n[m];
+                }
+#pragma unroll
+                for (int n = 0; n < NW; n++) bv[n] = bv_n[n];
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) {
+#pragma unroll
+                    for (int m = 0; m < MW; m++) av_n[m] = read_a(m, gnext);
+                }
+                read_b(j < 3 ? bbyte + (uint32_t)(j + 1) * lw2b : bbyte2, bv_n);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ACT) {
+#pragma unroll
+                    for (int n = 0; n < NW; n++) bv[n] = lrelu_f(bv[n], slope);
+                }
+#pragma unroll
+                for (int m = 0; m < MW; m++) {
+                    const float aval = j == 0 ? av[m].x : (j == 1 ? av[m].y : (j == 2 ? av[m].z : av[m].w));
+#pragma unroll
+                    for (int n = 0; n < NW; n++)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bv[n], acc[m][n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            g = g2;
+            tap = tap2;
+            bbyte = bbyte2;
         }
+        // drain the self-prefetch of the last group before its destination registers die
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // software pipeline over input-channel chunks, two stages, one barrier per chunk
+    const int nchunks = a.nchunks;
+    const bool dbg_nodma = a.flags & DBG_NO_DMA;
+    issue(0, stageP);
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+        __syncthreads();  // own DMA drained (vmcnt(0)) + everyone done reading stageQ
+        if (chunk + 1 < nchunks && !(dbg_nodma && chunk > 0)) issue(chunk + 1, stageQ);
+        compute(stageP);
+        if (chunk + 1 >= nchunks) break;
         __syncthreads();
-        for (int tap = 0; tap < K; tap++) {
-            const int col = tap * a.dil + wn * (NW * 32) + l31;
-            const int s4base = (chunk * K + tap) * g_per_tap;
-            for (int g = 0; g < g_per_tap; g++) {
-                float4 av[MW];
-#pragma unroll
-                for (int m = 0; m < MW; m++)
-                    av[m] = wp4[((int64_t)(mblk0 + m) * a.steps4 + s4base + g) * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float *brow = xs + (g * 8 + j * 2 + hi) * LW + col;
-                    float bv[NW];
-#pragma unroll
-                    for (int n = 0; n < NW; n++) bv[n] = brow[n * 32];
-#pragma unroll
-                    for (int m = 0; m < MW; m++) {
-                        const float aval = j == 0 ? av[m].x : (j == 1 ? av[m].y : (j == 2 ? av[m].z : av[m].w));
-#pragma unroll
-                        for (int n = 0; n < NW; n++)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bv[n], acc[m][n], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        if (chunk + 2 < nchunks && !dbg_nodma) issue(chunk + 2, stageP);
+        compute(stageQ);
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    // Branch-free per element: absent bias pointers read the zero page, flags become multipliers /
+    // clamps, loads of a tile are issued together (a per-element "load or not" branch makes hipcc wait
+    // vmcnt(0) per element).
     const int flags = a.flags;
+    if (flags & DBG_NO_EPI) {  // ablation only: keep the accumulators live, skip the stores
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < MW; m++)
+#pragma unroll
+            for (int n = 0; n < NW; n++) s += acc[m][n][0] + acc[m][n][7] + acc[m][n][15];
+        if (s == 12345.678f) a.out[tid] = s;
+        return;
+    }
     const int ups = a.ups;
-    const int64_t Tout = (int64_t)T * ups;
+    const int Tout = T * ups;
     float *ob = a.out + (int64_t)b * a.out_bstride;
+    float *ob2 = a.out2 ? a.out2 + (int64_t)b * a.out_bstride : nullptr;
     const float *rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
-    const float *bbp = a.bias_b ? a.bias_b + (int64_t)b * a.bias_b_stride : nullptr;
+    const float *biasp = a.bias ? a.bias : a.zeros;
+    const float *bbp = a.bias_b ? a.bias_b + (int64_t)b * a.bias_b_stride : a.zeros;
+    const int bb_on = a.bias_b ? 1 : 0, b_on = a.bias ? 1 : 0;
+    const float relu_floor = (flags & EPI_RELU) ? 0.f : -__builtin_inff();
+    const float inv_unused = 0.f;
+    (void)inv_unused;
+    const int mblk0 = mblk_base + wm * MW;
+    const float oslope = a.oslope, oslope2 = a.oslope2, div = a.div;
 #pragma unroll
     for (int m = 0; m < MW; m++) {
+        // per-row constants of this lane's 16 rows
+        float brow[16];
+        int orow[16];  // element offset of (co, t=0) inside the batch item; -1 = row out of range
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = (mblk0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool okc = co < a.Cout;
+            const int cc = okc ? co : 0;
+            brow[r] = biasp[cc * b_on] + bbp[cc * bb_on];
+            orow[r] = okc ? (ups == 1 ? co * T : (co / ups) * Tout + (co % ups)) : -1;
+        }
 #pragma unroll
         for (int n = 0; n < NW; n++) {
             const int t = t0 + wn * (NW * 32) + n * 32 + l31;
             if (t >= T) continue;
             const float mk = (t < len_b) ? 1.f : 0.f;
+            const float mk_sel = (flags & EPI_MASK) ? mk : 1.f;
+            const int tt = t * ups;
+            float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int co = (mblk0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (co >= a.Cout) continue;
-                float v = acc[m][n][r];
-                if (a.bias) v += a.bias[co];
-                if (bbp) v += bbp[co];
-                if (flags & EPI_RELU) v = v > 0.f ? v : 0.f;
-                int64_t o;
-                if (ups == 1)
-                    o = (int64_t)co * T + t;
-                else
-                    o = (int64_t)(co / ups) * Tout + (int64_t)t * ups + (co % ups);
-                if (flags & EPI_COUPLING) {
-                    ob[o] = (ob[o] - v * mk) * mk;
-                    continue;
-                }
-                if (flags & EPI_MASK) v *= mk;
-                if (flags & EPI_RES) v += rb[o];
-                if (flags & EPI_ACC) v += ob[o];
-                if (flags & EPI_DIV) v = v / a.div;
-                ob[o] = v;
+            for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[m][n][r] + brow[r], relu_floor);
+            if (flags & EPI_COUPLING) {
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) old[r] = orow[r] >= 0 ? ob[orow[r] + tt] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (orow[r] >= 0) ob[orow[r] + tt] = (old[r] - v[r] * mk) * mk;
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] *= mk_sel;
+            if (flags & EPI_RES) {
+                float rr[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) rr[r] = orow[r] >= 0 ? rb[orow[r] + tt] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] += rr[r];
+            }
+            if (flags & EPI_ACC) {
+                float oo[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) oo[r] = orow[r] >= 0 ? ob[orow[r] + tt] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] += oo[r];
+            }
+            if (flags & EPI_DIV) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) v[r] = v[r] / div;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (orow[r] >= 0) ob[orow[r] + tt] = lrelu_f(v[r], oslope);
+            if (ob2) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (orow[r] >= 0) ob2[orow[r] + tt] = lrelu_f(v[r], oslope2);
             }
         }
     }
 }
 
-inline int conv_tile_n(int cfg) { return cfg == 2 ? 128 : (cfg == 1 ? 256 : 512); }
-inline int conv_tile_m(int cfg) { return cfg == 2 ? 128 : (cfg == 1 ? 64 : 32); }
-
-// Launch on `stream`; `a.LW` is filled in here.  Returns hipError_t.
-inline hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
-    const int BN = conv_tile_n(cfg), BM = conv_tile_m(cfg);
-    a.LW = BN + (a.K - 1) * a.dil;
-    dim3 grid((a.T + BN - 1) / BN, (a.Cout + BM - 1) / BM, B);
-    size_t lds = (size_t)a.CK * a.LW * sizeof(float);
-    if (grid.x == 0 || grid.y == 0 || B == 0) return hipSuccess;
+// tile configs: index -> (BM, BN)
+//   0: 32x512   1: 64x256   2: 128x128   3: 64x64   4: 32x128
+inline int conv_tile_m(int cfg) { return cfg == 2 ? 128 : ((cfg == 1 || cfg == 3) ? 64 : 32); }
+inline int conv_tile_n(int cfg) {
     switch (cfg) {
-        case 2: conv_engine_kernel<2, 2, 2, 2><<<grid, 256, lds, stream>>>(a); break;
-        case 1: conv_engine_kernel<2, 2, 1, 4><<<grid, 256, lds, stream>>>(a); break;
-        default: conv_engine_kernel<1, 4, 1, 4><<<grid, 256, lds, stream>>>(a); break;
+        case 0: return 512;
+        case 1: return 256;
+        case 2: return 128;
+        case 3: return 64;
+        default: return 128;
+    }
+}
+
+// floats per pipeline stage available to a tile config (must match ConvTile::STAGE_FLOATS)
+inline int conv_stage_floats(int cfg) { return cfg <= 2 ? 9728 : 4864; }
+
+template <int MW, int NW, int WM, int WN>
+inline hipError_t launch_conv_t(const ConvArgs &a, dim3 grid, bool vec4, bool act, hipStream_t stream) {
+    if (vec4) {
+        if (act) conv_engine_kernel<MW, NW, WM, WN, 4, 1><<<grid, 256, 0, stream>>>(a);
+        else conv_engine_kernel<MW, NW, WM, WN, 4, 0><<<grid, 256, 0, stream>>>(a);
+    } else {
+        if (act) conv_engine_kernel<MW, NW, WM, WN, 1, 1><<<grid, 256, 0, stream>>>(a);
+        else conv_engine_kernel<MW, NW, WM, WN, 1, 0><<<grid, 256, 0, stream>>>(a);
     }
     return hipGetLastError();
+}
+
+// Launch on `stream`; LW / padLa / xs_floats / magic are filled in here.
+inline hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
+    const int BN = conv_tile_n(cfg), BM = conv_tile_m(cfg);
+    const int halo = (a.K - 1) * a.dil;
+    // 16-byte DMA needs 16-byte aligned rows: T % 4 == 0, aligned base/batch stride, no ragged input mask
+    const bool vec4 = (a.T % 4 == 0) && (a.x_bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
+                      !(a.flags & PRO_MASK);
+    if (vec4) {
+        a.padLa = (a.padL + 3) & ~3;
+        const int padRa = (halo - a.padL + 3) & ~3;
+        a.LW = BN + a.padLa + padRa;
+        a.xs_floats = (a.CK * a.LW + 1023) / 1024 * 1024;
+    } else {
+        a.padLa = a.padL;
+        a.LW = BN + halo;
+        a.xs_floats = (a.CK * a.LW + 255) / 256 * 256;
+    }
+    a.magic = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
+    if (a.oslope == 0.f) a.oslope = 1.f;
+    if (a.oslope2 == 0.f) a.oslope2 = 1.f;
+    const bool act = (a.flags & PRO_LRELU) && a.slope != 1.f;
+    dim3 grid((a.T + BN - 1) / BN, (a.Cout + BM - 1) / BM, B);
+    if (grid.x == 0 || grid.y == 0 || B == 0) return hipSuccess;
+    const size_t stage = (size_t)a.xs_floats + (size_t)(BM / 32) * (a.K * a.CK / 8) * 256;
+    if (stage > (size_t)conv_stage_floats(cfg)) return hipErrorInvalidValue;  // pick_tiling guarantees this never fires
+    if ((int64_t)a.Cout * a.T >= (int64_t)1 << 31) return hipErrorInvalidValue;  // 32-bit element offsets per utterance
+    switch (cfg) {
+        case 0: return launch_conv_t<1, 4, 1, 4>(a, grid, vec4, act, stream);
+        case 1: return launch_conv_t<2, 2, 1, 4>(a, grid, vec4, act, stream);
+        case 2: return launch_conv_t<2, 2, 2, 2>(a, grid, vec4, act, stream);
+        case 3: return launch_conv_t<1, 1, 2, 2>(a, grid, vec4, act, stream);
+        default: return launch_conv_t<1, 1, 1, 4>(a, grid, vec4, act, stream);
+    }
 }
 
 }  // namespace vitsmi

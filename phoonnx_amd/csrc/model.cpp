@@ -152,22 +152,72 @@ struct Packer {
     int64_t put(const TRef &r) { return put(r.p, r.numel()); }
 };
 
-int pick_cfg(int Cout) { return (Cout % 128 == 0) ? 2 : (Cout <= 32 ? 0 : 1); }
-int tile_m(int cfg) { return cfg == 2 ? 128 : (cfg == 1 ? 64 : 32); }
+// ---- tile / chunk selection (mirrors conv_engine.hip.hpp; kept here so model.cpp stays HIP-free)
+// cfg: 0: 32x512, 1: 64x256, 2: 128x128 (long sequences), 3: 64x64, 4: 32x128 (short sequences)
+int tile_m(int cfg) { return cfg == 2 ? 128 : ((cfg == 1 || cfg == 3) ? 64 : 32); }
+int tile_n(int cfg) {
+    static const int n[5] = {512, 256, 128, 64, 128};
+    return n[cfg];
+}
+// floats of ONE pipeline stage (x tile + A slab) in the 16-byte-DMA layout (the larger one)
+size_t stage_floats(int cfg, int K, int dil, int padL, int CK) {
+    const int BN = tile_n(cfg), BM = tile_m(cfg), halo = (K - 1) * dil;
+    const int padLa = (padL + 3) & ~3, padRa = (halo - padL + 3) & ~3;
+    const size_t LW = size_t(BN + padLa + padRa);
+    const size_t xs = (size_t(CK) * LW + 1023) / 1024 * 1024;
+    const size_t as = size_t(BM / 32) * size_t(K * CK / 8) * 256;
+    return xs + as;
+}
+size_t stage_capacity(int cfg) { return cfg <= 2 ? 9728 : 4864; }  // conv_engine.hip.hpp ConvTile::STAGE_FLOATS
+
+// hint: 0 = frame/sample domain (generator), 1 = frame domain (flow), 2 = token domain (encoder, durations)
+thread_local int t_cfg_override = -1, t_ck_override = -1;  // kernel tuning only (tools/conv_bench.py)
+
+void pick_tiling(int Cin, int Cout, int K, int dil, int padL, int hint, int &cfg, int &CK) {
+    if (t_cfg_override >= 0) {
+        cfg = t_cfg_override;
+        CK = t_ck_override > 0 ? t_ck_override : 8;
+        if (stage_floats(cfg, K, dil, padL, CK) > stage_capacity(cfg)) throw std::runtime_error("override does not fit LDS");
+        return;
+    }
+    std::vector<int> cands;
+    if (hint == 2) cands = {Cout <= 32 ? 4 : 3};
+    else if (hint == 1 && Cout % 128 != 0) cands = {Cout <= 32 ? 4 : 3};
+    // long-sequence tiles, also the fallback when a wide kernel does not fit a small tile's LDS stage
+    if (Cout <= 32) cands.push_back(0);
+    else if (Cout % 128 == 0) {
+        cands.push_back(2);
+        cands.push_back(1);
+    } else
+        cands.push_back(1);
+    const int cin8 = (Cin + 7) / 8 * 8;
+    for (int c : cands)
+        for (int ck : {32, 16, 8}) {
+            if (ck > cin8 && ck != 8) continue;
+            if (stage_floats(c, K, dil, padL, ck) <= stage_capacity(c)) {
+                cfg = c;
+                CK = ck;
+                return;
+            }
+        }
+    throw std::runtime_error("conv receptive field too wide for the LDS stage (kernel " + std::to_string(K) +
+                             ", dilation " + std::to_string(dil) + ")");
+}
+
+thread_local int t_hint = 0;  // size class of the layers being packed (set by Model::build)
 
 // W is addressed through a functor so that permutations / transposed-conv rewrites need no copies:
 // w(co, ci, tap) for co < Cout, ci < Cin, tap < K.
 template <class WF>
 ConvDesc pack_conv(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF w, const float *bias_virtual) {
+    const int hint = t_hint;
     ConvDesc d;
     d.Cin = Cin;
     d.Cout = Cout;
     d.K = K;
     d.dil = dil;
     d.padL = padL;
-    d.cfg = pick_cfg(Cout);
-    int cap = d.cfg == 2 ? 32 : 16;
-    d.CK = Cin <= 8 ? 8 : (Cin <= 16 ? 16 : cap);
+    pick_tiling(Cin, Cout, K, dil, padL, hint, d.cfg, d.CK);
     d.nchunks = (Cin + d.CK - 1) / d.CK;
     int bm = tile_m(d.cfg);
     d.mblocks = (Cout + bm - 1) / bm * (bm / 32);
@@ -176,12 +226,16 @@ ConvDesc pack_conv(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF w,
     d.w_off = P.alloc(per_block * d.mblocks);
     float *dst = P.arena.data() + d.w_off;
     int half = d.CK / 2;
+    // Layout: Wp[m-tile][chunk][block-in-tile][group][lane][4]: the A slab one workgroup needs for one
+    // chunk (MB blocks x spc groups x 1 KiB) is one contiguous range -> LDS-DMA pieces are base + i KiB.
+    const int MB = bm / 32, spc = K * d.CK / 8;
     for (int mb = 0; mb < d.mblocks; mb++)
         for (int chunk = 0; chunk < d.nchunks; chunk++)
             for (int tap = 0; tap < K; tap++)
                 for (int pair = 0; pair < half; pair++) {
-                    int step = (chunk * K + tap) * half + pair;
-                    float *g = dst + (int64_t(mb) * d.steps4 + step / 4) * 256 + (step & 3);
+                    int step = tap * half + pair;  // k-step inside the chunk
+                    int64_t slab = ((int64_t(mb / MB) * d.nchunks + chunk) * MB + (mb % MB)) * spc;
+                    float *g = dst + (slab + step / 4) * 256 + (step & 3);
                     for (int lane = 0; lane < 64; lane++) {
                         int co = mb * 32 + (lane & 31);
                         int ci = chunk * d.CK + 2 * pair + (lane >> 5);
@@ -284,18 +338,30 @@ DDSDesc pack_dds(Packer &P, const Resolver &R, const std::string &pfx) {
 
 }  // namespace
 
-std::string pack_test_conv(const float *w, const float *bias, int Cin, int Cout, int K, int dil, int pad_l, ConvDesc *d,
-                           std::vector<float> *arena) {
+void set_tiling_override(int cfg, int ck) {
+    t_cfg_override = cfg;
+    t_ck_override = ck;
+}
+
+std::string pack_test_conv(const float *w, const float *bias, int Cin, int Cout, int K, int dil, int pad_l, int hint,
+                           ConvDesc *d, std::vector<float> *arena) {
     if (Cin < 1 || Cout < 1 || K < 1 || dil < 1 || pad_l < 0) return "bad conv shape";
+    t_hint = hint;
     Packer P(*arena);
+    P.alloc(256);  // zero page at offset 0
     auto wf = [&](int co, int ci, int tap) { return w[(int64_t(co) * Cin + ci) * K + tap]; };
-    *d = pack_conv(P, Cin, Cout, K, dil, pad_l, wf, bias);
+    try {
+        *d = pack_conv(P, Cin, Cout, K, dil, pad_l, wf, bias);
+    } catch (const std::exception &e) {
+        return e.what();
+    }
     return "";
 }
 
 std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout, int K, int stride, ConvDesc *d,
                             std::vector<float> *arena) {
     try {
+        t_hint = 0;
         Resolver R;
         TRef t;
         t.p = w;
@@ -310,6 +376,7 @@ std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout
         R.ints["t.stride"] = stride;
         R.ints["t.pad"] = (K - stride) / 2;
         Packer P(*arena);
+        P.alloc(256);  // zero page at offset 0
         *d = pack_convT(P, R, "t");
     } catch (const std::exception &e) {
         return e.what();
@@ -322,10 +389,12 @@ std::string Model::build(const OnnxModel &om) {
         Resolver R;
         resolve(om, R);
         Packer P(arena);
+        zeros_off = P.alloc(1024);  // zero page: padding source of the conv engine's LDS-DMA
         input_names = om.inputs;
         meta = om.meta;
 
         // ---------------- text encoder (models.py:168-209, attentions.py)
+        t_hint = 2;
         const TRef &embw = R.req("enc_p.emb.weight");
         n_vocab = int(embw.dims[0]);
         H = int(embw.dims[1]);
@@ -417,6 +486,7 @@ std::string Model::build(const OnnxModel &om) {
         }
 
         // ---------------- flow (models.py:212-254), Flip folded into channel permutations
+        t_hint = 1;
         {
             int nfl = 0;
             while (R.get("flow.flows." + std::to_string(2 * nfl) + ".pre.weight")) nfl++;
@@ -453,6 +523,7 @@ std::string Model::build(const OnnxModel &om) {
         }
 
         // ---------------- generator (models.py:299-368)
+        t_hint = 0;
         conv_pre = pack_named(P, R, "dec.conv_pre", 1, 3);
         C0 = conv_pre.Cout;
         if (gin) {

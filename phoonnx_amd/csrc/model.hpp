@@ -24,7 +24,7 @@ struct ConvDesc {
     int mblocks = 0;      // packed 32-row blocks (padded to the tile config)
     int steps4 = 0;       // float4 groups per mblock = nchunks*K*CK/8
     int ups = 1;          // pixel-shuffle factor (transposed conv), real Cout = Cout/ups
-    int cfg = 0;          // 0: 32x512 tile, 1: 64x256, 2: 128x128
+    int cfg = 0;          // tile: 0: 32x512, 1: 64x256, 2: 128x128, 3: 64x64, 4: 32x128
     double macs_per_t = 0;   // algorithmic MACs per input time step (reference definition)
     bool valid() const { return w_off >= 0; }
 };
@@ -117,6 +117,7 @@ struct Model {
 
     // ---- packed arena (host copy)
     std::vector<float> arena;
+    int64_t zeros_off = 0;  // >= 1024 zero floats
 
     // Build from a parsed file.  Returns "" or an error message.
     std::string build(const OnnxModel &om);
@@ -127,8 +128,9 @@ struct Model {
 };
 
 // kernel-level test hooks: pack one conv / transposed conv into a private arena
-std::string pack_test_conv(const float *w, const float *bias, int Cin, int Cout, int K, int dil, int pad_l, ConvDesc *d,
-                           std::vector<float> *arena);
+std::string pack_test_conv(const float *w, const float *bias, int Cin, int Cout, int K, int dil, int pad_l, int hint,
+                           ConvDesc *d, std::vector<float> *arena);
+void set_tiling_override(int cfg, int ck);  // -1,-1 = automatic (kernel tuning only)
 std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout, int K, int stride, ConvDesc *d,
                             std::vector<float> *arena);
 

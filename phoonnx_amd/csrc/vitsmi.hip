@@ -124,7 +124,8 @@ struct Ctx {
 // Launch one conv through the engine; accounts algorithmic FLOPs/bytes per stage.
 void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, float *out, int64_t out_bstride,
           int flags, const int *len = nullptr, const float *res = nullptr, int64_t res_bstride = 0,
-          const float *bias_b = nullptr, int bias_b_stride = 0, float slope = 0.1f, float div = 1.f) {
+          const float *bias_b = nullptr, int bias_b_stride = 0, float slope = 0.1f, float div = 1.f,
+          float oslope = 1.f, float *out2 = nullptr, float oslope2 = 1.f) {
     ConvArgs a{};
     a.x = x;
     a.x_bstride = x_bstride;
@@ -138,6 +139,7 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
     a.out_bstride = out_bstride;
     a.res = res;
     a.res_bstride = res_bstride;
+    a.zeros = c.P(c.m.zeros_off);
     a.Cin = d.Cin;
     a.Cout = d.Cout;
     a.K = d.K;
@@ -150,6 +152,9 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
     a.flags = flags;
     a.slope = slope;
     a.div = div;
+    a.oslope = oslope;
+    a.out2 = out2;
+    a.oslope2 = oslope2;
     vits_handle *h = c.h;
     bool ev = h->timing;
     if (ev) {
@@ -378,58 +383,78 @@ size_t gen_region_floats(const Model &m, int B, int F) {
     return mx;
 }
 
+constexpr int kGenRegions = 10;
+
 int run_generator(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, const int *ylen, int B, int F,
                   const float *dec_cond, Slab &s) {
     const Model &m = h->model;
     hipStream_t st = h->stream;
     const size_t R = gen_region_floats(m, B, F);
-    float *reg[7];
-    for (int i = 0; i < 7; i++) reg[i] = slab_take<float>(s, R);
+    float *reg[kGenRegions];
+    for (int i = 0; i < kGenRegions; i++) reg[i] = slab_take<float>(s, R);
     h->cur_stage = 3;
     stage_mark(h, 3);
-    // x = conv_pre(z * y_mask) [+ cond(g)] (models.py:349-351)
-    float *x = reg[0];
-    conv(c, m.conv_pre, z, z_bstride, F, x, (int64_t)m.C0 * F, ylen ? PRO_MASK : 0, ylen, nullptr, 0, dec_cond, m.C0);
+    // Every leaky_relu of the generator (models.py:354,364; modules.py:303,307,357) is applied by the
+    // PRODUCER's epilogue, so no conv carries activation math in its MFMA loop (conv_engine.hip.hpp).
+    // A tensor that is needed both raw (residual) and activated (next conv input) is stored twice.
+    const float S = 0.1f;  // Generator.LRELU_SLOPE / ResBlock LRELU_SLOPE
+    const int nst = (int)m.ups.size();
+    // xa = leaky_relu(conv_pre(z * y_mask) [+ cond(g)], 0.1)            (models.py:349-354)
+    float *xa = reg[0];
+    conv(c, m.conv_pre, z, z_bstride, F, xa, (int64_t)m.C0 * F, ylen ? PRO_MASK : 0, ylen, nullptr, 0, dec_cond, m.C0,
+         1.f, 1.f, S);
     int T = F, Cc = m.C0, xs_idx = 0;
-    for (auto &stg : m.ups) {
-        // x = leaky_relu(x, 0.1); x = up(x) (models.py:354-355): transposed conv as a pixel-shuffled dense conv
-        float *y = reg[2];
+    for (int si = 0; si < nst; si++) {
+        const auto &stg = m.ups[si];
+        // y = up(xa) as a pixel-shuffled dense conv; stored raw (residual) and activated (conv input)
+        float *y = reg[2], *ya = reg[3];
         const int To = T * stg.u;
-        conv(c, stg.up, x, (int64_t)Cc * T, T, y, (int64_t)stg.C * To, PRO_LRELU, nullptr, nullptr, 0, nullptr, 0, 0.1f);
+        conv(c, stg.up, xa, (int64_t)Cc * T, T, y, (int64_t)stg.C * To, 0, nullptr, nullptr, 0, nullptr, 0, 1.f, 1.f, 1.f,
+             ya, S);
         T = To;
         Cc = stg.C;
         const int64_t sCT = (int64_t)Cc * T;
         xs_idx ^= 1;
-        float *xs = reg[xs_idx], *ra = reg[3], *rb = reg[4], *tmp = reg[5];
+        float *xs = reg[xs_idx];
+        float *ra[2] = {reg[4], reg[6]}, *raa[2] = {reg[5], reg[7]}, *tmp = reg[8];
         const int nk = (int)stg.rbs.size();
+        // slope applied to the stage output: 0.1 before the next upsampler, 0.01 before conv_post (:364)
+        const float out_slope = si == nst - 1 ? 0.01f : S;
         for (int j = 0; j < nk; j++) {
             const auto &rbk = stg.rbs[j];
-            const float *cur = y;
+            const float *cur = y, *cura = ya;
             // MRF accumulation (models.py:356-363): xs = rb0(x); xs += rb1(x); ... ; x = xs / nk
-            int last_flags = (j == 0 ? 0 : EPI_ACC) | (j == nk - 1 && nk > 1 ? EPI_DIV : 0);
-            if (nk == 1) last_flags = 0;
+            const bool final_rb = j == nk - 1;
+            const int last_flags = (j == 0 ? 0 : EPI_ACC) | (final_rb && nk > 1 ? EPI_DIV : 0);
+            const float last_oslope = final_rb ? out_slope : 1.f;
             for (int q = 0; q < rbk.n; q++) {
                 const bool last = q == rbk.n - 1;
-                float *dst = last ? xs : (q % 2 == 0 ? ra : rb);
-                if (rbk.type1) {  // modules.py:301-314
-                    conv(c, rbk.c1[q], cur, sCT, T, tmp, sCT, PRO_LRELU, nullptr, nullptr, 0, nullptr, 0, 0.1f);
-                    conv(c, rbk.c2[q], tmp, sCT, T, dst, sCT, PRO_LRELU | EPI_RES | (last ? last_flags : 0), nullptr, cur,
-                         sCT, nullptr, 0, 0.1f, (float)nk);
-                } else {  // modules.py:355-364
-                    conv(c, rbk.c1[q], cur, sCT, T, dst, sCT, PRO_LRELU | EPI_RES | (last ? last_flags : 0), nullptr, cur,
-                         sCT, nullptr, 0, 0.1f, (float)nk);
+                float *dst = last ? xs : ra[q & 1];
+                float *dsta = last ? nullptr : raa[q & 1];
+                const int fl = EPI_RES | (last ? last_flags : 0);
+                const float osl = last ? last_oslope : 1.f;
+                if (rbk.type1) {  // modules.py:301-314: x = c2(lrelu(c1(lrelu(x)))) + x
+                    conv(c, rbk.c1[q], cura, sCT, T, tmp, sCT, 0, nullptr, nullptr, 0, nullptr, 0, 1.f, 1.f, S);
+                    conv(c, rbk.c2[q], tmp, sCT, T, dst, sCT, fl, nullptr, cur, sCT, nullptr, 0, 1.f, (float)nk, osl, dsta,
+                         S);
+                } else {  // modules.py:355-364: x = c(lrelu(x)) + x
+                    conv(c, rbk.c1[q], cura, sCT, T, dst, sCT, fl, nullptr, cur, sCT, nullptr, 0, 1.f, (float)nk, osl, dsta,
+                         S);
                 }
                 cur = dst;
+                cura = dsta;
             }
         }
-        x = xs;
+        xa = xs;  // already activated for its only consumer
     }
+    float *x = xa;
     // x = leaky_relu(x) [slope 0.01]; conv_post; tanh (models.py:364-366)
     h->S = T;
-    h->d_out = reg[6];
+    h->d_out = reg[9];
     size_t lds = ((size_t)m.post_cin * (256 + m.post_k - 1) + (size_t)m.post_cin * m.post_k) * sizeof(float);
+    // (the leaky_relu(0.01) of models.py:364 was applied by the last stage's epilogue)
     post_conv_tanh_kernel<<<dim3((T + 255) / 256, B), 256, lds, st>>>(x, c.P(m.post_w), h->d_out, m.post_cin, m.post_k,
-                                                                      T, 0.01f);
+                                                                      T, 1.0f);
     c.note(hipGetLastError());
     h->stats.total_launches++;
     {
@@ -448,7 +473,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     if (d_noise_z && noise_z_stride < F)
         return fail(h, VITS_E_ARG, "noise_z has %lld frames per row but %d are needed", (long long)noise_z_stride, F);
     const size_t nCF = (size_t)B * C * F, nHF = (size_t)B * Hf * F;
-    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + 7 * al(gen_region_floats(m, B, F)) + (1 << 16);
+    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + kGenRegions * al(gen_region_floats(m, B, F)) + (1 << 16);
     for (auto &cd : m.flow) need += al((size_t)B * 2 * Hf * cd.n_wn);
     need += al((size_t)B * m.C0);
     if (int rc = slab_reserve(h, h->frm, need)) return rc;
@@ -811,7 +836,7 @@ int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t
     std::memset(&h->stats, 0, sizeof h->stats);
     h->conv_events_used = 0;
     const size_t nCF = (size_t)B * m.C * F;
-    size_t need = al(nCF) + 7 * al(gen_region_floats(m, B, F)) + al((size_t)B * m.C0) + (1 << 16);
+    size_t need = al(nCF) + kGenRegions * al(gen_region_floats(m, B, F)) + al((size_t)B * m.C0) + (1 << 16);
     if (int rc = slab_reserve(h, h->frm, need)) return rc;
     Slab &s = h->frm;
     s.used = 0;
@@ -941,6 +966,7 @@ static int run_test_conv(const ConvDesc &d, const std::vector<float> &arena, con
     a.bias = d.b_off >= 0 ? dA + d.b_off : nullptr;
     a.out = dout;
     a.out_bstride = out_bstride;
+    a.zeros = dA;  // pack_test_* reserve a zero page at offset 0
     a.Cin = d.Cin; a.Cout = d.Cout; a.K = d.K; a.dil = d.dil; a.padL = d.padL; a.CK = d.CK;
     a.nchunks = d.nchunks; a.steps4 = d.steps4; a.ups = d.ups;
     a.flags = ((flags & 1) ? PRO_LRELU : 0) | ((flags & 2) ? EPI_RELU : 0);
@@ -960,8 +986,72 @@ int vits_test_conv1d(int device_id, const float *x, int B, int Cin, int T, const
     if (int rc = test_dev(device_id)) return rc;
     ConvDesc d;
     std::vector<float> arena;
-    { std::string e = pack_test_conv(w, bias, Cin, Cout, K, dil, pad_l, &d, &arena); if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str()); }
+    { std::string e = pack_test_conv(w, bias, Cin, Cout, K, dil, pad_l, (flags >> 8) & 3, &d, &arena); if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str()); }
     return run_test_conv(d, arena, x, B, T, flags, slope, out, (size_t)B * Cout * T, (int64_t)Cout * T);
+}
+
+// Micro-benchmark of one conv shape on random data (kernel tuning; tools/conv_bench.py): returns the
+// average launch time in ms over `iters` back-to-back launches (HIP events on the null stream).
+int vits_bench_conv1d(int device_id, int B, int Cin, int Cout, int T, int K, int dil, int hint, int iters,
+                      int cfg_override, int ck_override, float *ms_out) {
+    if (int rc = test_dev(device_id)) return rc;
+    std::vector<float> w((size_t)Cout * Cin * K), x((size_t)B * Cin * T);
+    uint32_t s = 12345u;
+    auto rnd = [&]() {
+        s = s * 1664525u + 1013904223u;
+        return ((s >> 8) * (1.0f / 8388608.0f)) - 1.0f;
+    };
+    for (auto &v : w) v = rnd() * 0.05f;
+    for (auto &v : x) v = rnd();
+    ConvDesc d;
+    std::vector<float> arena;
+    set_tiling_override(cfg_override, ck_override);
+    const int dbg = hint >> 8;  // bit0: no DMA after warm-up chunks, bit1: no epilogue, bit2: no lrelu prologue
+    hint &= 3;
+    std::string e = pack_test_conv(w.data(), nullptr, Cin, Cout, K, dil, dil * (K - 1) / 2, hint, &d, &arena);
+    set_tiling_override(-1, -1);
+    if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
+    float *dA = nullptr, *dx = nullptr, *dout = nullptr;
+    TCHECK(hipMalloc((void **)&dA, arena.size() * 4));
+    TCHECK(hipMalloc((void **)&dx, x.size() * 4));
+    TCHECK(hipMalloc((void **)&dout, (size_t)B * Cout * T * 4));
+    TCHECK(hipMemcpy(dA, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    ConvArgs a{};
+    a.x = dx;
+    a.x_bstride = (int64_t)Cin * T;
+    a.T = T;
+    a.wp = dA + d.w_off;
+    a.out = dout;
+    a.out_bstride = (int64_t)Cout * T;
+    a.zeros = dA;
+    a.Cin = d.Cin; a.Cout = d.Cout; a.K = d.K; a.dil = d.dil; a.padL = d.padL; a.CK = d.CK;
+    a.nchunks = d.nchunks; a.steps4 = d.steps4; a.ups = 1;
+    a.flags = ((dbg & 4) ? 0 : PRO_LRELU) | ((dbg & 1) ? DBG_NO_DMA : 0) | ((dbg & 2) ? DBG_NO_EPI : 0);
+    a.slope = 0.1f;
+    a.div = 1.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 2; i++) TCHECK(launch_conv(a, d.cfg, B, nullptr));
+    TCHECK(hipDeviceSynchronize());
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; i++) TCHECK(launch_conv(a, d.cfg, B, nullptr));
+    hipEventRecord(e1, nullptr);
+    TCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) {
+        ms_out[0] = ms / iters;
+        ms_out[1] = (float)d.cfg;
+        ms_out[2] = (float)d.CK;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(dA);
+    hipFree(dx);
+    hipFree(dout);
+    return VITS_OK;
 }
 
 int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,

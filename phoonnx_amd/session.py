@@ -263,7 +263,8 @@ class MiSession:
 
 
 # kernel-level hooks (tests)
-def test_conv1d(x, w, bias=None, dil=1, pad_l=0, lrelu_slope=None, relu=False, device_id=0):
+def test_conv1d(x, w, bias=None, dil=1, pad_l=0, lrelu_slope=None, relu=False, device_id=0, hint=0):
+    """hint: tile-size class as chosen at pack time (0 generator, 1 flow, 2 token domain)."""
     lib = _ffi.load()
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
@@ -271,7 +272,7 @@ def test_conv1d(x, w, bias=None, dil=1, pad_l=0, lrelu_slope=None, relu=False, d
     Cout, _, K = w.shape
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     out = np.empty((B, Cout, T), np.float32)
-    flags = (1 if lrelu_slope is not None else 0) | (2 if relu else 0)
+    flags = (1 if lrelu_slope is not None else 0) | (2 if relu else 0) | ((hint & 3) << 8)
     rc = lib.vits_test_conv1d(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, dil, pad_l, flags,
                               float(lrelu_slope or 0.0), _ffi.ptr(out))
     if rc != 0:

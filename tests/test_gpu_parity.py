@@ -40,8 +40,11 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("hint", [0, 1, 2])
 @pytest.mark.parametrize("B,Cin,Cout,T,K,dil", CONV_CASES)
-def test_conv_engine_matches_oracle(B, Cin, Cout, T, K, dil):
+def test_conv_engine_matches_oracle(B, Cin, Cout, T, K, dil, hint):
+    # hint selects the tile family (generator / flow / token domain); T % 4 != 0 cases take the
+    # 4-byte LDS-DMA path, T % 4 == 0 the 16-byte one
     from phoonnx_amd.session import test_conv1d
     from vits_oracle import conv1d
     rng = np.random.default_rng(B * 1000 + Cin + Cout + T)
@@ -49,14 +52,29 @@ def test_conv_engine_matches_oracle(B, Cin, Cout, T, K, dil):
     w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
     pad = dil * (K - 1) // 2
-    got = test_conv1d(x, w, b, dil=dil, pad_l=pad)
+    got = test_conv1d(x, w, b, dil=dil, pad_l=pad, hint=hint)
     ref = conv1d(x, w, b, dil=dil, pad_l=pad, pad_r=dil * (K - 1) - pad)
     np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
     # fused leaky-relu prologue + relu epilogue
-    got = test_conv1d(x, w, None, dil=dil, pad_l=pad, lrelu_slope=0.1, relu=True)
+    got = test_conv1d(x, w, None, dil=dil, pad_l=pad, lrelu_slope=0.1, relu=True, hint=hint)
     xa = np.where(x > 0, x, x * np.float32(0.1)).astype(np.float32)
     ref = np.maximum(conv1d(xa, w, None, dil=dil, pad_l=pad, pad_r=dil * (K - 1) - pad), 0)
     np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("T", [128, 1000, 1024, 4100])
+def test_conv_engine_long_rows_many_chunks(T):
+    # several channel chunks (double-buffered LDS-DMA pipeline), wide halo, left pad not a multiple of 4
+    from phoonnx_amd.session import test_conv1d
+    from vits_oracle import conv1d
+    rng = np.random.default_rng(T)
+    x = rng.standard_normal((2, 128, T)).astype(np.float32)
+    w = (rng.standard_normal((128, 128, 11)) / np.sqrt(128 * 11)).astype(np.float32)
+    for dil in (1, 5):
+        pad = dil * 5
+        got = test_conv1d(x, w, None, dil=dil, pad_l=pad)
+        ref = conv1d(x, w, None, dil=dil, pad_l=pad, pad_r=pad)
+        np.testing.assert_allclose(got, ref, atol=3e-5, rtol=1e-5)
 
 
 def test_conv_engine_identity_asymmetric():
