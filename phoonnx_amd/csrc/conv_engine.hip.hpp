@@ -59,7 +59,8 @@ enum : int {
 
 struct ConvArgs {
     const float *x;
-    int64_t x_bstride;  // floats between batch items of x (channel stride is T)
+    int64_t x_bstride;  // floats between batch items of x
+    int x_cstride;      // floats between channels of x (0 = T); > T means rows padded with ZEROS up to it
     int T;              // input (= virtual output) length
     const int *len;     // [B] valid lengths or nullptr
     const float *wp;    // packed weights
@@ -67,7 +68,8 @@ struct ConvArgs {
     const float *bias_b;  // per-batch bias [B][bias_b_stride] or nullptr
     int bias_b_stride;
     float *out;
-    int64_t out_bstride;  // channel stride of out is T*ups
+    int64_t out_bstride;
+    int out_cstride;      // floats between channels of out/out2/res (0 = T*ups); pad columns are written as 0
     float *out2;          // optional second output: leaky_relu(final value, oslope2); same layout as out
     const float *res;
     int64_t res_bstride;
@@ -105,7 +107,7 @@ struct ConvTile {
 };
 
 template <int MW, int NW, int WM, int WN, int VEC, int ACT>
-__global__ __launch_bounds__(256) void conv_engine_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (MW * NW >= 4) ? 2 : 4) void conv_engine_kernel(ConvArgs a) {
     using Tile = ConvTile<MW, NW, WM, WN>;
     constexpr int BM = Tile::BM, BN = Tile::BN, MB = BM / 32;
     __shared__ __attribute__((aligned(16))) float stageP[Tile::STAGE_FLOATS];
@@ -135,14 +137,14 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(ConvArgs a) {
         for (int i = wave; i < na; i += 4) lds_dma<16>(src + i * 64, ab + i * 256);
         // x tile: CK rows x LW columns, linear in LDS; out-of-range lanes read the zero page
         const int rows_valid = (a.Cin - chunk * CK) < CK ? (a.Cin - chunk * CK) : CK;
-        const float *xc = xb + (int64_t)chunk * CK * T;
+        const float *xc = xb + (int64_t)chunk * CK * a.x_cstride;
         for (int s = 0; s < nxs; s++) {
             const int e = (s * 256 + tid) * VEC;
             const int r = (int)__umulhi((unsigned)e, a.magic);
             const int c = e - r * LW;
             const int t = t0 - a.padLa + c;
             const bool ok = r < rows_valid && t >= 0 && t < in_lim;
-            const float *src_x = ok ? xc + (int64_t)r * T + t : a.zeros + lane * VEC;
+            const float *src_x = ok ? xc + (int64_t)r * a.x_cstride + t : a.zeros + lane * VEC;
             lds_dma<VEC * 4>(src_x, stage + (s * 256 + wave * 64) * VEC);
         }
     };
@@ -246,6 +248,33 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // ---- per-lane epilogue constants, computed up front so their loads hide behind the main loop.
+    // C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+    const int flags = a.flags;
+    const int ups = a.ups;
+    const int Tout = T * ups;
+    float *ob = a.out + (int64_t)b * a.out_bstride;
+    const float *rb = a.res ? a.res + (int64_t)b * a.res_bstride : a.zeros;
+    const float *biasp = a.bias ? a.bias : a.zeros;
+    const float *bbp = a.bias_b ? a.bias_b + (int64_t)b * a.bias_b_stride : a.zeros;
+    const int bb_on = a.bias_b ? 1 : 0, b_on = a.bias ? 1 : 0;
+    const int mblk0 = mblk_base + wm * MW;
+    // element offset of (co, t = 0) inside the utterance, recomputed where needed (2 VALU ops) rather than
+    // kept in 32 registers across the main loop; -1 = row out of range
+    auto row_off = [&](int m, int r) -> int {
+        const int co = (mblk0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (co >= a.Cout) return -1;
+        return ups == 1 ? co * a.out_cstride : (co / ups) * Tout + (co % ups);
+    };
+    float brow[MW][16];
+#pragma unroll
+    for (int m = 0; m < MW; m++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = (mblk0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int cc = co < a.Cout ? co : 0;
+            brow[m][r] = biasp[cc * b_on] + bbp[cc * bb_on];
+        }
     // software pipeline over input-channel chunks, two stages, one barrier per chunk
     const int nchunks = a.nchunks;
     const bool dbg_nodma = a.flags & DBG_NO_DMA;
@@ -260,11 +289,9 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(ConvArgs a) {
         compute(stageQ);
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-    // Branch-free per element: absent bias pointers read the zero page, flags become multipliers /
-    // clamps, loads of a tile are issued together (a per-element "load or not" branch makes hipcc wait
-    // vmcnt(0) per element).
-    const int flags = a.flags;
+    // ---- epilogue: branch-free per element (absent bias pointers read the zero page, flags become
+    // multipliers / clamps; a per-element "load or not" branch makes hipcc wait vmcnt(0) per element).
+    // The residual / accumulate operands of all NW tiles of a block row are requested together.
     if (flags & DBG_NO_EPI) {  // ablation only: keep the accumulators live, skip the stores
         float s = 0.f;
 #pragma unroll
@@ -274,64 +301,64 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(ConvArgs a) {
         if (s == 12345.678f) a.out[tid] = s;
         return;
     }
-    const int ups = a.ups;
-    const int Tout = T * ups;
-    float *ob = a.out + (int64_t)b * a.out_bstride;
     float *ob2 = a.out2 ? a.out2 + (int64_t)b * a.out_bstride : nullptr;
-    const float *rb = a.res ? a.res + (int64_t)b * a.res_bstride : nullptr;
-    const float *biasp = a.bias ? a.bias : a.zeros;
-    const float *bbp = a.bias_b ? a.bias_b + (int64_t)b * a.bias_b_stride : a.zeros;
-    const int bb_on = a.bias_b ? 1 : 0, b_on = a.bias ? 1 : 0;
     const float relu_floor = (flags & EPI_RELU) ? 0.f : -__builtin_inff();
-    const float inv_unused = 0.f;
-    (void)inv_unused;
-    const int mblk0 = mblk_base + wm * MW;
     const float oslope = a.oslope, oslope2 = a.oslope2, div = a.div;
+    // second operand added to the value: the residual tensor, or (EPI_ACC / EPI_COUPLING) the old output
+    const float *addp = (flags & EPI_RES) ? rb : ob;
+    const bool has_add = flags & (EPI_RES | EPI_ACC | EPI_COUPLING);
 #pragma unroll
     for (int m = 0; m < MW; m++) {
-        // per-row constants of this lane's 16 rows
-        float brow[16];
-        int orow[16];  // element offset of (co, t=0) inside the batch item; -1 = row out of range
+        int orow_m[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int co = (mblk0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const bool okc = co < a.Cout;
-            const int cc = okc ? co : 0;
-            brow[r] = biasp[cc * b_on] + bbp[cc * bb_on];
-            orow[r] = okc ? (ups == 1 ? co * T : (co / ups) * Tout + (co % ups)) : -1;
+        for (int r = 0; r < 16; r++) orow_m[r] = row_off(m, r);
+        float ad[NW][16];
+        if (has_add) {
+#pragma unroll
+            for (int n = 0; n < NW; n++) {
+                const int t = t0 + wn * (NW * 32) + n * 32 + l31;
+                const int tt = t * ups;
+#pragma unroll
+                for (int r = 0; r < 16; r++) ad[n][r] = (orow_m[r] >= 0 && t < T) ? addp[orow_m[r] + tt] : 0.f;
+            }
         }
 #pragma unroll
         for (int n = 0; n < NW; n++) {
             const int t = t0 + wn * (NW * 32) + n * 32 + l31;
-            if (t >= T) continue;
+            if (t >= T) {
+                if (ups == 1 && t < a.out_cstride) {  // row padding up to the pitch: zeros (see x_cstride)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        if (orow_m[r] >= 0) {
+                            ob[orow_m[r] + t] = 0.f;
+                            if (ob2) ob2[orow_m[r] + t] = 0.f;
+                        }
+                }
+                continue;
+            }
             const float mk = (t < len_b) ? 1.f : 0.f;
             const float mk_sel = (flags & EPI_MASK) ? mk : 1.f;
             const int tt = t * ups;
             float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[m][n][r] + brow[r], relu_floor);
+            for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[m][n][r] + brow[m][r], relu_floor);
             if (flags & EPI_COUPLING) {
-                float old[16];
-#pragma unroll
-                for (int r = 0; r < 16; r++) old[r] = orow[r] >= 0 ? ob[orow[r] + tt] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    if (orow[r] >= 0) ob[orow[r] + tt] = (old[r] - v[r] * mk) * mk;
+                    if (orow_m[r] >= 0) ob[orow_m[r] + tt] = (ad[n][r] - v[r] * mk) * mk;
                 continue;
             }
+            if (has_add) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) v[r] *= mk_sel;
-            if (flags & EPI_RES) {
-                float rr[16];
+                for (int r = 0; r < 16; r++) v[r] = v[r] * mk_sel + ad[n][r];
+            } else {
 #pragma unroll
-                for (int r = 0; r < 16; r++) rr[r] = orow[r] >= 0 ? rb[orow[r] + tt] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) v[r] += rr[r];
+                for (int r = 0; r < 16; r++) v[r] *= mk_sel;
             }
-            if (flags & EPI_ACC) {
+            if ((flags & EPI_RES) && (flags & EPI_ACC)) {  // residual AND accumulate: second fetch (MRF tail)
                 float oo[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) oo[r] = orow[r] >= 0 ? ob[orow[r] + tt] : 0.f;
+                for (int r = 0; r < 16; r++) oo[r] = orow_m[r] >= 0 ? ob[orow_m[r] + tt] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[r] += oo[r];
             }
@@ -341,11 +368,11 @@ __global__ __launch_bounds__(256) void conv_engine_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < 16; r++)
-                if (orow[r] >= 0) ob[orow[r] + tt] = lrelu_f(v[r], oslope);
+                if (orow_m[r] >= 0) ob[orow_m[r] + tt] = lrelu_f(v[r], oslope);
             if (ob2) {
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    if (orow[r] >= 0) ob2[orow[r] + tt] = lrelu_f(v[r], oslope2);
+                    if (orow_m[r] >= 0) ob2[orow_m[r] + tt] = lrelu_f(v[r], oslope2);
             }
         }
     }
@@ -384,7 +411,10 @@ inline hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
     const int BN = conv_tile_n(cfg), BM = conv_tile_m(cfg);
     const int halo = (a.K - 1) * a.dil;
     // 16-byte DMA needs 16-byte aligned rows: T % 4 == 0, aligned base/batch stride, no ragged input mask
-    const bool vec4 = (a.T % 4 == 0) && (a.x_bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
+    if (a.x_cstride == 0) a.x_cstride = a.T;
+    if (a.out_cstride == 0) a.out_cstride = a.T * a.ups;
+    // (rows may be padded with zeros up to a pitch that is a multiple of 4: x_cstride)
+    const bool vec4 = (a.x_cstride % 4 == 0) && (a.x_bstride % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
                       !(a.flags & PRO_MASK);
     if (vec4) {
         a.padLa = (a.padL + 3) & ~3;
@@ -404,7 +434,7 @@ inline hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
     if (grid.x == 0 || grid.y == 0 || B == 0) return hipSuccess;
     const size_t stage = (size_t)a.xs_floats + (size_t)(BM / 32) * (a.K * a.CK / 8) * 256;
     if (stage > (size_t)conv_stage_floats(cfg)) return hipErrorInvalidValue;  // pick_tiling guarantees this never fires
-    if ((int64_t)a.Cout * a.T >= (int64_t)1 << 31) return hipErrorInvalidValue;  // 32-bit element offsets per utterance
+    if ((int64_t)a.Cout * (a.ups == 1 ? a.out_cstride : a.T) >= (int64_t)1 << 31) return hipErrorInvalidValue;  // 32-bit element offsets per utterance
     switch (cfg) {
         case 0: return launch_conv_t<1, 4, 1, 4>(a, grid, vec4, act, stream);
         case 1: return launch_conv_t<2, 2, 1, 4>(a, grid, vec4, act, stream);

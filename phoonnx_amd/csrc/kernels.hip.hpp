@@ -103,6 +103,82 @@ __global__ void dds_dw_ln_gelu_kernel(const float *x, float *y, const float *w, 
     for (int c = 0; c < C; c++) o[(int64_t)c * T] = gelu_erf((conv(c) - mean) * rs * gamma[c] + beta[c]);
 }
 
+// ---- tiled LayerNorm family (C <= 256): one workgroup = 32 time steps x 8 channel groups.
+// Thread (tl = tid&31, cg = tid>>5) owns channels cg, cg+8, ... of time step t0+tl, keeps them in
+// registers (one global read, one write), and the 8 partial sums per time step meet in LDS.  A wave reads
+// two 128-byte rows per instruction, and B*T/32 workgroups fill the chip where the one-lane-per-(b,t)
+// kernels above ran on 128 wavefronts.  DW = 1 computes the DDSConv depthwise conv of x*mask on the fly
+// (modules.py:121-122) instead of reading `in` directly.
+template <int DW>
+__global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *out, const float *gamma,
+                                                      const float *beta, const int *len, int C, int T, int flags,
+                                                      const float *dw_w, const float *dw_b, int K, int dil) {
+    __shared__ float red[8][32];
+    const int tid = threadIdx.x, tl = tid & 31, cg = tid >> 5;
+    const int t = blockIdx.x * 32 + tl, b = blockIdx.y;
+    const int L = len ? len[b] : T;
+    const bool tv = t < T;
+    const float *p = in + (int64_t)b * C * T;
+    float *o = out + (int64_t)b * C * T;
+    constexpr int CPT = 32;  // channels per thread, C <= 256
+    float v[CPT];
+    const int pad = (K * dil - dil) / 2;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg + 8 * i;
+        float x = 0.f;
+        if (c < C && tv) {
+            if (DW) {
+                x = dw_b[c];
+                for (int k = 0; k < K; k++) {
+                    const int tt = t + k * dil - pad;
+                    const float xv = (tt >= 0 && tt < T && tt < L) ? p[(int64_t)c * T + tt] : 0.f;
+                    x += dw_w[c * K + k] * xv;
+                }
+            } else {
+                x = p[(int64_t)c * T + t];
+                if (flags & LN_RELU_IN) x = fmaxf(x, 0.f);
+            }
+        }
+        v[i] = x;
+        s += x;
+    }
+    red[cg][tl] = s;
+    __syncthreads();
+    float mean = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; g++) mean += red[g][tl];
+    mean /= (float)C;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg + 8 * i;
+        const float d = (c < C) ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    red[cg][tl] = q;
+    __syncthreads();
+    float var = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; g++) var += red[g][tl];
+    var /= (float)C;
+    const float rs = 1.0f / sqrtf(var + 1e-5f);
+    const float mk = (!(flags & LN_MASK) || t < L) ? 1.f : 0.f;
+    if (!tv) return;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg + 8 * i;
+        if (c < C) {
+            float y = (v[i] - mean) * rs * gamma[c] + beta[c];
+            if (flags & LN_GELU) y = gelu_erf(y);
+            if (flags & LN_ACCUM) y += o[(int64_t)c * T + t];
+            o[(int64_t)c * T + t] = y * mk;
+        }
+    }
+}
+
 // ---- a7: ConvFlow pre (1 -> C) + conditioning add: h = w*z[ch] + b + cond (modules.py:498-499,119)
 __global__ void cf_pre_kernel(const float *z, int ch, const float *w, const float *bias, const float *cond,
                               float *h, int C, int T) {
@@ -297,7 +373,8 @@ __global__ void duration_kernel(const float *logw, const int *len, float length_
 // m_p / logs_p are strided views (batch stride `bstride`, channel stride T).
 __global__ void expand_prior_strided_kernel(const float *m_p, const float *logs_p, int64_t bstride, const int *cum,
                                             const int *len, const int *y_len, const float *noise,
-                                            int64_t noise_stride, float noise_scale, float *z_p, int C, int T, int F) {
+                                            int64_t noise_stride, float noise_scale, float *z_p, int C, int T, int F,
+                                            int Fnoise) {
     int f = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (f >= F) return;
     const int *cb = cum + (int64_t)b * T;
@@ -318,7 +395,7 @@ __global__ void expand_prior_strided_kernel(const float *m_p, const float *logs_
             mp = mb[(int64_t)c * T + tok];
             lp = lb[(int64_t)c * T + tok];
         }
-        float e = noise ? noise[((int64_t)b * C + c) * noise_stride + f] : 0.f;
+        float e = (noise && f < Fnoise) ? noise[((int64_t)b * C + c) * noise_stride + f] : 0.f;
         z_p[((int64_t)b * C + c) * F + f] = mp + e * expf(lp) * noise_scale;
     }
 }
@@ -335,9 +412,9 @@ __global__ void ylen_to_i64(const int *in, int64_t *out, int B) {
 }
 
 // copy a strided [B][C][T] view (batch stride bstride) into a contiguous buffer
-__global__ void gather_view_kernel(const float *in, int64_t bstride, float *out, int C, int T) {
+__global__ void gather_view_kernel(const float *in, int64_t bstride, int cstride, float *out, int C, int T) {
     int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
-    if (t < T) out[((int64_t)b * C + c) * T + t] = in[(int64_t)b * bstride + (int64_t)c * T + t];
+    if (t < T) out[((int64_t)b * C + c) * T + t] = in[(int64_t)b * bstride + (int64_t)c * cstride + t];
 }
 
 // ---- speaker conditioning: out[b,r] = bias[r] + W[r,:] . emb_g[sid[b],:] (1x1 conv on g) -------
@@ -450,12 +527,15 @@ __global__ void fill_normal_kernel(float *out, int64_t n, uint64_t seed, uint64_
 // Query columns live on lanes (lane&31) in both products, so the softmax statistics are per-lane
 // scalars and the only cross-lane traffic is one lane^32 exchange per block.
 template <int DKB>  // ceil(dk/32)
-__global__ __launch_bounds__(64) void attention_relpos_kernel(const float *qkv, float *out, const float *relk,
-                                                              const float *relv, const int *len, int Hc, int T,
-                                                              int dk, int win) {
+__global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv, float *out, const float *relk,
+                                                               const float *relv, const int *len, int Hc, int T,
+                                                               int dk, int win) {
+    // 4 wavefronts = 4 consecutive 32-query blocks of one (utterance, head); every 32-key block of K and V
+    // is staged ONCE in LDS (coalesced 128-byte rows) and shared by the four waves.
+    __shared__ float kt[DKB * 32 * 32];
     __shared__ float vs[DKB * 32 * 33];
-    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
-    const int i0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
     const int L = len[b] < T ? len[b] : T;
     const int i = i0 + l31;
     const float *q = qkv + ((int64_t)b * 3 * Hc + (int64_t)h * dk) * T;
@@ -463,17 +543,13 @@ __global__ __launch_bounds__(64) void attention_relpos_kernel(const float *qkv, 
     const float *v = k + (int64_t)Hc * T;
     float *o = out + ((int64_t)b * Hc + (int64_t)h * dk) * T;
     constexpr int STEPS = DKB * 16;
-    if (i0 >= L) {  // fully padded query block: defined zeros (never read by valid positions)
-        for (int d = hi; d < dk; d += 2)
-            if (i < T) o[(int64_t)d * T + i] = 0.f;
-        return;
-    }
+    const bool active = i0 < L;  // a fully padded query block only helps staging and writes zeros
     const float sq = sqrtf((float)dk);
     float qf[STEPS];
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
         int d = 2 * s + hi;
-        qf[s] = (d < dk && i < T) ? q[(int64_t)d * T + i] / sq : 0.f;
+        qf[s] = (active && d < dk && i < T) ? q[(int64_t)d * T + i] / sq : 0.f;
     }
     // relative-key logits of this lane's query: rq[m] = q_i . E_k[m]
     float rq[9];
@@ -502,21 +578,24 @@ __global__ __launch_bounds__(64) void attention_relpos_kernel(const float *qkv, 
         for (int r = 0; r < 16; r++) oacc[db][r] = 0.f;
 
     const int nkb = (L + 31) / 32;
+    const int srow = tid >> 5, scol = tid & 31;  // staging: 8 rows x 32 columns per pass
     for (int kb = 0; kb < nkb; kb++) {
         const int j0 = kb * 32;
         __syncthreads();
-        // stage V block [dk][32] (coalesced rows) into LDS with stride 33
-        for (int d = hi; d < DKB * 32; d += 2) {
-            int j = j0 + l31;
-            vs[d * 33 + l31] = (d < dk && j < T) ? v[(int64_t)d * T + j] : 0.f;
+        for (int d = srow; d < DKB * 32; d += 8) {
+            const int j = j0 + scol;
+            const bool ok = d < dk && j < T;
+            kt[d * 32 + scol] = ok ? k[(int64_t)d * T + j] : 0.f;
+            vs[d * 33 + scol] = ok ? v[(int64_t)d * T + j] : 0.f;
         }
+        __syncthreads();
+        if (!active) continue;
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; r++) s[r] = 0.f;
 #pragma unroll
         for (int st = 0; st < STEPS; st++) {
-            int d = 2 * st + hi, j = j0 + l31;
-            float a = (d < dk && j < T) ? k[(int64_t)d * T + j] : 0.f;
+            const float a = kt[(2 * st + hi) * 32 + l31];
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qf[st], s, 0, 0, 0);
         }
         const bool near = (j0 + 31 >= i0 - win) && (j0 <= i0 + 31 + win);
@@ -564,7 +643,6 @@ __global__ __launch_bounds__(64) void attention_relpos_kernel(const float *qkv, 
                     if (mm == m && mm < nrel) wrel[mm] += s[r];
             }
         }
-        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -574,6 +652,11 @@ __global__ __launch_bounds__(64) void attention_relpos_kernel(const float *qkv, 
                 oacc[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[r], oacc[db], 0, 0, 0);
             }
         }
+    }
+    if (!active) {
+        for (int d = hi; d < dk; d += 2)
+            if (i < T) o[(int64_t)d * T + i] = 0.f;
+        return;
     }
 #pragma unroll
     for (int m = 0; m < 9; m++) wrel[m] += __shfl_xor(wrel[m], 32);

@@ -48,6 +48,7 @@ struct vits_handle {
     std::string err;
     // last-run state (for taps / outputs)
     int B = 0, T = 0, F = 0, S = 0;
+    int Fpitch = 0;  // row pitch of the frame-domain flow tensors (F rounded up to 4)
     float *d_x = nullptr, *d_mp = nullptr, *d_logs = nullptr, *d_logw = nullptr, *d_wceil = nullptr;
     float *d_zp = nullptr, *d_z = nullptr, *d_out = nullptr;
     int *d_len = nullptr, *d_ylen = nullptr, *d_cum = nullptr;
@@ -125,7 +126,7 @@ struct Ctx {
 void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, float *out, int64_t out_bstride,
           int flags, const int *len = nullptr, const float *res = nullptr, int64_t res_bstride = 0,
           const float *bias_b = nullptr, int bias_b_stride = 0, float slope = 0.1f, float div = 1.f,
-          float oslope = 1.f, float *out2 = nullptr, float oslope2 = 1.f) {
+          float oslope = 1.f, float *out2 = nullptr, float oslope2 = 1.f, int x_cstride = 0, int out_cstride = 0) {
     ConvArgs a{};
     a.x = x;
     a.x_bstride = x_bstride;
@@ -155,6 +156,8 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
     a.oslope = oslope;
     a.out2 = out2;
     a.oslope2 = oslope2;
+    a.x_cstride = x_cstride;
+    a.out_cstride = out_cstride;
     vits_handle *h = c.h;
     bool ev = h->timing;
     if (ev) {
@@ -188,7 +191,11 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
 inline dim3 grid_t(int T, int y, int z = 1) { return dim3((T + 255) / 256, y, z); }
 
 void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const int *len, int C, int T, int flags) {
-    layernorm_c_kernel<<<dim3((T + 63) / 64, c.B), 64, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags);
+    if (C <= 256)
+        ln_tile_kernel<0><<<dim3((T + 31) / 32, c.B), 256, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags, nullptr,
+                                                                      nullptr, 1, 1);
+    else
+        layernorm_c_kernel<<<dim3((T + 63) / 64, c.B), 64, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags);
     c.note(hipGetLastError());
     c.h->stats.total_launches++;
 }
@@ -197,9 +204,13 @@ void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const 
 void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const int *len, int C, int T) {
     for (int l = 0; l < d.n_layers; l++) {
         const auto &L = d.l[l];
-        dds_dw_ln_gelu_kernel<<<dim3((T + 63) / 64, c.B), 64, 0, c.st>>>(hbuf, y, c.P(L.dw_w), c.P(L.dw_b),
-                                                                         c.P(L.ln1_g), c.P(L.ln1_b), len, C, T, d.K,
-                                                                         L.dil);
+        if (C <= 256)
+            ln_tile_kernel<1><<<dim3((T + 31) / 32, c.B), 256, 0, c.st>>>(hbuf, y, c.P(L.ln1_g), c.P(L.ln1_b), len, C, T,
+                                                                          LN_GELU, c.P(L.dw_w), c.P(L.dw_b), d.K, L.dil);
+        else
+            dds_dw_ln_gelu_kernel<<<dim3((T + 63) / 64, c.B), 64, 0, c.st>>>(hbuf, y, c.P(L.dw_w), c.P(L.dw_b),
+                                                                             c.P(L.ln1_g), c.P(L.ln1_b), len, C, T, d.K,
+                                                                             L.dil);
         c.note(hipGetLastError());
         c.h->stats.total_launches++;
         conv(c, L.pw, y, (int64_t)C * T, T, y2, (int64_t)C * T, 0);
@@ -258,24 +269,27 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     for (auto &L : m.enc) {
         // q|k|v = 1x1 convs (attentions.py:216-218), fused into one [3H,H] GEMM
         conv(c, L.qkv, x, sHT, T, qkv, 3 * sHT, 0);
-        dim3 ag((T + 31) / 32, m.n_heads, B);
+        dim3 ag((T + 127) / 128, m.n_heads, B);
         int dkb = (m.dk + 31) / 32;
         switch (dkb) {
-            case 1: attention_relpos_kernel<1><<<ag, 64, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
-            case 2: attention_relpos_kernel<2><<<ag, 64, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
-            case 3: attention_relpos_kernel<3><<<ag, 64, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
-            default: attention_relpos_kernel<4><<<ag, 64, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
+            case 1: attention_relpos_kernel<1><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
+            case 2: attention_relpos_kernel<2><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
+            case 3: attention_relpos_kernel<3><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
+            default: attention_relpos_kernel<4><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
         }
         c.note(hipGetLastError());
         h->stats.total_launches++;
         h->stats.enc_flops += 2.0 * B * m.n_heads * (2.0 * m.dk * T * (double)T);
         // x = LN(x + conv_o(att))  (attentions.py:66-68)
         conv(c, L.o, att, sHT, T, x, sHT, EPI_RES, nullptr, x, sHT);
-        layernorm(c, x, x, L.ln1_g, L.ln1_b, len, H, T, 0);
+        // Padded positions never reach valid ones (keys are masked, every other op is per-position or reads
+        // x*mask), so masking the LayerNorm outputs changes no observable value and lets the FFN convs read
+        // their input without a ragged mask (16-byte LDS-DMA path).
+        layernorm(c, x, x, L.ln1_g, L.ln1_b, len, H, T, LN_MASK);
         // FFN (attentions.py:386-407): conv(x*mask) -> relu -> conv(h*mask) -> *mask ; x = LN(x + y)
-        conv(c, L.ffn1, x, sHT, T, ffh, (int64_t)m.FF * T, PRO_MASK | EPI_RELU, len);
-        conv(c, L.ffn2, ffh, (int64_t)m.FF * T, T, x, sHT, PRO_MASK | EPI_MASK | EPI_RES, len, x, sHT);
-        layernorm(c, x, x, L.ln2_g, L.ln2_b, len, H, T, 0);
+        conv(c, L.ffn1, x, sHT, T, ffh, (int64_t)m.FF * T, EPI_RELU | EPI_MASK, len);
+        conv(c, L.ffn2, ffh, (int64_t)m.FF * T, T, x, sHT, EPI_MASK | EPI_RES, len, x, sHT);
+        layernorm(c, x, x, L.ln2_g, L.ln2_b, len, H, T, LN_MASK);
     }
     // x = x * mask ; stats = proj(x) * mask (models.py:205-208)
     mask_kernel<<<dim3((T + 255) / 256, H, B), 256, 0, st>>>(x, len, H, T);
@@ -373,7 +387,7 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
 
 // frame-domain layout: flow buffers + generator ping-pong regions
 size_t gen_region_floats(const Model &m, int B, int F) {
-    size_t mx = (size_t)B * m.C0 * F;
+    size_t mx = (size_t)B * m.C0 * ((F + 3) & ~3);
     int64_t t = F;
     for (auto &st : m.ups) {
         t *= st.u;
@@ -385,8 +399,8 @@ size_t gen_region_floats(const Model &m, int B, int F) {
 
 constexpr int kGenRegions = 10;
 
-int run_generator(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, const int *ylen, int B, int F,
-                  const float *dec_cond, Slab &s) {
+int run_generator(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B,
+                  int F, const float *dec_cond, Slab &s) {
     const Model &m = h->model;
     hipStream_t st = h->stream;
     const size_t R = gen_region_floats(m, B, F);
@@ -401,16 +415,19 @@ int run_generator(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, con
     const int nst = (int)m.ups.size();
     // xa = leaky_relu(conv_pre(z * y_mask) [+ cond(g)], 0.1)            (models.py:349-354)
     float *xa = reg[0];
-    conv(c, m.conv_pre, z, z_bstride, F, xa, (int64_t)m.C0 * F, ylen ? PRO_MASK : 0, ylen, nullptr, 0, dec_cond, m.C0,
-         1.f, 1.f, S);
+    const int Fp = (F + 3) & ~3;  // pitch of conv_pre's output rows: lets ups[0] use the 16-byte DMA path
+    conv(c, m.conv_pre, z, z_bstride, F, xa, (int64_t)m.C0 * Fp, ylen ? PRO_MASK : 0, ylen, nullptr, 0, dec_cond, m.C0,
+         1.f, 1.f, S, nullptr, 1.f, z_cstride, Fp);
     int T = F, Cc = m.C0, xs_idx = 0;
+    int in_pitch = Fp;
     for (int si = 0; si < nst; si++) {
         const auto &stg = m.ups[si];
         // y = up(xa) as a pixel-shuffled dense conv; stored raw (residual) and activated (conv input)
         float *y = reg[2], *ya = reg[3];
         const int To = T * stg.u;
-        conv(c, stg.up, xa, (int64_t)Cc * T, T, y, (int64_t)stg.C * To, 0, nullptr, nullptr, 0, nullptr, 0, 1.f, 1.f, 1.f,
-             ya, S);
+        conv(c, stg.up, xa, (int64_t)Cc * in_pitch, T, y, (int64_t)stg.C * To, 0, nullptr, nullptr, 0, nullptr, 0, 1.f, 1.f,
+             1.f, ya, S, in_pitch, 0);
+        in_pitch = To;
         T = To;
         Cc = stg.C;
         const int64_t sCT = (int64_t)Cc * T;
@@ -469,9 +486,15 @@ int run_generator(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, con
 int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t *d_sid, const float *d_noise_z,
                int64_t noise_z_stride, uint64_t seed) {
     const Model &m = h->model;
-    const int C = m.C, F = h->F, Hf = m.flow_H;
-    if (d_noise_z && noise_z_stride < F)
-        return fail(h, VITS_E_ARG, "noise_z has %lld frames per row but %d are needed", (long long)noise_z_stride, F);
+    const int C = m.C, Freal = h->F, Hf = m.flow_H;
+    if (d_noise_z && noise_z_stride < Freal)
+        return fail(h, VITS_E_ARG, "noise_z has %lld frames per row but %d are needed", (long long)noise_z_stride, Freal);
+    // The flow runs on F rounded up to a multiple of 4 frames: every tensor in it is masked by y_len, so the
+    // extra (masked) frames change nothing, and all its rows become 16-byte aligned for the conv engine's
+    // 16-byte LDS-DMA.  The generator, which is NOT masked, runs on exactly Freal frames and reads z through
+    // its row pitch.
+    const int F = (Freal + 3) & ~3;
+    h->Fpitch = F;
     const size_t nCF = (size_t)B * C * F, nHF = (size_t)B * Hf * F;
     size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + kGenRegions * al(gen_region_floats(m, B, F)) + (1 << 16);
     for (auto &cd : m.flow) need += al((size_t)B * 2 * Hf * cd.n_wn);
@@ -503,7 +526,8 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     }
     // m_p / logs_p are the two halves of the proj output: channel stride T, batch stride 2*C*T
     expand_prior_strided_kernel<<<dim3((F + 63) / 64, B), 64, 0, st>>>(h->d_mp, h->d_logs, (int64_t)2 * C * T, h->d_cum,
-                                                                       len, ylen, nz, nzs, noise_scale, zp, C, T, F);
+                                                                       len, ylen, nz, nzs, noise_scale, zp, C, T, F,
+                                                                       nz == d_noise_z ? Freal : F);
     h->stats.total_launches++;
     HIPCHECK(h, hipMemcpyAsync(z, zp, nCF * 4, hipMemcpyDeviceToDevice, st));
 
@@ -547,7 +571,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
                                                                     c.P(m.dec_cond_b), dec_cond, m.C0, m.gin);
         h->stats.total_launches++;
     }
-    if (int rc = run_generator(h, c, z, sCF, ylen, B, F, dec_cond, s)) return rc;
+    if (int rc = run_generator(h, c, z, sCF, F, ylen, B, Freal, dec_cond, s)) return rc;
     if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
     return 0;
 }
@@ -855,7 +879,7 @@ int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t
     }
     h->B = B;
     h->F = F;
-    if (int rc = run_generator(h, c, dz, (int64_t)m.C * F, nullptr, B, F, dec_cond, s)) return rc;
+    if (int rc = run_generator(h, c, dz, (int64_t)m.C * F, F, nullptr, B, F, dec_cond, s)) return rc;
     if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
     size_t n = (size_t)B * h->S;
     float *host = nullptr;
@@ -880,14 +904,14 @@ int vits_tap(vits_handle *h, const char *name, float *buf, size_t buf_elems, int
     std::string k = name;
     const float *src = nullptr;
     int64_t bstride = 0;
-    int nd = 3, C = 0, L = 0;
+    int nd = 3, C = 0, L = 0, cstride = 0;
     if (k == "x") { src = h->d_x; C = m.H; L = T; bstride = (int64_t)C * L; }
     else if (k == "m_p") { src = h->d_mp; C = m.C; L = T; bstride = (int64_t)2 * C * L; }
     else if (k == "logs_p") { src = h->d_logs; C = m.C; L = T; bstride = (int64_t)2 * C * L; }
     else if (k == "logw") { src = h->d_logw; C = 1; L = T; bstride = L; }
     else if (k == "w_ceil") { src = h->d_wceil; C = 1; L = T; bstride = L; nd = 2; }
-    else if (k == "z_p") { src = h->d_zp; C = m.C; L = F; bstride = (int64_t)C * L; }
-    else if (k == "z") { src = h->d_z; C = m.C; L = F; bstride = (int64_t)C * L; }
+    else if (k == "z_p") { src = h->d_zp; C = m.C; L = F; cstride = h->Fpitch; bstride = (int64_t)C * cstride; }
+    else if (k == "z") { src = h->d_z; C = m.C; L = F; cstride = h->Fpitch; bstride = (int64_t)C * cstride; }
     else return fail(h, VITS_E_ARG, "unknown tap %s", name);
     if (!src || B == 0) return fail(h, VITS_E_ARG, "no completed run to tap");
     if (nd == 2) { dims[0] = B; dims[1] = L; }
@@ -897,7 +921,7 @@ int vits_tap(vits_handle *h, const char *name, float *buf, size_t buf_elems, int
     if (buf_elems < n) return fail(h, VITS_E_ARG, "tap buffer too small: %zu < %zu", buf_elems, n);
     float *tmp = nullptr;
     HIPCHECK(h, hipMalloc((void **)&tmp, n * 4 + 16));
-    gather_view_kernel<<<dim3((L + 255) / 256, C, B), 256, 0, h->stream>>>(src, bstride, tmp, C, L);
+    gather_view_kernel<<<dim3((L + 255) / 256, C, B), 256, 0, h->stream>>>(src, bstride, cstride ? cstride : L, tmp, C, L);
     hipError_t e = hipMemcpyAsync(buf, tmp, n * 4, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(tmp);
@@ -1028,6 +1052,12 @@ int vits_bench_conv1d(int device_id, int B, int Cin, int Cout, int T, int K, int
     a.Cin = d.Cin; a.Cout = d.Cout; a.K = d.K; a.dil = d.dil; a.padL = d.padL; a.CK = d.CK;
     a.nchunks = d.nchunks; a.steps4 = d.steps4; a.ups = 1;
     a.flags = ((dbg & 4) ? 0 : PRO_LRELU) | ((dbg & 1) ? DBG_NO_DMA : 0) | ((dbg & 2) ? DBG_NO_EPI : 0);
+    if ((dbg & 8) && Cin == Cout) {  // residual epilogue + pre-activated second output, as the generator runs it
+        a.flags |= EPI_RES;
+        a.res = dx;
+        a.res_bstride = (int64_t)Cin * T;
+        a.oslope2 = 0.1f;
+    }
     a.slope = 0.1f;
     a.div = 1.f;
     hipEvent_t e0, e1;
@@ -1082,12 +1112,12 @@ int vits_test_attention(int device_id, const float *qkv, int B, int C, int T, in
     TCHECK(hipMemcpy(drk, rel_k, nr * 4, hipMemcpyHostToDevice));
     TCHECK(hipMemcpy(drv, rel_v, nr * 4, hipMemcpyHostToDevice));
     TCHECK(hipMemcpy(dlen, l32.data(), B * 4, hipMemcpyHostToDevice));
-    dim3 ag((T + 31) / 32, n_heads, B);
+    dim3 ag((T + 127) / 128, n_heads, B);
     switch ((dk + 31) / 32) {
-        case 1: attention_relpos_kernel<1><<<ag, 64>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
-        case 2: attention_relpos_kernel<2><<<ag, 64>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
-        case 3: attention_relpos_kernel<3><<<ag, 64>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
-        default: attention_relpos_kernel<4><<<ag, 64>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
+        case 1: attention_relpos_kernel<1><<<ag, 256>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
+        case 2: attention_relpos_kernel<2><<<ag, 256>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
+        case 3: attention_relpos_kernel<3><<<ag, 256>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
+        default: attention_relpos_kernel<4><<<ag, 256>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
     }
     TCHECK(hipGetLastError());
     TCHECK(hipDeviceSynchronize());

@@ -62,7 +62,7 @@ def main():
         line = f"{name:24s} T={T:7d} cfg{cfg} CK{ck:2d}  {ms:8.3f} ms  {tf:6.1f} TF/s ({100 * tf / PEAK:4.1f}%)"
         if a.ablate:
             parts = []
-            for tag, dbg in (("noDMA", 1), ("noEPI", 2), ("noDMA+noEPI", 3), ("noLRELU", 4), ("none", 7)):
+            for tag, dbg in (("noACT", 4), ("noACT+res", 12), ("noACT+noDMA", 5), ("noACT+noEPI", 6), ("none", 7)):
                 rr = bench(lib, B, Cin, Cout, T, K, dil, hint | (dbg << 8), a.iters)
                 if rr:
                     parts.append(f"{tag}:{rr[1]:.0f}")
