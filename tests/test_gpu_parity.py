@@ -260,3 +260,47 @@ def test_vocoder_only_matches_oracle():
         assert got.shape == ref.shape
         np.testing.assert_allclose(got, ref, atol=1e-4)
         s.close()
+
+
+# ------------------------------------------------------------------ the user-facing API on top
+
+def test_ttsvoice_load_and_synthesize_wav(tmp_path):
+    """TTSVoice.load() -> synthesize_wav() through the engine (config 1 of BASELINE.json, on the GPU):
+    the WAV holds exactly the int16 rendering of what the session returns for each sentence."""
+    import io
+    import json
+    import shutil
+    import wave
+    from phoonnx_amd.config import SynthesisConfig
+    from phoonnx_amd.voice import TTSVoice
+    model = tmp_path / "voice.onnx"
+    shutil.copy(os.path.join(GOLDEN, "tiny_rb1.onnx"), model)
+    id_map = {chr(97 + i): i + 4 for i in range(26)}
+    id_map.update({"_": 0, "^": 1, "$": 2, " ": 3})
+    (tmp_path / "voice.onnx.json").write_text(json.dumps({
+        "phoneme_type": "raw", "lang_code": "en", "alphabet": "ipa", "audio": {"sample_rate": 22050},
+        "phoneme_id_map": id_map, "pad": "_", "blank": "_", "bos": "^", "eos": "$",
+        "inference": {"noise_scale": 0.0, "length_scale": 1.5, "noise_w": 0.0}}))
+    voice = TTSVoice.load(str(model))
+    voice.dedupe_sentences = True
+    text = "hello world. this is a test."
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as w:
+        voice.synthesize_wav(text, w)
+    with wave.open(io.BytesIO(buf.getvalue())) as r:
+        assert (r.getframerate(), r.getsampwidth(), r.getnchannels()) == (22050, 2, 1)
+        frames = np.frombuffer(r.readframes(r.getnframes()), np.int16)
+    chunks = list(voice.synthesize(text))
+    assert len(chunks) == 2
+    assert np.array_equal(frames, np.concatenate([c.audio_int16_array for c in chunks]))
+    # sentence batching (extension f1): same ids in one padded batch; each item trimmed to its own length.
+    # Interior samples agree with the sequential rendering; the unmasked generator differs near the end.
+    batched = list(voice.synthesize(text, batch_sentences=True))
+    assert [len(c.audio_float_array) for c in batched] == [len(c.audio_float_array) for c in chunks]
+    longest = int(np.argmax([len(c.audio_float_array) for c in chunks]))
+    np.testing.assert_allclose(batched[longest].audio_float_array, chunks[longest].audio_float_array, atol=2e-4)
+    # a reference-style voice object: session.run() returns rank-4, squeeze() gives [S]
+    ids = voice.phonemes_to_ids(list("hello"))
+    audio = voice.phoneme_ids_to_audio(ids, SynthesisConfig())
+    assert audio.ndim == 1 and audio.dtype == np.float32 and len(audio) % voice.session.hparam("hop") == 0
+    voice.session.close()

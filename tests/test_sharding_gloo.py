@@ -1,0 +1,80 @@
+"""N > 1 path on CPU: two processes, gloo backend.  Covers what can be checked without a GPU:
+the utterance partition / restore-order logic and the weight-arena broadcast (rank 0 parses and
+packs the .onnx, every rank ends up with the same bytes a local pack would produce)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+from phoonnx_amd.sharding import pad_batch, partition
+
+
+def test_partition_covers_everything_and_restores_order():
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 5, 8, 37, 256):
+            lengths = rng.integers(1, 300, n)
+            shards, inv = partition(lengths, world)
+            assert len(shards) == world
+            flat = np.concatenate(shards) if n else np.zeros(0, np.int64)
+            assert sorted(flat.tolist()) == list(range(n))              # every utterance exactly once
+            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= max(1, (n + world - 1) // world)
+            # longest-first: a shard never holds an utterance longer than any in the previous shard
+            for a, b in zip(shards[:-1], shards[1:]):
+                if len(a) and len(b):
+                    assert lengths[a].min() >= lengths[b].max()
+            results = [f"utt{i}" for i in flat]                          # "concatenated per-rank results"
+            assert [results[inv[i]] for i in range(n)] == [f"utt{i}" for i in range(n)]
+
+
+def test_pad_batch_layout():
+    ids, lens = pad_batch([[5, 6, 7], [1], [2, 3]])
+    assert ids.dtype == np.int64 and lens.dtype == np.int64
+    assert ids.tolist() == [[5, 6, 7], [1, 0, 0], [2, 3, 0]] and lens.tolist() == [3, 1, 2]
+
+
+def _worker(rank, world, port, onnx_path, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from phoonnx_amd import MiSession
+    from phoonnx_amd.sharding import broadcast_arena, partition as part
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        arena = broadcast_arena(onnx_path, dist, device=None, src=0)
+        local = MiSession(onnx_path, host_only=True)
+        same = bool(np.array_equal(arena.numpy(), np.asarray(local.arena_host())))
+        # each rank synthesises only its shard; shards are disjoint and cover the request
+        shards, _ = part([9, 3, 7, 1, 5], world)
+        objs = [None] * world
+        dist.all_gather_object(objs, shards[rank].tolist())
+        q.put((rank, same, int(arena.numel()), objs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_arena_broadcast_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    path = os.path.join(GOLDEN, "tiny_rb2_ms.onnx")
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort()
+    assert [g[0] for g in got] == [0, 1]
+    assert all(g[1] for g in got), "broadcast arena differs from a local pack"
+    assert got[0][2] == got[1][2] > 0
+    assert sorted(got[0][3][0] + got[0][3][1]) == [0, 1, 2, 3, 4] and got[0][3] == got[1][3]
