@@ -32,6 +32,27 @@ _PHONEME_BLOCK = re.compile(r"(\[\[.*?\]\])")
 _MAX_WAV_VALUE = 32767.0
 
 
+def config_from_metadata(meta: dict) -> dict:
+    """Voice-config dict from the `.onnx` metadata_props (keys of export_onnx.py:335-345).
+    Raises ValueError when the file carries no usable metadata."""
+    if not meta or "phoneme_id_map" not in meta:
+        raise ValueError("no voice config JSON and the .onnx has no phoonnx metadata_props to rebuild it from")
+    try:
+        id_map = json.loads(meta["phoneme_id_map"])
+    except json.JSONDecodeError as exc:
+        raise ValueError("metadata_props['phoneme_id_map'] is not valid JSON") from exc
+    return {
+        "phoneme_type": meta.get("phoneme_type") or "raw",
+        "alphabet": meta.get("alphabet") or None,
+        "phonemizer_model": meta.get("phonemizer_model") or None,
+        "lang_code": meta.get("lang_code") or "und",
+        "audio": {"sample_rate": int(meta.get("sample_rate", 22050))},
+        "num_symbols": int(meta.get("n_vocab", 256)),
+        "num_speakers": int(meta.get("n_speakers", 1)),
+        "phoneme_id_map": id_map,
+    }
+
+
 @dataclass
 class AudioChunk:
     """A chunk of raw audio: float samples in [-1, 1] plus their PCM16 rendering."""
@@ -76,16 +97,25 @@ class TTSVoice:
              phonemizer: Optional[Any] = None) -> "TTSVoice":
         """Load a voice: `<model>.onnx` + `<model>.onnx.json` (voice.py:125-172).  `use_cuda` is
         accepted for signature compatibility; the engine always runs on the MI355X `device_id`."""
+        import os
         from .session import MiSession
         if config_path is None:
             config_path = f"{model_path}.json"
             LOG.debug("Guessing voice config path: %s", config_path)
-        with open(config_path, "r", encoding="utf-8") as fh:
-            config_dict = json.load(fh)
-        config = VoiceConfig.from_dict(config_dict, phonemes_txt=phonemes_txt, lang_code=lang_code,
-                                       phoneme_type_str=phoneme_type_str)
         session = MiSession(str(model_path), sess_options=None, providers=["MI355XExecutionProvider"],
                             device_id=device_id)
+        if os.path.exists(config_path):
+            with open(config_path, "r", encoding="utf-8") as fh:
+                config_dict = json.load(fh)
+        else:
+            # extension (SURVEY §8 f3): no JSON next to the model -> rebuild the config from the
+            # metadata_props export_onnx.py:335-350 wrote into the .onnx itself
+            config_dict = config_from_metadata(session.get_modelmeta().custom_metadata_map)
+        config = VoiceConfig.from_dict(config_dict, phonemes_txt=phonemes_txt, lang_code=lang_code,
+                                       phoneme_type_str=phoneme_type_str)
+        n_spk = session.hparam("n_speakers")
+        if config.num_speakers != n_spk:
+            LOG.warning("config says %d speakers, the graph has %d", config.num_speakers, n_spk)
         return TTSVoice(session=session, config=config, phonemizer=phonemizer)
 
     # ------------------------------------------------------------------ text -> phonemes -> ids

@@ -145,6 +145,22 @@ def test_silent_audio_and_dedupe_option(G):
     assert len(list(voice.synthesize("ab. ba.", None))) == 2   # declared deviation switch: no doubling
 
 
+def test_config_from_onnx_metadata():
+    # the keys export_onnx.py:335-345 writes; values are strings in metadata_props
+    from phoonnx_amd.voice import config_from_metadata
+    meta = {"model_type": "vits", "n_speakers": "4", "n_vocab": "130", "sample_rate": "16000", "alphabet": "ipa",
+            "phoneme_type": "raw", "phonemizer_model": "", "phoneme_id_map": json.dumps({"a": 1, " ": 2}),
+            "has_espeak": "False"}
+    vc = VoiceConfig.from_dict(config_from_metadata(meta))
+    assert (vc.sample_rate, vc.num_speakers, vc.num_symbols) == (16000, 4, 130)
+    assert vc.phoneme_id_map == {"a": 1, " ": 2} and vc.include_whitespace is True
+    assert vc.phoneme_type.value == "raw" and vc.phonemizer_model is None
+    with pytest.raises(ValueError):
+        config_from_metadata({})
+    with pytest.raises(ValueError):
+        config_from_metadata({"phoneme_id_map": "{not json"})
+
+
 def test_audio_chunk_int16():
     c = AudioChunk(22050, 2, 1, np.array([0.0, 1.0, -1.0, 0.5, 2.0, -3.0], np.float32))
     assert c.audio_int16_array.tolist() == [0, 32767, -32767, 16383, 32767, -32767]
