@@ -75,7 +75,7 @@ struct ConvArgs {
     int64_t res_bstride;
     const float *zeros;   // >= 256 zero floats, 16-byte aligned (padding source for the DMA)
     int Cin, Cout, K, dil, padL, CK, nchunks, steps4, ups;
-    int LW, padLa, xs_floats;  // filled by launch_conv
+    int LW, padLa, xs_floats, stage_floats;  // filled by launch_conv
     unsigned magic;            // ceil(2^32 / LW)
     int flags;
     float slope, div;
@@ -98,20 +98,17 @@ __device__ __forceinline__ float lrelu_f(float v, float slope) {
     return __builtin_amdgcn_fmed3f(v, v * slope, __builtin_inff());
 }
 
-// LDS floats per pipeline stage (x tile + A slab), per tile config.  The two stages are two DISTINCT
-// static __shared__ arrays: only distinct objects are provably disjoint for hipcc's LDS-DMA tracking.
-template <int MW, int NW, int WM, int WN>
-struct ConvTile {
-    static constexpr int BM = WM * MW * 32, BN = WN * NW * 32;
-    static constexpr int STAGE_FLOATS = (MW * NW >= 4) ? 9728 : 4864;  // 38 KiB / 19 KiB per stage
-};
-
+// The two pipeline stages (x tile + A slab each) live in ONE dynamic LDS allocation whose size follows the
+// layer (kernel width, chunk depth): narrow kernels take 2 x <= 26 KiB so three workgroups share a CU's
+// 160 KiB, the widest (k = 11) take 2 x 38 KiB (two workgroups).  This is safe only because every LDS read of
+// the main loop is inline asm: for compiler-visible reads hipcc could not prove the stages disjoint and would
+// wait `vmcnt(0)` (drain the prefetch) in front of them.
 template <int MW, int NW, int WM, int WN, int VEC, int ACT>
-__global__ __launch_bounds__(256, (MW * NW >= 4) ? 2 : 4) void conv_engine_kernel(ConvArgs a) {
-    using Tile = ConvTile<MW, NW, WM, WN>;
-    constexpr int BM = Tile::BM, BN = Tile::BN, MB = BM / 32;
-    __shared__ __attribute__((aligned(16))) float stageP[Tile::STAGE_FLOATS];
-    __shared__ __attribute__((aligned(16))) float stageQ[Tile::STAGE_FLOATS];
+__global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kernel(ConvArgs a) {
+    constexpr int BM = WM * MW * 32, BN = WN * NW * 32, MB = BM / 32;
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    float *const stageP = lds_dyn;
+    float *const stageQ = lds_dyn + a.stage_floats;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -266,15 +263,6 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 2 : 4) void conv_engine_kerne
         if (co >= a.Cout) return -1;
         return ups == 1 ? co * a.out_cstride : (co / ups) * Tout + (co % ups);
     };
-    float brow[MW][16];
-#pragma unroll
-    for (int m = 0; m < MW; m++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int co = (mblk0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int cc = co < a.Cout ? co : 0;
-            brow[m][r] = biasp[cc * b_on] + bbp[cc * bb_on];
-        }
     // software pipeline over input-channel chunks, two stages, one barrier per chunk
     const int nchunks = a.nchunks;
     const bool dbg_nodma = a.flags & DBG_NO_DMA;
@@ -310,20 +298,27 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 2 : 4) void conv_engine_kerne
 #pragma unroll
     for (int m = 0; m < MW; m++) {
         int orow_m[16];
+        float brow_m[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) orow_m[r] = row_off(m, r);
-        float ad[NW][16];
-        if (has_add) {
-#pragma unroll
-            for (int n = 0; n < NW; n++) {
-                const int t = t0 + wn * (NW * 32) + n * 32 + l31;
-                const int tt = t * ups;
-#pragma unroll
-                for (int r = 0; r < 16; r++) ad[n][r] = (orow_m[r] >= 0 && t < T) ? addp[orow_m[r] + tt] : 0.f;
-            }
+        for (int r = 0; r < 16; r++) {
+            orow_m[r] = row_off(m, r);
+            const int co = (mblk0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int cc = co < a.Cout ? co : 0;
+            brow_m[r] = biasp[cc * b_on] + bbp[cc * bb_on];
         }
+        constexpr int NB = NW >= 4 ? 2 : NW;  // tiles whose add-operands are in flight together (register budget)
+        float ad[NB][16];
 #pragma unroll
         for (int n = 0; n < NW; n++) {
+            if (has_add && (n % NB) == 0) {
+#pragma unroll
+                for (int q = 0; q < NB; q++) {
+                    const int tq = t0 + wn * (NW * 32) + (n + q) * 32 + l31;
+                    const int ttq = tq * ups;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) ad[q][r] = (orow_m[r] >= 0 && tq < T) ? addp[orow_m[r] + ttq] : 0.f;
+                }
+            }
             const int t = t0 + wn * (NW * 32) + n * 32 + l31;
             if (t >= T) {
                 if (ups == 1 && t < a.out_cstride) {  // row padding up to the pitch: zeros (see x_cstride)
@@ -341,16 +336,16 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 2 : 4) void conv_engine_kerne
             const int tt = t * ups;
             float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[m][n][r] + brow[m][r], relu_floor);
+            for (int r = 0; r < 16; r++) v[r] = fmaxf(acc[m][n][r] + brow_m[r], relu_floor);
             if (flags & EPI_COUPLING) {
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    if (orow_m[r] >= 0) ob[orow_m[r] + tt] = (ad[n][r] - v[r] * mk) * mk;
+                    if (orow_m[r] >= 0) ob[orow_m[r] + tt] = (ad[n % NB][r] - v[r] * mk) * mk;
                 continue;
             }
             if (has_add) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) v[r] = v[r] * mk_sel + ad[n][r];
+                for (int r = 0; r < 16; r++) v[r] = v[r] * mk_sel + ad[n % NB][r];
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[r] *= mk_sel;
@@ -391,19 +386,27 @@ inline int conv_tile_n(int cfg) {
     }
 }
 
-// floats per pipeline stage available to a tile config (must match ConvTile::STAGE_FLOATS)
+// largest pipeline stage (floats) a layer may use: 38 KiB (two workgroups per CU)
 inline int conv_stage_floats(int cfg) { return cfg <= 2 ? 9728 : 4864; }
 
-template <int MW, int NW, int WM, int WN>
-inline hipError_t launch_conv_t(const ConvArgs &a, dim3 grid, bool vec4, bool act, hipStream_t stream) {
-    if (vec4) {
-        if (act) conv_engine_kernel<MW, NW, WM, WN, 4, 1><<<grid, 256, 0, stream>>>(a);
-        else conv_engine_kernel<MW, NW, WM, WN, 4, 0><<<grid, 256, 0, stream>>>(a);
-    } else {
-        if (act) conv_engine_kernel<MW, NW, WM, WN, 1, 1><<<grid, 256, 0, stream>>>(a);
-        else conv_engine_kernel<MW, NW, WM, WN, 1, 0><<<grid, 256, 0, stream>>>(a);
+template <int MW, int NW, int WM, int WN, int VEC, int ACT>
+inline hipError_t launch_conv_k(const ConvArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;  // allow > 64 KiB of dynamic LDS, once per instantiation
+    auto kern = conv_engine_kernel<MW, NW, WM, WN, VEC, ACT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
     }
+    kern<<<grid, 256, lds, stream>>>(a);
     return hipGetLastError();
+}
+
+template <int MW, int NW, int WM, int WN>
+inline hipError_t launch_conv_t(const ConvArgs &a, dim3 grid, bool vec4, bool act, size_t lds, hipStream_t stream) {
+    if (vec4) return act ? launch_conv_k<MW, NW, WM, WN, 4, 1>(a, grid, lds, stream) : launch_conv_k<MW, NW, WM, WN, 4, 0>(a, grid, lds, stream);
+    return act ? launch_conv_k<MW, NW, WM, WN, 1, 1>(a, grid, lds, stream) : launch_conv_k<MW, NW, WM, WN, 1, 0>(a, grid, lds, stream);
 }
 
 // Launch on `stream`; LW / padLa / xs_floats / magic are filled in here.
@@ -434,13 +437,15 @@ inline hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
     if (grid.x == 0 || grid.y == 0 || B == 0) return hipSuccess;
     const size_t stage = (size_t)a.xs_floats + (size_t)(BM / 32) * (a.K * a.CK / 8) * 256;
     if (stage > (size_t)conv_stage_floats(cfg)) return hipErrorInvalidValue;  // pick_tiling guarantees this never fires
+    a.stage_floats = (int)((stage + 63) / 64 * 64);
+    const size_t lds = 2 * (size_t)a.stage_floats * sizeof(float);
     if ((int64_t)a.Cout * (a.ups == 1 ? a.out_cstride : a.T) >= (int64_t)1 << 31) return hipErrorInvalidValue;  // 32-bit element offsets per utterance
     switch (cfg) {
-        case 0: return launch_conv_t<1, 4, 1, 4>(a, grid, vec4, act, stream);
-        case 1: return launch_conv_t<2, 2, 1, 4>(a, grid, vec4, act, stream);
-        case 2: return launch_conv_t<2, 2, 2, 2>(a, grid, vec4, act, stream);
-        case 3: return launch_conv_t<1, 1, 2, 2>(a, grid, vec4, act, stream);
-        default: return launch_conv_t<1, 1, 1, 4>(a, grid, vec4, act, stream);
+        case 0: return launch_conv_t<1, 4, 1, 4>(a, grid, vec4, act, lds, stream);
+        case 1: return launch_conv_t<2, 2, 1, 4>(a, grid, vec4, act, lds, stream);
+        case 2: return launch_conv_t<2, 2, 2, 2>(a, grid, vec4, act, lds, stream);
+        case 3: return launch_conv_t<1, 1, 2, 2>(a, grid, vec4, act, lds, stream);
+        default: return launch_conv_t<1, 1, 1, 4>(a, grid, vec4, act, lds, stream);
     }
 }
 

@@ -191,15 +191,19 @@ void pick_tiling(int Cin, int Cout, int K, int dil, int padL, int hint, int &cfg
     } else
         cands.push_back(1);
     const int cin8 = (Cin + 7) / 8 * 8;
-    for (int c : cands)
-        for (int ck : {32, 16, 8}) {
-            if (ck > cin8 && ck != 8) continue;
-            if (stage_floats(c, K, dil, padL, ck) <= stage_capacity(c)) {
-                cfg = c;
-                CK = ck;
-                return;
+    // first choice: a stage of <= 26 KiB, so that three workgroups (12 waves) share a CU; the widest kernels
+    // (k = 11) only fit the 38 KiB stage (two workgroups)
+    for (size_t cap : {size_t(6656), size_t(0)})
+        for (int c : cands)
+            for (int ck : {32, 16, 8}) {
+                if (ck > cin8 && ck != 8) continue;
+                const size_t lim = (cap && c <= 2) ? cap : stage_capacity(c);
+                if (stage_floats(c, K, dil, padL, ck) <= lim) {
+                    cfg = c;
+                    CK = ck;
+                    return;
+                }
             }
-        }
     throw std::runtime_error("conv receptive field too wide for the LDS stage (kernel " + std::to_string(K) +
                              ", dilation " + std::to_string(dil) + ")");
 }
