@@ -127,6 +127,12 @@ int vits_sync(vits_handle *h);
  * (no synchronisation).  Writes min(n, B) values, returns B. */
 int vits_last_y_lengths(vits_handle *h, int64_t *buf, int n);
 
+/* synthesize()'s post-processing on the device, for the LAST run (phoonnx/voice.py:271-282 and AudioChunk,
+ * voice.py:88-91): per utterance, over its y_lengths*hop valid samples: peak-normalise (if `normalize`),
+ * scale by `volume`, clip, convert to int16 exactly as the NumPy code does.  `out` is host int16 [B, S];
+ * samples past an utterance's length are 0. */
+int vits_last_pcm16(vits_handle *h, int normalize, float volume, int16_t *out, size_t out_elems);
+
 /* Vocoder only (BASELINE config 2, and teacher-forced parity): z is [B, inter, F] host
  * float32, already masked; output as vits_run. */
 int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t *sid, vits_output *out);

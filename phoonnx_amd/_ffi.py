@@ -31,7 +31,7 @@ class VitsStats(C.Structure):
 EXPORTS = [
     "vits_open", "vits_open_with_arena", "vits_open_host", "vits_close", "vits_last_error", "vits_num_inputs",
     "vits_input_name", "vits_meta", "vits_hparam", "vits_arena_bytes", "vits_arena_host", "vits_arena_device",
-    "vits_run", "vits_free_output", "vits_run_device", "vits_sync", "vits_last_y_lengths", "vits_run_vocoder",
+    "vits_run", "vits_free_output", "vits_run_device", "vits_sync", "vits_last_y_lengths", "vits_last_pcm16", "vits_run_vocoder",
     "vits_tap",
     "vits_set_timing", "vits_get_stats", "vits_stream", "vits_test_conv1d", "vits_test_conv_transpose1d",
     "vits_test_attention", "vits_bench_conv1d",
@@ -77,6 +77,7 @@ def load():
     lib.vits_free_output.restype = None
     lib.vits_sync.argtypes = [vp]
     lib.vits_last_y_lengths.argtypes = [vp, i64p, C.c_int]
+    lib.vits_last_pcm16.argtypes = [vp, C.c_int, C.c_float, vp, C.c_size_t]
     lib.vits_run_vocoder.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(VitsOutput)]
     lib.vits_tap.argtypes = [vp, C.c_char_p, vp, C.c_size_t, i64p]
     lib.vits_set_timing.argtypes = [vp, C.c_int]

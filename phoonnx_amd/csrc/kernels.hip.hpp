@@ -411,6 +411,40 @@ __global__ void ylen_to_i64(const int *in, int64_t *out, int B) {
     if (b < B) out[b] = in[b];
 }
 
+// ---- f2: synthesize()'s post-processing on the device (voice.py:271-282 + AudioChunk, :88-91) ----------
+// per utterance: peak = max|x| over its valid samples; x = peak < 1e-8 ? 0 : x / peak; x *= volume;
+// clip to [-1,1]; int16 = trunc(clip(x * 32767, -32767, 32767)).  Same float32 operations in the same
+// order as the NumPy code, so the PCM is bit-identical.
+__global__ void peak_abs_kernel(const float *x, const int *y_len, int hop, int S, unsigned *peak_bits) {
+    const int b = blockIdx.y;
+    const int n = y_len[b] * hop < S ? y_len[b] * hop : S;
+    float m = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[(int64_t)b * S + i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(&peak_bits[b], __float_as_uint(m));  // non-negative floats order as uints
+}
+
+__global__ void pcm16_kernel(const float *x, const int *y_len, int hop, int S, const unsigned *peak_bits,
+                             int normalize, float volume, int16_t *out) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S) return;
+    const int n = y_len[b] * hop < S ? y_len[b] * hop : S;
+    float v = 0.f;
+    if (i < n) {
+        v = x[(int64_t)b * S + i];
+        if (normalize) {
+            const float peak = __uint_as_float(peak_bits[b]);
+            v = peak < 1e-8f ? 0.f : v / peak;
+        }
+        if (volume != 1.0f) v = v * volume;
+        v = fminf(fmaxf(v, -1.0f), 1.0f);
+        v = fminf(fmaxf(v * 32767.0f, -32767.0f), 32767.0f);
+    }
+    out[(int64_t)b * S + i] = (int16_t)v;
+}
+
 // copy a strided [B][C][T] view (batch stride bstride) into a contiguous buffer
 __global__ void gather_view_kernel(const float *in, int64_t bstride, int cstride, float *out, int C, int T) {
     int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;

@@ -851,6 +851,35 @@ void vits_free_output(vits_handle *h, vits_output *out) {
     out->y_lengths = nullptr;
 }
 
+int vits_last_pcm16(vits_handle *h, int normalize, float volume, int16_t *out, size_t out_elems) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int B = h->B, S = h->S;
+    if (!h->d_out || !h->d_ylen || B <= 0 || S <= 0) return fail(h, VITS_E_ARG, "no completed run to post-process");
+    const size_t n = (size_t)B * S;
+    if (!out || out_elems < n) return fail(h, VITS_E_ARG, "pcm16 buffer too small: %zu < %zu", out_elems, n);
+    int16_t *d_pcm = nullptr;
+    unsigned *d_peak = nullptr;
+    HIPCHECK(h, hipMalloc((void **)&d_pcm, n * 2 + 64));
+    HIPCHECK(h, hipMalloc((void **)&d_peak, (size_t)B * 4));
+    hipStream_t st = h->stream;
+    hipError_t e = hipMemsetAsync(d_peak, 0, (size_t)B * 4, st);
+    const int hop = h->model.hop;
+    if (e == hipSuccess) {
+        int gx = (S + 255) / 256;
+        gx = gx > 256 ? 256 : gx;
+        peak_abs_kernel<<<dim3(gx, B), 256, 0, st>>>(h->d_out, h->d_ylen, hop, S, d_peak);
+        pcm16_kernel<<<dim3((S + 255) / 256, B), 256, 0, st>>>(h->d_out, h->d_ylen, hop, S, d_peak, normalize, volume, d_pcm);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_pcm, n * 2, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipFree(d_pcm);
+    hipFree(d_peak);
+    if (e != hipSuccess) return fail(h, VITS_E_DEVICE, "pcm16 post-processing failed: %s", hipGetErrorString(e));
+    return VITS_OK;
+}
+
 int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t *sid, vits_output *out) {
     if (int rc = check_dev(h)) return rc;
     std::lock_guard<std::mutex> lk(h->mu);

@@ -257,6 +257,17 @@ class MiSession:
             self._lib.vits_last_y_lengths(self._h, buf.ctypes.data_as(C.POINTER(C.c_int64)), n)
         return buf
 
+    def last_pcm16(self, normalize: bool = True, volume: float = 1.0, shape=None) -> np.ndarray:
+        """int16 PCM of the last run, post-processed on the GPU exactly as TTSVoice.synthesize + AudioChunk do
+        (voice.py:271-282, 88-91); [B, S], zeros past each utterance's length."""
+        if shape is None:
+            raise SessionError("last_pcm16 needs the [B, S] shape of the last output")
+        out = np.zeros(shape, np.int16)
+        rc = self._lib.vits_last_pcm16(self._h, 1 if normalize else 0, float(volume), _ffi.ptr(out), out.size)
+        if rc != 0:
+            raise SessionError(f"vits_last_pcm16 failed [{rc}]: {self._err()}")
+        return out
+
     def sync(self):
         if self._lib.vits_sync(self._h) != 0:
             raise SessionError(self._err())

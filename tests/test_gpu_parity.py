@@ -304,3 +304,29 @@ def test_ttsvoice_load_and_synthesize_wav(tmp_path):
     audio = voice.phoneme_ids_to_audio(ids, SynthesisConfig())
     assert audio.ndim == 1 and audio.dtype == np.float32 and len(audio) % voice.session.hparam("hop") == 0
     voice.session.close()
+
+
+@pytest.mark.parametrize("normalize,volume", [(True, 1.0), (True, 0.5), (False, 1.0), (False, 2.5)])
+def test_device_pcm16_matches_numpy_postprocessing(normalize, volume):
+    """f2: peak-normalise / volume / clip / int16 on the GPU is bit-identical to what
+    TTSVoice.synthesize + AudioChunk.audio_int16_array compute with NumPy (voice.py:271-282, 88-91)."""
+    from phoonnx_amd.config import SynthesisConfig
+    from phoonnx_amd.voice import AudioChunk, TTSVoice
+    s = _session("tiny_rb1")
+    rng = np.random.default_rng(12)
+    ids = np.zeros((3, 40), np.int64)
+    lens = np.array([40, 21, 9], np.int64)
+    for b in range(3):
+        ids[b, :lens[b]] = rng.integers(1, 200, lens[b])
+    r = s.synthesize_batch(ids, lens, np.array([0.3, 1.4, 0.5], np.float32))
+    B, S = r["output"].shape[0], r["output"].shape[3]
+    pcm = s.last_pcm16(normalize, volume, shape=(B, S))
+    hop = s.hparam("hop")
+    post = TTSVoice._postprocess  # the NumPy path of the interface mirror (pinned to the reference's bytes)
+    syn = SynthesisConfig(normalize_audio=normalize, volume=volume)
+    for b in range(B):
+        n = int(r["y_lengths"][b]) * hop
+        ref = AudioChunk(22050, 2, 1, post(None, r["output"][b, 0, 0, :n], syn)).audio_int16_array
+        assert np.array_equal(pcm[b, :n], ref), (b, np.abs(pcm[b, :n].astype(int) - ref.astype(int)).max())
+        assert not pcm[b, n:].any()
+    s.close()
