@@ -176,6 +176,17 @@ int vits_bench_conv1d(int device_id, int B, int Cin, int Cout, int T, int K, int
 /* out[B,Cout,T*stride] = conv_transpose1d(x, w[Cin,Cout,K], bias, stride, pad=(K-stride)/2). */
 int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, int T, const float *w,
                                const float *bias, int Cout, int K, int stride, float *out);
+/* The same three hooks through the split-exact bf16 engine the generator runs on when all of its channel counts
+ * are multiples of 32 (csrc/conv_sx_engine.hip.hpp); needs Cin % 16 == 0 and Cout % 32 == 0.
+ * vits_test_conv1d_sx flags: bit0 -> out = leaky_relu(conv, slope) read back from the three bf16 output planes
+ * (else the fp32 raw output), bit2 -> residual epilogue with res = x (Cin == Cout).
+ * vits_bench_conv1d_sx dbg bits: 1 no DMA after the first step, 2 no epilogue, 8 residual epilogue. */
+int vits_test_conv1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
+                        int Cout, int K, int dil, int pad_l, int flags, float slope, float *out);
+int vits_test_conv_transpose1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w,
+                                  const float *bias, int Cout, int K, int stride, float *out);
+int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, int dil, int dbg, int iters,
+                         float *ms_out);
 /* Relative-position multi-head self-attention core (attentions.py:225-272): q,k,v
  * [B,C,T] host, emb_rel_k/v [2w+1, dk], lens int64[B]; out [B,C,T]. */
 int vits_test_attention(int device_id, const float *qkv, int B, int C, int T, int n_heads, const float *rel_k,

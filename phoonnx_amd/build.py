@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvitsmi.so")
 SOURCES = ["vitsmi.hip", "model.cpp", "onnx_reader.cpp"]
-HEADERS = ["kernels.hip.hpp", "conv_engine.hip.hpp", "model.hpp", "onnx_reader.hpp", "../../include/vitsmi.h"]
+HEADERS = ["kernels.hip.hpp", "conv_engine.hip.hpp", "conv_sx_engine.hip.hpp", "model.hpp", "onnx_reader.hpp", "../../include/vitsmi.h"]
 
 
 def hipcc():

@@ -74,7 +74,7 @@ struct ConvArgs {
     const float *res;
     int64_t res_bstride;
     const float *zeros;   // >= 256 zero floats, 16-byte aligned (padding source for the DMA)
-    int Cin, Cout, K, dil, padL, CK, nchunks, steps4, ups;
+    int Cin, Cout, K, dil, padL, CK, nchunks, ups;
     int LW, padLa, xs_floats, stage_floats;  // filled by launch_conv
     unsigned magic;            // ceil(2^32 / LW)
     int flags;

@@ -517,6 +517,38 @@ __global__ __launch_bounds__(256) void post_conv_tanh_kernel(const float *x, con
     out[(int64_t)b * T + t] = tanhf(acc);
 }
 
+// Same tail for the split-exact generator: x is the fp32 raw layout [C/8][T][8] (conv_sx_engine.hip.hpp) and
+// already carries the leaky_relu(0.01) (applied by the last stage's epilogue).  Same (channel, tap)
+// summation order as above.
+__global__ __launch_bounds__(256) void post_conv_tanh_blocked_kernel(const float *x, const float *w, float *out, int C,
+                                                                     int K, int T) {
+    extern __shared__ float sm[];  // [C][256 + K - 1] staged tile, then weights [C*K]
+    const int LW = 256 + K - 1;
+    float *ws = sm + (size_t)C * LW;
+    int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+    const float *xb = x + (int64_t)b * C * T;
+    for (int i = tid; i < C * K; i += 256) ws[i] = w[i];
+    const int pad = (K - 1) / 2;
+    // one thread moves half a cell (4 channels of one time step) per round
+    for (int i = tid; i < (C / 4) * LW; i += 256) {
+        const int col = i % LW, c4 = i / LW;  // c4 = cell-half index: channels 4*c4 .. +3
+        const int t = t0 - pad + col;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T) v = *reinterpret_cast<const float4 *>(xb + ((int64_t)(c4 >> 1) * T + t) * 8 + (c4 & 1) * 4);
+        sm[(c4 * 4 + 0) * LW + col] = v.x;
+        sm[(c4 * 4 + 1) * LW + col] = v.y;
+        sm[(c4 * 4 + 2) * LW + col] = v.z;
+        sm[(c4 * 4 + 3) * LW + col] = v.w;
+    }
+    __syncthreads();
+    int t = t0 + tid;
+    if (t >= T) return;
+    float acc = 0.f;
+    for (int c = 0; c < C; c++)
+        for (int k = 0; k < K; k++) acc += ws[c * K + k] * sm[c * LW + tid + k];
+    out[(int64_t)b * T + t] = tanhf(acc);
+}
+
 // ---- noise: Philox4x32-10 counter RNG + Box-Muller (production path; parity uses injected noise) ---
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t out[4]) {

@@ -8,6 +8,7 @@
 #include "model.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <stdexcept>
@@ -225,8 +226,7 @@ ConvDesc pack_conv(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF w,
     d.nchunks = (Cin + d.CK - 1) / d.CK;
     int bm = tile_m(d.cfg);
     d.mblocks = (Cout + bm - 1) / bm * (bm / 32);
-    d.steps4 = d.nchunks * K * d.CK / 8;
-    int64_t per_block = int64_t(d.steps4) * 64 * 4;
+    int64_t per_block = int64_t(d.nchunks * K * d.CK / 8) * 64 * 4;  // float4 groups x lanes x 4
     d.w_off = P.alloc(per_block * d.mblocks);
     float *dst = P.arena.data() + d.w_off;
     int half = d.CK / 2;
@@ -314,6 +314,110 @@ ConvDesc pack_convT(Packer &P, const Resolver &R, const std::string &name) {
     return d;
 }
 
+// ---- split-exact (sx) packing: weights as three bf16 planes in the A-operand lane order of
+// v_mfma_f32_32x32x16_bf16 (lane l: row l&31, k = 8*(l>>5) .. +7 = eight consecutive input channels).
+int sx_tile_m(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
+int sx_tile_n(int cfg) { return cfg == 0 ? 128 : 256; }
+int sx_pick_cfg(int Cout) { return Cout % 128 == 0 ? 0 : (Cout % 64 == 0 ? 1 : 2); }
+
+template <class WF>
+ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF w, const float *bias_virtual) {
+    if (!sx_supported(Cin, Cout, Cout, K, dil)) throw std::runtime_error("conv shape not supported by the sx engine");
+    ConvDesc d;
+    d.sx = true;
+    d.Cin = Cin;
+    d.Cout = Cout;
+    d.K = K;
+    d.dil = dil;
+    d.padL = padL;
+    d.CK = 16;
+    d.nchunks = Cin / 16;
+    d.cfg = sx_pick_cfg(Cout);
+    d.mblocks = Cout / 32;
+    const int MB = sx_tile_m(d.cfg) / 32;
+    const int64_t kib = int64_t(d.mblocks) * d.nchunks * K * 3;  // 1 KiB = one (block, plane) fragment set
+    d.w_off = P.alloc(kib * 256);
+    uint16_t *dst = reinterpret_cast<uint16_t *>(P.arena.data() + d.w_off);
+    for (int mb = 0; mb < d.mblocks; mb++)
+        for (int chunk = 0; chunk < d.nchunks; chunk++)
+            for (int tap = 0; tap < K; tap++) {
+                const int64_t base = ((((int64_t)(mb / MB) * d.nchunks + chunk) * K + tap) * MB + (mb % MB)) * 3;
+                for (int lane = 0; lane < 64; lane++)
+                    for (int i = 0; i < 8; i++) {
+                        uint16_t p[3];
+                        split3_host(w(mb * 32 + (lane & 31), chunk * 16 + 8 * (lane >> 5) + i, tap), p);
+                        for (int pl = 0; pl < 3; pl++) dst[(base + pl) * 512 + lane * 8 + i] = p[pl];
+                    }
+            }
+    if (bias_virtual) d.b_off = P.put(bias_virtual, Cout);
+    d.macs_per_t = double(Cin) * Cout * K;
+    return d;
+}
+
+ConvDesc pack_named_sx(Packer &P, const Resolver &R, const std::string &name, int dil, int padL) {
+    const TRef &w = R.req(name + ".weight");
+    if (w.dims.size() != 3) throw std::runtime_error(name + ".weight is not rank 3");
+    int Cout = int(w.dims[0]), Cin = int(w.dims[1]), K = int(w.dims[2]);
+    if (R.geti(name + ".group", 1) != 1) throw std::runtime_error(name + ": grouped conv not expected here");
+    const TRef *b = R.get(name + ".bias");
+    const float *wp = w.p;
+    auto wf = [&](int co, int ci, int tap) { return wp[(int64_t(co) * Cin + ci) * K + tap]; };
+    return pack_conv_sx(P, Cin, Cout, K, dil, padL, wf, b ? b->p : nullptr);
+}
+
+// geometry of ConvTranspose1d [Cin, Cout, K] (stride u, padding p) as a dense conv over taps o_min..o_max
+struct ConvTGeom {
+    int Cin, Cout, K, u, p, o_min, o_max;
+};
+ConvTGeom convt_geom(const Resolver &R, const std::string &name) {
+    const TRef &w = R.req(name + ".weight");
+    ConvTGeom g;
+    g.Cin = int(w.dims[0]);
+    g.Cout = int(w.dims[1]);
+    g.K = int(w.dims[2]);
+    g.u = int(R.geti(name + ".stride", -1));
+    g.p = int(R.geti(name + ".pad", -1));
+    if (g.u < 1 || g.p < 0) throw std::runtime_error(name + ": missing stride/pads attributes");
+    if (g.K - 2 * g.p != g.u) throw std::runtime_error(name + ": transposed conv with K-2*pad != stride is unsupported");
+    g.o_max = -1000000;
+    g.o_min = 1000000;
+    for (int r = 0; r < g.u; r++) {
+        int j0 = (r + g.p) % g.u, e = (r + g.p) / g.u;
+        int M = (g.K - j0 + g.u - 1) / g.u;
+        if (M <= 0) continue;
+        if (e > g.o_max) g.o_max = e;
+        if (e - (M - 1) < g.o_min) g.o_min = e - (M - 1);
+    }
+    return g;
+}
+
+// Same rewrite as pack_convT, but virtual rows are r-major (row = r*Cout + co): a 32-row block then holds
+// 32 consecutive real channels of ONE output phase r, which is what the sx epilogue's cell stores need.
+ConvDesc pack_convT_sx(Packer &P, const Resolver &R, const std::string &name) {
+    const ConvTGeom g = convt_geom(R, name);
+    const float *wp = R.req(name + ".weight").p;
+    const int Kv = g.o_max - g.o_min + 1;
+    auto wf = [&](int cov, int ci, int tapv) -> float {
+        int r = cov / g.Cout, co = cov % g.Cout;
+        int j0 = (r + g.p) % g.u, e = (r + g.p) / g.u;
+        int m = e - g.o_min - tapv;
+        int j = j0 + m * g.u;
+        if (m < 0 || j >= g.K) return 0.f;
+        return wp[(int64_t(ci) * g.Cout + co) * g.K + j];
+    };
+    std::vector<float> bv;
+    const TRef *b = R.get(name + ".bias");
+    if (b) {
+        bv.resize(size_t(g.Cout) * g.u);
+        for (int c = 0; c < g.Cout * g.u; c++) bv[c] = b->p[c % g.Cout];
+    }
+    if (g.Cout % 32) throw std::runtime_error(name + ": sx transposed conv needs Cout % 32 == 0");
+    ConvDesc d = pack_conv_sx(P, g.Cin, g.Cout * g.u, Kv, 1, -g.o_min, wf, b ? bv.data() : nullptr);
+    d.ups = g.u;
+    d.macs_per_t = double(g.Cin) * g.Cout * g.K;
+    return d;
+}
+
 int same_pad(int K, int dil) { return (K * dil - dil) / 2; }  // commons.py:17-18, modules.py:102,163
 
 DDSDesc pack_dds(Packer &P, const Resolver &R, const std::string &pfx) {
@@ -342,6 +446,37 @@ DDSDesc pack_dds(Packer &P, const Resolver &R, const std::string &pfx) {
 
 }  // namespace
 
+uint16_t bf16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return uint16_t((u >> 16) | 0x40);  // NaN stays NaN
+    return uint16_t((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+float bf16_to_f32(uint16_t h) {
+    uint32_t u = uint32_t(h) << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+void split3_host(float v, uint16_t p[3]) {
+    p[0] = bf16_rne(v);
+    const float r1 = v - bf16_to_f32(p[0]);
+    p[1] = bf16_rne(r1);
+    const float r2 = r1 - bf16_to_f32(p[1]);
+    p[2] = bf16_rne(r2);
+}
+
+bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil) {
+    if (Cin < 16 || Cin % 16 || Cout_virtual % 32 || Cr % 32 || K < 1 || dil < 1) return false;
+    const int cfg = sx_pick_cfg(Cout_virtual);
+    // two x stages + two single-tap A stages must fit the CU's 160 KiB (conv_sx_engine.hip.hpp launch_conv_sx)
+    const size_t LW = size_t(sx_tile_n(cfg)) + size_t(K - 1) * dil;
+    const size_t x_bytes = (6 * LW * 16 + 4095) / 4096 * 4096, a_bytes = size_t(sx_tile_m(cfg) / 32) * 3072;
+    return 2 * (x_bytes + a_bytes) <= 160 * 1024;
+}
+
 void set_tiling_override(int cfg, int ck) {
     t_cfg_override = cfg;
     t_ck_override = ck;
@@ -355,7 +490,8 @@ std::string pack_test_conv(const float *w, const float *bias, int Cin, int Cout,
     P.alloc(256);  // zero page at offset 0
     auto wf = [&](int co, int ci, int tap) { return w[(int64_t(co) * Cin + ci) * K + tap]; };
     try {
-        *d = pack_conv(P, Cin, Cout, K, dil, pad_l, wf, bias);
+        if (hint == 3) *d = pack_conv_sx(P, Cin, Cout, K, dil, pad_l, wf, bias);
+        else *d = pack_conv(P, Cin, Cout, K, dil, pad_l, wf, bias);
     } catch (const std::exception &e) {
         return e.what();
     }
@@ -363,7 +499,7 @@ std::string pack_test_conv(const float *w, const float *bias, int Cin, int Cout,
 }
 
 std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout, int K, int stride, ConvDesc *d,
-                            std::vector<float> *arena) {
+                            std::vector<float> *arena, bool sx) {
     try {
         t_hint = 0;
         Resolver R;
@@ -381,7 +517,7 @@ std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout
         R.ints["t.pad"] = (K - stride) / 2;
         Packer P(*arena);
         P.alloc(256);  // zero page at offset 0
-        *d = pack_convT(P, R, "t");
+        *d = sx ? pack_convT_sx(P, R, "t") : pack_convT(P, R, "t");
     } catch (const std::exception &e) {
         return e.what();
     }
@@ -528,12 +664,6 @@ std::string Model::build(const OnnxModel &om) {
 
         // ---------------- generator (models.py:299-368)
         t_hint = 0;
-        conv_pre = pack_named(P, R, "dec.conv_pre", 1, 3);
-        C0 = conv_pre.Cout;
-        if (gin) {
-            dec_cond_w = P.put(R.req("dec.cond.weight"));
-            dec_cond_b = P.put(R.req("dec.cond.bias"));
-        }
         int nups = 0;
         while (R.get("dec.ups." + std::to_string(nups) + ".weight")) nups++;
         int nrb = 0;
@@ -541,11 +671,46 @@ std::string Model::build(const OnnxModel &om) {
                R.get("dec.resblocks." + std::to_string(nrb) + ".convs.0.weight"))
             nrb++;
         if (!nups || nrb % nups) throw std::runtime_error("unexpected generator structure");
-        int nk = nrb / nups;
+        const int nk = nrb / nups;
+        // Engine choice for the whole generator (its tensors change layout with the engine): split-exact bf16
+        // when every conv qualifies, else the f32 engine.  VITSMI_GEN_ENGINE=f32 forces the latter (A/B runs).
+        {
+            const char *env = std::getenv("VITSMI_GEN_ENGINE");
+            bool ok = !(env && std::string(env) == "f32");
+            auto conv_ok = [&](const std::string &name) {
+                const TRef *w = R.get(name + ".weight");
+                if (!w || w->dims.size() != 3) return false;
+                const int k = int(w->dims[2]), dil = int(R.geti(name + ".dilation", 1));
+                return sx_supported(int(w->dims[1]), int(w->dims[0]), int(w->dims[0]), k, dil);
+            };
+            ok = ok && conv_ok("dec.conv_pre");
+            for (int i = 0; ok && i < nups; i++) {
+                const ConvTGeom g = convt_geom(R, "dec.ups." + std::to_string(i));
+                ok = sx_supported(g.Cin, g.Cout * g.u, g.Cout, g.o_max - g.o_min + 1, 1);
+            }
+            for (int j = 0; ok && j < nrb; j++)
+                for (int q = 0; ok && q < 4; q++) {
+                    const std::string rb = "dec.resblocks." + std::to_string(j);
+                    const bool t1 = R.get(rb + ".convs1.0.weight") != nullptr;
+                    const std::string c1 = rb + (t1 ? ".convs1." : ".convs.") + std::to_string(q);
+                    if (!R.get(c1 + ".weight")) break;
+                    ok = conv_ok(c1) && (!t1 || conv_ok(rb + ".convs2." + std::to_string(q)));
+                }
+            gen_sx = ok;
+        }
+        auto gconv = [&](const std::string &name, int dil, int padL) {
+            return gen_sx ? pack_named_sx(P, R, name, dil, padL) : pack_named(P, R, name, dil, padL);
+        };
+        conv_pre = gconv("dec.conv_pre", 1, 3);
+        C0 = conv_pre.Cout;
+        if (gin) {
+            dec_cond_w = P.put(R.req("dec.cond.weight"));
+            dec_cond_b = P.put(R.req("dec.cond.bias"));
+        }
         hop = 1;
         for (int i = 0; i < nups; i++) {
             UpStageDesc st;
-            st.up = pack_convT(P, R, "dec.ups." + std::to_string(i));
+            st.up = gen_sx ? pack_convT_sx(P, R, "dec.ups." + std::to_string(i)) : pack_convT(P, R, "dec.ups." + std::to_string(i));
             st.u = st.up.ups;
             st.C = st.up.Cout / st.u;
             hop *= st.u;
@@ -559,13 +724,13 @@ std::string Model::build(const OnnxModel &om) {
                     if (!w) break;
                     int k = int(w->dims[2]);
                     int dil = int(R.geti(c1 + ".dilation", 1));
-                    rd.c1[q] = pack_named(P, R, c1, dil, same_pad(k, dil));
+                    rd.c1[q] = gconv(c1, dil, same_pad(k, dil));
                     if (rd.type1) {
                         std::string c2 = rb + ".convs2." + std::to_string(q);
                         const TRef &w2 = R.req(c2 + ".weight");
                         int k2 = int(w2.dims[2]);
                         int d2 = int(R.geti(c2 + ".dilation", 1));
-                        rd.c2[q] = pack_named(P, R, c2, d2, same_pad(k2, d2));
+                        rd.c2[q] = gconv(c2, d2, same_pad(k2, d2));
                     }
                     rd.n = q + 1;
                 }

@@ -22,9 +22,12 @@ struct ConvDesc {
     int K = 1, dil = 1, padL = 0;
     int CK = 8, nchunks = 0;
     int mblocks = 0;      // packed 32-row blocks (padded to the tile config)
-    int steps4 = 0;       // float4 groups per mblock = nchunks*K*CK/8
     int ups = 1;          // pixel-shuffle factor (transposed conv), real Cout = Cout/ups
     int cfg = 0;          // tile: 0: 32x512, 1: 64x256, 2: 128x128, 3: 64x64, 4: 32x128
+    // sx = packed for the split-exact bf16 engine (conv_sx_engine.hip.hpp) instead: weights as three bf16
+    // planes [m-tile][chunk of 16 ci][tap][32-row block][plane][lane][8]; cfg then indexes the sx tiles
+    // (0: 128x128, 1: 64x256, 2: 32x256) and a transposed conv's virtual rows are r-major (r*Cr + co).
+    bool sx = false;
     double macs_per_t = 0;   // algorithmic MACs per input time step (reference definition)
     bool valid() const { return w_off >= 0; }
 };
@@ -111,6 +114,7 @@ struct Model {
     // ---- generator
     ConvDesc conv_pre;
     int C0 = 0;
+    bool gen_sx = false;  // generator packed for the split-exact bf16 engine (all channel counts % 32 == 0)
     std::vector<UpStageDesc> ups;
     int64_t post_w = -1;  // [Cin, K] conv_post weight (Cout = 1, no bias)
     int post_cin = 0, post_k = 7;
@@ -132,6 +136,13 @@ std::string pack_test_conv(const float *w, const float *bias, int Cin, int Cout,
                            ConvDesc *d, std::vector<float> *arena);
 void set_tiling_override(int cfg, int ck);  // -1,-1 = automatic (kernel tuning only)
 std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout, int K, int stride, ConvDesc *d,
-                            std::vector<float> *arena);
+                            std::vector<float> *arena, bool sx = false);
+
+// fp32 -> bf16 planes of the split-exact engine (host mirror of split3 in conv_sx_engine.hip.hpp)
+uint16_t bf16_rne(float f);
+float bf16_to_f32(uint16_t h);
+void split3_host(float v, uint16_t p[3]);
+// may this conv shape run on the sx engine (channel multiples, LDS budget)?
+bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil);
 
 }  // namespace vitsmi

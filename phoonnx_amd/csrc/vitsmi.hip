@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/vitsmi.h"
+#include "conv_sx_engine.hip.hpp"
 #include "kernels.hip.hpp"
 #include "model.hpp"
 
@@ -30,8 +31,12 @@ struct Slab {
     size_t cap = 0, used = 0;
 };
 
-struct StageTimer {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+// Pinned host buffer handed out by vits_run()/vits_run_vocoder() and returned by vits_free_output():
+// one per handle, reused across calls (hipHostMalloc costs more than a whole B=1 run).
+struct PinnedPool {
+    char *base = nullptr;
+    size_t cap = 0;
+    bool busy = false;
 };
 
 }  // namespace
@@ -44,6 +49,8 @@ struct vits_handle {
     float *arena_dev = nullptr;
     bool arena_owned = false;
     Slab tok, frm;  // token-domain and frame-domain workspaces
+    Slab io;        // device staging of vits_run()'s host inputs
+    PinnedPool pin;
     std::mutex mu;
     std::string err;
     // last-run state (for taps / outputs)
@@ -122,6 +129,40 @@ struct Ctx {
     }
 };
 
+// algorithmic FLOPs / layer-granular bytes of one conv launch, per pipeline stage
+void conv_account(Ctx &c, const ConvDesc &d, int T) {
+    vits_handle *h = c.h;
+    double fl = 2.0 * d.macs_per_t * (double)T * c.B;
+    double by = 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T);
+    h->stats.conv_flops += fl;
+    h->stats.conv_bytes += by;
+    h->stats.conv_launches++;
+    h->stats.total_launches++;
+    switch (h->cur_stage) {
+        case 0: h->stats.enc_flops += fl; break;
+        case 1: h->stats.dp_flops += fl; break;
+        case 2: h->stats.flow_flops += fl; break;
+        default:
+            h->stats.dec_flops += fl;
+            h->stats.dec_bytes += by;
+            break;
+    }
+}
+
+// with timing enabled: record the start event of the next conv launch (the caller records the end event)
+bool conv_event_begin(Ctx &c) {
+    vits_handle *h = c.h;
+    if (!h->timing) return false;
+    if (h->conv_events_used == h->conv_events.size()) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        h->conv_events.push_back({e0, e1});
+    }
+    hipEventRecord(h->conv_events[h->conv_events_used].first, c.st);
+    return true;
+}
+
 // Launch one conv through the engine; accounts algorithmic FLOPs/bytes per stage.
 void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, float *out, int64_t out_bstride,
           int flags, const int *len = nullptr, const float *res = nullptr, int64_t res_bstride = 0,
@@ -148,7 +189,6 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
     a.padL = d.padL;
     a.CK = d.CK;
     a.nchunks = d.nchunks;
-    a.steps4 = d.steps4;
     a.ups = d.ups;
     a.flags = flags;
     a.slope = slope;
@@ -159,36 +199,78 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
     a.x_cstride = x_cstride;
     a.out_cstride = out_cstride;
     vits_handle *h = c.h;
-    bool ev = h->timing;
-    if (ev) {
-        if (h->conv_events_used == h->conv_events.size()) {
-            hipEvent_t e0, e1;
-            hipEventCreate(&e0);
-            hipEventCreate(&e1);
-            h->conv_events.push_back({e0, e1});
-        }
-        hipEventRecord(h->conv_events[h->conv_events_used].first, c.st);
-    }
+    const bool ev = conv_event_begin(c);
     c.note(launch_conv(a, d.cfg, c.B, c.st));
     if (ev) hipEventRecord(h->conv_events[h->conv_events_used++].second, c.st);
-    double fl = 2.0 * d.macs_per_t * (double)T * c.B;
-    double by = 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T);
-    h->stats.conv_flops += fl;
-    h->stats.conv_bytes += by;
-    h->stats.conv_launches++;
-    h->stats.total_launches++;
-    switch (h->cur_stage) {
-        case 0: h->stats.enc_flops += fl; break;
-        case 1: h->stats.dp_flops += fl; break;
-        case 2: h->stats.flow_flops += fl; break;
-        default:
-            h->stats.dec_flops += fl;
-            h->stats.dec_bytes += by;
-            break;
-    }
+    conv_account(c, d, T);
 }
 
-inline dim3 grid_t(int T, int y, int z = 1) { return dim3((T + 255) / 256, y, z); }
+// One conv through the split-exact bf16 engine (conv_sx_engine.hip.hpp).  Tensors are whole utterance
+// batches in the engine's layouts: input planes [B][3][Cin/8][T][8], outputs raw [B][Cr/8][T*u][8] and/or
+// planes [B][3][Cr/8][T*u][8]; `res` has the raw layout of the output.
+void conv_sx(Ctx &c, const ConvDesc &d, const uint16_t *xp, int T, float *out_raw, uint16_t *out_pl, int flags,
+             const float *res = nullptr, const float *bias_b = nullptr, int bias_b_stride = 0, float div = 1.f,
+             float oslope = 1.f, float oslope2 = 1.f) {
+    SxArgs a{};
+    const int Cr = d.Cout / d.ups;
+    const int64_t Tout = (int64_t)T * d.ups;
+    a.xp = reinterpret_cast<const u32x4 *>(xp);
+    a.x_bstride = (int64_t)3 * (d.Cin / 8) * T;
+    a.T = T;
+    a.wp = reinterpret_cast<const u32x4 *>(c.P(d.w_off));
+    a.bias = c.P(d.b_off);
+    a.bias_b = bias_b;
+    a.bias_b_stride = bias_b_stride;
+    a.out_raw = out_raw;
+    a.raw_bstride = (int64_t)Cr * Tout;
+    a.out_pl = out_pl;
+    a.pl_bstride = (int64_t)3 * Cr * Tout;
+    a.res = res;
+    a.zeros = c.P(c.m.zeros_off);
+    a.Cin = d.Cin;
+    a.Cout = d.Cout;
+    a.Cr = Cr;
+    a.K = d.K;
+    a.dil = d.dil;
+    a.padL = d.padL;
+    a.nchunks = d.nchunks;
+    a.ups = d.ups;
+    a.flags = flags;
+    a.div = div;
+    a.oslope = oslope;
+    a.oslope2 = oslope2;
+    vits_handle *h = c.h;
+    const bool ev = conv_event_begin(c);
+    c.note(launch_conv_sx(a, d.cfg, c.B, c.st));
+    if (ev) hipEventRecord(h->conv_events[h->conv_events_used++].second, c.st);
+    conv_account(c, d, T);
+}
+
+// Pinned output buffer of `bytes` bytes: the handle's pool when it is free (grown on demand), else a fresh
+// allocation (the caller still holds an earlier output).  Released by pinned_put().
+void *pinned_get(vits_handle *h, size_t bytes) {
+    PinnedPool &p = h->pin;
+    if (!p.busy) {
+        if (bytes > p.cap) {
+            if (p.base) hipHostFree(p.base);
+            p.base = nullptr;
+            p.cap = 0;
+            size_t want = bytes + bytes / 4 + 4096;
+            if (hipHostMalloc((void **)&p.base, want) != hipSuccess) return nullptr;
+            p.cap = want;
+        }
+        p.busy = true;
+        return p.base;
+    }
+    void *q = nullptr;
+    return hipHostMalloc(&q, bytes) == hipSuccess ? q : nullptr;
+}
+
+void pinned_put(vits_handle *h, void *q) {
+    if (!q) return;
+    if (h && q == h->pin.base) h->pin.busy = false;
+    else hipHostFree(q);
+}
 
 void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const int *len, int C, int T, int flags) {
     if (C <= 256)
@@ -387,7 +469,7 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
 
 // frame-domain layout: flow buffers + generator ping-pong regions
 size_t gen_region_floats(const Model &m, int B, int F) {
-    size_t mx = (size_t)B * m.C0 * ((F + 3) & ~3);
+    size_t mx = (size_t)B * (m.C0 > m.C ? m.C0 : m.C) * ((F + 3) & ~3);
     int64_t t = F;
     for (auto &st : m.ups) {
         t *= st.u;
@@ -397,11 +479,99 @@ size_t gen_region_floats(const Model &m, int B, int F) {
     return mx;
 }
 
-constexpr int kGenRegions = 10;
+constexpr int kGenRegions = 10;     // f32 engine: ten fp32 regions
+constexpr int kGenRegionsSx = 15;   // sx engine: 4 raw + 6 plane tensors (1.5 regions each) + the waveform, rounded up
+
+// bytes of generator workspace (the largest tensor decides the region size)
+size_t gen_ws_bytes(const Model &m, int B, int F) {
+    return (size_t)(m.gen_sx ? kGenRegionsSx : kGenRegions) * al(gen_region_floats(m, B, F));
+}
+
+// The generator on the split-exact bf16 engine.  Same dataflow as run_generator below; tensors that feed a conv
+// are stored as bf16 planes (already leaky-ReLU'd by their producer), the residual stream as fp32 raw cells.
+int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B,
+                     int F, const float *dec_cond, Slab &s) {
+    const Model &m = h->model;
+    hipStream_t st = h->stream;
+    const size_t R = gen_region_floats(m, B, F);
+    const size_t RP = R + R / 2 + 64;  // floats holding R elements as three bf16 planes
+    auto planes = [&]() { return reinterpret_cast<uint16_t *>(slab_take<float>(s, RP)); };
+    uint16_t *stage_in[2] = {planes(), planes()}, *y_pl = planes(), *raa[2] = {planes(), planes()}, *tmp_pl = planes();
+    float *y_raw = slab_take<float>(s, R), *ra[2] = {slab_take<float>(s, R), slab_take<float>(s, R)};
+    float *xs_raw = slab_take<float>(s, R);
+    h->cur_stage = 3;
+    stage_mark(h, 3);
+    const float S = 0.1f;  // Generator.LRELU_SLOPE / ResBlock LRELU_SLOPE
+    const int nst = (int)m.ups.size();
+    // z * y_mask -> planes (models.py:349); conv_pre [+ cond(g)] -> leaky_relu(0.1) planes (models.py:349-354)
+    sx_split_planes_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_pl, m.C, F);
+    c.note(hipGetLastError());
+    h->stats.total_launches++;
+    uint16_t *xa = stage_in[0];
+    conv_sx(c, m.conv_pre, tmp_pl, F, nullptr, xa, 0, nullptr, dec_cond, m.C0, 1.f, 1.f, S);
+    int T = F;
+    for (int si = 0; si < nst; si++) {
+        const auto &stg = m.ups[si];
+        // y = up(xa): pixel-shuffled dense conv; raw (residual) + leaky_relu planes (conv input)
+        conv_sx(c, stg.up, xa, T, y_raw, y_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
+        T *= stg.u;
+        uint16_t *xs_pl = stage_in[(si + 1) & 1];
+        const int nk = (int)stg.rbs.size();
+        const bool last_stage = si == nst - 1;
+        for (int j = 0; j < nk; j++) {
+            const auto &rbk = stg.rbs[j];
+            const float *cur = y_raw;
+            const uint16_t *cura = y_pl;
+            // MRF accumulation (models.py:356-363): xs = rb0(x); xs += rb1(x); ... ; x = xs / nk
+            const bool final_rb = j == nk - 1;
+            for (int q = 0; q < rbk.n; q++) {
+                const bool last = q == rbk.n - 1;
+                int fl = EPI_RES;
+                float *dst = ra[q & 1];
+                uint16_t *dsta = raa[q & 1];
+                float osl = 1.f, osl2 = S;
+                if (last) {
+                    fl |= (j == 0 ? 0 : EPI_ACC) | (final_rb && nk > 1 ? EPI_DIV : 0);
+                    dst = xs_raw;
+                    dsta = nullptr;
+                    if (final_rb && last_stage) osl = 0.01f;  // leaky_relu before conv_post (models.py:364)
+                    else if (final_rb) {                      // the next upsampler reads leaky_relu(0.1) planes only
+                        dsta = xs_pl;
+                        fl |= SX_NO_RAW_STORE;
+                    }
+                }
+                if (rbk.type1) {  // modules.py:301-314: x = c2(lrelu(c1(lrelu(x)))) + x
+                    conv_sx(c, rbk.c1[q], cura, T, nullptr, tmp_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
+                    conv_sx(c, rbk.c2[q], tmp_pl, T, dst, dsta, fl, cur, nullptr, 0, (float)nk, osl, osl2);
+                } else  // modules.py:355-364: x = c(lrelu(x)) + x
+                    conv_sx(c, rbk.c1[q], cura, T, dst, dsta, fl, cur, nullptr, 0, (float)nk, osl, osl2);
+                cur = dst;
+                cura = dsta;
+            }
+        }
+        xa = xs_pl;
+    }
+    // conv_post; tanh (models.py:365-366) on the leaky_relu(0.01)'d raw tensor
+    h->S = T;
+    h->d_out = slab_take<float>(s, (size_t)B * T);
+    size_t lds = ((size_t)m.post_cin * (256 + m.post_k - 1) + (size_t)m.post_cin * m.post_k) * sizeof(float);
+    post_conv_tanh_blocked_kernel<<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out, m.post_cin,
+                                                                             m.post_k, T);
+    c.note(hipGetLastError());
+    h->stats.total_launches++;
+    {
+        double fl = 2.0 * m.post_cin * m.post_k * (double)T * B, by = 4.0 * B * ((double)m.post_cin * T + T);
+        h->stats.dec_flops += fl;
+        h->stats.dec_bytes += by;
+    }
+    stage_mark(h, 4);
+    return 0;
+}
 
 int run_generator(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B,
                   int F, const float *dec_cond, Slab &s) {
     const Model &m = h->model;
+    if (m.gen_sx) return run_generator_sx(h, c, z, z_bstride, z_cstride, ylen, B, F, dec_cond, s);
     hipStream_t st = h->stream;
     const size_t R = gen_region_floats(m, B, F);
     float *reg[kGenRegions];
@@ -496,7 +666,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     const int F = (Freal + 3) & ~3;
     h->Fpitch = F;
     const size_t nCF = (size_t)B * C * F, nHF = (size_t)B * Hf * F;
-    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + kGenRegions * al(gen_region_floats(m, B, F)) + (1 << 16);
+    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + gen_ws_bytes(m, B, F) + (1 << 16);
     for (auto &cd : m.flow) need += al((size_t)B * 2 * Hf * cd.n_wn);
     need += al((size_t)B * m.C0);
     if (int rc = slab_reserve(h, h->frm, need)) return rc;
@@ -649,6 +819,8 @@ void vits_close(vits_handle *h) {
         if (h->arena_owned && h->arena_dev) hipFree(h->arena_dev);
         if (h->tok.base) hipFree(h->tok.base);
         if (h->frm.base) hipFree(h->frm.base);
+        if (h->io.base) hipFree(h->io.base);
+        if (h->pin.base) hipHostFree(h->pin.base);
         for (auto &p : h->conv_events) {
             hipEventDestroy(p.first);
             hipEventDestroy(p.second);
@@ -793,8 +965,8 @@ int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int
     size_t nb = (size_t)B * T * 8 + (size_t)B * 16 + 1024;
     size_t ndp = noise && noise->noise_dp ? (size_t)B * 2 * T * 4 : 0;
     size_t nz = noise && noise->noise_z ? (size_t)B * m.C * (size_t)noise->noise_z_stride * 4 : 0;
-    char *stage = nullptr;
-    HIPCHECK(h, hipMalloc((void **)&stage, nb + ndp + nz + 1024));
+    if (int rc0 = slab_reserve(h, h->io, nb + ndp + nz + 1024)) return rc0;
+    char *stage = h->io.base;
     int64_t *d_ids = (int64_t *)stage, *d_lens = d_ids + (size_t)B * T, *d_sid = d_lens + B;
     float *d_ndp = (float *)(stage + ((nb + 255) & ~size_t(255)));
     float *d_nz = (float *)((char *)d_ndp + ((ndp + 255) & ~size_t(255)));
@@ -822,31 +994,32 @@ int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int
     vits_output dev{};
     if (rc == VITS_OK) rc = run_device_locked(h, d_ids, d_lens, B, T, scales, sid ? d_sid : nullptr, noise ? &dn : nullptr, &dev);
     if (rc == VITS_OK) {
-        size_t n = (size_t)B * h->S;
-        float *host = nullptr;
-        int64_t *hy = nullptr;
-        if (hipHostMalloc((void **)&host, n * 4 + 64) != hipSuccess || hipHostMalloc((void **)&hy, (size_t)B * 8 + 64) != hipSuccess)
+        // one pinned block: [samples | frame counts]
+        const size_t n = (size_t)B * h->S, ybase = (n * 4 + 63) & ~size_t(63);
+        char *host = (char *)pinned_get(h, ybase + (size_t)B * 8);
+        if (!host)
             rc = fail(h, VITS_E_NOMEM, "cannot allocate pinned output (%zu bytes)", n * 4);
         else if (hipMemcpyAsync(host, dev.data, n * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-                 hipStreamSynchronize(st) != hipSuccess)
+                 hipStreamSynchronize(st) != hipSuccess) {
+            pinned_put(h, host);
             rc = fail(h, VITS_E_DEVICE, "device-to-host copy failed: %s", hipGetErrorString(hipGetLastError()));
-        else {
+        } else {
+            int64_t *hy = (int64_t *)(host + ybase);
             for (int b = 0; b < B; b++) hy[b] = h->h_ylen[b];
-            out->data = host;
+            out->data = (float *)host;
             std::memcpy(out->dims, dev.dims, sizeof dev.dims);
             out->y_lengths = hy;
         }
     }
-    hipStreamSynchronize(st);
-    hipFree(stage);
+    if (rc != VITS_OK) hipStreamSynchronize(st);  // the staging slab is reused by the next call
     return rc;
 }
 
 void vits_free_output(vits_handle *h, vits_output *out) {
-    (void)h;
     if (!out) return;
-    if (out->data) hipHostFree(out->data);
-    if (out->y_lengths) hipHostFree(out->y_lengths);
+    std::unique_lock<std::mutex> lk;
+    if (h) lk = std::unique_lock<std::mutex>(h->mu);
+    pinned_put(h, out->data);  // y_lengths lives in the same block
     out->data = nullptr;
     out->y_lengths = nullptr;
 }
@@ -858,10 +1031,11 @@ int vits_last_pcm16(vits_handle *h, int normalize, float volume, int16_t *out, s
     if (!h->d_out || !h->d_ylen || B <= 0 || S <= 0) return fail(h, VITS_E_ARG, "no completed run to post-process");
     const size_t n = (size_t)B * S;
     if (!out || out_elems < n) return fail(h, VITS_E_ARG, "pcm16 buffer too small: %zu < %zu", out_elems, n);
-    int16_t *d_pcm = nullptr;
-    unsigned *d_peak = nullptr;
-    HIPCHECK(h, hipMalloc((void **)&d_pcm, n * 2 + 64));
-    HIPCHECK(h, hipMalloc((void **)&d_peak, (size_t)B * 4));
+    // the staging slab is idle between runs (vits_run has consumed its inputs before it returns)
+    const size_t pcm_bytes = (n * 2 + 255) & ~size_t(255);
+    if (int rc = slab_reserve(h, h->io, pcm_bytes + (size_t)B * 4 + 256)) return rc;
+    int16_t *d_pcm = (int16_t *)h->io.base;
+    unsigned *d_peak = (unsigned *)(h->io.base + pcm_bytes);
     hipStream_t st = h->stream;
     hipError_t e = hipMemsetAsync(d_peak, 0, (size_t)B * 4, st);
     const int hop = h->model.hop;
@@ -874,8 +1048,6 @@ int vits_last_pcm16(vits_handle *h, int normalize, float volume, int16_t *out, s
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_pcm, n * 2, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipFree(d_pcm);
-    hipFree(d_peak);
     if (e != hipSuccess) return fail(h, VITS_E_DEVICE, "pcm16 post-processing failed: %s", hipGetErrorString(e));
     return VITS_OK;
 }
@@ -889,7 +1061,7 @@ int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t
     std::memset(&h->stats, 0, sizeof h->stats);
     h->conv_events_used = 0;
     const size_t nCF = (size_t)B * m.C * F;
-    size_t need = al(nCF) + kGenRegions * al(gen_region_floats(m, B, F)) + al((size_t)B * m.C0) + (1 << 16);
+    size_t need = al(nCF) + gen_ws_bytes(m, B, F) + al((size_t)B * m.C0) + (1 << 16);
     if (int rc = slab_reserve(h, h->frm, need)) return rc;
     Slab &s = h->frm;
     s.used = 0;
@@ -911,10 +1083,14 @@ int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t
     if (int rc = run_generator(h, c, dz, (int64_t)m.C * F, F, nullptr, B, F, dec_cond, s)) return rc;
     if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
     size_t n = (size_t)B * h->S;
-    float *host = nullptr;
-    if (hipHostMalloc((void **)&host, n * 4 + 64) != hipSuccess) return fail(h, VITS_E_NOMEM, "pinned alloc failed");
-    HIPCHECK(h, hipMemcpyAsync(host, h->d_out, n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHECK(h, hipStreamSynchronize(st));
+    float *host = (float *)pinned_get(h, n * 4 + 64);
+    if (!host) return fail(h, VITS_E_NOMEM, "pinned alloc failed");
+    hipError_t ce = hipMemcpyAsync(host, h->d_out, n * 4, hipMemcpyDeviceToHost, st);
+    if (ce == hipSuccess) ce = hipStreamSynchronize(st);
+    if (ce != hipSuccess) {
+        pinned_put(h, host);
+        return fail(h, VITS_E_DEVICE, "device-to-host copy failed: %s", hipGetErrorString(ce));
+    }
     out->data = host;
     out->dims[0] = B;
     out->dims[1] = 1;
@@ -1021,7 +1197,7 @@ static int run_test_conv(const ConvDesc &d, const std::vector<float> &arena, con
     a.out_bstride = out_bstride;
     a.zeros = dA;  // pack_test_* reserve a zero page at offset 0
     a.Cin = d.Cin; a.Cout = d.Cout; a.K = d.K; a.dil = d.dil; a.padL = d.padL; a.CK = d.CK;
-    a.nchunks = d.nchunks; a.steps4 = d.steps4; a.ups = d.ups;
+    a.nchunks = d.nchunks; a.ups = d.ups;
     a.flags = ((flags & 1) ? PRO_LRELU : 0) | ((flags & 2) ? EPI_RELU : 0);
     a.slope = slope;
     a.div = 1.f;
@@ -1079,7 +1255,7 @@ int vits_bench_conv1d(int device_id, int B, int Cin, int Cout, int T, int K, int
     a.out_bstride = (int64_t)Cout * T;
     a.zeros = dA;
     a.Cin = d.Cin; a.Cout = d.Cout; a.K = d.K; a.dil = d.dil; a.padL = d.padL; a.CK = d.CK;
-    a.nchunks = d.nchunks; a.steps4 = d.steps4; a.ups = 1;
+    a.nchunks = d.nchunks; a.ups = 1;
     a.flags = ((dbg & 4) ? 0 : PRO_LRELU) | ((dbg & 1) ? DBG_NO_DMA : 0) | ((dbg & 2) ? DBG_NO_EPI : 0);
     if ((dbg & 8) && Cin == Cout) {  // residual epilogue + pre-activated second output, as the generator runs it
         a.flags |= EPI_RES;
@@ -1120,6 +1296,144 @@ int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, in
     std::vector<float> arena;
     { std::string e = pack_test_convT(w, bias, Cin, Cout, K, stride, &d, &arena); if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str()); }
     return run_test_conv(d, arena, x, B, T, 0, 0.f, out, (size_t)B * Cout * T * stride, (int64_t)Cout * T * stride);
+}
+
+// ---- the same hooks through the split-exact bf16 engine: planar host tensors are converted to the engine's
+// plane / raw layouts on the device, the result is converted back.
+static void fill_sx_args(SxArgs &a, const ConvDesc &d, const float *dA, int T) {
+    const int Cr = d.Cout / d.ups;
+    a.x_bstride = (int64_t)3 * (d.Cin / 8) * T;
+    a.T = T;
+    a.wp = reinterpret_cast<const u32x4 *>(dA + d.w_off);
+    a.bias = d.b_off >= 0 ? dA + d.b_off : nullptr;
+    a.raw_bstride = (int64_t)Cr * T * d.ups;
+    a.pl_bstride = 3 * a.raw_bstride;
+    a.zeros = dA;  // pack_test_* reserve a zero page at offset 0
+    a.Cin = d.Cin; a.Cout = d.Cout; a.Cr = Cr; a.K = d.K; a.dil = d.dil; a.padL = d.padL;
+    a.nchunks = d.nchunks; a.ups = d.ups;
+    a.div = 1.f;
+}
+
+static int run_test_conv_sx(const ConvDesc &d, const std::vector<float> &arena, const float *x, int B, int T, int flags,
+                            float slope, float *out) {
+    const int Cr = d.Cout / d.ups, To = T * d.ups;
+    const size_t nx = (size_t)B * d.Cin * T, no = (size_t)B * Cr * To;
+    float *dA = nullptr, *dx = nullptr, *dres = nullptr, *draw = nullptr, *dout = nullptr;
+    uint16_t *dxp = nullptr, *dop = nullptr;
+    TCHECK(hipMalloc((void **)&dA, arena.size() * 4));
+    TCHECK(hipMalloc((void **)&dx, nx * 4 + 16));
+    TCHECK(hipMalloc((void **)&dxp, nx * 6 + 16));
+    TCHECK(hipMalloc((void **)&draw, no * 4 + 16));
+    TCHECK(hipMalloc((void **)&dop, no * 6 + 16));
+    TCHECK(hipMalloc((void **)&dout, no * 4 + 16));
+    TCHECK(hipMemcpy(dA, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemset(draw, 0, no * 4));
+    TCHECK(hipMemset(dop, 0, no * 6));
+    sx_split_planes_kernel<<<dim3((T + 255) / 256, d.Cin / 8, B), 256>>>(dx, (int64_t)d.Cin * T, T, nullptr, dxp, d.Cin, T);
+    SxArgs a{};
+    fill_sx_args(a, d, dA, T);
+    a.xp = reinterpret_cast<const u32x4 *>(dxp);
+    a.out_raw = draw;
+    a.out_pl = dop;
+    a.oslope = 1.f;
+    a.oslope2 = (flags & 1) ? slope : 1.f;
+    if (flags & 4) {  // residual: res = x (same shape only)
+        if (d.Cin != d.Cout || d.ups != 1) return fail(nullptr, VITS_E_ARG, "residual test needs Cin == Cout");
+        TCHECK(hipMalloc((void **)&dres, nx * 4 + 16));
+        sx_block_kernel<<<dim3((T + 255) / 256, d.Cin / 8, B), 256>>>(dx, dres, d.Cin, T);
+        a.res = dres;
+        a.flags |= EPI_RES;
+    }
+    TCHECK(launch_conv_sx(a, d.cfg, B, nullptr));
+    sx_unblock_kernel<<<dim3((To + 255) / 256, Cr / 8, B), 256>>>(draw, (flags & 1) ? dop : nullptr, dout, Cr, To);
+    TCHECK(hipGetLastError());
+    TCHECK(hipDeviceSynchronize());
+    TCHECK(hipMemcpy(out, dout, no * 4, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dx); hipFree(dxp); hipFree(draw); hipFree(dop); hipFree(dout);
+    if (dres) hipFree(dres);
+    return VITS_OK;
+}
+
+int vits_test_conv1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias, int Cout,
+                        int K, int dil, int pad_l, int flags, float slope, float *out) {
+    if (int rc = test_dev(device_id)) return rc;
+    ConvDesc d;
+    std::vector<float> arena;
+    std::string e = pack_test_conv(w, bias, Cin, Cout, K, dil, pad_l, 3, &d, &arena);
+    if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
+    return run_test_conv_sx(d, arena, x, B, T, flags, slope, out);
+}
+
+int vits_test_conv_transpose1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
+                                  int Cout, int K, int stride, float *out) {
+    if (int rc = test_dev(device_id)) return rc;
+    ConvDesc d;
+    std::vector<float> arena;
+    std::string e = pack_test_convT(w, bias, Cin, Cout, K, stride, &d, &arena, true);
+    if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
+    return run_test_conv_sx(d, arena, x, B, T, 0, 0.f, out);
+}
+
+int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, int dil, int dbg, int iters,
+                         float *ms_out) {
+    if (int rc = test_dev(device_id)) return rc;
+    std::vector<float> w((size_t)Cout * Cin * K), x((size_t)B * Cin * T);
+    uint32_t s = 12345u;
+    auto rnd = [&]() {
+        s = s * 1664525u + 1013904223u;
+        return ((s >> 8) * (1.0f / 8388608.0f)) - 1.0f;
+    };
+    for (auto &v : w) v = rnd() * 0.05f;
+    for (auto &v : x) v = rnd();
+    ConvDesc d;
+    std::vector<float> arena;
+    std::string e = pack_test_conv(w.data(), nullptr, Cin, Cout, K, dil, dil * (K - 1) / 2, 3, &d, &arena);
+    if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
+    float *dA = nullptr, *dx = nullptr, *draw = nullptr, *dres = nullptr;
+    uint16_t *dxp = nullptr, *dop = nullptr;
+    const size_t nx = x.size(), no = (size_t)B * Cout * T;
+    TCHECK(hipMalloc((void **)&dA, arena.size() * 4));
+    TCHECK(hipMalloc((void **)&dx, nx * 4));
+    TCHECK(hipMalloc((void **)&dxp, nx * 6));
+    TCHECK(hipMalloc((void **)&draw, no * 4));
+    TCHECK(hipMalloc((void **)&dres, no * 4));
+    TCHECK(hipMalloc((void **)&dop, no * 6));
+    TCHECK(hipMemcpy(dA, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dx, x.data(), nx * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemset(dres, 0, no * 4));
+    sx_split_planes_kernel<<<dim3((T + 255) / 256, Cin / 8, B), 256>>>(dx, (int64_t)Cin * T, T, nullptr, dxp, Cin, T);
+    SxArgs a{};
+    fill_sx_args(a, d, dA, T);
+    a.xp = reinterpret_cast<const u32x4 *>(dxp);
+    a.out_pl = dop;  // as the generator's inner convs: planes out
+    a.oslope2 = 0.1f;
+    a.flags = ((dbg & 1) ? DBG_NO_DMA : 0) | ((dbg & 2) ? DBG_NO_EPI : 0);
+    if (dbg & 8) {  // residual epilogue with raw + planes outputs (ResBlock tail)
+        a.flags |= EPI_RES;
+        a.res = dres;
+        a.out_raw = draw;
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 2; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr));
+    TCHECK(hipDeviceSynchronize());
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr));
+    hipEventRecord(e1, nullptr);
+    TCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms_out) {
+        ms_out[0] = ms / iters;
+        ms_out[1] = (float)d.cfg;
+        ms_out[2] = 0.f;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(dA); hipFree(dx); hipFree(dxp); hipFree(draw); hipFree(dres); hipFree(dop);
+    return VITS_OK;
 }
 
 int vits_test_attention(int device_id, const float *qkv, int B, int C, int T, int n_heads, const float *rel_k,

@@ -291,7 +291,36 @@ def test_conv1d(x, w, bias=None, dil=1, pad_l=0, lrelu_slope=None, relu=False, d
     return out
 
 
-def test_conv_transpose1d(x, w, bias, stride, device_id=0):
+def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=False, device_id=0):
+    """The split-exact bf16 engine (Cin % 16 == 0, Cout % 32 == 0).  planes_slope: read the result back from
+    the three bf16 output planes, which carry leaky_relu(conv, planes_slope); residual: out = conv(x) + x."""
+    lib = _ffi.load()
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    B, Cin, T = x.shape
+    Cout, _, K = w.shape
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    out = np.empty((B, Cout, T), np.float32)
+    flags = (1 if planes_slope is not None else 0) | (4 if residual else 0)
+    rc = lib.vits_test_conv1d_sx(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, dil, pad_l,
+                                 flags, float(planes_slope or 0.0), _ffi.ptr(out))
+    if rc != 0:
+        raise SessionError(_ffi.last_error(None))
+    return out
+
+
+def bench_conv1d_sx(B, Cin, Cout, T, K, dil=1, dbg=0, iters=20, device_id=0):
+    """Average launch time (ms) of one conv shape on the split-exact engine -> (ms, tile config)."""
+    lib = _ffi.load()
+    res = np.zeros(3, np.float32)
+    rc = lib.vits_bench_conv1d_sx(device_id, B, Cin, Cout, T, K, dil, dbg, iters,
+                                  res.ctypes.data_as(_ffi.C.POINTER(_ffi.C.c_float)))
+    if rc != 0:
+        raise SessionError(_ffi.last_error(None))
+    return float(res[0]), int(res[1])
+
+
+def test_conv_transpose1d(x, w, bias, stride, device_id=0, sx=False):
     lib = _ffi.load()
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
@@ -299,7 +328,8 @@ def test_conv_transpose1d(x, w, bias, stride, device_id=0):
     _, Cout, K = w.shape
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     out = np.empty((B, Cout, T * stride), np.float32)
-    rc = lib.vits_test_conv_transpose1d(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, stride,
+    fn = lib.vits_test_conv_transpose1d_sx if sx else lib.vits_test_conv_transpose1d
+    rc = fn(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, stride,
                                         _ffi.ptr(out))
     if rc != 0:
         raise SessionError(_ffi.last_error(None))

@@ -103,6 +103,84 @@ def test_conv_transpose_matches_oracle(B, Cin, Cout, T, K, u):
     np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
 
 
+# ------------------------------------------------------------------ kernel level: split-exact bf16 engine
+
+SX_CASES = [
+    # (B, Cin, Cout, T, K, dil)                      sx tile config exercised
+    (2, 32, 32, 300, 3, 1),     # 32x256, two chunks
+    (1, 64, 64, 513, 11, 5),    # 64x256, widest receptive field of the "high" preset
+    (2, 128, 128, 700, 7, 3),   # 128x128
+    (1, 192, 512, 45, 7, 1),    # conv_pre of the "high" preset
+    (1, 16, 96, 260, 5, 2),     # single chunk, Cout % 64 != 0
+    (1, 256, 128, 130, 3, 1),   # sixteen chunks
+    (3, 48, 32, 257, 1, 1),     # k = 1, ragged T
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,dil", SX_CASES)
+def test_conv_sx_engine_matches_oracle(B, Cin, Cout, T, K, dil):
+    from phoonnx_amd.session import test_conv1d_sx
+    from vits_oracle import conv1d
+    rng = np.random.default_rng(B * 1000 + Cin + Cout + T)
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    pad = dil * (K - 1) // 2
+    ref = conv1d(x, w, b, dil=dil, pad_l=pad, pad_r=dil * (K - 1) - pad)
+    got = test_conv1d_sx(x, w, b, dil=dil, pad_l=pad)                       # fp32 raw output
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
+    got = test_conv1d_sx(x, w, b, dil=dil, pad_l=pad, planes_slope=0.1)     # bf16 planes of leaky_relu(out)
+    np.testing.assert_allclose(got, np.where(ref > 0, ref, ref * np.float32(0.1)), atol=2e-5, rtol=1e-5)
+    if Cin == Cout:                                                          # residual epilogue
+        got = test_conv1d_sx(x, w, b, dil=dil, pad_l=pad, residual=True)
+        np.testing.assert_allclose(got, ref + x, atol=2e-5, rtol=1e-5)
+
+
+def test_conv_sx_engine_is_exact_on_identity():
+    # W = I: every product is (1.0 x plane), so the three planes must reassemble each fp32 input bit for bit
+    # (exactness of the split, the operand layouts and the C/D map in one check)
+    from phoonnx_amd.session import test_conv1d_sx
+    C, T = 64, 301
+    rng = np.random.default_rng(7)
+    w = np.zeros((C, C, 1), np.float32)
+    w[np.arange(C), np.arange(C), 0] = 1
+    x = (rng.standard_normal((2, C, T)) * np.exp(rng.uniform(-20, 20, (2, C, T)))).astype(np.float32)
+    assert np.array_equal(test_conv1d_sx(x, w), x)
+    assert np.array_equal(test_conv1d_sx(x, w, planes_slope=1.0), x)
+
+
+def test_conv_sx_engine_error_is_fp32_grade():
+    # against float64: the split-exact engine must be as accurate as the fp32-FMA engine (it drops only
+    # terms below 2^-24 relative), not bf16-grade
+    from phoonnx_amd.session import test_conv1d, test_conv1d_sx
+    rng = np.random.default_rng(11)
+    B, C, T, K, dil = 1, 128, 640, 7, 3
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    w = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    pad = dil * (K - 1) // 2
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (pad, pad)))
+    ref = sum(np.einsum("oc,bct->bot", w[:, :, k].astype(np.float64), xp[:, :, k * dil:k * dil + T]) for k in range(K))
+    e_sx = np.abs(test_conv1d_sx(x, w, dil=dil, pad_l=pad) - ref).max()
+    e_f32 = np.abs(test_conv1d(x, w, dil=dil, pad_l=pad) - ref).max()
+    assert e_sx <= 2 * e_f32 + 1e-7, (e_sx, e_f32)
+    assert e_sx < 5e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,u", [(2, 32, 32, 50, 16, 8), (1, 64, 32, 37, 8, 4), (2, 128, 64, 129, 4, 2),
+                                              (1, 512, 256, 9, 16, 8)])
+def test_conv_transpose_sx_matches_oracle(B, Cin, Cout, T, K, u):
+    from phoonnx_amd.session import test_conv_transpose1d
+    from vits_oracle import conv_transpose1d
+    rng = np.random.default_rng(K * 100 + u)
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(Cin * K / u)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    got = test_conv_transpose1d(x, w, b, u, sx=True)
+    ref = conv_transpose1d(x, w, b, u, (K - u) // 2)
+    assert got.shape == ref.shape == (B, Cout, T * u)
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
+
+
 # ------------------------------------------------------------------ kernel level: attention
 
 @pytest.mark.parametrize("B,heads,dk,T,lens", [(2, 2, 16, 40, [40, 17]), (1, 2, 96, 256, [256]), (3, 4, 8, 5, [5, 1, 3]),
