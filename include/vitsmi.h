@@ -180,7 +180,9 @@ int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, in
  * are multiples of 32 (csrc/conv_sx_engine.hip.hpp); needs Cin % 16 == 0 and Cout % 32 == 0.
  * vits_test_conv1d_sx flags: bit0 -> out = leaky_relu(conv, slope) read back from the three bf16 output planes
  * (else the fp32 raw output), bit2 -> residual epilogue with res = x (Cin == Cout).
- * vits_bench_conv1d_sx dbg bits: 1 no DMA after the first step, 2 no epilogue, 8 residual epilogue. */
+ * vits_bench_conv1d_sx dbg bits: 1 no DMA after the first step, 2 no epilogue, 8 residual epilogue, 16 in-kernel
+ * cycle breakdown (128-row tiles only).  ms_out holds 8 floats: [0] ms per launch, [1] tile config, [3..7] with
+ * bit 16: s_memtime ticks per pipeline step spent in {LDS wait, DMA wait, barrier, DMA issue, loads + MFMA}. */
 int vits_test_conv1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
                         int Cout, int K, int dil, int pad_l, int flags, float slope, float *out);
 int vits_test_conv_transpose1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w,

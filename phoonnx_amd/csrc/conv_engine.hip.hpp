@@ -267,14 +267,18 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
     const int nchunks = a.nchunks;
     const bool dbg_nodma = a.flags & DBG_NO_DMA;
     issue(0, stageP);
-    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    // (no exit from the middle of the unrolled pair: a mid-loop break makes hipcc copy the accumulators)
+    for (int chunk = 0; chunk + 1 < nchunks; chunk += 2) {
         __syncthreads();  // own DMA drained (vmcnt(0)) + everyone done reading stageQ
-        if (chunk + 1 < nchunks && !(dbg_nodma && chunk > 0)) issue(chunk + 1, stageQ);
+        if (!(dbg_nodma && chunk > 0)) issue(chunk + 1, stageQ);
         compute(stageP);
-        if (chunk + 1 >= nchunks) break;
         __syncthreads();
         if (chunk + 2 < nchunks && !dbg_nodma) issue(chunk + 2, stageP);
         compute(stageQ);
+    }
+    if (nchunks & 1) {
+        __syncthreads();
+        compute(stageP);
     }
 
     // ---- epilogue: branch-free per element (absent bias pointers read the zero page, flags become

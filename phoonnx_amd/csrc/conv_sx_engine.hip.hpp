@@ -19,8 +19,10 @@
 //   weights bf16 [m-tile][chunk of 16 ci][tap][32-row block][plane][lane][8]  (model.cpp pack_conv_sx):
 //                                 the A slab of a (chunk, tap group) is one contiguous range
 // Both operands reach LDS by 16-byte LDS-DMA; zero padding = out-of-range cells read a zero page.
-// Pipeline: the A slab streams per step (= TG taps of one chunk), double-buffered; the x tile of the NEXT
-// chunk is fetched in slices spread over the steps of the current chunk; one barrier per step.
+// Pipeline: one step = one tap of one 16-channel chunk.  The A slab of a step streams through a ring of three
+// LDS slots, fetched three steps ahead; the x tile of the NEXT chunk is fetched in slices spread over the
+// taps of the current chunk; one (raw, vmcnt-counted) barrier per step; the MFMA fragments of step s+1 are
+// read from LDS while step s's 6*MW*NW MFMAs run.
 // Epilogue: bias, per-utterance bias, residual, multi-receptive-field accumulate and /n, leaky-ReLU,
 // pixel shuffle of the transposed conv (virtual rows are r-major: row = r*Cr + co), then an fp32 raw
 // store and/or a split into the three planes the next conv reads.
@@ -56,12 +58,12 @@ struct SxArgs {
     const float *zeros;   // >= 1 KiB of zeros, 16-byte aligned
     int Cin, Cout, Cr;    // Cout = virtual rows (Cr * ups)
     int K, dil, padL, nchunks, ups;
-    int TG;               // taps per pipeline step                      (filled by launch_conv_sx)
     int LW;               // x tile width in cells                       ( " )
     unsigned magic;       // ceil(2^32 / LW)                             ( " )
-    unsigned x_bytes, a_bytes;  // bytes of one x stage / one A stage    ( " )
+    unsigned x_bytes;     // bytes of one x stage                        ( " )
     int flags;            // EPI_RES | EPI_ACC | EPI_DIV | DBG_*
     float div, oslope, oslope2;
+    unsigned long long *prof;  // PROF instantiation only: cycle counters [lgkm wait, vm wait, barrier, DMA issue, loads+MFMA, steps]
 };
 
 template <int OFF>
@@ -95,43 +97,72 @@ __device__ __forceinline__ void split3(float v, unsigned short &p0, unsigned sho
 }
 
 // One 256-thread workgroup = 4 waves arranged WM x WN, each owning MW x NW 32x32 accumulator blocks.
-template <int MW, int NW, int WM, int WN>
+template <int MW, int NW, int WM, int WN, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     constexpr int BM = MW * WM * 32, BN = NW * WN * 32, MB = BM / 32;
     static_assert(WM * WN == 4, "four waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_sx[];  // [x0][x1][a0][a1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave index as a SCALAR: the DMA bookkeeping (piece loops, vmcnt counts) then stays on the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, t0 = blockIdx.x * BN;
-    const int T = a.T, LW = a.LW, K = a.K, TG = a.TG, CG = a.Cin >> 3;
+    const int T = a.T, LW = a.LW, K = a.K, CG = a.Cin >> 3;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_sx;
-    const uint32_t XB = a.x_bytes, AB = a.a_bytes;
+    const uint32_t XB = a.x_bytes;
     const u32x4 *xb = a.xp + (int64_t)b * a.x_bstride;
     const int64_t pstride = (int64_t)CG * T;  // cells per plane
-    constexpr int TAPCELLS = MB * 3 * 64;      // cells of one tap of the A slab
+    constexpr int TAPCELLS = MB * 3 * 64;      // cells of one step's A slab (one tap of one 16-channel chunk)
+    constexpr uint32_t SLOT = MB * 3 * 1024;   // ... in bytes
     const u32x4 *wmt = a.wp + (int64_t)blockIdx.y * a.nchunks * K * TAPCELLS + lane;
     const int npieces = 6 * LW;                // x tile: rows (plane, channel-group half) x LW cells
     const int nit = (npieces + 255) >> 8;      // DMA rounds of 256 pieces
-    const int spc = (K + TG - 1) / TG;         // steps per chunk
-    const int ips = (nit + spc - 1) / spc;     // x rounds issued per step
+    const int nsl = K - 2;                     // steps of a chunk that carry a slice of the next chunk's x tile
+    const int ips = (nit + nsl - 1) / nsl;     // x rounds per such step
+    const uint32_t xbuf0 = lds0, abuf0 = lds0 + 2 * XB;
 
-    auto issue_a = [&](int chunk, int tap0, int nt, uint32_t abuf) {
-        const u32x4 *src = wmt + ((int64_t)chunk * K + tap0) * TAPCELLS;
-        const int n = nt * MB * 3;  // 1 KiB pieces
-        for (int i = wave; i < n; i += 4)
-            lds_dma<16>(src + i * 64, reinterpret_cast<float *>(lds_sx + (abuf - lds0) + i * 1024));
+    // Both return the number of DMA instructions THIS wave issued (for the vmcnt bookkeeping below).
+    auto issue_a = [&](int step, int slot) -> int {  // steps (chunk, tap) are consecutive in the packed weights
+        const u32x4 *src = wmt + (int64_t)step * TAPCELLS;
+        int cnt = 0;
+        for (int i = wave; i < MB * 3; i += 4, cnt++)
+            lds_dma<16>(src + i * 64, reinterpret_cast<float *>(lds_sx + 2 * XB + slot * SLOT + i * 1024));
+        return cnt;
     };
-    auto issue_x = [&](int chunk, int it0, int it1, uint32_t xbuf) {
+    auto issue_x = [&](int chunk, int it0, int it1, uint32_t xoff) -> int {
+        int cnt = 0;
         for (int it = it0; it < it1; it++) {
-            const int i = it * 256 + tid;
+            const int base = it * 256 + wave * 64;
+            if (base >= npieces) break;  // wave-uniform: this 1 KiB group lies past the tile
+            const int i = base + lane;
             const int row = (int)__umulhi((unsigned)i, a.magic);
             const int col = i - row * LW;
             const int t = t0 - a.padL + col;
             const bool ok = row < 6 && t >= 0 && t < T;
             const u32x4 *src = ok ? xb + ((row >> 1) * pstride + (int64_t)(2 * chunk + (row & 1)) * T + t)
                                   : reinterpret_cast<const u32x4 *>(a.zeros) + lane;
-            lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + (xbuf - lds0) + (it * 256 + wave * 64) * 16));
+            lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + xoff + base * 16));
+            cnt++;
+        }
+        return cnt;
+    };
+    // wait until at most n of this wave's DMA instructions are still in flight (they complete in order)
+    auto wait_vm = [&](int n) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;  // stricter than needed: safe
         }
     };
 
@@ -146,13 +177,13 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     struct Frag {
         u32x4 fa[MW][3], fb[NW][3];
     };
-    const uint32_t a_lane = (uint32_t)(wm * MW * 3) * 1024u + (uint32_t)lane * 16u;
-    const uint32_t b_lane = (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u;
+    const uint32_t a_lane = abuf0 + (uint32_t)(wm * MW * 3) * 1024u + (uint32_t)lane * 16u;
+    const uint32_t b_lane = xbuf0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u;
     const uint32_t plane_b = (uint32_t)(2 * LW) * 16u;
 
-    auto load = [&](Frag &f, uint32_t abuf, uint32_t xbuf, int tap_in_step, int tap) {
-        const uint32_t aa = abuf + a_lane + (uint32_t)tap_in_step * (uint32_t)(TAPCELLS * 16);
-        const uint32_t bb0 = xbuf + b_lane + (uint32_t)(tap * a.dil) * 16u;
+    auto load = [&](Frag &f, int slot, int chunk, int tap) {
+        const uint32_t aa = a_lane + (uint32_t)slot * SLOT;
+        const uint32_t bb0 = b_lane + (uint32_t)(chunk & 1) * XB + (uint32_t)(tap * a.dil) * 16u;
         const uint32_t bb1 = bb0 + plane_b, bb2 = bb1 + plane_b;
         static_for<MW>([&](auto M) {
             constexpr int m = decltype(M)::value;
@@ -180,49 +211,79 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
                                                                         __builtin_bit_cast(bf16x8, f.fb[n][PB[c]]),
                                                                         acc[m][n], 0, 0, 0);
     };
-    // taps [tap0, tap0+nt) of one chunk; fragments of tap+1 are fetched while tap's MFMAs run
-    auto compute = [&](uint32_t abuf, uint32_t xbuf, int tap0, int nt) {
-        Frag f0, f1;
-        load(f0, abuf, xbuf, 0, tap0);
-        for (int i = 0; i < nt; i += 2) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 1 < nt) load(f1, abuf, xbuf, i + 1, tap0 + i + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(f0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 1 >= nt) break;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            if (i + 2 < nt) load(f0, abuf, xbuf, i + 2, tap0 + i + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(f1);
-            __builtin_amdgcn_sched_barrier(0);
+
+    // ---- main loop over steps s = (chunk, tap).  A slabs live in a ring of three slots and are fetched THREE
+    // steps ahead; the x tile of chunk c+1 is fetched in slices during taps 0..K-3 of chunk c.  At the barrier
+    // of step s everything issued before step s-1 has landed (vmcnt(n_prev) leaves only step s-1's DMAs in
+    // flight), i.e. slab s+1 and, on a chunk's last tap, the next x tile: so the fragments of step s+1 are read
+    // from LDS while step s's MFMAs run, and the DMA has two full steps to complete.  Slot s%3 is dead at that
+    // barrier (its fragments sit in registers) and receives slab s+3.
+    const int nchunks = a.nchunks, S = nchunks * K;
+    const bool dbg_nodma = a.flags & DBG_NO_DMA;
+    int n_prev = 0;
+    issue_x(0, 0, nit, 0);
+    for (int p = 0; p < 3 && p < S; p++) {
+        const int c = issue_a(p, p);
+        n_prev = p == 2 ? c : 0;
+    }
+    wait_vm(n_prev);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    Frag f0, f1;
+    load(f0, 0, 0, 0);
+    int chunk = 0, tap = 0, slot = 0;
+    // PROF: where a step's cycles go (s_memtime stamps; tools/conv_bench.py --sx --prof)
+    unsigned long long pt = 0;
+    unsigned pc[5] = {0, 0, 0, 0, 0};
+    auto stamp = [&](int i) {
+        if constexpr (PROF) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            pc[i] += (unsigned)(now - pt);
+            pt = now;
         }
     };
-
-    const uint32_t xbuf0 = lds0, abuf0 = lds0 + 2 * XB;
-    const int nchunks = a.nchunks;
-    const bool dbg_nodma = a.flags & DBG_NO_DMA;
-    issue_x(0, 0, nit, xbuf0);
-    issue_a(0, 0, TG < K ? TG : K, abuf0);
-    int s = 0;
-    for (int chunk = 0; chunk < nchunks; chunk++) {
-        const uint32_t xcur = xbuf0 + (chunk & 1) * XB, xnext = xbuf0 + ((chunk + 1) & 1) * XB;
-        for (int g = 0; g < spc; g++, s++) {
-            __syncthreads();  // own DMA drained; everyone is done with the buffers refilled below
-            const int tap0 = g * TG, nt = (K - tap0) < TG ? (K - tap0) : TG;
-            // next step's A slab
-            int nchunk = chunk, ntap0 = tap0 + TG;
-            if (ntap0 >= K) { nchunk++; ntap0 = 0; }
-            if (nchunk < nchunks && !(dbg_nodma && s > 0))
-                issue_a(nchunk, ntap0, (K - ntap0) < TG ? (K - ntap0) : TG, abuf0 + ((s + 1) & 1) * AB);
-            // a slice of the next chunk's x tile
-            if (chunk + 1 < nchunks && !dbg_nodma) {
-                const int it0 = g * ips, it1 = (it0 + ips) < nit ? (it0 + ips) : nit;
-                issue_x(chunk + 1, it0, it1, xnext);
+    if constexpr (PROF) pt = __builtin_amdgcn_s_memtime();
+    auto step = [&](Frag &fc, Frag &fn, int s) {
+        stamp(4);  // fragment-load issue + MFMA issue of the previous step
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments of step s have landed
+        stamp(0);
+        wait_vm(n_prev);
+        stamp(1);
+        __builtin_amdgcn_s_barrier();  // (s = 0: everyone has read slab 0's fragments before slot 0 is refilled)
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(2);
+        n_prev = 0;
+        if (!dbg_nodma) {
+            if (s + 3 < S) n_prev += issue_a(s + 3, slot);
+            if (chunk + 1 < nchunks && tap < nsl) {
+                const int it0 = tap * ips, it1 = (it0 + ips) < nit ? (it0 + ips) : nit;
+                n_prev += issue_x(chunk + 1, it0, it1, ((chunk + 1) & 1) * XB);
             }
-            compute(abuf0 + (s & 1) * AB, xcur, tap0, nt);
+        }
+        int ntap = tap + 1, nchunk = chunk, nslot = slot + 1;
+        if (ntap == K) { ntap = 0; nchunk++; }
+        if (nslot == 3) nslot = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(3);
+        if (s + 1 < S) load(fn, nslot, nchunk, ntap);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fc);
+        __builtin_amdgcn_sched_barrier(0);
+        tap = ntap;
+        chunk = nchunk;
+        slot = nslot;
+    };
+    // (no exit from the middle of the unrolled pair: a mid-loop break makes hipcc copy all accumulators per step)
+    for (int s = 0; s + 1 < S; s += 2) {
+        step(f0, f1, s);
+        step(f1, f0, s + 1);
+    }
+    if (S & 1) step(f0, f1, S - 1);
+    if constexpr (PROF) {
+        stamp(4);
+        if (a.prof && tid == 0) {
+            for (int i = 0; i < 5; i++) atomicAdd(a.prof + i, (unsigned long long)pc[i]);
+            atomicAdd(a.prof + 5, (unsigned long long)S);
         }
     }
 
@@ -315,12 +376,11 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
 // sx tile configs: index -> (BM, BN): 0: 128x128, 1: 64x256, 2: 32x256
 inline int sx_tile_m(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
 inline int sx_tile_n(int cfg) { return cfg == 0 ? 128 : 256; }
-constexpr size_t kSxLdsBudget = 80 * 1024;  // two workgroups per CU
 
-template <int MW, int NW, int WM, int WN>
+template <int MW, int NW, int WM, int WN, bool PROF = false>
 inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
-    auto kern = conv_sx_kernel<MW, NW, WM, WN>;
+    auto kern = conv_sx_kernel<MW, NW, WM, WN, PROF>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
@@ -335,19 +395,15 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream) {
     const int BM = sx_tile_m(cfg), BN = sx_tile_n(cfg), MB = BM / 32;
     a.LW = BN + (a.K - 1) * a.dil;
     a.magic = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
-    a.x_bytes = (unsigned)(((size_t)6 * a.LW * 16 + 4095) / 4096 * 4096);
-    int tg = 4 / MB > 0 ? 4 / MB : 1;  // 12 KiB A stage
-    if (tg > a.K) tg = a.K;
-    while (tg > 1 && 2 * ((size_t)a.x_bytes + (size_t)tg * MB * 3072) > kSxLdsBudget) tg >>= 1;
-    a.TG = tg;
-    a.a_bytes = (unsigned)(tg * MB * 3072);
-    const size_t lds = 2 * ((size_t)a.x_bytes + a.a_bytes);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    a.x_bytes = (unsigned)(((size_t)6 * a.LW * 16 + 1023) / 1024 * 1024);
+    const size_t lds = 2 * (size_t)a.x_bytes + 3 * (size_t)MB * 3072;  // two x stages + ring of three A slabs
+    if (lds > 160 * 1024 || a.K < 3) return hipErrorInvalidValue;     // (pack_conv_sx pads narrower kernels to 3 taps)
     if (a.oslope == 0.f) a.oslope = 1.f;
     if (a.oslope2 == 0.f) a.oslope2 = 1.f;
     if (a.Cin % 16 || a.Cout % 32 || a.Cr % 32 || a.Cout % BM) return hipErrorInvalidValue;
     dim3 grid((a.T + BN - 1) / BN, a.Cout / BM, B);
     if (grid.x == 0 || B == 0) return hipSuccess;
+    if (a.prof && cfg == 0) return launch_conv_sx_k<2, 2, 2, 2, true>(a, grid, lds, stream);
     switch (cfg) {
         case 0: return launch_conv_sx_k<2, 2, 2, 2>(a, grid, lds, stream);
         case 1: return launch_conv_sx_k<2, 2, 1, 4>(a, grid, lds, stream);

@@ -323,6 +323,10 @@ int sx_pick_cfg(int Cout) { return Cout % 128 == 0 ? 0 : (Cout % 64 == 0 ? 1 : 2
 template <class WF>
 ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF w, const float *bias_virtual) {
     if (!sx_supported(Cin, Cout, Cout, K, dil)) throw std::runtime_error("conv shape not supported by the sx engine");
+    // the engine's pipeline needs >= 3 taps per chunk: narrower kernels get zero taps appended on the right
+    const int Kreal = K;
+    if (K < 3) K = 3;
+    auto wz = [&](int co, int ci, int tap) { return tap < Kreal ? w(co, ci, tap) : 0.f; };
     ConvDesc d;
     d.sx = true;
     d.Cin = Cin;
@@ -345,12 +349,12 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
                 for (int lane = 0; lane < 64; lane++)
                     for (int i = 0; i < 8; i++) {
                         uint16_t p[3];
-                        split3_host(w(mb * 32 + (lane & 31), chunk * 16 + 8 * (lane >> 5) + i, tap), p);
+                        split3_host(wz(mb * 32 + (lane & 31), chunk * 16 + 8 * (lane >> 5) + i, tap), p);
                         for (int pl = 0; pl < 3; pl++) dst[(base + pl) * 512 + lane * 8 + i] = p[pl];
                     }
             }
     if (bias_virtual) d.b_off = P.put(bias_virtual, Cout);
-    d.macs_per_t = double(Cin) * Cout * K;
+    d.macs_per_t = double(Cin) * Cout * Kreal;
     return d;
 }
 
@@ -471,10 +475,10 @@ void split3_host(float v, uint16_t p[3]) {
 bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil) {
     if (Cin < 16 || Cin % 16 || Cout_virtual % 32 || Cr % 32 || K < 1 || dil < 1) return false;
     const int cfg = sx_pick_cfg(Cout_virtual);
-    // two x stages + two single-tap A stages must fit the CU's 160 KiB (conv_sx_engine.hip.hpp launch_conv_sx)
-    const size_t LW = size_t(sx_tile_n(cfg)) + size_t(K - 1) * dil;
-    const size_t x_bytes = (6 * LW * 16 + 4095) / 4096 * 4096, a_bytes = size_t(sx_tile_m(cfg) / 32) * 3072;
-    return 2 * (x_bytes + a_bytes) <= 160 * 1024;
+    // two x stages + a ring of three A slabs must fit the CU's 160 KiB (conv_sx_engine.hip.hpp launch_conv_sx)
+    const size_t LW = size_t(sx_tile_n(cfg)) + size_t((K < 3 ? 3 : K) - 1) * dil;
+    const size_t x_bytes = (6 * LW * 16 + 1023) / 1024 * 1024, a_bytes = size_t(sx_tile_m(cfg) / 32) * 3072;
+    return 2 * x_bytes + 3 * a_bytes <= 160 * 1024;
 }
 
 void set_tiling_override(int cfg, int ck) {

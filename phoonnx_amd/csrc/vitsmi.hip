@@ -1414,11 +1414,18 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
         a.res = dres;
         a.out_raw = draw;
     }
+    unsigned long long *dprof = nullptr;
+    if (dbg & 16) {  // per-step cycle breakdown (128x128 tile only), returned in ms_out[3..8]
+        TCHECK(hipMalloc((void **)&dprof, 64));
+        TCHECK(hipMemset(dprof, 0, 64));
+        a.prof = dprof;
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     for (int i = 0; i < 2; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr));
     TCHECK(hipDeviceSynchronize());
+    if (dprof) TCHECK(hipMemset(dprof, 0, 64));
     hipEventRecord(e0, nullptr);
     for (int i = 0; i < iters; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr));
     hipEventRecord(e1, nullptr);
@@ -1429,9 +1436,15 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
         ms_out[0] = ms / iters;
         ms_out[1] = (float)d.cfg;
         ms_out[2] = 0.f;
+        if (dprof) {
+            unsigned long long hp[6];
+            TCHECK(hipMemcpy(hp, dprof, sizeof hp, hipMemcpyDeviceToHost));
+            for (int i = 0; i < 5; i++) ms_out[3 + i] = hp[5] ? (float)((double)hp[i] / (double)hp[5]) : 0.f;  // per step
+        }
     }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
+    if (dprof) hipFree(dprof);
     hipFree(dA); hipFree(dx); hipFree(dxp); hipFree(draw); hipFree(dres); hipFree(dop);
     return VITS_OK;
 }

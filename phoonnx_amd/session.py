@@ -312,11 +312,13 @@ def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=
 def bench_conv1d_sx(B, Cin, Cout, T, K, dil=1, dbg=0, iters=20, device_id=0):
     """Average launch time (ms) of one conv shape on the split-exact engine -> (ms, tile config)."""
     lib = _ffi.load()
-    res = np.zeros(3, np.float32)
+    res = np.zeros(8, np.float32)
     rc = lib.vits_bench_conv1d_sx(device_id, B, Cin, Cout, T, K, dil, dbg, iters,
                                   res.ctypes.data_as(_ffi.C.POINTER(_ffi.C.c_float)))
     if rc != 0:
         raise SessionError(_ffi.last_error(None))
+    if dbg & 16:
+        return float(res[0]), int(res[1]), [float(v) for v in res[3:8]]
     return float(res[0]), int(res[1])
 
 

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--sweep", action="store_true", help="try every tile config / chunk depth that fits")
     ap.add_argument("--ablate", action="store_true", help="time with DMA / epilogue / prologue switched off")
+    ap.add_argument("--prof", action="store_true", help="with --sx: per-step cycle breakdown of the 128x128 kernel")
+    ap.add_argument("--sx", action="store_true", help="benchmark the split-exact bf16 engine instead")
     a = ap.parse_args()
     lib = _ffi.load()
     F, B = a.frames, a.batch
@@ -53,6 +55,27 @@ def main():
         ("enc ffn1 192->768 k3", 192, 768, a.tokens, 3, 1, 2), ("enc ffn2 768->192 k3", 768, 192, a.tokens, 3, 1, 2),
         ("enc qkv 192->576", 192, 576, a.tokens, 1, 1, 2), ("enc 1x1 192->192", 192, 192, a.tokens, 1, 1, 2),
     ]
+    if a.sx:  # split-exact bf16 engine: generator shapes only (Cin % 16 == 0, Cout % 32 == 0)
+        from phoonnx_amd.session import bench_conv1d_sx
+        for name, Cin, Cout, T, K, dil, hint in shapes:
+            if hint != 0:
+                continue
+            line = f"{name:24s} T={T:7d}"
+            for tag, dbg in (("planes", 0), ("res+raw+planes", 8), ("noDMA", 1), ("noEPI", 2), ("none", 3)):
+                ms, cfg = bench_conv1d_sx(B, Cin, Cout, T, K, dil, dbg, a.iters)
+                tf = 2.0 * B * Cin * Cout * K * T / (ms * 1e-3) / 1e12
+                if dbg == 0:
+                    line += f" sx{cfg} {ms:8.3f} ms"
+                line += f"  {tag}:{tf:5.0f}"
+                if not a.ablate and dbg == 8:
+                    break
+            print(line + "  TF/s fp32-equivalent", flush=True)
+            if a.prof and Cout % 128 == 0:
+                for dbg in (16, 16 | 3):
+                    ms, cfg, pc = bench_conv1d_sx(B, Cin, Cout, T, K, dil, dbg, a.iters)
+                    print(f"      prof dbg={dbg & 15}: s_memtime ticks/step: lgkm {pc[0]:.0f} vmwait {pc[1]:.0f} barrier {pc[2]:.0f} "
+                          f"dma-issue {pc[3]:.0f} loads+mfma {pc[4]:.0f}  (sum {sum(pc):.0f})", flush=True)
+        return
     for name, Cin, Cout, T, K, dil, hint in shapes:
         r = bench(lib, B, Cin, Cout, T, K, dil, hint, a.iters)
         if r is None:

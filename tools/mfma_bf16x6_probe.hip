@@ -10,7 +10,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int WM, int WN, bool LDS>
+template <int WM, int WN, bool LDS, int BAR = 0>
 __global__ __launch_bounds__(256) void k(const float *in, float *out, int iters) {
     __shared__ __attribute__((aligned(16))) unsigned lds[16384];  // 64 KiB
     const int tid = threadIdx.x, lane = tid & 63;
@@ -26,8 +26,17 @@ __global__ __launch_bounds__(256) void k(const float *in, float *out, int iters)
         for (int p = 0; p < 3; p++) a[i][p] = base[(i * 3 + p) * 64];
     for (int j = 0; j < WN; j++)
         for (int p = 0; p < 3; p++) b[j][p] = base[((WM + j) * 3 + p) * 64];
+    unsigned sdummy = blockIdx.x, vdummy = threadIdx.x;
     for (int it = 0; it < iters; it++) {
         bf16x8 an[WM][3], bn[WN][3];
+        if (BAR >= 1) __builtin_amdgcn_s_barrier();
+        if (BAR >= 2) {
+#pragma unroll
+            for (int q = 0; q < 100; q++) {
+                if (BAR == 2) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sdummy) : : "scc");
+                else asm volatile("v_add_u32 %0, %0, 1" : "+v"(vdummy));
+            }
+        }
         if (LDS) {
             const bf16x8 *q = base + ((it & 7) * 512);
             for (int i = 0; i < WM; i++)
@@ -56,10 +65,10 @@ __global__ __launch_bounds__(256) void k(const float *in, float *out, int iters)
     for (int i = 0; i < WM; i++)
         for (int j = 0; j < WN; j++)
             for (int r = 0; r < 16; r++) s += acc[i][j][r];
-    out[blockIdx.x * 256 + tid] = s;
+    out[blockIdx.x * 256 + tid] = s + (float)sdummy + (float)vdummy;
 }
 
-template <int WM, int WN, bool LDS>
+template <int WM, int WN, bool LDS, int BAR = 0>
 void run(const float *in, float *out, const char *name) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -68,7 +77,7 @@ void run(const float *in, float *out, const char *name) {
     for (int wgs : {256, 512}) {
         for (int rep = 0; rep < 2; rep++) {
             hipEventRecord(e0);
-            k<WM, WN, LDS><<<wgs, 256>>>(in, out, iters);
+            k<WM, WN, LDS, BAR><<<wgs, 256>>>(in, out, iters);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
         }
@@ -81,6 +90,7 @@ void run(const float *in, float *out, const char *name) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     const int n = 1 << 20;
     std::vector<float> h(n);
     unsigned s = 1;
@@ -91,6 +101,9 @@ int main() {
     hipMemcpy(in, h.data(), n * 4, hipMemcpyHostToDevice);
     run<2, 2, false>(in, out, "2x2 registers only");
     run<2, 2, true>(in, out, "2x2 operands from LDS");
+    run<2, 2, true, 1>(in, out, "2x2 LDS + barrier/step");
+    run<2, 2, true, 2>(in, out, "2x2 LDS + barrier + 100 salu");
+    run<2, 2, true, 3>(in, out, "2x2 LDS + barrier + 100 valu");
     run<4, 2, true>(in, out, "4x2 operands from LDS");
     run<2, 4, true>(in, out, "2x4 operands from LDS");
     run<1, 4, true>(in, out, "1x4 operands from LDS");
