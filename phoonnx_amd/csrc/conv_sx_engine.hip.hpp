@@ -73,6 +73,14 @@ __device__ __forceinline__ u32x4 ds_read128(uint32_t addr) {
     return r;
 }
 
+// 16 bytes per lane from global memory at (uniform base + per-lane byte offset + OFF), asynchronous
+template <int OFF>
+__device__ __forceinline__ u32x4 global_read128(uint32_t voff, const void *sbase) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    return r;
+}
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -101,7 +109,8 @@ template <int MW, int NW, int WM, int WN, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     constexpr int BM = MW * WM * 32, BN = NW * WN * 32, MB = BM / 32;
     static_assert(WM * WN == 4, "four waves per workgroup");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_sx[];  // [x0][x1][a0][a1]
+    static_assert(MW <= 2, "load_a addresses two block rows");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_sx[];  // two x stages
     const int tid = threadIdx.x, lane = tid & 63;
     // wave index as a SCALAR: the DMA bookkeeping (piece loops, vmcnt counts) then stays on the scalar unit
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,28 +122,16 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     const uint32_t XB = a.x_bytes;
     const u32x4 *xb = a.xp + (int64_t)b * a.x_bstride;
     const int64_t pstride = (int64_t)CG * T;  // cells per plane
-    constexpr int TAPCELLS = MB * 3 * 64;      // cells of one step's A slab (one tap of one 16-channel chunk)
-    constexpr uint32_t SLOT = MB * 3 * 1024;   // ... in bytes
-    const u32x4 *wmt = a.wp + (int64_t)blockIdx.y * a.nchunks * K * TAPCELLS + lane;
-    const int npieces = 6 * LW;                // x tile: rows (plane, channel-group half) x LW cells
-    const int nit = (npieces + 255) >> 8;      // DMA rounds of 256 pieces
-    const int nsl = K - 2;                     // steps of a chunk that carry a slice of the next chunk's x tile
-    const int ips = (nit + nsl - 1) / nsl;     // x rounds per such step
-    const uint32_t xbuf0 = lds0, abuf0 = lds0 + 2 * XB;
+    constexpr int STEPBYTES = MB * 3 * 1024;   // packed weights of one step (one tap of one 16-channel chunk)
+    // this wave's A rows of step 0 (uniform address: lives in SGPRs)
+    const char *wbase = reinterpret_cast<const char *>(a.wp) + (int64_t)blockIdx.y * a.nchunks * K * STEPBYTES +
+                        wm * (MW * 3 * 1024);
+    const int nit = a.x_bytes >> 12;           // DMA rounds of 256 cells per x tile (the stage is padded to 4 KiB)
 
-    // Both return the number of DMA instructions THIS wave issued (for the vmcnt bookkeeping below).
-    auto issue_a = [&](int step, int slot) -> int {  // steps (chunk, tap) are consecutive in the packed weights
-        const u32x4 *src = wmt + (int64_t)step * TAPCELLS;
-        int cnt = 0;
-        for (int i = wave; i < MB * 3; i += 4, cnt++)
-            lds_dma<16>(src + i * 64, reinterpret_cast<float *>(lds_sx + 2 * XB + slot * SLOT + i * 1024));
-        return cnt;
-    };
-    auto issue_x = [&](int chunk, int it0, int it1, uint32_t xoff) -> int {
-        int cnt = 0;
-        for (int it = it0; it < it1; it++) {
+    // x tile of one chunk -> LDS: rows (plane, channel-group half) x LW cells; every wave issues `nit` DMAs
+    auto issue_x = [&](int chunk, uint32_t xoff) {
+        for (int it = 0; it < nit; it++) {
             const int base = it * 256 + wave * 64;
-            if (base >= npieces) break;  // wave-uniform: this 1 KiB group lies past the tile
             const int i = base + lane;
             const int row = (int)__umulhi((unsigned)i, a.magic);
             const int col = i - row * LW;
@@ -143,11 +140,9 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             const u32x4 *src = ok ? xb + ((row >> 1) * pstride + (int64_t)(2 * chunk + (row & 1)) * T + t)
                                   : reinterpret_cast<const u32x4 *>(a.zeros) + lane;
             lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + xoff + base * 16));
-            cnt++;
         }
-        return cnt;
     };
-    // wait until at most n of this wave's DMA instructions are still in flight (they complete in order)
+    // wait until at most n of this wave's vector-memory operations are still in flight (they retire in order)
     auto wait_vm = [&](int n) {
         switch (n) {
             case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -162,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
             case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
             case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;  // stricter than needed: safe
+            default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;  // (launch_conv_sx keeps nit <= 12)
         }
     };
 
@@ -177,20 +172,25 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     struct Frag {
         u32x4 fa[MW][3], fb[NW][3];
     };
-    const uint32_t a_lane = abuf0 + (uint32_t)(wm * MW * 3) * 1024u + (uint32_t)lane * 16u;
-    const uint32_t b_lane = xbuf0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u;
+    const uint32_t b_lane = lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u;
     const uint32_t plane_b = (uint32_t)(2 * LW) * 16u;
+    const uint32_t voff0 = (uint32_t)lane * 16u, voff1 = voff0 + 3072u;  // second block row: + 3 KiB (13-bit imm)
 
-    auto load = [&](Frag &f, int slot, int chunk, int tap) {
-        const uint32_t aa = a_lane + (uint32_t)slot * SLOT;
-        const uint32_t bb0 = b_lane + (uint32_t)(chunk & 1) * XB + (uint32_t)(tap * a.dil) * 16u;
-        const uint32_t bb1 = bb0 + plane_b, bb2 = bb1 + plane_b;
+    // A fragments: straight from the packed weights (L2-resident) into registers, one 1 KiB wave-load per
+    // (block row, plane); asynchronous like the ds_reads: the consumer waits on vmcnt itself.
+    auto load_a = [&](Frag &f, int step) {
+        const char *sb = wbase + (int64_t)step * STEPBYTES;
         static_for<MW>([&](auto M) {
             constexpr int m = decltype(M)::value;
-            f.fa[m][0] = ds_read128<(m * 3 + 0) * 1024>(aa);
-            f.fa[m][1] = ds_read128<(m * 3 + 1) * 1024>(aa);
-            f.fa[m][2] = ds_read128<(m * 3 + 2) * 1024>(aa);
+            const uint32_t vo = m == 0 ? voff0 : voff1;
+            f.fa[m][0] = global_read128<0>(vo, sb);
+            f.fa[m][1] = global_read128<1024>(vo, sb);
+            f.fa[m][2] = global_read128<2048>(vo, sb);
         });
+    };
+    auto load_b = [&](Frag &f, int chunk, int tap) {
+        const uint32_t bb0 = b_lane + (uint32_t)(chunk & 1) * XB + (uint32_t)(tap * a.dil) * 16u;
+        const uint32_t bb1 = bb0 + plane_b, bb2 = bb1 + plane_b;
         static_for<NW>([&](auto N) {
             constexpr int n = decltype(N)::value;
             f.fb[n][0] = ds_read128<n * 512>(bb0);
@@ -212,26 +212,18 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
                                                                         acc[m][n], 0, 0, 0);
     };
 
-    // ---- main loop over steps s = (chunk, tap).  A slabs live in a ring of three slots and are fetched THREE
-    // steps ahead; the x tile of chunk c+1 is fetched in slices during taps 0..K-3 of chunk c.  At the barrier
-    // of step s everything issued before step s-1 has landed (vmcnt(n_prev) leaves only step s-1's DMAs in
-    // flight), i.e. slab s+1 and, on a chunk's last tap, the next x tile: so the fragments of step s+1 are read
-    // from LDS while step s's MFMAs run, and the DMA has two full steps to complete.  Slot s%3 is dead at that
-    // barrier (its fragments sit in registers) and receives slab s+3.
+    // ---- main loop over steps s = (chunk, tap).  Per step a wave runs its 6*MW*NW MFMAs on the fragments in
+    // one register set while the other set is being filled: A(s+1) by global loads, B(s+1) by ds_reads.  Only
+    // the x tile goes through LDS: the tile of chunk c+1 is DMA'd right after the barrier that opens chunk c
+    // (issued AFTER that step's A loads, so the A wait of tap 1 can leave exactly those `nit` DMAs in flight:
+    // vector-memory operations retire in order); it has two steps to land before the tap-2 wait needs it done.
+    // One barrier per chunk: it publishes x(c) and frees the buffer x(c+1) goes to.
     const int nchunks = a.nchunks, S = nchunks * K;
     const bool dbg_nodma = a.flags & DBG_NO_DMA;
-    int n_prev = 0;
-    issue_x(0, 0, nit, 0);
-    for (int p = 0; p < 3 && p < S; p++) {
-        const int c = issue_a(p, p);
-        n_prev = p == 2 ? c : 0;
-    }
-    wait_vm(n_prev);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
     Frag f0, f1;
-    load(f0, 0, 0, 0);
-    int chunk = 0, tap = 0, slot = 0;
+    issue_x(0, 0);
+    load_a(f0, 0);
+    int chunk = 0, tap = 0;
     // PROF: where a step's cycles go (s_memtime stamps; tools/conv_bench.py --sx --prof)
     unsigned long long pt = 0;
     unsigned pc[5] = {0, 0, 0, 0, 0};
@@ -245,33 +237,36 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     if constexpr (PROF) pt = __builtin_amdgcn_s_memtime();
     auto step = [&](Frag &fc, Frag &fn, int s) {
         stamp(4);  // fragment-load issue + MFMA issue of the previous step
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments of step s have landed
-        stamp(0);
-        wait_vm(n_prev);
-        stamp(1);
-        __builtin_amdgcn_s_barrier();  // (s = 0: everyone has read slab 0's fragments before slot 0 is refilled)
-        __builtin_amdgcn_sched_barrier(0);
-        stamp(2);
-        n_prev = 0;
-        if (!dbg_nodma) {
-            if (s + 3 < S) n_prev += issue_a(s + 3, slot);
-            if (chunk + 1 < nchunks && tap < nsl) {
-                const int it0 = tap * ips, it1 = (it0 + ips) < nit ? (it0 + ips) : nit;
-                n_prev += issue_x(chunk + 1, it0, it1, ((chunk + 1) & 1) * XB);
-            }
+        const bool more_x = chunk + 1 < nchunks && !dbg_nodma;
+        if (tap == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A(s) and this wave's share of x(chunk) have landed
+            stamp(1);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(2);
+            load_b(fc, chunk, 0);
+        } else {
+            // A(s) landed; on tap 1 the x DMAs issued behind it may stay in flight
+            if (tap == 1 && more_x) wait_vm(nit);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(1);
         }
-        int ntap = tap + 1, nchunk = chunk, nslot = slot + 1;
-        if (ntap == K) { ntap = 0; nchunk++; }
-        if (nslot == 3) nslot = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < S && !(dbg_nodma && s > 0)) load_a(fn, s + 1);
+        if (tap == 0 && more_x) issue_x(chunk + 1, ((chunk + 1) & 1) * XB);
         __builtin_amdgcn_sched_barrier(0);
         stamp(3);
-        if (s + 1 < S) load(fn, nslot, nchunk, ntap);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // B(s) has landed
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(0);
+        if (tap + 1 < K) load_b(fn, chunk, tap + 1);
         __builtin_amdgcn_sched_barrier(0);
         mma(fc);
         __builtin_amdgcn_sched_barrier(0);
-        tap = ntap;
-        chunk = nchunk;
-        slot = nslot;
+        if (++tap == K) {
+            tap = 0;
+            chunk++;
+        }
     };
     // (no exit from the middle of the unrolled pair: a mid-loop break makes hipcc copy all accumulators per step)
     for (int s = 0; s + 1 < S; s += 2) {
@@ -395,9 +390,12 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream) {
     const int BM = sx_tile_m(cfg), BN = sx_tile_n(cfg), MB = BM / 32;
     a.LW = BN + (a.K - 1) * a.dil;
     a.magic = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
-    a.x_bytes = (unsigned)(((size_t)6 * a.LW * 16 + 1023) / 1024 * 1024);
-    const size_t lds = 2 * (size_t)a.x_bytes + 3 * (size_t)MB * 3072;  // two x stages + ring of three A slabs
-    if (lds > 160 * 1024 || a.K < 3) return hipErrorInvalidValue;     // (pack_conv_sx pads narrower kernels to 3 taps)
+    // an x stage is padded to whole DMA rounds (256 cells = 4 KiB), so that every wave issues the same count
+    a.x_bytes = (unsigned)(((size_t)6 * a.LW * 16 + 4095) / 4096 * 4096);
+    const size_t lds = 2 * (size_t)a.x_bytes;  // two x stages; the weights never touch LDS
+    (void)MB;
+    // (pack_conv_sx pads narrower kernels to 3 taps; model.cpp sx_supported() mirrors the size limits)
+    if (lds > 160 * 1024 || a.x_bytes > 12 * 4096 || a.K < 3) return hipErrorInvalidValue;
     if (a.oslope == 0.f) a.oslope = 1.f;
     if (a.oslope2 == 0.f) a.oslope2 = 1.f;
     if (a.Cin % 16 || a.Cout % 32 || a.Cr % 32 || a.Cout % BM) return hipErrorInvalidValue;

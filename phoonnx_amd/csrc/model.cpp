@@ -475,10 +475,10 @@ void split3_host(float v, uint16_t p[3]) {
 bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil) {
     if (Cin < 16 || Cin % 16 || Cout_virtual % 32 || Cr % 32 || K < 1 || dil < 1) return false;
     const int cfg = sx_pick_cfg(Cout_virtual);
-    // two x stages + a ring of three A slabs must fit the CU's 160 KiB (conv_sx_engine.hip.hpp launch_conv_sx)
+    // an x stage is at most 12 DMA rounds of 4 KiB (conv_sx_engine.hip.hpp launch_conv_sx)
     const size_t LW = size_t(sx_tile_n(cfg)) + size_t((K < 3 ? 3 : K) - 1) * dil;
-    const size_t x_bytes = (6 * LW * 16 + 1023) / 1024 * 1024, a_bytes = size_t(sx_tile_m(cfg) / 32) * 3072;
-    return 2 * x_bytes + 3 * a_bytes <= 160 * 1024;
+    const size_t x_bytes = (6 * LW * 16 + 4095) / 4096 * 4096;
+    return x_bytes <= 12 * 4096;
 }
 
 void set_tiling_override(int cfg, int ck) {
