@@ -169,16 +169,22 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
 
-    struct Frag {
-        u32x4 fa[MW][3], fb[NW][3];
+    // Register sets: A fragments ping-pong between two sets (global loads are slow: a whole step ahead); the B
+    // fragments have ONE set whose two halves (block columns [0, NH) and [NH, NW)) are refilled as soon as the
+    // MFMAs that read them have been issued, i.e. half a step ahead.
+    constexpr int NH = NW / 2;
+    static_assert(NW % 2 == 0, "the B set is refilled in two halves");
+    struct ASet {
+        u32x4 fa[MW][3];
     };
+    u32x4 fb[NW][3];
     const uint32_t b_lane = lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u;
     const uint32_t plane_b = (uint32_t)(2 * LW) * 16u;
     const uint32_t voff0 = (uint32_t)lane * 16u, voff1 = voff0 + 3072u;  // second block row: + 3 KiB (13-bit imm)
 
     // A fragments: straight from the packed weights (L2-resident) into registers, one 1 KiB wave-load per
     // (block row, plane); asynchronous like the ds_reads: the consumer waits on vmcnt itself.
-    auto load_a = [&](Frag &f, int step) {
+    auto load_a = [&](ASet &f, int step) {
         const char *sb = wbase + (int64_t)step * STEPBYTES;
         static_for<MW>([&](auto M) {
             constexpr int m = decltype(M)::value;
@@ -188,17 +194,19 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             f.fa[m][2] = global_read128<2048>(vo, sb);
         });
     };
-    auto load_b = [&](Frag &f, int chunk, int tap) {
+    auto load_b_half = [&](auto H, int chunk, int tap) {
+        constexpr int h = decltype(H)::value;
         const uint32_t bb0 = b_lane + (uint32_t)(chunk & 1) * XB + (uint32_t)(tap * a.dil) * 16u;
         const uint32_t bb1 = bb0 + plane_b, bb2 = bb1 + plane_b;
-        static_for<NW>([&](auto N) {
-            constexpr int n = decltype(N)::value;
-            f.fb[n][0] = ds_read128<n * 512>(bb0);
-            f.fb[n][1] = ds_read128<n * 512>(bb1);
-            f.fb[n][2] = ds_read128<n * 512>(bb2);
+        static_for<NH>([&](auto N) {
+            constexpr int n = h * NH + decltype(N)::value;
+            fb[n][0] = ds_read128<n * 512>(bb0);
+            fb[n][1] = ds_read128<n * 512>(bb1);
+            fb[n][2] = ds_read128<n * 512>(bb2);
         });
     };
-    auto mma = [&](const Frag &f) {
+    auto mma_half = [&](const ASet &f, auto H) {
+        constexpr int h = decltype(H)::value;
         // plane pairs of combined order <= 2, smallest terms first; consecutive MFMAs hit different accumulators
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
@@ -206,21 +214,28 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
 #pragma unroll
             for (int m = 0; m < MW; m++)
 #pragma unroll
-                for (int n = 0; n < NW; n++)
+                for (int n = h * NH; n < (h + 1) * NH; n++)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.fa[m][PA[c]]),
-                                                                        __builtin_bit_cast(bf16x8, f.fb[n][PB[c]]),
+                                                                        __builtin_bit_cast(bf16x8, fb[n][PB[c]]),
                                                                         acc[m][n], 0, 0, 0);
     };
+    // LDS reads return in order: "at most NH*3 outstanding" = the older half has landed
+    auto wait_lds_older_half = [&]() {
+        if constexpr (NH == 1) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    };
+    static_assert(NH == 1 || NH == 2, "lgkmcnt immediates above");
+    const std::integral_constant<int, 0> H0{};
+    const std::integral_constant<int, 1> H1{};
 
-    // ---- main loop over steps s = (chunk, tap).  Per step a wave runs its 6*MW*NW MFMAs on the fragments in
-    // one register set while the other set is being filled: A(s+1) by global loads, B(s+1) by ds_reads.  Only
-    // the x tile goes through LDS: the tile of chunk c+1 is DMA'd right after the barrier that opens chunk c
-    // (issued AFTER that step's A loads, so the A wait of tap 1 can leave exactly those `nit` DMAs in flight:
-    // vector-memory operations retire in order); it has two steps to land before the tap-2 wait needs it done.
-    // One barrier per chunk: it publishes x(c) and frees the buffer x(c+1) goes to.
+    // ---- main loop over steps s = (chunk, tap).  Only the x tile goes through LDS: the tile of chunk c+1 is
+    // DMA'd right after the barrier that opens chunk c (issued AFTER that step's A loads, so the A wait of tap 1
+    // can leave exactly those `nit` DMAs in flight: vector-memory operations retire in order); it has two steps
+    // to land before the tap-2 wait needs it done.  One barrier per chunk: it publishes x(c) and frees the
+    // buffer x(c+1) goes to.  Within a chunk the B halves of tap+1 are requested while tap's MFMAs run.
     const int nchunks = a.nchunks, S = nchunks * K;
     const bool dbg_nodma = a.flags & DBG_NO_DMA;
-    Frag f0, f1;
+    ASet f0, f1;
     issue_x(0, 0);
     load_a(f0, 0);
     int chunk = 0, tap = 0;
@@ -234,9 +249,13 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             pt = now;
         }
     };
-    if constexpr (PROF) pt = __builtin_amdgcn_s_memtime();
-    auto step = [&](Frag &fc, Frag &fn, int s) {
-        stamp(4);  // fragment-load issue + MFMA issue of the previous step
+    unsigned long long prt0 = 0, pt0 = 0;
+    if constexpr (PROF) {
+        pt = pt0 = __builtin_amdgcn_s_memtime();
+        prt0 = __builtin_amdgcn_s_memrealtime();
+    }
+    auto step = [&](ASet &fc, ASet &fn, int s) {
+        stamp(4);  // MFMA issue of the previous step
         const bool more_x = chunk + 1 < nchunks && !dbg_nodma;
         if (tap == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A(s) and this wave's share of x(chunk) have landed
@@ -244,7 +263,8 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             stamp(2);
-            load_b(fc, chunk, 0);
+            load_b_half(H0, chunk, 0);
+            load_b_half(H1, chunk, 0);
         } else {
             // A(s) landed; on tap 1 the x DMAs issued behind it may stay in flight
             if (tap == 1 && more_x) wait_vm(nit);
@@ -256,12 +276,21 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
         if (tap == 0 && more_x) issue_x(chunk + 1, ((chunk + 1) & 1) * XB);
         __builtin_amdgcn_sched_barrier(0);
         stamp(3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // B(s) has landed
+        const bool more_taps = tap + 1 < K;
+        wait_lds_older_half();  // half 0 of B(s) has landed (half 1 may still be in flight)
         __builtin_amdgcn_sched_barrier(0);
         stamp(0);
-        if (tap + 1 < K) load_b(fn, chunk, tap + 1);
+        mma_half(fc, H0);
         __builtin_amdgcn_sched_barrier(0);
-        mma(fc);
+        if (more_taps) {
+            load_b_half(H0, chunk, tap + 1);
+            wait_lds_older_half();  // half 1 of B(s)
+        } else
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(fc, H1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more_taps) load_b_half(H1, chunk, tap + 1);
         __builtin_amdgcn_sched_barrier(0);
         if (++tap == K) {
             tap = 0;
@@ -279,6 +308,8 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
         if (a.prof && tid == 0) {
             for (int i = 0; i < 5; i++) atomicAdd(a.prof + i, (unsigned long long)pc[i]);
             atomicAdd(a.prof + 5, (unsigned long long)S);
+            atomicAdd(a.prof + 6, __builtin_amdgcn_s_memtime() - pt0);          // shader cycles ...
+            atomicAdd(a.prof + 7, __builtin_amdgcn_s_memrealtime() - prt0);     // ... per 100 MHz ticks = clock
         }
     }
 
@@ -316,31 +347,35 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             if (a.bias_b)
                 bq[q] += *reinterpret_cast<const f32x4 *>(a.bias_b + (int64_t)b * a.bias_b_stride + co0 + 8 * q + 4 * hi);
         }
-        f32x4 ad[NW][4], ad2[NW][4];
-        int64_t cell[NW][4];
-        bool okn[NW];
+        // the residual / accumulate operands of two block columns are requested together (register budget)
 #pragma unroll
-        for (int n = 0; n < NW; n++) {
-            const int t = t0 + (wn * NW + n) * 32 + l31;
-            okn[n] = t < T;
+        for (int n0 = 0; n0 < NW; n0 += 2) {
+        f32x4 ad[2][4], ad2[2][4];
+        int64_t cell[2][4];
+        bool okn[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int t = t0 + (wn * NW + n0 + j) * 32 + l31;
+            okn[j] = t < T;
             const int to = t * u + r;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                cell[n][q] = ((int64_t)((co0 >> 3) + q) * Tout + to) * 8 + 4 * hi;  // element offset inside raw / a plane
-                if (has_add && okn[n]) ad[n][q] = *reinterpret_cast<const f32x4 *>(addp + cell[n][q]);
-                if (two_adds && okn[n]) ad2[n][q] = *reinterpret_cast<const f32x4 *>(rawb + cell[n][q]);
+                cell[j][q] = ((int64_t)((co0 >> 3) + q) * Tout + to) * 8 + 4 * hi;  // element offset inside raw / a plane
+                if (has_add && okn[j]) ad[j][q] = *reinterpret_cast<const f32x4 *>(addp + cell[j][q]);
+                if (two_adds && okn[j]) ad2[j][q] = *reinterpret_cast<const f32x4 *>(rawb + cell[j][q]);
             }
         }
 #pragma unroll
-        for (int n = 0; n < NW; n++) {
-            if (!okn[n]) continue;
+        for (int j = 0; j < 2; j++) {
+            if (!okn[j]) continue;
+            const int n = n0 + j;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = acc[m][n][4 * q + e] + bq[q][e];
-                if (has_add) v += ad[n][q];
-                if (two_adds) v += ad2[n][q];
+                if (has_add) v += ad[j][q];
+                if (two_adds) v += ad2[j][q];
                 if (flags & EPI_DIV) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = v[e] / rdiv;
@@ -349,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; e++) o[e] = lrelu_f(v[e], oslope);
-                    *reinterpret_cast<f32x4 *>(rawb + cell[n][q]) = o;
+                    *reinterpret_cast<f32x4 *>(rawb + cell[j][q]) = o;
                 }
                 if (plb) {
                     unsigned short p[3][4];
@@ -360,17 +395,20 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
                         u32x2 w;
                         w.x = (unsigned)p[pl][0] | ((unsigned)p[pl][1] << 16);
                         w.y = (unsigned)p[pl][2] | ((unsigned)p[pl][3] << 16);
-                        *reinterpret_cast<u32x2 *>(plb + pl * plane_elems + cell[n][q]) = w;
+                        *reinterpret_cast<u32x2 *>(plb + pl * plane_elems + cell[j][q]) = w;
                     }
                 }
             }
         }
+        }
     }
 }
 
-// sx tile configs: index -> (BM, BN): 0: 128x128, 1: 64x256, 2: 32x256
+// sx tile configs: index -> (BM, BN, waves WM x WN, blocks per wave MW x NW):
+//   0: 128x256 (2x2 waves of 64x128)   1: 64x256 (2x2 waves of 32x128)   2: 32x256 (1x4 waves of 32x64)
+// All are 256 columns wide: the weights of a step then serve 4 (2) block columns per register load.
 inline int sx_tile_m(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
-inline int sx_tile_n(int cfg) { return cfg == 0 ? 128 : 256; }
+inline int sx_tile_n(int) { return 256; }
 
 template <int MW, int NW, int WM, int WN, bool PROF = false>
 inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
@@ -401,10 +439,10 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream) {
     if (a.Cin % 16 || a.Cout % 32 || a.Cr % 32 || a.Cout % BM) return hipErrorInvalidValue;
     dim3 grid((a.T + BN - 1) / BN, a.Cout / BM, B);
     if (grid.x == 0 || B == 0) return hipSuccess;
-    if (a.prof && cfg == 0) return launch_conv_sx_k<2, 2, 2, 2, true>(a, grid, lds, stream);
+    if (a.prof && cfg == 0) return launch_conv_sx_k<2, 4, 2, 2, true>(a, grid, lds, stream);
     switch (cfg) {
-        case 0: return launch_conv_sx_k<2, 2, 2, 2>(a, grid, lds, stream);
-        case 1: return launch_conv_sx_k<2, 2, 1, 4>(a, grid, lds, stream);
+        case 0: return launch_conv_sx_k<2, 4, 2, 2>(a, grid, lds, stream);
+        case 1: return launch_conv_sx_k<1, 4, 2, 2>(a, grid, lds, stream);
         default: return launch_conv_sx_k<1, 2, 1, 4>(a, grid, lds, stream);
     }
 }

@@ -317,7 +317,7 @@ ConvDesc pack_convT(Packer &P, const Resolver &R, const std::string &name) {
 // ---- split-exact (sx) packing: weights as three bf16 planes in the A-operand lane order of
 // v_mfma_f32_32x32x16_bf16 (lane l: row l&31, k = 8*(l>>5) .. +7 = eight consecutive input channels).
 int sx_tile_m(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
-int sx_tile_n(int cfg) { return cfg == 0 ? 128 : 256; }
+int sx_tile_n(int) { return 256; }
 int sx_pick_cfg(int Cout) { return Cout % 128 == 0 ? 0 : (Cout % 64 == 0 ? 1 : 2); }
 
 template <class WF>

@@ -26,7 +26,7 @@ struct ConvDesc {
     int cfg = 0;          // tile: 0: 32x512, 1: 64x256, 2: 128x128, 3: 64x64, 4: 32x128
     // sx = packed for the split-exact bf16 engine (conv_sx_engine.hip.hpp) instead: weights as three bf16
     // planes [m-tile][chunk of 16 ci][tap][32-row block][plane][lane][8]; cfg then indexes the sx tiles
-    // (0: 128x128, 1: 64x256, 2: 32x256) and a transposed conv's virtual rows are r-major (r*Cr + co).
+    // (0: 128x256, 1: 64x256, 2: 32x256) and a transposed conv's virtual rows are r-major (r*Cr + co).
     bool sx = false;
     double macs_per_t = 0;   // algorithmic MACs per input time step (reference definition)
     bool valid() const { return w_off >= 0; }

@@ -1437,9 +1437,10 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
         ms_out[1] = (float)d.cfg;
         ms_out[2] = 0.f;
         if (dprof) {
-            unsigned long long hp[6];
+            unsigned long long hp[8];
             TCHECK(hipMemcpy(hp, dprof, sizeof hp, hipMemcpyDeviceToHost));
             for (int i = 0; i < 5; i++) ms_out[3 + i] = hp[5] ? (float)((double)hp[i] / (double)hp[5]) : 0.f;  // per step
+            ms_out[2] = hp[7] ? (float)((double)hp[6] / (double)hp[7] * 0.1) : 0.f;  // shader clock, GHz
         }
     }
     hipEventDestroy(e0);

@@ -318,7 +318,7 @@ def bench_conv1d_sx(B, Cin, Cout, T, K, dil=1, dbg=0, iters=20, device_id=0):
     if rc != 0:
         raise SessionError(_ffi.last_error(None))
     if dbg & 16:
-        return float(res[0]), int(res[1]), [float(v) for v in res[3:8]]
+        return float(res[0]), int(res[1]), [float(v) for v in res[3:8]] + [float(res[2])]
     return float(res[0]), int(res[1])
 
 

@@ -74,7 +74,7 @@ def main():
                 for dbg in (16, 16 | 3):
                     ms, cfg, pc = bench_conv1d_sx(B, Cin, Cout, T, K, dil, dbg, a.iters)
                     print(f"      prof dbg={dbg & 15}: s_memtime ticks/step: lgkm {pc[0]:.0f} vmwait {pc[1]:.0f} barrier {pc[2]:.0f} "
-                          f"dma-issue {pc[3]:.0f} loads+mfma {pc[4]:.0f}  (sum {sum(pc):.0f})", flush=True)
+                          f"dma-issue {pc[3]:.0f} loads+mfma {pc[4]:.0f}  (sum {sum(pc[:5]):.0f})  clock {pc[5]:.2f} GHz", flush=True)
         return
     for name, Cin, Cout, T, K, dil, hint in shapes:
         r = bench(lib, B, Cin, Cout, T, K, dil, hint, a.iters)
