@@ -104,8 +104,35 @@ __device__ __forceinline__ void split3(float v, unsigned short &p0, unsigned sho
     p2 = __builtin_bit_cast(unsigned short, h2);
 }
 
+// The same split for a pair of values, in the packed form the planes are stored in (lo half = first value):
+// one v_cvt_pk_bf16_f32 per plane and pair, 5.5 VALU operations per value in all.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned &w0, unsigned &w1, unsigned &w2) {
+    w0 = cvt_pk_bf16(x, y);
+    const float rx = x - __uint_as_float(w0 << 16), ry = y - __uint_as_float(w0 & 0xffff0000u);
+    w1 = cvt_pk_bf16(rx, ry);
+    const float sx = rx - __uint_as_float(w1 << 16), sy = ry - __uint_as_float(w1 & 0xffff0000u);
+    w2 = cvt_pk_bf16(sx, sy);
+}
+
+// Epilogue description bits beyond EPI_RES / EPI_ACC / EPI_DIV (conv_engine.hip.hpp).  The first group is
+// derived from the arguments by launch_conv_sx; a kernel instantiated with EPI >= 0 has the whole description
+// as a compile-time constant (the common generator epilogues), EPI = -1 reads it at run time.
+enum : int {
+    SX_HAS_RAW = 1 << 9,    // out_raw is written
+    SX_HAS_PL = 1 << 10,    // out_pl is written
+    SX_RAW_ACT = 1 << 11,   // oslope != 1
+    SX_PL_ACT = 1 << 12,    // oslope2 != 1
+    SX_HAS_BIASB = 1 << 13  // per-utterance bias
+};
+constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB;
+
 // One 256-thread workgroup = 4 waves arranged WM x WN, each owning MW x NW 32x32 accumulator blocks.
-template <int MW, int NW, int WM, int WN, bool PROF = false>
+template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false>
 __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     constexpr int BM = MW * WM * 32, BN = NW * WN * 32, MB = BM / 32;
     static_assert(WM * WN == 4, "four waves per workgroup");
@@ -315,8 +342,9 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
 
     // ---- epilogue.  C/D layout of a 32x32 block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5):
     // register quad q holds 4 consecutive channels 8q + 4*hi .. +3 of one time step = half a cell.
-    const int flags = a.flags;
-    if (flags & DBG_NO_EPI) {
+    // `flags` is a compile-time constant in the specialised instantiations: every test below then folds away
+    const int flags = EPI >= 0 ? EPI : a.flags;
+    if (a.flags & DBG_NO_EPI) {
         float sdbg = 0.f;
 #pragma unroll
         for (int m = 0; m < MW; m++)
@@ -326,14 +354,16 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
         return;
     }
     const int u = a.ups, Cr = a.Cr, Tout = T * u, CGo = Cr >> 3;
-    float *rawb = a.out_raw ? a.out_raw + (int64_t)b * a.raw_bstride : nullptr;
-    uint16_t *plb = a.out_pl ? a.out_pl + (int64_t)b * a.pl_bstride : nullptr;
-    const float *resb = a.res ? a.res + (int64_t)b * a.raw_bstride : nullptr;
+    float *rawb = a.out_raw + (int64_t)b * a.raw_bstride;     // (only dereferenced when the flags say so)
+    uint16_t *plb = a.out_pl + (int64_t)b * a.pl_bstride;
+    const float *resb = a.res + (int64_t)b * a.raw_bstride;
     const float *addp = (flags & EPI_RES) ? resb : rawb;
     const bool has_add = (flags & (EPI_RES | EPI_ACC)) != 0;
     const bool two_adds = (flags & EPI_RES) && (flags & EPI_ACC);
     const float oslope = a.oslope, oslope2 = a.oslope2, rdiv = a.div;
     const int64_t plane_elems = (int64_t)CGo * Tout * 8;
+    const float *biasp = a.bias ? a.bias : a.zeros;  // a missing bias reads the zero page (no branch per quad)
+    const int b_on = a.bias ? 1 : 0;
 #pragma unroll
     for (int m = 0; m < MW; m++) {
         const int row0 = blockIdx.y * BM + (wm * MW + m) * 32;
@@ -343,8 +373,8 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
         f32x4 bq[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            bq[q] = a.bias ? *reinterpret_cast<const f32x4 *>(a.bias + row0 + 8 * q + 4 * hi) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.bias_b)
+            bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
+            if (flags & SX_HAS_BIASB)
                 bq[q] += *reinterpret_cast<const f32x4 *>(a.bias_b + (int64_t)b * a.bias_b_stride + co0 + 8 * q + 4 * hi);
         }
         // the residual / accumulate operands of two block columns are requested together (register budget)
@@ -380,23 +410,26 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = v[e] / rdiv;
                 }
-                if (rawb && !(flags & SX_NO_RAW_STORE)) {
-                    f32x4 o;
+                if (flags & SX_HAS_RAW) {
+                    f32x4 o = v;
+                    if (flags & SX_RAW_ACT) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) o[e] = lrelu_f(v[e], oslope);
+                        for (int e = 0; e < 4; e++) o[e] = fmaxf(v[e], v[e] * oslope);  // leaky_relu, 0 < slope < 1
+                    }
                     *reinterpret_cast<f32x4 *>(rawb + cell[j][q]) = o;
                 }
-                if (plb) {
-                    unsigned short p[3][4];
+                if (flags & SX_HAS_PL) {
+                    f32x4 o = v;
+                    if (flags & SX_PL_ACT) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) split3(lrelu_f(v[e], oslope2), p[0][e], p[1][e], p[2][e]);
-#pragma unroll
-                    for (int pl = 0; pl < 3; pl++) {
-                        u32x2 w;
-                        w.x = (unsigned)p[pl][0] | ((unsigned)p[pl][1] << 16);
-                        w.y = (unsigned)p[pl][2] | ((unsigned)p[pl][3] << 16);
-                        *reinterpret_cast<u32x2 *>(plb + pl * plane_elems + cell[j][q]) = w;
+                        for (int e = 0; e < 4; e++) o[e] = fmaxf(v[e], v[e] * oslope2);
                     }
+                    unsigned wa[3], wb[3];
+                    split3_pair(o[0], o[1], wa[0], wa[1], wa[2]);
+                    split3_pair(o[2], o[3], wb[0], wb[1], wb[2]);
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++)
+                        *reinterpret_cast<u32x2 *>(plb + pl * plane_elems + cell[j][q]) = u32x2{wa[pl], wb[pl]};
                 }
             }
         }
@@ -410,10 +443,10 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
 inline int sx_tile_m(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
 inline int sx_tile_n(int) { return 256; }
 
-template <int MW, int NW, int WM, int WN, bool PROF = false>
+template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false>
 inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
-    auto kern = conv_sx_kernel<MW, NW, WM, WN, PROF>;
+    auto kern = conv_sx_kernel<MW, NW, WM, WN, EPI, PROF>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
@@ -422,6 +455,26 @@ inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipSt
     }
     kern<<<grid, 256, lds, stream>>>(a);
     return hipGetLastError();
+}
+
+// the generator's frequent epilogues get their own instantiation (compile-time flags), the rest run generic
+constexpr int kSxEpiPlanes = SX_HAS_PL | SX_PL_ACT;                                  // first conv of a ResBlock1 pair
+constexpr int kSxEpiUp = SX_HAS_RAW | SX_HAS_PL | SX_PL_ACT;                         // upsampler
+constexpr int kSxEpiInner = EPI_RES | SX_HAS_RAW | SX_HAS_PL | SX_PL_ACT;            // residual conv inside a block
+constexpr int kSxEpiFirst = EPI_RES | SX_HAS_RAW;                                    // xs  = block output
+constexpr int kSxEpiAccum = EPI_RES | EPI_ACC | SX_HAS_RAW;                          // xs += block output
+
+template <int MW, int NW, int WM, int WN>
+inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+    if (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) return launch_conv_sx_k<MW, NW, WM, WN>(a, grid, lds, stream);
+    switch (epi) {
+        case kSxEpiPlanes: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiPlanes>(a, grid, lds, stream);
+        case kSxEpiUp: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiUp>(a, grid, lds, stream);
+        case kSxEpiInner: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiInner>(a, grid, lds, stream);
+        case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst>(a, grid, lds, stream);
+        case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum>(a, grid, lds, stream);
+        default: return launch_conv_sx_k<MW, NW, WM, WN>(a, grid, lds, stream);
+    }
 }
 
 inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream) {
@@ -439,11 +492,19 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream) {
     if (a.Cin % 16 || a.Cout % 32 || a.Cr % 32 || a.Cout % BM) return hipErrorInvalidValue;
     dim3 grid((a.T + BN - 1) / BN, a.Cout / BM, B);
     if (grid.x == 0 || B == 0) return hipSuccess;
-    if (a.prof && cfg == 0) return launch_conv_sx_k<2, 4, 2, 2, true>(a, grid, lds, stream);
+    // epilogue description (see the SX_* bits): derived from the arguments, then matched against the instantiations
+    int epi = a.flags & (EPI_RES | EPI_ACC | EPI_DIV);
+    if (a.out_raw && !(a.flags & SX_NO_RAW_STORE)) epi |= SX_HAS_RAW | (a.oslope != 1.f ? SX_RAW_ACT : 0);
+    if (a.out_pl) epi |= SX_HAS_PL | (a.oslope2 != 1.f ? SX_PL_ACT : 0);
+    if (a.bias_b) epi |= SX_HAS_BIASB;
+    if ((epi & EPI_RES) && !a.res) return hipErrorInvalidValue;
+    if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
+    a.flags = (a.flags & ~kSxEpiMask) | epi;
+    if (a.prof && cfg == 0) return launch_conv_sx_k<2, 4, 2, 2, -1, true>(a, grid, lds, stream);
     switch (cfg) {
-        case 0: return launch_conv_sx_k<2, 4, 2, 2>(a, grid, lds, stream);
-        case 1: return launch_conv_sx_k<1, 4, 2, 2>(a, grid, lds, stream);
-        default: return launch_conv_sx_k<1, 2, 1, 4>(a, grid, lds, stream);
+        case 0: return launch_conv_sx_epi<2, 4, 2, 2>(a, epi, grid, lds, stream);
+        case 1: return launch_conv_sx_epi<1, 4, 2, 2>(a, epi, grid, lds, stream);
+        default: return launch_conv_sx_epi<1, 2, 1, 4>(a, epi, grid, lds, stream);
     }
 }
 
