@@ -22,6 +22,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
+# split-exact engine: dense bf16 MFMA peak (256 CUs x 4096 FLOP/clk x 2.4 GHz = 2516.6 TFLOP/s) / 6 plane products
+SX_PEAK_TFLOPS = 2516.6 / 6
+# HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/, DESIGN.md "Measurement");
+# filled per preset for the default workload only
+PMC_TRAFFIC = {}
 LENGTH_SCALE = {"high": 1.5, "medium": 1.5, "small": 1.5}  # gives ~3 frames per phoneme id with synth weights
 
 
@@ -90,6 +95,7 @@ def main():
     # weights: rank 0 reads + packs, RCCL broadcast of the arena, every rank opens on its GPU
     sess, arena_keepalive = open_sharded(voice, local_rank, dist)
     hop = sess.hparam("hop")
+    sess_gen_sx = bool(sess.hparam("gen_sx"))
     sess.set_seed(1234 + rank)
 
     B, T = a.batch, a.tokens
@@ -145,14 +151,28 @@ def main():
             by += st["conv_bytes"]
             ms += st["conv_ms"]
             launches += st["conv_launches"]
-            for k in ("enc_ms", "dp_ms", "flow_ms", "dec_ms", "total_ms", "dec_flops", "dec_bytes", "flow_flops"):
+            for k in ("enc_ms", "dp_ms", "flow_ms", "dec_ms", "total_ms", "dec_flops", "dec_bytes", "flow_flops",
+                      "sx_flops", "sx_ms", "sx_launches"):
                 agg[k] = agg.get(k, 0.0) + st[k]
         sess.set_timing(False)
-        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "conv_engine_kernel (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)",
-                    "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-                    "traffic": None, "launches_per_step": launches // n_t,
-                    "avg_launch_ms": ms / max(launches, 1),
+        if agg.get("sx_launches", 0) > 0:
+            # dominant kernel: the generator's split-exact conv (six bf16 MFMA plane products per fp32 product)
+            kfl, kms, kn = agg["sx_flops"], agg["sx_ms"], int(agg["sx_launches"])
+            kname = "conv_sx_kernel (implicit-GEMM Conv1d, fp32-exact via 3 bf16 planes, v_mfma_f32_32x32x16_bf16)"
+            peak = SX_PEAK_TFLOPS
+        else:
+            kfl, kms, kn = fl, ms, launches
+            kname = "conv_engine_kernel (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)"
+            peak = FP32_PEAK_TFLOPS
+        ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": kname,
+                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "traffic": PMC_TRAFFIC.get(a.preset) if (B, T) == (32, 256) else None,
+                    "launches_per_step": kn // n_t,
+                    "avg_launch_ms": kms / max(kn, 1),
+                    "algorithmic_gflop_per_launch": kfl / max(kn, 1) / 1e9,
+                    "all_conv_launches_per_step": launches // n_t,
+                    "all_conv_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                     "algorithmic_gflop_per_step": fl / n_t / 1e9,
                     "algorithmic_gbytes_per_step": by / n_t / 1e9,
                     "hbm_frac_of_8TBs": (by / (ms * 1e-3)) / 8.0e12 if ms > 0 else 0.0}
@@ -175,6 +195,9 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": ("fp32 operands and fp32 accumulation everywhere; the generator's convs evaluate each fp32 product "
+                           "exactly-to-2^-24 as six bf16 MFMA plane products (three bf16 planes per operand)"
+                           if sess_gen_sx else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),
             "rtf": dt_max / (samples_all / world / 22050.0) if samples_all else None,
             "config": {"workload": f"VITS full pipeline (encoder+duration+flow+HiFi-GAN), preset={a.preset}, "
                                    f"batch={B}/GPU x {T} phoneme ids, scales=[0.667,{scales[1]:.2f},0.8], "

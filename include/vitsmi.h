@@ -74,7 +74,8 @@ const char *vits_input_name(vits_handle *h, int i);  /* "input","input_lengths",
 int vits_meta(vits_handle *h, const char *key, char *buf, size_t n);
 
 /* Derived hyper-parameters: "hidden","inter","filter","n_heads","n_layers","n_vocab",
- * "n_speakers","gin","use_sdp","hop" (= product of upsample rates),"n_ups","resblock". */
+ * "n_speakers","gin","use_sdp","hop" (= product of upsample rates),"n_ups","resblock",
+ * "gen_sx" (1: the generator runs on the split-exact bf16 engine, 0: on the f32 engine). */
 int vits_hparam(vits_handle *h, const char *key, int64_t *out);
 
 /* ---- weight arena (multi-GPU: one rank reads + packs, RCCL broadcasts the bytes) ---- */
@@ -152,6 +153,10 @@ typedef struct {
     float conv_ms;          /* HIP-event time of all conv-engine launches (needs timing enabled) */
     float dec_ms, flow_ms, enc_ms, dp_ms, total_ms;
     int conv_launches, total_launches;
+    /* the subset of the conv launches that ran on the split-exact bf16 engine (the generator's convs) */
+    double sx_flops;
+    float sx_ms;
+    int sx_launches;
 } vits_stats;
 
 /* Enable per-stage HIP-event timing (adds event records on the handle's stream). */

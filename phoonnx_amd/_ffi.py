@@ -25,7 +25,7 @@ class VitsStats(C.Structure):
                 ("dec_bytes", C.c_double), ("flow_flops", C.c_double), ("enc_flops", C.c_double),
                 ("dp_flops", C.c_double), ("conv_ms", C.c_float), ("dec_ms", C.c_float), ("flow_ms", C.c_float),
                 ("enc_ms", C.c_float), ("dp_ms", C.c_float), ("total_ms", C.c_float), ("conv_launches", C.c_int),
-                ("total_launches", C.c_int)]
+                ("total_launches", C.c_int), ("sx_flops", C.c_double), ("sx_ms", C.c_float), ("sx_launches", C.c_int)]
 
 
 EXPORTS = [

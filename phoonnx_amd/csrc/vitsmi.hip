@@ -65,6 +65,7 @@ struct vits_handle {
     bool timing = false;
     vits_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;
+    std::vector<char> conv_event_sx;  // 1: that launch went through the split-exact engine
     size_t conv_events_used = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int cur_stage = 0;  // 0 enc, 1 dp, 2 flow, 3 dec
@@ -159,6 +160,7 @@ bool conv_event_begin(Ctx &c) {
         hipEventCreate(&e1);
         h->conv_events.push_back({e0, e1});
     }
+    if (h->conv_events_used < h->conv_event_sx.size()) h->conv_event_sx[h->conv_events_used] = 0;
     hipEventRecord(h->conv_events[h->conv_events_used].first, c.st);
     return true;
 }
@@ -242,8 +244,14 @@ void conv_sx(Ctx &c, const ConvDesc &d, const uint16_t *xp, int T, float *out_ra
     vits_handle *h = c.h;
     const bool ev = conv_event_begin(c);
     c.note(launch_conv_sx(a, d.cfg, c.B, c.st));
-    if (ev) hipEventRecord(h->conv_events[h->conv_events_used++].second, c.st);
+    if (ev) {
+        if (h->conv_event_sx.size() < h->conv_events.size()) h->conv_event_sx.resize(h->conv_events.size(), 0);
+        h->conv_event_sx[h->conv_events_used] = 1;
+        hipEventRecord(h->conv_events[h->conv_events_used++].second, c.st);
+    }
     conv_account(c, d, T);
+    h->stats.sx_flops += 2.0 * d.macs_per_t * (double)T * c.B;
+    h->stats.sx_launches++;
 }
 
 // Pinned output buffer of `bytes` bytes: the handle's pool when it is free (grown on demand), else a fresh
@@ -864,6 +872,7 @@ int vits_hparam(vits_handle *h, const char *key, int64_t *out) {
     else if (k == "n_vocab") *out = m.n_vocab;
     else if (k == "n_speakers") *out = m.n_speakers;
     else if (k == "gin") *out = m.gin;
+    else if (k == "gen_sx") *out = m.gen_sx ? 1 : 0;
     else if (k == "use_sdp") *out = m.use_sdp;
     else if (k == "hop") *out = m.hop;
     else if (k == "n_ups") *out = (int64_t)m.ups.size();
@@ -1140,11 +1149,14 @@ int vits_get_stats(vits_handle *h, vits_stats *out) {
         hipSetDevice(h->device);
         hipStreamSynchronize(h->stream);
         if (h->timing) {
-            float ms = 0.f, tot = 0.f;
+            float ms = 0.f, tot = 0.f, tot_sx = 0.f;
             for (size_t i = 0; i < h->conv_events_used; i++) {
-                if (hipEventElapsedTime(&ms, h->conv_events[i].first, h->conv_events[i].second) == hipSuccess) tot += ms;
+                if (hipEventElapsedTime(&ms, h->conv_events[i].first, h->conv_events[i].second) != hipSuccess) continue;
+                tot += ms;
+                if (i < h->conv_event_sx.size() && h->conv_event_sx[i]) tot_sx += ms;
             }
             h->stats.conv_ms = tot;
+            h->stats.sx_ms = tot_sx;
             auto el = [&](int a, int b) {
                 float v = 0.f;
                 if (hipEventElapsedTime(&v, h->ev[a], h->ev[b]) != hipSuccess) v = 0.f;
