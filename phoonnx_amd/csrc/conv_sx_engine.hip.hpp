@@ -45,6 +45,8 @@ enum : int { SX_NO_RAW_STORE = 256 };  // out_raw is only the EPI_ACC operand, n
 struct SxArgs {
     const u32x4 *xp;      // input planes, cells of 8 bf16
     int64_t x_bstride;    // cells between batch items (= 3 * Cin/8 * T)
+    const float *xr;      // RAWIN kernels instead: fp32 raw input [Cin/8][T][8] per utterance ...
+    float islope;         // ... with leaky_relu(islope) applied on the way in (1 = none)
     int T;                // input length
     const u32x4 *wp;      // packed weights
     const float *bias;    // [virtual rows] or nullptr
@@ -79,6 +81,17 @@ __device__ __forceinline__ u32x4 global_read128(uint32_t voff, const void *sbase
     u32x4 r;
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
     return r;
+}
+
+// ... at a per-lane address
+template <int OFF>
+__device__ __forceinline__ u32x4 global_read128_v(const void *p) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
+    return r;
+}
+__device__ __forceinline__ void ds_write128(uint32_t addr, u32x4 v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 template <class F, int... I>
@@ -132,7 +145,10 @@ enum : int {
 constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB;
 
 // One 256-thread workgroup = 4 waves arranged WM x WN, each owning MW x NW 32x32 accumulator blocks.
-template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false>
+// RAWIN: the input is the fp32 raw tensor itself; each x tile is loaded into registers, leaky-ReLU'd (islope) and
+// split into the three bf16 planes on its way into LDS.  Used where the layer is HBM-bound (<= 64 channels):
+// such tensors then exist only once, as 4-byte raw values, instead of raw + 6-byte planes.
+template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false>
 __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     constexpr int BM = MW * WM * 32, BN = NW * WN * 32, MB = BM / 32;
     static_assert(WM * WN == 4, "four waves per workgroup");
@@ -169,6 +185,63 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + xoff + base * 16));
         }
     };
+    // ---- RAWIN: x tile through registers.  A thread owns cells i = it*256 + tid of the [2 channel groups][LW]
+    // tile (8 fp32 = two 16-byte loads each); rows past the tile and out-of-range columns read the zero page.
+    constexpr int NXC = 3;  // cells per thread: 2 * LW <= 768 (launch_conv_sx)
+    u32x4 xst[NXC][2];
+    const float *xrb = RAWIN ? a.xr + (int64_t)b * a.Cin * T : nullptr;
+    const int nxc = (2 * LW + 255) >> 8;
+    auto xcell = [&](int it, int &kh, int &col) {
+        const int i = it * 256 + tid;
+        kh = (i >= LW ? 1 : 0) + (i >= 2 * LW ? 1 : 0);
+        col = i - kh * LW;
+    };
+    auto xload = [&](int chunk) {
+        static_for<NXC>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            if (it < nxc) {
+                int kh, col;
+                xcell(it, kh, col);
+                const int t = t0 - a.padL + col;
+                const bool ok = kh < 2 && t >= 0 && t < T;
+                const float *src = ok ? xrb + ((int64_t)(2 * chunk + kh) * T + t) * 8 : a.zeros;
+                xst[it][0] = global_read128_v<0>(src);
+                xst[it][1] = global_read128_v<16>(src);
+            }
+        });
+    };
+    auto xstore = [&](uint32_t xoff) {  // registers -> leaky-ReLU -> three planes -> LDS stage at byte offset xoff
+        const float isl = a.islope;
+        static_for<NXC>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            if (it < nxc) {
+                int kh, col;
+                xcell(it, kh, col);
+                if (kh < 2) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float x = __uint_as_float(xst[it][e >> 2][e & 3]);
+                        v[e] = fmaxf(x, x * isl);  // leaky_relu for 0 < islope <= 1 (1 = none)
+                    }
+                    u32x4 w0, w1, w2;
+                    unsigned p0[4], p1[4], p2[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) split3_pair(v[2 * e], v[2 * e + 1], p0[e], p1[e], p2[e]);
+                    w0 = u32x4{p0[0], p0[1], p0[2], p0[3]};
+                    w1 = u32x4{p1[0], p1[1], p1[2], p1[3]};
+                    w2 = u32x4{p2[0], p2[1], p2[2], p2[3]};
+                    const uint32_t ad = lds0 + xoff + (uint32_t)(kh * LW + col) * 16u;
+                    const uint32_t pb = (uint32_t)(2 * LW) * 16u;
+                    ds_write128(ad, w0);
+                    ds_write128(ad + pb, w1);
+                    ds_write128(ad + 2 * pb, w2);
+                }
+            }
+        });
+    };
+    const int nxv = RAWIN ? 2 * nxc : nit;  // vector-memory operations per wave for one x tile
+
     // wait until at most n of this wave's vector-memory operations are still in flight (they retire in order)
     auto wait_vm = [&](int n) {
         switch (n) {
@@ -263,7 +336,13 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     const int nchunks = a.nchunks, S = nchunks * K;
     const bool dbg_nodma = a.flags & DBG_NO_DMA;
     ASet f0, f1;
-    issue_x(0, 0);
+    if constexpr (RAWIN) {
+        xload(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xstore(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the barrier of step 0 publishes it
+    } else
+        issue_x(0, 0);
     load_a(f0, 0);
     int chunk = 0, tap = 0;
     // PROF: where a step's cycles go (s_memtime stamps; tools/conv_bench.py --sx --prof)
@@ -285,6 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
         stamp(4);  // MFMA issue of the previous step
         const bool more_x = chunk + 1 < nchunks && !dbg_nodma;
         if (tap == 0) {
+            if constexpr (RAWIN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's x(chunk) writes
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A(s) and this wave's share of x(chunk) have landed
             stamp(1);
             __builtin_amdgcn_s_barrier();
@@ -294,13 +374,16 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             load_b_half(H1, chunk, 0);
         } else {
             // A(s) landed; on tap 1 the x DMAs issued behind it may stay in flight
-            if (tap == 1 && more_x) wait_vm(nit);
+            if (tap == 1 && more_x) wait_vm(nxv);
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             stamp(1);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < S && !(dbg_nodma && s > 0)) load_a(fn, s + 1);
-        if (tap == 0 && more_x) issue_x(chunk + 1, ((chunk + 1) & 1) * XB);
+        if (tap == 0 && more_x) {
+            if constexpr (RAWIN) xload(chunk + 1);
+            else issue_x(chunk + 1, ((chunk + 1) & 1) * XB);
+        }
         __builtin_amdgcn_sched_barrier(0);
         stamp(3);
         const bool more_taps = tap + 1 < K;
@@ -317,6 +400,13 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         mma_half(fc, H1);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RAWIN) {
+            // tap 2: the vmcnt(0) above has retired the next chunk's x loads; convert and write them while the
+            // MFMAs run.  The writes sit between the two B-half requests in the LDS queue, so the next step's
+            // "older half" wait covers them (LDS operations retire in order).
+            if (tap == 2 && more_x) xstore(((chunk + 1) & 1) * XB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (more_taps) load_b_half(H1, chunk, tap + 1);
         __builtin_amdgcn_sched_barrier(0);
         if (++tap == K) {
@@ -443,10 +533,10 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
 inline int sx_tile_m(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
 inline int sx_tile_n(int) { return 256; }
 
-template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false>
+template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false>
 inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
-    auto kern = conv_sx_kernel<MW, NW, WM, WN, EPI, PROF>;
+    auto kern = conv_sx_kernel<MW, NW, WM, WN, EPI, PROF, RAWIN>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
@@ -463,6 +553,7 @@ constexpr int kSxEpiUp = SX_HAS_RAW | SX_HAS_PL | SX_PL_ACT;                    
 constexpr int kSxEpiInner = EPI_RES | SX_HAS_RAW | SX_HAS_PL | SX_PL_ACT;            // residual conv inside a block
 constexpr int kSxEpiFirst = EPI_RES | SX_HAS_RAW;                                    // xs  = block output
 constexpr int kSxEpiAccum = EPI_RES | EPI_ACC | SX_HAS_RAW;                          // xs += block output
+constexpr int kSxEpiRaw = SX_HAS_RAW;                                                // raw only (raw-format stages)
 
 template <int MW, int NW, int WM, int WN>
 inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
@@ -477,18 +568,33 @@ inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t
     }
 }
 
-inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream) {
-    const int BM = sx_tile_m(cfg), BN = sx_tile_n(cfg), MB = BM / 32;
+// raw-input kernels (tensors of <= 64 channels): outputs are raw only
+template <int MW, int NW, int WM, int WN>
+inline hipError_t launch_conv_sx_rawin(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+    if (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) return launch_conv_sx_k<MW, NW, WM, WN, -1, false, true>(a, grid, lds, stream);
+    switch (epi) {
+        case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw, false, true>(a, grid, lds, stream);
+        case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst, false, true>(a, grid, lds, stream);
+        case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum, false, true>(a, grid, lds, stream);
+        default: return launch_conv_sx_k<MW, NW, WM, WN, -1, false, true>(a, grid, lds, stream);
+    }
+}
+
+// rawin: the input is a.xr (fp32 raw) instead of a.xp (planes); only the 64- and 32-row tiles have the
+// registers for it (cfg 1 / 2).
+inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin = false) {
+    const int BM = sx_tile_m(cfg), BN = sx_tile_n(cfg);
     a.LW = BN + (a.K - 1) * a.dil;
     a.magic = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
     // an x stage is padded to whole DMA rounds (256 cells = 4 KiB), so that every wave issues the same count
     a.x_bytes = (unsigned)(((size_t)6 * a.LW * 16 + 4095) / 4096 * 4096);
     const size_t lds = 2 * (size_t)a.x_bytes;  // two x stages; the weights never touch LDS
-    (void)MB;
     // (pack_conv_sx pads narrower kernels to 3 taps; model.cpp sx_supported() mirrors the size limits)
     if (lds > 160 * 1024 || a.x_bytes > 12 * 4096 || a.K < 3) return hipErrorInvalidValue;
+    if (rawin && (cfg == 0 || 2 * a.LW > 768 || !a.xr)) return hipErrorInvalidValue;
     if (a.oslope == 0.f) a.oslope = 1.f;
     if (a.oslope2 == 0.f) a.oslope2 = 1.f;
+    if (a.islope == 0.f) a.islope = 1.f;
     if (a.Cin % 16 || a.Cout % 32 || a.Cr % 32 || a.Cout % BM) return hipErrorInvalidValue;
     dim3 grid((a.T + BN - 1) / BN, a.Cout / BM, B);
     if (grid.x == 0 || B == 0) return hipSuccess;
@@ -500,6 +606,9 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream) {
     if ((epi & EPI_RES) && !a.res) return hipErrorInvalidValue;
     if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
     a.flags = (a.flags & ~kSxEpiMask) | epi;
+    if (rawin)
+        return cfg == 1 ? launch_conv_sx_rawin<1, 4, 2, 2>(a, epi, grid, lds, stream)
+                        : launch_conv_sx_rawin<1, 2, 1, 4>(a, epi, grid, lds, stream);
     if (a.prof && cfg == 0) return launch_conv_sx_k<2, 4, 2, 2, -1, true>(a, grid, lds, stream);
     switch (cfg) {
         case 0: return launch_conv_sx_epi<2, 4, 2, 2>(a, epi, grid, lds, stream);
@@ -536,13 +645,16 @@ __global__ __launch_bounds__(256) void sx_split_planes_kernel(const float *x, in
     }
 }
 
-// planar fp32 [C][T] -> raw fp32 [C/8][T][8]
-__global__ __launch_bounds__(256) void sx_block_kernel(const float *x, float *raw, int C, int T) {
+// planar fp32 x[b][c][t] (row pitch `pitch`, optionally masked by t < len[b]) -> raw fp32 [C/8][T][8]
+__global__ __launch_bounds__(256) void sx_block_kernel(const float *x, int64_t x_bstride, int pitch, const int *len,
+                                                       float *raw, int C, int T) {
     const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
     if (t >= T) return;
+    const bool live = !len || t < len[b];
+    const float *xb = x + (int64_t)b * x_bstride + (int64_t)cg * 8 * pitch + t;
 #pragma unroll
     for (int e = 0; e < 8; e++)
-        raw[(int64_t)b * C * T + ((int64_t)cg * T + t) * 8 + e] = x[(int64_t)b * C * T + (int64_t)(cg * 8 + e) * T + t];
+        raw[(int64_t)b * C * T + ((int64_t)cg * T + t) * 8 + e] = live ? xb[(int64_t)e * pitch] : 0.f;
 }
 
 // raw fp32 [C/8][T][8] (or, with planes != nullptr, the sum of the three planes) -> planar [C][T]

@@ -517,11 +517,10 @@ __global__ __launch_bounds__(256) void post_conv_tanh_kernel(const float *x, con
     out[(int64_t)b * T + t] = tanhf(acc);
 }
 
-// Same tail for the split-exact generator: x is the fp32 raw layout [C/8][T][8] (conv_sx_engine.hip.hpp) and
-// already carries the leaky_relu(0.01) (applied by the last stage's epilogue).  Same (channel, tap)
-// summation order as above.
+// Same tail for the split-exact generator: x is the fp32 raw layout [C/8][T][8] (conv_sx_engine.hip.hpp).
+// Same (channel, tap) summation order as above.
 __global__ __launch_bounds__(256) void post_conv_tanh_blocked_kernel(const float *x, const float *w, float *out, int C,
-                                                                     int K, int T) {
+                                                                     int K, int T, float slope) {
     extern __shared__ float sm[];  // [C][256 + K - 1] staged tile, then weights [C*K]
     const int LW = 256 + K - 1;
     float *ws = sm + (size_t)C * LW;
@@ -535,10 +534,10 @@ __global__ __launch_bounds__(256) void post_conv_tanh_blocked_kernel(const float
         const int t = t0 - pad + col;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t >= 0 && t < T) v = *reinterpret_cast<const float4 *>(xb + ((int64_t)(c4 >> 1) * T + t) * 8 + (c4 & 1) * 4);
-        sm[(c4 * 4 + 0) * LW + col] = v.x;
-        sm[(c4 * 4 + 1) * LW + col] = v.y;
-        sm[(c4 * 4 + 2) * LW + col] = v.z;
-        sm[(c4 * 4 + 3) * LW + col] = v.w;
+        sm[(c4 * 4 + 0) * LW + col] = v.x > 0.f ? v.x : v.x * slope;
+        sm[(c4 * 4 + 1) * LW + col] = v.y > 0.f ? v.y : v.y * slope;
+        sm[(c4 * 4 + 2) * LW + col] = v.z > 0.f ? v.z : v.z * slope;
+        sm[(c4 * 4 + 3) * LW + col] = v.w > 0.f ? v.w : v.w * slope;
     }
     __syncthreads();
     int t = t0 + tid;

@@ -336,7 +336,9 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     d.padL = padL;
     d.CK = 16;
     d.nchunks = Cin / 16;
+    d.rawin = sx_raw_format(Cin);
     d.cfg = sx_pick_cfg(Cout);
+    if (d.rawin && d.cfg == 0) d.cfg = 1;  // the raw-input path exists for the 64- and 32-row tiles only
     d.mblocks = Cout / 32;
     const int MB = sx_tile_m(d.cfg) / 32;
     const int64_t kib = int64_t(d.mblocks) * d.nchunks * K * 3;  // 1 KiB = one (block, plane) fragment set
@@ -478,6 +480,7 @@ bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil) {
     // an x stage is at most 12 DMA rounds of 4 KiB (conv_sx_engine.hip.hpp launch_conv_sx)
     const size_t LW = size_t(sx_tile_n(cfg)) + size_t((K < 3 ? 3 : K) - 1) * dil;
     const size_t x_bytes = (6 * LW * 16 + 4095) / 4096 * 4096;
+    if (sx_raw_format(Cin) && 2 * LW > 768) return false;  // raw-input staging: three cells per thread
     return x_bytes <= 12 * 4096;
 }
 

@@ -28,6 +28,9 @@ struct ConvDesc {
     // planes [m-tile][chunk of 16 ci][tap][32-row block][plane][lane][8]; cfg then indexes the sx tiles
     // (0: 128x256, 1: 64x256, 2: 32x256) and a transposed conv's virtual rows are r-major (r*Cr + co).
     bool sx = false;
+    // sx only: the input tensor is in the fp32 raw layout and is split into planes inside the kernel (tensors of
+    // <= 64 channels, see sx_raw_format); such convs use the 64- or 32-row tiles
+    bool rawin = false;
     double macs_per_t = 0;   // algorithmic MACs per input time step (reference definition)
     bool valid() const { return w_off >= 0; }
 };
@@ -144,5 +147,8 @@ float bf16_to_f32(uint16_t h);
 void split3_host(float v, uint16_t p[3]);
 // may this conv shape run on the sx engine (channel multiples, LDS budget)?
 bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil);
+// Storage format of a generator tensor with C channels on the sx path: true = fp32 raw only (its consumers
+// split it on the fly; layers this narrow are HBM-bound), false = bf16 planes (+ raw where it is a residual).
+inline bool sx_raw_format(int C) { return C <= 64; }
 
 }  // namespace vitsmi

@@ -210,13 +210,16 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
 // One conv through the split-exact bf16 engine (conv_sx_engine.hip.hpp).  Tensors are whole utterance
 // batches in the engine's layouts: input planes [B][3][Cin/8][T][8], outputs raw [B][Cr/8][T*u][8] and/or
 // planes [B][3][Cr/8][T*u][8]; `res` has the raw layout of the output.
-void conv_sx(Ctx &c, const ConvDesc &d, const uint16_t *xp, int T, float *out_raw, uint16_t *out_pl, int flags,
+// `x` is the plane tensor, or (d.rawin) the fp32 raw tensor, to which the kernel applies leaky_relu(islope).
+void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, uint16_t *out_pl, int flags,
              const float *res = nullptr, const float *bias_b = nullptr, int bias_b_stride = 0, float div = 1.f,
-             float oslope = 1.f, float oslope2 = 1.f) {
+             float oslope = 1.f, float oslope2 = 1.f, float islope = 1.f) {
     SxArgs a{};
     const int Cr = d.Cout / d.ups;
     const int64_t Tout = (int64_t)T * d.ups;
-    a.xp = reinterpret_cast<const u32x4 *>(xp);
+    if (d.rawin) a.xr = static_cast<const float *>(x);
+    else a.xp = static_cast<const u32x4 *>(x);
+    a.islope = islope;
     a.x_bstride = (int64_t)3 * (d.Cin / 8) * T;
     a.T = T;
     a.wp = reinterpret_cast<const u32x4 *>(c.P(d.w_off));
@@ -243,7 +246,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const uint16_t *xp, int T, float *out_ra
     a.oslope2 = oslope2;
     vits_handle *h = c.h;
     const bool ev = conv_event_begin(c);
-    c.note(launch_conv_sx(a, d.cfg, c.B, c.st));
+    c.note(launch_conv_sx(a, d.cfg, c.B, c.st, d.rawin));
     if (ev) {
         if (h->conv_event_sx.size() < h->conv_events.size()) h->conv_event_sx.resize(h->conv_events.size(), 0);
         h->conv_event_sx[h->conv_events_used] = 1;
@@ -507,64 +510,93 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
     uint16_t *stage_in[2] = {planes(), planes()}, *y_pl = planes(), *raa[2] = {planes(), planes()}, *tmp_pl = planes();
     float *y_raw = slab_take<float>(s, R), *ra[2] = {slab_take<float>(s, R), slab_take<float>(s, R)};
     float *xs_raw = slab_take<float>(s, R);
+    // the plane regions double as fp32 raw buffers where a stage uses the raw format (RP >= R floats)
+    float *tmp_raw = reinterpret_cast<float *>(tmp_pl), *xin_raw = reinterpret_cast<float *>(stage_in[0]);
     h->cur_stage = 3;
     stage_mark(h, 3);
     const float S = 0.1f;  // Generator.LRELU_SLOPE / ResBlock LRELU_SLOPE
     const int nst = (int)m.ups.size();
-    // z * y_mask -> planes (models.py:349); conv_pre [+ cond(g)] -> leaky_relu(0.1) planes (models.py:349-354)
-    sx_split_planes_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_pl, m.C, F);
+    // Tensor formats (model.hpp sx_raw_format): > 64 channels: bf16 planes that already carry the consumer's
+    // leaky_relu (+ fp32 raw where the tensor is also a residual); <= 64 channels: fp32 raw only, the consuming
+    // conv applies the leaky_relu and the split while loading (its `islope`).
+    // ---- z * y_mask (models.py:349) in conv_pre's input format
+    const void *zin;
+    if (sx_raw_format(m.C)) {
+        sx_block_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_raw, m.C, F);
+        zin = tmp_raw;
+    } else {
+        sx_split_planes_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_pl, m.C, F);
+        zin = tmp_pl;
+    }
     c.note(hipGetLastError());
     h->stats.total_launches++;
-    uint16_t *xa = stage_in[0];
-    conv_sx(c, m.conv_pre, tmp_pl, F, nullptr, xa, 0, nullptr, dec_cond, m.C0, 1.f, 1.f, S);
+    // ---- xa = conv_pre(z) [+ cond(g)]; leaky_relu(0.1) follows (models.py:349-354)
+    bool xa_is_raw = sx_raw_format(m.C0);
+    const void *xa;
+    if (xa_is_raw) {
+        conv_sx(c, m.conv_pre, zin, F, xin_raw, nullptr, 0, nullptr, dec_cond, m.C0);
+        xa = xin_raw;
+    } else {
+        conv_sx(c, m.conv_pre, zin, F, nullptr, stage_in[0], 0, nullptr, dec_cond, m.C0, 1.f, 1.f, S);
+        xa = stage_in[0];
+    }
     int T = F;
     for (int si = 0; si < nst; si++) {
         const auto &stg = m.ups[si];
-        // y = up(xa): pixel-shuffled dense conv; raw (residual) + leaky_relu planes (conv input)
-        conv_sx(c, stg.up, xa, T, y_raw, y_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
+        const bool fr = sx_raw_format(stg.C);  // format of this stage's tensors
+        // y = up(leaky_relu(xa)): pixel-shuffled dense conv; raw (residual / raw-format input) [+ planes]
+        conv_sx(c, stg.up, xa, T, y_raw, fr ? nullptr : y_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S, S);
         T *= stg.u;
         uint16_t *xs_pl = stage_in[(si + 1) & 1];
         const int nk = (int)stg.rbs.size();
         const bool last_stage = si == nst - 1;
         for (int j = 0; j < nk; j++) {
             const auto &rbk = stg.rbs[j];
-            const float *cur = y_raw;
-            const uint16_t *cura = y_pl;
+            const float *cur = y_raw;          // residual operand
+            const uint16_t *cura = y_pl;       // plane format: leaky_relu(cur) as planes
             // MRF accumulation (models.py:356-363): xs = rb0(x); xs += rb1(x); ... ; x = xs / nk
             const bool final_rb = j == nk - 1;
             for (int q = 0; q < rbk.n; q++) {
                 const bool last = q == rbk.n - 1;
                 int fl = EPI_RES;
                 float *dst = ra[q & 1];
-                uint16_t *dsta = raa[q & 1];
-                float osl = 1.f, osl2 = S;
+                uint16_t *dsta = fr ? nullptr : raa[q & 1];
                 if (last) {
                     fl |= (j == 0 ? 0 : EPI_ACC) | (final_rb && nk > 1 ? EPI_DIV : 0);
                     dst = xs_raw;
                     dsta = nullptr;
-                    if (final_rb && last_stage) osl = 0.01f;  // leaky_relu before conv_post (models.py:364)
-                    else if (final_rb) {                      // the next upsampler reads leaky_relu(0.1) planes only
+                    // the stage output x = xs / nk feeds the next upsampler (leaky_relu 0.1) or conv_post (0.01):
+                    // planes carry the activation, raw tensors get it from their consumer
+                    if (final_rb && !last_stage && !fr) {
                         dsta = xs_pl;
                         fl |= SX_NO_RAW_STORE;
                     }
                 }
+                const void *in = fr ? static_cast<const void *>(cur) : static_cast<const void *>(cura);
                 if (rbk.type1) {  // modules.py:301-314: x = c2(lrelu(c1(lrelu(x)))) + x
-                    conv_sx(c, rbk.c1[q], cura, T, nullptr, tmp_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
-                    conv_sx(c, rbk.c2[q], tmp_pl, T, dst, dsta, fl, cur, nullptr, 0, (float)nk, osl, osl2);
+                    if (fr) {
+                        conv_sx(c, rbk.c1[q], in, T, tmp_raw, nullptr, 0, nullptr, nullptr, 0, 1.f, 1.f, 1.f, S);
+                        conv_sx(c, rbk.c2[q], tmp_raw, T, dst, nullptr, fl, cur, nullptr, 0, (float)nk, 1.f, 1.f, S);
+                    } else {
+                        conv_sx(c, rbk.c1[q], in, T, nullptr, tmp_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
+                        conv_sx(c, rbk.c2[q], tmp_pl, T, dst, dsta, fl, cur, nullptr, 0, (float)nk, 1.f, S);
+                    }
                 } else  // modules.py:355-364: x = c(lrelu(x)) + x
-                    conv_sx(c, rbk.c1[q], cura, T, dst, dsta, fl, cur, nullptr, 0, (float)nk, osl, osl2);
+                    conv_sx(c, rbk.c1[q], in, T, dst, dsta, fl, cur, nullptr, 0, (float)nk, 1.f, S, S);
                 cur = dst;
                 cura = dsta;
             }
         }
-        xa = xs_pl;
+        // next stage input: the planes written by the final conv, or the raw x = xs / nk itself
+        xa_is_raw = fr || last_stage;
+        xa = (fr || last_stage) ? static_cast<const void *>(xs_raw) : static_cast<const void *>(xs_pl);
     }
-    // conv_post; tanh (models.py:365-366) on the leaky_relu(0.01)'d raw tensor
+    // leaky_relu(0.01), conv_post, tanh (models.py:364-366) from the raw stage output
     h->S = T;
     h->d_out = slab_take<float>(s, (size_t)B * T);
     size_t lds = ((size_t)m.post_cin * (256 + m.post_k - 1) + (size_t)m.post_cin * m.post_k) * sizeof(float);
     post_conv_tanh_blocked_kernel<<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out, m.post_cin,
-                                                                             m.post_k, T);
+                                                                             m.post_k, T, 0.01f);
     c.note(hipGetLastError());
     h->stats.total_launches++;
     {
@@ -573,6 +605,7 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
         h->stats.dec_bytes += by;
     }
     stage_mark(h, 4);
+    (void)xa_is_raw;
     return 0;
 }
 
@@ -1343,21 +1376,23 @@ static int run_test_conv_sx(const ConvDesc &d, const std::vector<float> &arena, 
     TCHECK(hipMemset(draw, 0, no * 4));
     TCHECK(hipMemset(dop, 0, no * 6));
     sx_split_planes_kernel<<<dim3((T + 255) / 256, d.Cin / 8, B), 256>>>(dx, (int64_t)d.Cin * T, T, nullptr, dxp, d.Cin, T);
+    TCHECK(hipMalloc((void **)&dres, nx * 4 + 16));  // x in the raw layout: raw-input operand and residual
+    sx_block_kernel<<<dim3((T + 255) / 256, d.Cin / 8, B), 256>>>(dx, (int64_t)d.Cin * T, T, nullptr, dres, d.Cin, T);
     SxArgs a{};
     fill_sx_args(a, d, dA, T);
     a.xp = reinterpret_cast<const u32x4 *>(dxp);
+    a.xr = dres;
+    a.islope = (flags & 8) ? slope : 1.f;  // (raw-input convs only)
     a.out_raw = draw;
     a.out_pl = dop;
     a.oslope = 1.f;
     a.oslope2 = (flags & 1) ? slope : 1.f;
     if (flags & 4) {  // residual: res = x (same shape only)
         if (d.Cin != d.Cout || d.ups != 1) return fail(nullptr, VITS_E_ARG, "residual test needs Cin == Cout");
-        TCHECK(hipMalloc((void **)&dres, nx * 4 + 16));
-        sx_block_kernel<<<dim3((T + 255) / 256, d.Cin / 8, B), 256>>>(dx, dres, d.Cin, T);
         a.res = dres;
         a.flags |= EPI_RES;
     }
-    TCHECK(launch_conv_sx(a, d.cfg, B, nullptr));
+    TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin));
     sx_unblock_kernel<<<dim3((To + 255) / 256, Cr / 8, B), 256>>>(draw, (flags & 1) ? dop : nullptr, dout, Cr, To);
     TCHECK(hipGetLastError());
     TCHECK(hipDeviceSynchronize());
@@ -1426,6 +1461,12 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
         a.res = dres;
         a.out_raw = draw;
     }
+    if (d.rawin) {  // <= 64 input channels: as the generator runs such layers: fp32 raw in (lrelu on load), raw out
+        a.xr = dx;
+        a.islope = 0.1f;
+        a.out_pl = nullptr;
+        a.out_raw = draw;
+    }
     unsigned long long *dprof = nullptr;
     if (dbg & 16) {  // per-step cycle breakdown (128x128 tile only), returned in ms_out[3..8]
         TCHECK(hipMalloc((void **)&dprof, 64));
@@ -1435,11 +1476,11 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr));
+    for (int i = 0; i < 2; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin));
     TCHECK(hipDeviceSynchronize());
     if (dprof) TCHECK(hipMemset(dprof, 0, 64));
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr));
+    for (int i = 0; i < iters; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin));
     hipEventRecord(e1, nullptr);
     TCHECK(hipEventSynchronize(e1));
     float ms = 0.f;

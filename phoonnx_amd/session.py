@@ -291,9 +291,10 @@ def test_conv1d(x, w, bias=None, dil=1, pad_l=0, lrelu_slope=None, relu=False, d
     return out
 
 
-def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=False, device_id=0):
+def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=False, in_slope=None, device_id=0):
     """The split-exact bf16 engine (Cin % 16 == 0, Cout % 32 == 0).  planes_slope: read the result back from
-    the three bf16 output planes, which carry leaky_relu(conv, planes_slope); residual: out = conv(x) + x."""
+    the three bf16 output planes, which carry leaky_relu(conv, planes_slope); residual: out = conv(x) + x;
+    in_slope (Cin <= 64 only: the raw-input kernels): out = conv(leaky_relu(x, in_slope))."""
     lib = _ffi.load()
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
@@ -301,9 +302,14 @@ def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=
     Cout, _, K = w.shape
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     out = np.empty((B, Cout, T), np.float32)
-    flags = (1 if planes_slope is not None else 0) | (4 if residual else 0)
+    flags = (1 if planes_slope is not None else 0) | (4 if residual else 0) | (8 if in_slope is not None else 0)
+    if in_slope is not None and planes_slope is not None and in_slope != planes_slope:
+        raise ValueError("the hook takes one slope value")
+    if in_slope is not None and Cin > 64:
+        raise ValueError("in_slope needs a raw-input conv (Cin <= 64)")
+    slope = planes_slope if planes_slope is not None else in_slope
     rc = lib.vits_test_conv1d_sx(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, dil, pad_l,
-                                 flags, float(planes_slope or 0.0), _ffi.ptr(out))
+                                 flags, float(slope or 0.0), _ffi.ptr(out))
     if rc != 0:
         raise SessionError(_ffi.last_error(None))
     return out

@@ -134,6 +134,11 @@ def test_conv_sx_engine_matches_oracle(B, Cin, Cout, T, K, dil):
     if Cin == Cout:                                                          # residual epilogue
         got = test_conv1d_sx(x, w, b, dil=dil, pad_l=pad, residual=True)
         np.testing.assert_allclose(got, ref + x, atol=2e-5, rtol=1e-5)
+    if Cin <= 64:   # raw-input kernels (fp32 tile split into planes in the kernel): leaky_relu on the way in
+        xa = np.where(x > 0, x, x * np.float32(0.1)).astype(np.float32)
+        ref = conv1d(xa, w, b, dil=dil, pad_l=pad, pad_r=dil * (K - 1) - pad)
+        got = test_conv1d_sx(x, w, b, dil=dil, pad_l=pad, in_slope=0.1, residual=Cin == Cout)
+        np.testing.assert_allclose(got, ref + (x if Cin == Cout else 0), atol=2e-5, rtol=1e-5)
 
 
 def test_conv_sx_engine_is_exact_on_identity():

@@ -1,9 +1,11 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence bench.py's roofline numbers are checked against (run on the GPU box):
 #   tools/profile_gpu.sh <preset> <tag>        e.g.  tools/profile_gpu.sh high r01_v3
-# Pass 1: --kernel-trace --stats (per-kernel time).  Pass 2/3: PMC counters, each set in its own run
-# (MI355X_MICROARCH.md: separate --pmc passes; FETCH_SIZE is reported at half the streamed bytes on gfx950).
-# Raw output goes to gpurun_out/prof_<tag>_<preset>/, the summaries to profiles/ and gpurun_out/.
+# Pass "stats": --kernel-trace --stats (per-kernel time).  Passes "pmc*": PMC counters, each set in its own
+# run (MI355X_MICROARCH.md: separate --pmc passes; FETCH_SIZE and WRITE_SIZE do not fit one pass, and
+# FETCH_SIZE is reported at half the streamed bytes on gfx950).  Every pass runs under its own `timeout`:
+# a counter set the hardware refuses makes rocprofv3 abort and then hang in its finaliser.
+# Raw output goes to gpurun_out/prof_<tag>_<preset>/, the summaries to profiles/.
 set -u
 PRESET=${1:-high}
 TAG=${2:-r01}
@@ -12,7 +14,9 @@ OUT=$R/gpurun_out/prof_${TAG}_${PRESET}
 mkdir -p "$OUT" "$R/profiles"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --preset $PRESET --steps 3 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s -- $BENCH > "$OUT/stats.log" 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc1" -o p -- $BENCH > "$OUT/pmc1.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE -d "$OUT/pmc2" -o p -- $BENCH > "$OUT/pmc2.log" 2>&1
+T="timeout -k 10 240"
+$T rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s -- $BENCH > "$OUT/stats.log" 2>&1
+$T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc1" -o p -- $BENCH > "$OUT/pmc1.log" 2>&1
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc2" -o p -- $BENCH > "$OUT/pmc2.log" 2>&1
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc3" -o p -- $BENCH > "$OUT/pmc3.log" 2>&1
 python3 "$R/tools/rocprof_summary.py" "$OUT" "$R/profiles/${TAG}_${PRESET}_b32" --preset "$PRESET"
