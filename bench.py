@@ -24,9 +24,26 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
 # split-exact engine: dense bf16 MFMA peak (256 CUs x 4096 FLOP/clk x 2.4 GHz = 2516.6 TFLOP/s) / 6 plane products
 SX_PEAK_TFLOPS = 2516.6 / 6
-# HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/, DESIGN.md "Measurement");
-# filled per preset for the default workload only
-PMC_TRAFFIC = {}
+
+
+def pmc_traffic(preset, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel family from the committed PMC passes of the SAME command
+    (profiles/*_<preset>_b32_pmc.json, written by tools/profile_gpu.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate
+    passes, per MI355X_MICROARCH.md).  Launch-weighted mean over the family's instantiations; None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{preset}_b32_pmc.json")))
+    if not files:
+        return None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None
+    tot = n = 0.0
+    for name, c in ks.items():
+        if kernel_prefix in name and "hbm_read_bytes_per_launch" in c and "hbm_write_bytes_per_launch" in c:
+            tot += (c["hbm_read_bytes_per_launch"] + c["hbm_write_bytes_per_launch"]) * c["launches"]
+            n += c["launches"]
+    return {"bytes_per_launch": tot / n, "source": os.path.basename(files[-1])} if n else None
 LENGTH_SCALE = {"high": 1.5, "medium": 1.5, "small": 1.5}  # gives ~3 frames per phoneme id with synth weights
 
 
@@ -167,7 +184,9 @@ def main():
         ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                    "traffic": PMC_TRAFFIC.get(a.preset) if (B, T) == (32, 256) else None,
+                    "traffic": (pmc_traffic(a.preset, kname.split(" ")[0]) or {}).get("bytes_per_launch")
+                    if (B, T) == (32, 256) else None,
+                    "traffic_source": (pmc_traffic(a.preset, kname.split(" ")[0]) or {}).get("source"),
                     "launches_per_step": kn // n_t,
                     "avg_launch_ms": kms / max(kn, 1),
                     "algorithmic_gflop_per_launch": kfl / max(kn, 1) / 1e9,

@@ -30,6 +30,7 @@ def build(force=False, verbose=False):
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
            "-Wno-unused-result", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd[1:1] = os.environ.get("VITSMI_CXXFLAGS", "").split()  # kernel experiments (-DSX_EXP_...)
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)

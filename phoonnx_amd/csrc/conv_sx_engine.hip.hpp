@@ -17,15 +17,25 @@
 //                                 exactly one lane's B operand (8 k-values) of the MFMA
 //   raw     fp32 [C/8][T][8]      residual stream (same cell structure, 32-byte cells)
 //   weights bf16 [m-tile][chunk of 16 ci][tap][32-row block][plane][lane][8]  (model.cpp pack_conv_sx):
-//                                 the A slab of a (chunk, tap group) is one contiguous range
-// Both operands reach LDS by 16-byte LDS-DMA; zero padding = out-of-range cells read a zero page.
-// Pipeline: one step = one tap of one 16-channel chunk.  The A slab of a step streams through a ring of three
-// LDS slots, fetched three steps ahead; the x tile of the NEXT chunk is fetched in slices spread over the
-// taps of the current chunk; one (raw, vmcnt-counted) barrier per step; the MFMA fragments of step s+1 are
-// read from LDS while step s's 6*MW*NW MFMAs run.
+//                                 MFMA A-operand lane order, one 1 KiB wave-load per (block row, plane)
+// Tensors of <= 64 channels are HBM-bound layers: they are kept as raw only and the consuming conv (RAWIN
+// instantiation) applies the leaky-ReLU and the split while it loads its tile.
+// Pipeline: one step = one tap of one 16-channel chunk = 6*MW*NW MFMAs per wave.
+//   A (weights): global_load straight into registers (L2-resident, no LDS), two register sets, one step ahead.
+//   B (x tile):  [3 planes][2 channel-group halves][BN + halo] cells in LDS, double-buffered per chunk, brought
+//                by 16-byte LDS-DMA (zero padding = out-of-range cells read a zero page) or, RAWIN, through
+//                registers; one barrier per chunk; B fragments are re-read in two halves, half a step ahead.
+//   Waits are counted (`vmcnt(n)` / `lgkmcnt(n)`, raw `s_barrier`): a `__syncthreads()` would drain the
+//   prefetches in flight.
 // Epilogue: bias, per-utterance bias, residual, multi-receptive-field accumulate and /n, leaky-ReLU,
 // pixel shuffle of the transposed conv (virtual rows are r-major: row = r*Cr + co), then an fp32 raw
-// store and/or a split into the three planes the next conv reads.
+// store and/or a split into the three planes the next conv reads; the common combinations are compile-time
+// specialisations (EPI template parameter).
+// What shaped it (tools/conv_bench.py --sx --prof, profiles/): LDS-DMA and global loads cost 60-180 issue
+// cycles per 1 KiB wave-instruction next to a saturated matrix pipe, so the design minimises their count per
+// MFMA (256-column tiles: one A load serves 4 block columns); a mid-loop `break` in the unrolled step pair
+// makes hipcc copy all accumulators every step; at this load the chip runs at 1.7-1.9 GHz (power), so the
+// matrix pipe's busy share (60-66 % on the 128-row tiles), not the nominal 2.4 GHz peak, is the honest gauge.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
