@@ -15,6 +15,7 @@ CACHE = os.environ.get("VITSMI_BENCH_CACHE", "/tmp/vitsmi_bench")
 def _voice(preset, **over):
     from phoonnx_amd.synth import write_voice
     tag = preset + "".join(f"_{k}{v}" for k, v in sorted(over.items()))
+    tag = "".join(ch if ch.isalnum() or ch in "_-" else "" for ch in tag)
     path = os.path.join(CACHE, f"synth_{tag}.onnx")
     if not os.path.exists(path):
         os.makedirs(CACHE, exist_ok=True)
@@ -24,7 +25,10 @@ def _voice(preset, **over):
 
 
 @pytest.mark.parametrize("preset,over,B,T", [("medium", {}, 3, 96), ("high", {}, 2, 64),
-                                             ("medium", {"n_speakers": 4}, 2, 80)])
+                                             ("medium", {"n_speakers": 4}, 2, 80),
+                                             # 64 -> 128 -> 64 -> 32 channels: raw-format z / conv_pre input and stages
+                                             ("small", {"upsample_initial_channel": 128, "upsample_rates": (8, 4),
+                                                        "upsample_kernel_sizes": (16, 8)}, 3, 70)])
 def test_fullsize_pipeline_matches_oracle(preset, over, B, T):
     from phoonnx_amd import MiSession
     from vits_oracle import VitsOracle
@@ -38,7 +42,7 @@ def test_fullsize_pipeline_matches_oracle(preset, over, B, T):
     sid = rng.integers(0, 4, B).astype(np.int64) if over.get("n_speakers", 1) > 1 else None
     scales = np.array([0.667, 1.4, 0.8], np.float32)
     ndp = rng.standard_normal((B, 2, T)).astype(np.float32)
-    nz = rng.standard_normal((B, 192, T * 8)).astype(np.float32)
+    nz = rng.standard_normal((B, s.hparam("inter"), T * 8)).astype(np.float32)
     ref = o.infer(ids, lens, scales, sid, ndp, nz)
     got = s.synthesize_batch(ids, lens, scales, sid, ndp, nz, taps=("x", "m_p", "logs_p", "logw", "w_ceil", "z_p", "z"))
     assert np.array_equal(got["w_ceil"], ref["w_ceil"])          # integer durations: exact
@@ -50,6 +54,32 @@ def test_fullsize_pipeline_matches_oracle(preset, over, B, T):
     assert err < 1e-3, err                                        # north_star tolerance
     assert 0.02 < np.abs(ref["output"]).max() < 0.999             # the comparison is not vacuous
     s.close()
+
+
+def test_generator_engines_agree(monkeypatch):
+    """The same voice through the split-exact bf16 generator and (VITSMI_GEN_ENGINE=f32) through the f32-MFMA
+    generator: two independent implementations of the same fp32 arithmetic must agree to rounding."""
+    from phoonnx_amd import MiSession
+    path = _voice("medium")
+    rng = np.random.default_rng(5)
+    B, T = 4, 128
+    ids = rng.integers(0, 256, (B, T)).astype(np.int64)
+    lens = np.array([T, T - 17, T // 2, T - 1], np.int64)
+    sc = np.array([0.667, 1.3, 0.8], np.float32)
+    ndp = rng.standard_normal((B, 2, T)).astype(np.float32)
+    nz = rng.standard_normal((B, 192, T * 8)).astype(np.float32)
+    s1 = MiSession(path)
+    assert s1.hparam("gen_sx") == 1
+    a = s1.synthesize_batch(ids, lens, sc, None, ndp, nz)
+    s1.close()
+    monkeypatch.setenv("VITSMI_GEN_ENGINE", "f32")
+    s2 = MiSession(path)
+    assert s2.hparam("gen_sx") == 0
+    b = s2.synthesize_batch(ids, lens, sc, None, ndp, nz)
+    s2.close()
+    assert np.array_equal(a["y_lengths"], b["y_lengths"])
+    assert np.abs(a["output"]).max() > 0.02
+    np.testing.assert_allclose(a["output"], b["output"], atol=2e-5, rtol=0)
 
 
 def test_baseline_batch_properties():
