@@ -473,6 +473,21 @@ __global__ void wn_gate_kernel(const float *a, float *acts, int H, int T) {
     acts[((int64_t)b * H + c) * T + t] = tanhf(ta) * sigmoid_f(sa);
 }
 
+// The same gate when `a` comes from the split-exact conv engine: raw layout [2H/8][T][8] per utterance
+// (conv_sx_engine.hip.hpp); acts stays planar [H][T] with row pitch T.  One thread = 8 channels of one frame.
+__global__ __launch_bounds__(256) void wn_gate_blocked_kernel(const float *a, float *acts, int H, int T) {
+    const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const float *ab = a + (int64_t)b * 2 * H * T;
+    const float4 *pt = reinterpret_cast<const float4 *>(ab + ((int64_t)cg * T + t) * 8);
+    const float4 *ps = reinterpret_cast<const float4 *>(ab + ((int64_t)(H / 8 + cg) * T + t) * 8);
+    const float4 t0 = pt[0], t1 = pt[1], s0 = ps[0], s1 = ps[1];
+    const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int e = 0; e < 8; e++) acts[((int64_t)b * H + cg * 8 + e) * T + t] = tanhf(tv[e]) * sigmoid_f(sv[e]);
+}
+
 // ---- a11: WN residual/skip update (modules.py:203-209) --------------------------------------------
 // not last: x = (x + rs[:, :H]) * mask; skip (+)= rs[:, H:]      last: skip = (skip + rs) * mask
 __global__ void wn_update_kernel(float *x, float *skip, const float *rs, const int *len, int H, int T, int first,

@@ -656,7 +656,15 @@ std::string Model::build(const OnnxModel &om) {
                     if (!w) break;
                     int k = int(w->dims[2]);
                     int dil = int(R.geti(in + ".dilation", 1));
-                    cd.wn[i].in = pack_named(P, R, in, dil, same_pad(k, dil));
+                    // the WN dilated conv carries 83 % of the flow's FLOPs: split-exact engine when the shape allows
+                    // (plane input, 128/64-row tiles); VITSMI_GEN_ENGINE=f32 keeps everything on the f32 engine
+                    const char *env = std::getenv("VITSMI_GEN_ENGINE");
+                    const bool f32_only = env && std::string(env) == "f32";
+                    const int ci = int(w->dims[1]), co = int(w->dims[0]);
+                    if (!f32_only && !sx_raw_format(ci) && co % 64 == 0 && ci % 8 == 0 && sx_supported(ci, co, co, k, dil))
+                        cd.wn[i].in = pack_named_sx(P, R, in, dil, same_pad(k, dil));
+                    else
+                        cd.wn[i].in = pack_named(P, R, in, dil, same_pad(k, dil));
                     cd.wn[i].rs = pack_named(P, R, s + ".enc.res_skip_layers." + std::to_string(i), 1, 0);
                     cd.n_wn = i + 1;
                 }

@@ -707,7 +707,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     const int F = (Freal + 3) & ~3;
     h->Fpitch = F;
     const size_t nCF = (size_t)B * C * F, nHF = (size_t)B * Hf * F;
-    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + gen_ws_bytes(m, B, F) + (1 << 16);
+    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + al(nHF * 2) + gen_ws_bytes(m, B, F) + (1 << 16);
     for (auto &cd : m.flow) need += al((size_t)B * 2 * Hf * cd.n_wn);
     need += al((size_t)B * m.C0);
     if (int rc = slab_reserve(h, h->frm, need)) return rc;
@@ -745,6 +745,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     // ---- inverse coupling flow (models.py:247-254, modules.py:447-466); Flips folded at pack time
     float *hx = slab_take<float>(s, nHF), *skip = slab_take<float>(s, nHF), *acts = slab_take<float>(s, nHF);
     float *a2 = slab_take<float>(s, nHF * 2), *rs = slab_take<float>(s, nHF * 2);
+    uint16_t *hx_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, nHF * 2));  // planes of hx (sx in-layers)
     const int half = C / 2;
     const int64_t sCF = (int64_t)C * F, sHF = (int64_t)Hf * F;
     for (auto &cd : m.flow) {
@@ -763,9 +764,17 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
         for (int i = 0; i < cd.n_wn; i++) {
             const bool last = i == cd.n_wn - 1;
             // x_in = in_layer(h) + g_l ; acts = tanh * sigmoid ; rs = res_skip(acts)
-            conv(c, cd.wn[i].in, hx, sHF, F, a2, 2 * sHF, 0, nullptr, nullptr, 0, gc ? gc + (int64_t)i * 2 * Hf : nullptr,
-                 gc_rows);
-            wn_gate_kernel<<<dim3((F + 255) / 256, Hf, B), 256, 0, st>>>(a2, acts, Hf, F);
+            if (cd.wn[i].in.sx) {
+                // split-exact engine: hx -> three bf16 planes, conv to the raw cell layout, gate reads that layout
+                sx_split_planes_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(hx, sHF, F, nullptr, hx_pl, Hf, F);
+                h->stats.total_launches++;
+                conv_sx(c, cd.wn[i].in, hx_pl, F, a2, nullptr, 0, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr, gc_rows);
+                wn_gate_blocked_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(a2, acts, Hf, F);
+            } else {
+                conv(c, cd.wn[i].in, hx, sHF, F, a2, 2 * sHF, 0, nullptr, nullptr, 0,
+                     gc ? gc + (int64_t)i * 2 * Hf : nullptr, gc_rows);
+                wn_gate_kernel<<<dim3((F + 255) / 256, Hf, B), 256, 0, st>>>(a2, acts, Hf, F);
+            }
             conv(c, cd.wn[i].rs, acts, sHF, F, rs, (int64_t)cd.wn[i].rs.Cout * F, 0);
             wn_update_kernel<<<dim3((F + 255) / 256, Hf, B), 256, 0, st>>>(hx, skip, rs, ylen, Hf, F, i == 0, last);
             h->stats.total_launches += 2;
