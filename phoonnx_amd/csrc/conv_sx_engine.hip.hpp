@@ -574,6 +574,7 @@ inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t
         case kSxEpiInner: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiInner>(a, grid, lds, stream);
         case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst>(a, grid, lds, stream);
         case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum>(a, grid, lds, stream);
+        case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw>(a, grid, lds, stream);  // flow WN convs
         default: return launch_conv_sx_k<MW, NW, WM, WN>(a, grid, lds, stream);
     }
 }

@@ -114,6 +114,8 @@ SX_CASES = [
     (1, 16, 96, 260, 5, 2),     # single chunk, Cout % 64 != 0
     (1, 256, 128, 130, 3, 1),   # sixteen chunks
     (3, 48, 32, 257, 1, 1),     # k = 1, ragged T
+    (1, 64, 64, 5, 7, 1),       # sequence shorter than the kernel (raw-input path, everything is halo)
+    (2, 128, 128, 31, 3, 1),    # sequence much shorter than the 256-column tile (plane-input path)
 ]
 
 
