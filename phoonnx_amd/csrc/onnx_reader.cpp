@@ -104,6 +104,12 @@ OnnxTensor tensor(Span s) {
             default: break;
         }
     }
+    // raw_data sits at an arbitrary byte offset of the file: a float view of it needs 4-byte alignment
+    if (t.dtype == 1 && t.raw && (reinterpret_cast<uintptr_t>(t.raw) & 3u)) {
+        t.f32.resize(t.raw_bytes / 4);
+        std::memcpy(t.f32.data(), t.raw, t.f32.size() * 4);
+        t.raw = nullptr;
+    }
     return t;
 }
 

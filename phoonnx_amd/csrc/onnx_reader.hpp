@@ -20,11 +20,22 @@ struct OnnxTensor {
         for (auto d : dims) n *= d;
         return n;
     }
-    // float view (nullptr if not float32)
+    // float view (nullptr if not float32, or if the file holds fewer values than the dims claim)
     const float *data() const {
-        if (dtype != 1) return nullptr;
+        if (dtype != 1 || !consistent()) return nullptr;
         if (raw) return reinterpret_cast<const float *>(raw);
         return f32.empty() ? nullptr : f32.data();
+    }
+    // do the dims describe exactly what the file stores?  (damaged files: never trust a length field)
+    bool consistent() const {
+        int64_t n = 1;
+        for (auto d : dims) {
+            if (d < 0 || d > (int64_t(1) << 31)) return false;
+            n *= d;
+            if (n > (int64_t(1) << 33)) return false;
+        }
+        const size_t have = raw ? raw_bytes / 4 : f32.size();
+        return size_t(n) <= have;
     }
 };
 

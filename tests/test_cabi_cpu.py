@@ -66,6 +66,42 @@ def test_open_errors():
         MiSession(bad, host_only=True)
 
 
+def test_damaged_files_are_rejected_not_crashed_on(tmp_path):
+    """Truncated and byte-flipped .onnx files must either load or raise SessionError: the protobuf walker and the
+    packer never trust a length field.  Runs in a child process so that a crash would fail this test only."""
+    import subprocess
+    import sys
+    code = r'''
+import random, sys
+sys.path.insert(0, sys.argv[1])
+from phoonnx_amd import MiSession
+from phoonnx_amd.session import SessionError
+src = open(sys.argv[2], "rb").read()
+rng = random.Random(7)
+ok = err = 0
+for it in range(60):
+    b = bytearray(src)
+    if it % 2:
+        b = b[:rng.randrange(0, len(b))]
+    else:
+        for _ in range(rng.randrange(1, 8)):
+            b[rng.randrange(len(b))] = rng.randrange(256)
+    p = sys.argv[3]
+    open(p, "wb").write(bytes(b))
+    try:
+        MiSession(p, host_only=True).close()
+        ok += 1
+    except SessionError:
+        err += 1
+print("survived", ok, err)
+'''
+    r = subprocess.run([sys.executable, "-c", code, ROOT, os.path.join(GOLDEN, "tiny_rb1.onnx"),
+                        str(tmp_path / "damaged.onnx")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "survived" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-300:])
+    n_ok, n_err = (int(v) for v in r.stdout.split()[-2:])
+    assert n_ok + n_err == 60 and n_err >= 30   # every truncation is rejected
+
+
 def test_work_counts_match_survey_formulas():
     # SURVEY App. C formulas evaluated for the tiny preset: conv MACs per frame of the generator
     import json
