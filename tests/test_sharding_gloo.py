@@ -57,7 +57,8 @@ def _worker(rank, world, port, onnx_path, q):
         dist.destroy_process_group()
 
 
-def test_arena_broadcast_two_ranks_gloo():
+@pytest.mark.parametrize("voice", ["fixture", "split_exact"])
+def test_arena_broadcast_two_ranks_gloo(voice, tmp_path):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -65,7 +66,17 @@ def test_arena_broadcast_two_ranks_gloo():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    path = os.path.join(GOLDEN, "tiny_rb2_ms.onnx")
+    if voice == "fixture":
+        path = os.path.join(GOLDEN, "tiny_rb2_ms.onnx")
+    else:  # channel counts that put the generator and the flow on the split-exact engine (bf16-plane weights)
+        from phoonnx_amd import MiSession
+        from phoonnx_amd.synth import write_voice
+        path = str(tmp_path / "sx_voice.onnx")
+        write_voice(path, "small", seed=3, upsample_initial_channel=128, upsample_rates=(8, 4),
+                    upsample_kernel_sizes=(16, 8))
+        probe = MiSession(path, host_only=True)
+        assert probe.hparam("gen_sx") == 1
+        probe.close()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, path, q)) for r in range(2)]
     for p in procs:
         p.start()
