@@ -110,7 +110,9 @@ typedef struct {
  *   scales float32 [3]  [noise_scale, length_scale, noise_w]  (voice.py:364-367)
  *   sid   int64 [B] or NULL              (voice.py:370)
  * `out->data` / `out->y_lengths` are allocated by the library (pinned host memory);
- * release with vits_free_output(). */
+ * release with vits_free_output().  `out` may be NULL: the batch is rendered and kept on the device, to be
+ * fetched as 16-bit PCM with vits_last_pcm16() (no fp32 copy to the host at all) together with
+ * vits_last_y_lengths(). */
 int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
              const int64_t *sid, const vits_noise *noise, vits_output *out);
 void vits_free_output(vits_handle *h, vits_output *out);

@@ -997,7 +997,7 @@ int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int
     if (int rc = check_dev(h)) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
     if (B <= 0 || T <= 0) return fail(h, VITS_E_ARG, "empty batch or sequence (B=%d, T=%d)", B, T);
-    if (!ids || !lens || !scales || !out) return fail(h, VITS_E_ARG, "null argument");
+    if (!ids || !lens || !scales) return fail(h, VITS_E_ARG, "null argument");  // (out == NULL: run only)
     const Model &m = h->model;
     for (int b = 0; b < B; b++) {
         if (lens[b] < 0 || lens[b] > T)
@@ -1044,7 +1044,11 @@ int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int
     }
     vits_output dev{};
     if (rc == VITS_OK) rc = run_device_locked(h, d_ids, d_lens, B, T, scales, sid ? d_sid : nullptr, noise ? &dn : nullptr, &dev);
-    if (rc == VITS_OK) {
+    if (rc == VITS_OK && !out) {
+        // run only: the caller fetches what it needs afterwards (vits_last_pcm16, vits_last_y_lengths, vits_tap)
+        if (hipStreamSynchronize(st) != hipSuccess)
+            rc = fail(h, VITS_E_DEVICE, "synchronisation failed: %s", hipGetErrorString(hipGetLastError()));
+    } else if (rc == VITS_OK) {
         // one pinned block: [samples | frame counts]
         const size_t n = (size_t)B * h->S, ybase = (n * 4 + 63) & ~size_t(63);
         char *host = (char *)pinned_get(h, ybase + (size_t)B * 8);

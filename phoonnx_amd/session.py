@@ -268,6 +268,28 @@ class MiSession:
             raise SessionError(f"vits_last_pcm16 failed [{rc}]: {self._err()}")
         return out
 
+    def synthesize_batch_pcm16(self, ids, lens, scales, sid=None, normalize: bool = True, volume: float = 1.0):
+        """One batched run whose result leaves the GPU as 16-bit PCM only: peak-normalise / volume / clip / int16
+        happen on the device (bit-identical to TTSVoice._postprocess + AudioChunk), the fp32 waveform is never
+        copied to the host.  Returns (pcm int16 [B, S], y_lengths int64 [B])."""
+        ids = np.ascontiguousarray(ids, np.int64)
+        lens = np.ascontiguousarray(lens, np.int64)
+        scales = np.ascontiguousarray(scales, np.float32)
+        if ids.ndim != 2 or lens.shape != (ids.shape[0],) or scales.shape != (3,):
+            raise SessionError(f"Invalid rank/shape for input: {ids.shape} / input_lengths: {lens.shape}")
+        B, T = ids.shape
+        if sid is not None:
+            sid = np.ascontiguousarray(sid, np.int64)
+        noise = _ffi.VitsNoise()
+        noise.seed = self._seed
+        rc = self._lib.vits_run(self._h, _ffi.ptr(ids), _ffi.ptr(lens), B, T, _ffi.ptr(scales), _ffi.ptr(sid),
+                                C.byref(noise), None)
+        if rc != 0:
+            raise SessionError(f"vits_run failed [{rc}]: {self._err()}")
+        ylen = self.last_y_lengths()
+        S = int(ylen.max()) * self.hparam("hop")
+        return self.last_pcm16(normalize, volume, shape=(B, S)), ylen
+
     def sync(self):
         if self._lib.vits_sync(self._h) != 0:
             raise SessionError(self._err())

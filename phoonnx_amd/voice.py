@@ -188,8 +188,12 @@ class TTSVoice:
                              audio_float_array=self._postprocess(audio, syn_config))
 
     def synthesize_wav(self, text: str, wav_file: wave.Wave_write, syn_config: Optional[SynthesisConfig] = None,
-                       set_wav_format: bool = True, batch_sentences: bool = False) -> None:
-        """Synthesize and write 16-bit PCM frames (voice.py:291-326)."""
+                       set_wav_format: bool = True, batch_sentences: bool = False, device_pcm16: bool = False) -> None:
+        """Synthesize and write 16-bit PCM frames (voice.py:291-326).  `device_pcm16=True` (extension):
+        all sentences in one batch, peak-normalise / volume / clip / int16 on the GPU, only PCM bytes cross PCIe;
+        the frames written are bit-identical to the default path's."""
+        if device_pcm16 and hasattr(self.session, "synthesize_batch_pcm16"):
+            return self._synthesize_wav_device_pcm16(text, wav_file, syn_config or SynthesisConfig(), set_wav_format)
         sentence_silence = 0.0  # seconds of silence after each sentence (fixed in the reference)
         silence = bytes(int(self.config.sample_rate * sentence_silence * 2))
         first = True
@@ -203,6 +207,30 @@ class TTSVoice:
             if not first:
                 wav_file.writeframes(silence)
             wav_file.writeframes(chunk.audio_int16_bytes)
+
+    def _synthesize_wav_device_pcm16(self, text: str, wav_file: wave.Wave_write, syn_config: SynthesisConfig,
+                                     set_wav_format: bool) -> None:
+        from .sharding import pad_batch
+        if self.phonetic_spellings and syn_config.enable_phonetic_spellings:
+            text = self.phonetic_spellings.apply(text)
+        if syn_config.add_diacritics:
+            text = self.phonemizer.add_diacritics(text, self.config.lang_code)
+        all_ids = [self.phonemes_to_ids(p) for p in self.phonemize(text) if p]
+        all_ids = [ids for ids in all_ids if ids]
+        if set_wav_format:
+            wav_file.setframerate(self.config.sample_rate)
+            wav_file.setsampwidth(2)
+            wav_file.setnchannels(1)
+        if not all_ids:
+            return
+        ids, lens = pad_batch(all_ids)
+        expected = [i.name for i in self.session.get_inputs()]
+        sid = np.full((len(all_ids),), syn_config.speaker_id or 0, np.int64) if "sid" in expected else None
+        pcm, ylen = self.session.synthesize_batch_pcm16(ids, lens, self._scales(syn_config), sid,
+                                                        normalize=syn_config.normalize_audio, volume=syn_config.volume)
+        hop = self.session.hparam("hop")
+        for b in range(len(all_ids)):
+            wav_file.writeframes(pcm[b, :int(ylen[b]) * hop].tobytes())
 
     def _scales(self, syn_config: SynthesisConfig) -> np.ndarray:
         c = self.config

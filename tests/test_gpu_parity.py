@@ -384,6 +384,15 @@ def test_ttsvoice_load_and_synthesize_wav(tmp_path):
     assert [len(c.audio_float_array) for c in batched] == [len(c.audio_float_array) for c in chunks]
     longest = int(np.argmax([len(c.audio_float_array) for c in chunks]))
     np.testing.assert_allclose(batched[longest].audio_float_array, chunks[longest].audio_float_array, atol=2e-4)
+    # device-side post-processing (extension f2): the same batch leaves the GPU as PCM16 only; the WAV frames
+    # are bit-identical to the int16 rendering of the batched float path
+    buf2 = io.BytesIO()
+    with wave.open(buf2, "wb") as w:
+        voice.synthesize_wav(text, w, device_pcm16=True)
+    with wave.open(io.BytesIO(buf2.getvalue())) as r:
+        assert (r.getframerate(), r.getsampwidth(), r.getnchannels()) == (22050, 2, 1)
+        frames2 = np.frombuffer(r.readframes(r.getnframes()), np.int16)
+    assert np.array_equal(frames2, np.concatenate([c.audio_int16_array for c in batched]))
     # a reference-style voice object: session.run() returns rank-4, squeeze() gives [S]
     ids = voice.phonemes_to_ids(list("hello"))
     audio = voice.phoneme_ids_to_audio(ids, SynthesisConfig())
