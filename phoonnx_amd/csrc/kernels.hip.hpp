@@ -543,16 +543,20 @@ __global__ __launch_bounds__(256) void post_conv_tanh_blocked_kernel(const float
     const float *xb = x + (int64_t)b * C * T;
     for (int i = tid; i < C * K; i += 256) ws[i] = w[i];
     const int pad = (K - 1) / 2;
-    // one thread moves half a cell (4 channels of one time step) per round
-    for (int i = tid; i < (C / 4) * LW; i += 256) {
-        const int col = i % LW, c4 = i / LW;  // c4 = cell-half index: channels 4*c4 .. +3
+    // one thread moves a whole cell (8 channels of one time step, 32 contiguous bytes) per round: a wave reads
+    // 2 KiB of consecutive addresses
+    for (int i = tid; i < (C / 8) * LW; i += 256) {
+        const int col = i % LW, cg = i / LW;
         const int t = t0 - pad + col;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < T) v = *reinterpret_cast<const float4 *>(xb + ((int64_t)(c4 >> 1) * T + t) * 8 + (c4 & 1) * 4);
-        sm[(c4 * 4 + 0) * LW + col] = v.x > 0.f ? v.x : v.x * slope;
-        sm[(c4 * 4 + 1) * LW + col] = v.y > 0.f ? v.y : v.y * slope;
-        sm[(c4 * 4 + 2) * LW + col] = v.z > 0.f ? v.z : v.z * slope;
-        sm[(c4 * 4 + 3) * LW + col] = v.w > 0.f ? v.w : v.w * slope;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (t >= 0 && t < T) {
+            const float4 *p = reinterpret_cast<const float4 *>(xb + ((int64_t)cg * T + t) * 8);
+            v0 = p[0];
+            v1 = p[1];
+        }
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; e++) sm[(cg * 8 + e) * LW + col] = v[e] > 0.f ? v[e] : v[e] * slope;
     }
     __syncthreads();
     int t = t0 + tid;

@@ -594,9 +594,11 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
     // leaky_relu(0.01), conv_post, tanh (models.py:364-366) from the raw stage output
     h->S = T;
     h->d_out = slab_take<float>(s, (size_t)B * T);
-    size_t lds = ((size_t)m.post_cin * (256 + m.post_k - 1) + (size_t)m.post_cin * m.post_k) * sizeof(float);
-    post_conv_tanh_blocked_kernel<<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out, m.post_cin,
-                                                                             m.post_k, T, 0.01f);
+    {
+        const size_t lds = ((size_t)m.post_cin * (256 + m.post_k - 1) + (size_t)m.post_cin * m.post_k) * sizeof(float);
+        post_conv_tanh_blocked_kernel<<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out,
+                                                                                 m.post_cin, m.post_k, T, 0.01f);
+    }
     c.note(hipGetLastError());
     h->stats.total_launches++;
     {
