@@ -81,7 +81,13 @@ def main():
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gen-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="f32 (default, the headline metric): every fp32 product exact; bf16x3 / bf16: the declared "
+                         "reduced-precision vocoder modes of BASELINE config 4 (reported with their dtype, never as "
+                         "the headline number)")
     a = ap.parse_args()
+    if a.gen_precision != "f32":
+        os.environ["VITSMI_GEN_PRECISION"] = a.gen_precision
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -113,6 +119,7 @@ def main():
     sess, arena_keepalive = open_sharded(voice, local_rank, dist)
     hop = sess.hparam("hop")
     sess_gen_sx = bool(sess.hparam("gen_sx"))
+    gen_nprod = int(sess.hparam("gen_nprod"))
     sess.set_seed(1234 + rank)
 
     B, T = a.batch, a.tokens
@@ -176,7 +183,7 @@ def main():
             # dominant kernel: the generator's split-exact conv (six bf16 MFMA plane products per fp32 product)
             kfl, kms, kn = agg["sx_flops"], agg["sx_ms"], int(agg["sx_launches"])
             kname = "conv_sx_kernel (implicit-GEMM Conv1d, fp32-exact via 3 bf16 planes, v_mfma_f32_32x32x16_bf16)"
-            peak = SX_PEAK_TFLOPS
+            peak = SX_PEAK_TFLOPS if gen_nprod == 6 else 2516.6 / gen_nprod  # (reduced modes: fewer plane products)
         else:
             kfl, kms, kn = fl, ms, launches
             kname = "conv_engine_kernel (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)"
@@ -213,7 +220,8 @@ def main():
             "metric": "audio samples/sec (22.05 kHz), batch-32 256-phoneme utterances",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if gen_nprod == 6 else f"f32 + {a.gen_precision} vocoder (reduced precision)",
+            "data": "synthetic",
             "dtype_note": ("fp32 operands and fp32 accumulation everywhere; the generator's convs evaluate each fp32 product "
                            "exactly-to-2^-24 as six bf16 MFMA plane products (three bf16 planes per operand)"
                            if sess_gen_sx else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),

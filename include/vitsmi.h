@@ -75,7 +75,9 @@ int vits_meta(vits_handle *h, const char *key, char *buf, size_t n);
 
 /* Derived hyper-parameters: "hidden","inter","filter","n_heads","n_layers","n_vocab",
  * "n_speakers","gin","use_sdp","hop" (= product of upsample rates),"n_ups","resblock",
- * "gen_sx" (1: the generator runs on the split-exact bf16 engine, 0: on the f32 engine). */
+ * "gen_sx" (1: the generator runs on the split-exact bf16 engine, 0: on the f32 engine),
+ * "gen_nprod" (bf16 plane products per fp32 product in the generator: 6 = exact, the default; 3 / 1 with
+ * VITSMI_GEN_PRECISION=bf16x3 / bf16 in the environment at open time: BASELINE config 4's "bf16 vocoder"). */
 int vits_hparam(vits_handle *h, const char *key, int64_t *out);
 
 /* ---- weight arena (multi-GPU: one rank reads + packs, RCCL broadcasts the bytes) ---- */
@@ -186,7 +188,9 @@ int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, in
 /* The same three hooks through the split-exact bf16 engine the generator runs on when all of its channel counts
  * are multiples of 32 (csrc/conv_sx_engine.hip.hpp); needs Cin % 16 == 0 and Cout % 32 == 0.
  * vits_test_conv1d_sx flags: bit0 -> out = leaky_relu(conv, slope) read back from the three bf16 output planes
- * (else the fp32 raw output), bit2 -> residual epilogue with res = x (Cin == Cout).
+ * (else the fp32 raw output), bit2 -> residual epilogue with res = x (Cin == Cout), bit3 -> leaky_relu(slope) on the
+ * input (raw-input kernels, Cin <= 64), bits 4-5 -> precision mode: 0 exact (six plane products), 1 bf16x3, 2 bf16
+ * (the declared reduced-precision vocoder modes of VITSMI_GEN_PRECISION; vits_bench_conv1d_sx: dbg bits 32 / 64).
  * vits_bench_conv1d_sx dbg bits: 1 no DMA after the first step, 2 no epilogue, 8 residual epilogue, 16 in-kernel
  * cycle breakdown (128-row tiles only).  ms_out holds 8 floats: [0] ms per launch, [1] tile config, [3..7] with
  * bit 16: s_memtime ticks per pipeline step spent in {LDS wait, DMA wait, barrier, DMA issue, loads + MFMA}. */

@@ -158,9 +158,14 @@ constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL 
 // RAWIN: the input is the fp32 raw tensor itself; each x tile is loaded into registers, leaky-ReLU'd (islope) and
 // split into the three bf16 planes on its way into LDS.  Used where the layer is HBM-bound (<= 64 channels):
 // such tensors then exist only once, as 4-byte raw values, instead of raw + 6-byte planes.
-template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false>
+// NP = plane products per fp32 product: 6 = exact (default); 3 (w0x0 + w0x1 + w1x0, ~2^-16 relative) and
+// 1 (w0x0, plain bf16) are the declared reduced-precision vocoder modes (VITSMI_GEN_PRECISION, BASELINE config 4):
+// they read only the planes they use.
+template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false, int NP = 6>
 __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     constexpr int BM = MW * WM * 32, BN = NW * WN * 32, MB = BM / 32;
+    static_assert(NP == 6 || NP == 3 || NP == 1, "plane products");
+    constexpr int NPL = NP == 6 ? 3 : (NP == 3 ? 2 : 1);  // planes read per operand
     static_assert(WM * WN == 4, "four waves per workgroup");
     static_assert(MW <= 2, "load_a addresses two block rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_sx[];  // two x stages
@@ -300,8 +305,8 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             constexpr int m = decltype(M)::value;
             const uint32_t vo = m == 0 ? voff0 : voff1;
             f.fa[m][0] = global_read128<0>(vo, sb);
-            f.fa[m][1] = global_read128<1024>(vo, sb);
-            f.fa[m][2] = global_read128<2048>(vo, sb);
+            if constexpr (NPL > 1) f.fa[m][1] = global_read128<1024>(vo, sb);
+            if constexpr (NPL > 2) f.fa[m][2] = global_read128<2048>(vo, sb);
         });
     };
     auto load_b_half = [&](auto H, int chunk, int tap) {
@@ -311,16 +316,17 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
         static_for<NH>([&](auto N) {
             constexpr int n = h * NH + decltype(N)::value;
             fb[n][0] = ds_read128<n * 512>(bb0);
-            fb[n][1] = ds_read128<n * 512>(bb1);
-            fb[n][2] = ds_read128<n * 512>(bb2);
+            if constexpr (NPL > 1) fb[n][1] = ds_read128<n * 512>(bb1);
+            if constexpr (NPL > 2) fb[n][2] = ds_read128<n * 512>(bb2);
         });
     };
     auto mma_half = [&](const ASet &f, auto H) {
         constexpr int h = decltype(H)::value;
         // plane pairs of combined order <= 2, smallest terms first; consecutive MFMAs hit different accumulators
+        // (NP < 6 keeps the LAST NP pairs of the list: the three / one most significant products)
         constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int c = 0; c < 6; c++)
+        for (int c = 6 - NP; c < 6; c++)
 #pragma unroll
             for (int m = 0; m < MW; m++)
 #pragma unroll
@@ -330,8 +336,11 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
                                                                         acc[m][n], 0, 0, 0);
     };
     // LDS reads return in order: "at most NH*3 outstanding" = the older half has landed
-    auto wait_lds_older_half = [&]() {
-        if constexpr (NH == 1) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+    auto wait_lds_older_half = [&]() {  // a half = NH * NPL reads
+        if constexpr (NH * NPL == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else if constexpr (NH * NPL == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if constexpr (NH * NPL == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else if constexpr (NH * NPL == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
     };
     static_assert(NH == 1 || NH == 2, "lgkmcnt immediates above");
@@ -543,10 +552,10 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
 inline int sx_tile_m(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
 inline int sx_tile_n(int) { return 256; }
 
-template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false>
+template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false, int NP = 6>
 inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
-    auto kern = conv_sx_kernel<MW, NW, WM, WN, EPI, PROF, RAWIN>;
+    auto kern = conv_sx_kernel<MW, NW, WM, WN, EPI, PROF, RAWIN, NP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
@@ -591,9 +600,16 @@ inline hipError_t launch_conv_sx_rawin(const SxArgs &a, int epi, dim3 grid, size
     }
 }
 
+// reduced-precision modes (NP = 3 or 1 plane products): generic epilogue only
+template <int MW, int NW, int WM, int WN, bool RAWIN>
+inline hipError_t launch_conv_sx_np(const SxArgs &a, int nprod, dim3 grid, size_t lds, hipStream_t stream) {
+    if (nprod == 3) return launch_conv_sx_k<MW, NW, WM, WN, -1, false, RAWIN, 3>(a, grid, lds, stream);
+    return launch_conv_sx_k<MW, NW, WM, WN, -1, false, RAWIN, 1>(a, grid, lds, stream);
+}
+
 // rawin: the input is a.xr (fp32 raw) instead of a.xp (planes); only the 64- and 32-row tiles have the
-// registers for it (cfg 1 / 2).
-inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin = false) {
+// registers for it (cfg 1 / 2).  nprod: 6 (exact, default), 3 or 1 (declared reduced-precision modes).
+inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin = false, int nprod = 6) {
     const int BM = sx_tile_m(cfg), BN = sx_tile_n(cfg);
     a.LW = BN + (a.K - 1) * a.dil;
     a.magic = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
@@ -617,6 +633,17 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     if ((epi & EPI_RES) && !a.res) return hipErrorInvalidValue;
     if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
     a.flags = (a.flags & ~kSxEpiMask) | epi;
+    if (nprod != 6) {
+        if (nprod != 3 && nprod != 1) return hipErrorInvalidValue;
+        if (rawin)
+            return cfg == 1 ? launch_conv_sx_np<1, 4, 2, 2, true>(a, nprod, grid, lds, stream)
+                            : launch_conv_sx_np<1, 2, 1, 4, true>(a, nprod, grid, lds, stream);
+        switch (cfg) {
+            case 0: return launch_conv_sx_np<2, 4, 2, 2, false>(a, nprod, grid, lds, stream);
+            case 1: return launch_conv_sx_np<1, 4, 2, 2, false>(a, nprod, grid, lds, stream);
+            default: return launch_conv_sx_np<1, 2, 1, 4, false>(a, nprod, grid, lds, stream);
+        }
+    }
     if (rawin)
         return cfg == 1 ? launch_conv_sx_rawin<1, 4, 2, 2>(a, epi, grid, lds, stream)
                         : launch_conv_sx_rawin<1, 2, 1, 4>(a, epi, grid, lds, stream);

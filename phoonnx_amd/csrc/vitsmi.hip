@@ -70,6 +70,7 @@ struct vits_handle {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int cur_stage = 0;  // 0 enc, 1 dp, 2 flow, 3 dec
     uint64_t run_counter = 0;
+    int gen_nprod = 6;  // bf16 plane products per fp32 product in the generator: 6 exact, 3 / 1 reduced (VITSMI_GEN_PRECISION)
 };
 
 namespace {
@@ -246,7 +247,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.oslope2 = oslope2;
     vits_handle *h = c.h;
     const bool ev = conv_event_begin(c);
-    c.note(launch_conv_sx(a, d.cfg, c.B, c.st, d.rawin));
+    c.note(launch_conv_sx(a, d.cfg, c.B, c.st, d.rawin, h->cur_stage == 3 ? h->gen_nprod : 6));
     if (ev) {
         if (h->conv_event_sx.size() < h->conv_events.size()) h->conv_event_sx.resize(h->conv_events.size(), 0);
         h->conv_event_sx[h->conv_events_used] = 1;
@@ -820,6 +821,19 @@ static int open_common(const char *path, vits_handle **out, bool host_only, int 
         return fail(nullptr, VITS_E_FORMAT, "attention window %d > 4 is unsupported", h->model.window);
     }
     h->host_only = host_only;
+    {
+        // Declared reduced-precision vocoder modes (BASELINE config 4, "bf16 vocoder"); the default computes every
+        // fp32 product exactly.  They apply to the generator's convs only and need the split-exact engine.
+        const char *pe = std::getenv("VITSMI_GEN_PRECISION");
+        const std::string ps = pe ? pe : "";
+        if (ps == "bf16x3") h->gen_nprod = 3;
+        else if (ps == "bf16") h->gen_nprod = 1;
+        else if (!ps.empty() && ps != "f32") {
+            delete h;
+            return fail(nullptr, VITS_E_ARG, "VITSMI_GEN_PRECISION must be f32, bf16x3 or bf16 (got '%s')", pe);
+        }
+        if (!h->model.gen_sx) h->gen_nprod = 6;
+    }
     if (!host_only) {
         int n = 0;
         hipError_t er = hipGetDeviceCount(&n);
@@ -917,6 +931,7 @@ int vits_hparam(vits_handle *h, const char *key, int64_t *out) {
     else if (k == "n_speakers") *out = m.n_speakers;
     else if (k == "gin") *out = m.gin;
     else if (k == "gen_sx") *out = m.gen_sx ? 1 : 0;
+    else if (k == "gen_nprod") *out = h->gen_nprod;
     else if (k == "use_sdp") *out = m.use_sdp;
     else if (k == "hop") *out = m.hop;
     else if (k == "n_ups") *out = (int64_t)m.ups.size();
@@ -1407,7 +1422,8 @@ static int run_test_conv_sx(const ConvDesc &d, const std::vector<float> &arena, 
         a.res = dres;
         a.flags |= EPI_RES;
     }
-    TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin));
+    const int nprod = ((flags >> 4) & 3) == 1 ? 3 : (((flags >> 4) & 3) == 2 ? 1 : 6);
+    TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, nprod));
     sx_unblock_kernel<<<dim3((To + 255) / 256, Cr / 8, B), 256>>>(draw, (flags & 1) ? dop : nullptr, dout, Cr, To);
     TCHECK(hipGetLastError());
     TCHECK(hipDeviceSynchronize());
@@ -1491,11 +1507,11 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin));
+    for (int i = 0; i < 2; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, (dbg & 32) ? 3 : ((dbg & 64) ? 1 : 6)));
     TCHECK(hipDeviceSynchronize());
     if (dprof) TCHECK(hipMemset(dprof, 0, 64));
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin));
+    for (int i = 0; i < iters; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, (dbg & 32) ? 3 : ((dbg & 64) ? 1 : 6)));
     hipEventRecord(e1, nullptr);
     TCHECK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -313,7 +313,8 @@ def test_conv1d(x, w, bias=None, dil=1, pad_l=0, lrelu_slope=None, relu=False, d
     return out
 
 
-def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=False, in_slope=None, device_id=0):
+def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=False, in_slope=None, device_id=0,
+                   precision="f32"):
     """The split-exact bf16 engine (Cin % 16 == 0, Cout % 32 == 0).  planes_slope: read the result back from
     the three bf16 output planes, which carry leaky_relu(conv, planes_slope); residual: out = conv(x) + x;
     in_slope (Cin <= 64 only: the raw-input kernels): out = conv(leaky_relu(x, in_slope))."""
@@ -324,7 +325,9 @@ def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=
     Cout, _, K = w.shape
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     out = np.empty((B, Cout, T), np.float32)
+    # precision: "f32" = six exact plane products; "bf16x3" / "bf16" = the declared reduced-precision vocoder modes
     flags = (1 if planes_slope is not None else 0) | (4 if residual else 0) | (8 if in_slope is not None else 0)
+    flags |= {"f32": 0, "bf16x3": 1, "bf16": 2}[precision] << 4
     if in_slope is not None and planes_slope is not None and in_slope != planes_slope:
         raise ValueError("the hook takes one slope value")
     if in_slope is not None and Cin > 64:

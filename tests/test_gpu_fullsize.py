@@ -82,6 +82,39 @@ def test_generator_engines_agree(monkeypatch):
     np.testing.assert_allclose(a["output"], b["output"], atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-3), ("bf16", 8e-2)])
+def test_config4_multispeaker_mixed_lengths_reduced_precision_vocoder(monkeypatch, mode, tol):
+    """BASELINE config 4: multi-speaker voice, mixed-length padded batch, reduced-precision vocoder
+    (VITSMI_GEN_PRECISION).  Everything up to z is computed exactly as always; the generator then uses three
+    (bf16x3) or one (bf16) plane product per fp32 product.  Declared waveform tolerances: bf16x3 stays inside
+    north_star's 1e-3; plain bf16 is a quality/speed trade-off, 8e-2 max-abs on a unit-scale waveform."""
+    from phoonnx_amd import MiSession
+    from vits_oracle import VitsOracle
+    path = _voice("medium", n_speakers=4)
+    monkeypatch.setenv("VITSMI_GEN_PRECISION", mode)
+    s, o = MiSession(path), VitsOracle(path)
+    assert s.hparam("gen_nprod") == {"bf16x3": 3, "bf16": 1}[mode]
+    rng = np.random.default_rng(4)
+    B, T = 8, 72
+    lens = np.array([T] + [int(v) for v in rng.integers(T // 4, T, B - 1)], np.int64)
+    ids = np.zeros((B, T), np.int64)
+    for b in range(B):
+        ids[b, :lens[b]] = rng.integers(0, 256, lens[b])
+    sid = rng.integers(0, 4, B).astype(np.int64)
+    scales = np.array([0.667, 1.2, 0.8], np.float32)
+    ndp = rng.standard_normal((B, 2, T)).astype(np.float32)
+    nz = rng.standard_normal((B, 192, T * 8)).astype(np.float32)
+    ref = o.infer(ids, lens, scales, sid, ndp, nz)
+    got = s.synthesize_batch(ids, lens, scales, sid, ndp, nz, taps=("z",))
+    assert np.array_equal(got["y_lengths"], ref["y_lengths"])
+    np.testing.assert_allclose(got["z"], ref["z"], atol=5e-4, rtol=0)      # exact part of the pipeline
+    hop = s.hparam("hop")
+    err = max(float(np.abs(got["output"][b, 0, 0, :int(ref["y_lengths"][b]) * hop] -
+                           ref["output"][b, 0, 0, :int(ref["y_lengths"][b]) * hop]).max()) for b in range(B))
+    assert err < tol, (mode, err)
+    s.close()
+
+
 def test_baseline_batch_properties():
     """B=32 x 256 ids (BASELINE config 3) is too slow for the CPU oracle inside a test, so check
     size-independent properties: batch-composition invariance of durations, shape law

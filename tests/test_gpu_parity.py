@@ -173,6 +173,22 @@ def test_conv_sx_engine_error_is_fp32_grade():
     assert e_sx < 5e-6
 
 
+def test_conv_sx_reduced_precision_modes_have_their_declared_error():
+    # the optional vocoder modes (VITSMI_GEN_PRECISION, BASELINE config 4): three plane products ~ 2^-16 relative,
+    # one plane product = plain bf16 operands; measured against float64 on unit-variance outputs
+    from phoonnx_amd.session import test_conv1d_sx
+    rng = np.random.default_rng(21)
+    B, C, T, K, dil = 1, 128, 512, 7, 1
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    w = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (3, 3)))
+    ref = sum(np.einsum("oc,bct->bot", w[:, :, k].astype(np.float64), xp[:, :, k:k + T]) for k in range(K))
+    err = {p: float(np.abs(test_conv1d_sx(x, w, pad_l=3, precision=p) - ref).max()) for p in ("f32", "bf16x3", "bf16")}
+    assert err["f32"] < 1e-5, err               # measured 5.5e-6 (fp32 accumulation of 896 terms)
+    assert 1e-5 < err["bf16x3"] < 2e-4, err     # measured 2.1e-5
+    assert 2e-4 < err["bf16"] < 5e-2, err       # measured 1.0e-2
+
+
 @pytest.mark.parametrize("B,Cin,Cout,T,K,u", [(2, 32, 32, 50, 16, 8), (1, 64, 32, 37, 8, 4), (2, 128, 64, 129, 4, 2),
                                               (1, 512, 256, 9, 16, 8)])
 def test_conv_transpose_sx_matches_oracle(B, Cin, Cout, T, K, u):
