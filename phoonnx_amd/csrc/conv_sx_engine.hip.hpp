@@ -73,6 +73,7 @@ struct SxArgs {
     int LW;               // x tile width in cells                       ( " )
     unsigned magic;       // ceil(2^32 / LW)                             ( " )
     unsigned x_bytes;     // bytes of one x stage                        ( " )
+    int NT, MT, B;        // tiles along time / along rows, utterances   ( " )
     int flags;            // EPI_RES | EPI_ACC | EPI_DIV | DBG_*
     float div, oslope, oslope2;
     unsigned long long *prof;  // PROF instantiation only: cycle counters [lgkm wait, vm wait, barrier, DMA issue, loads+MFMA, steps]
@@ -174,7 +175,14 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, t0 = blockIdx.x * BN;
+    // XCD-aware tile order (1-D grid).  Workgroup ids go round-robin over the 8 XCDs, each with its own L2: the
+    // row tiles (mt) of one (time tile, utterance) get consecutive slots of the SAME XCD, so the x tile they all
+    // read comes from HBM once and from that L2 for the others.
+    const int wg_xcd = blockIdx.x & 7, wg_seq = blockIdx.x >> 3;
+    const int mt = __builtin_amdgcn_readfirstlane(wg_seq % a.MT);  // (readfirstlane: keep these provably uniform)
+    const int tile_nb = __builtin_amdgcn_readfirstlane((wg_seq / a.MT) * 8 + wg_xcd);  // (time tile, utterance) index
+    if (tile_nb >= a.NT * a.B) return;                 // padding workgroups of the last round (uniform exit)
+    const int b = tile_nb / a.NT, t0 = (tile_nb - b * a.NT) * BN;
     const int T = a.T, LW = a.LW, K = a.K, CG = a.Cin >> 3;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_sx;
     const uint32_t XB = a.x_bytes;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     const int64_t pstride = (int64_t)CG * T;  // cells per plane
     constexpr int STEPBYTES = MB * 3 * 1024;   // packed weights of one step (one tap of one 16-channel chunk)
     // this wave's A rows of step 0 (uniform address: lives in SGPRs)
-    const char *wbase = reinterpret_cast<const char *>(a.wp) + (int64_t)blockIdx.y * a.nchunks * K * STEPBYTES +
+    const char *wbase = reinterpret_cast<const char *>(a.wp) + (int64_t)mt * a.nchunks * K * STEPBYTES +
                         wm * (MW * 3 * 1024);
     const int nit = a.x_bytes >> 12;           // DMA rounds of 256 cells per x tile (the stage is padded to 4 KiB)
 
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     const int b_on = a.bias ? 1 : 0;
 #pragma unroll
     for (int m = 0; m < MW; m++) {
-        const int row0 = blockIdx.y * BM + (wm * MW + m) * 32;
+        const int row0 = mt * BM + (wm * MW + m) * 32;
         if (row0 >= a.Cout) continue;
         const int r = u == 1 ? 0 : row0 / Cr;
         const int co0 = row0 - r * Cr;
@@ -623,8 +631,14 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     if (a.oslope2 == 0.f) a.oslope2 = 1.f;
     if (a.islope == 0.f) a.islope = 1.f;
     if (a.Cin % 16 || a.Cout % 32 || a.Cr % 32 || a.Cout % BM) return hipErrorInvalidValue;
-    dim3 grid((a.T + BN - 1) / BN, a.Cout / BM, B);
-    if (grid.x == 0 || B == 0) return hipSuccess;
+    a.NT = (a.T + BN - 1) / BN;
+    a.MT = a.Cout / BM;
+    a.B = B;
+    const long long nb = (long long)a.NT * B;  // (time tile, utterance) pairs, dealt round-robin to the 8 XCDs
+    if (nb == 0) return hipSuccess;
+    const long long wgs = (nb + 7) / 8 * 8 * a.MT;
+    if (wgs >= (1ll << 31)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs, 1, 1);
     // epilogue description (see the SX_* bits): derived from the arguments, then matched against the instantiations
     int epi = a.flags & (EPI_RES | EPI_ACC | EPI_DIV);
     if (a.out_raw && !(a.flags & SX_NO_RAW_STORE)) epi |= SX_HAS_RAW | (a.oslope != 1.f ? SX_RAW_ACT : 0);

@@ -2,6 +2,7 @@
 // Host-side C++17; no HIP types here so CPU-only tests can exercise it.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -149,6 +150,12 @@ void split3_host(float v, uint16_t p[3]);
 bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil);
 // Storage format of a generator tensor with C channels on the sx path: true = fp32 raw only (its consumers
 // split it on the fly; layers this narrow are HBM-bound), false = bf16 planes (+ raw where it is a residual).
-inline bool sx_raw_format(int C) { return C <= 64; }
+inline bool sx_raw_format(int C) {
+    static const int maxc = [] {
+        const char *e = std::getenv("VITSMI_SX_RAW_MAXC");  // tuning experiments only
+        return e ? std::atoi(e) : 64;
+    }();
+    return C <= maxc;
+}
 
 }  // namespace vitsmi
