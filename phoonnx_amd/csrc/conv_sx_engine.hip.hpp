@@ -40,6 +40,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <utility>
 
 #include "conv_engine.hip.hpp"
