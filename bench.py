@@ -85,6 +85,9 @@ def main():
                     help="f32 (default, the headline metric): every fp32 product exact; bf16x3 / bf16: the declared "
                          "reduced-precision vocoder modes of BASELINE config 4 (reported with their dtype, never as "
                          "the headline number)")
+    ap.add_argument("--parts", type=int, default=2,
+                    help="render each batch as this many sub-batches on as many engine handles / HIP streams sharing "
+                         "one weight arena (PipelinedSession); 1 = a single handle")
     a = ap.parse_args()
     if a.gen_precision != "f32":
         os.environ["VITSMI_GEN_PRECISION"] = a.gen_precision
@@ -102,7 +105,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from phoonnx_amd import MiSession
+    from phoonnx_amd import PipelinedSession
     from phoonnx_amd.sharding import open_sharded
     from phoonnx_amd.synth import write_voice
 
@@ -120,7 +123,9 @@ def main():
     hop = sess.hparam("hop")
     sess_gen_sx = bool(sess.hparam("gen_sx"))
     gen_nprod = int(sess.hparam("gen_nprod"))
-    sess.set_seed(1234 + rank)
+    sess.set_seed(1234 + rank * 16)
+    pipe = PipelinedSession(sess, max(1, a.parts))  # extra handles borrow sess's weight arena
+    pipe.set_seed(1234 + rank * 16)
 
     B, T = a.batch, a.tokens
     scales = np.array([0.667, LENGTH_SCALE[a.preset], 0.8], np.float32)
@@ -130,8 +135,11 @@ def main():
     torch.cuda.synchronize()
 
     def step():
+        pipe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+        return int(pipe.last_y_lengths(B).sum()) * hop
+
+    def step_one():  # the whole batch on the first handle: per-kernel timing for the roofline block
         sess.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
-        return int(sess.last_y_lengths().sum()) * hop
 
     for _ in range(a.warmup):
         step()
@@ -169,7 +177,7 @@ def main():
         agg = {}
         n_t = max(3, min(a.steps, 5))
         for _ in range(n_t):
-            step()
+            step_one()
             st = sess.stats()
             fl += st["conv_flops"]
             by += st["conv_bytes"]
@@ -230,6 +238,7 @@ def main():
                                    f"batch={B}/GPU x {T} phoneme ids, scales=[0.667,{scales[1]:.2f},0.8], "
                                    f"device Philox noise, seeded synthetic weights",
                        "preset": a.preset, "batch_per_gpu": B, "tokens": T, "hop": hop,
+                       "pipeline_parts": len(pipe.parts),
                        "samples_per_step": samples_all / a.steps,
                        "frames_per_id": samples_all / a.steps / hop / (B * world * T),
                        "weights": "RCCL broadcast of packed arena" if world > 1 else "local"},
@@ -238,7 +247,7 @@ def main():
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = value / world / cpu["value"]
         print(json.dumps(line), flush=True)
-    sess.close()
+    pipe.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()

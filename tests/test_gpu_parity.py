@@ -348,6 +348,31 @@ def test_padded_batch_interior_equals_single(tmp_path):
     s.close()
 
 
+def test_pipelined_session_equals_plain_session():
+    # two handles / streams sharing one weight arena, each rendering half of the batch: same utterances, same audio
+    # (equal-length rows, so every part pads to the same frame count; zero noise scales make it deterministic)
+    from phoonnx_amd import PipelinedSession
+    s = _session("tiny_rb2_ms")
+    p = PipelinedSession(s, parts=2)
+    assert p.parts[1].arena_device() == s.arena_device() and p.parts[1].arena_bytes() == s.arena_bytes()
+    rng = np.random.default_rng(8)
+    B, T = 5, 40
+    ids = rng.integers(1, 200, (B, T)).astype(np.int64)
+    lens = np.full(B, T, np.int64)
+    sid = rng.integers(0, 4, B).astype(np.int64)
+    sc = np.array([0, 2.0, 0], np.float32)
+    plain = s.synthesize_batch(ids, lens, sc, sid)
+    piped = p.synthesize_batch(ids, lens, sc, sid)
+    assert np.array_equal(plain["y_lengths"], piped["y_lengths"])
+    hop = s.hparam("hop")
+    rf = 40
+    for b in range(B):
+        n = (int(plain["y_lengths"][b]) - rf) * hop  # the unmasked generator's tail depends on the padding after it
+        assert n > 0
+        np.testing.assert_allclose(piped["output"][b, 0, 0, :n], plain["output"][b, 0, 0, :n], atol=1e-5)
+    p.close()
+
+
 def test_vocoder_only_matches_oracle():
     from vits_oracle import VitsOracle
     for preset in ("tiny_rb1", "tiny_rb2_ms"):
