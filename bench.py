@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
 # split-exact engine: dense bf16 MFMA peak (256 CUs x 4096 FLOP/clk x 2.4 GHz = 2516.6 TFLOP/s) / 6 plane products
 SX_PEAK_TFLOPS = 2516.6 / 6
+# ... the same pipe (f16 MFMA has the bf16 rate) / 3 products of the default two-fp16-plane arithmetic
+SX_F16_PEAK_TFLOPS = 2516.6 / 3
 
 
 def pmc_traffic(preset, kernel_prefix):
@@ -81,16 +83,17 @@ def main():
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--gen-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
-                    help="f32 (default, the headline metric): every fp32 product exact; bf16x3 / bf16: the declared "
-                         "reduced-precision vocoder modes of BASELINE config 4 (reported with their dtype, never as "
-                         "the headline number)")
+    ap.add_argument("--gen-precision", default="f16x3", choices=["f16x3", "bf16x6", "bf16x3", "bf16"],
+                    help="arithmetic of the generator's convs (fp32 operands and results in every mode).  f16x3 (default): "
+                         "two fp16 planes per operand, three MFMA products per fp32 product, error no larger than the "
+                         "f32-MFMA engine's; bf16x6: three bf16 planes, six products, every product exact; bf16x3 / "
+                         "bf16: the declared reduced-precision vocoder modes of BASELINE config 4 (reported with their "
+                         "dtype, never as the headline number)")
     ap.add_argument("--parts", type=int, default=2,
                     help="render each batch as this many sub-batches on as many engine handles / HIP streams sharing "
                          "one weight arena (PipelinedSession); 1 = a single handle")
     a = ap.parse_args()
-    if a.gen_precision != "f32":
-        os.environ["VITSMI_GEN_PRECISION"] = a.gen_precision
+    os.environ["VITSMI_GEN_PRECISION"] = a.gen_precision
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -190,8 +193,12 @@ def main():
         if agg.get("sx_launches", 0) > 0:
             # dominant kernel: the generator's split-exact conv (six bf16 MFMA plane products per fp32 product)
             kfl, kms, kn = agg["sx_flops"], agg["sx_ms"], int(agg["sx_launches"])
-            kname = "conv_sx_kernel (implicit-GEMM Conv1d, fp32-exact via 3 bf16 planes, v_mfma_f32_32x32x16_bf16)"
-            peak = SX_PEAK_TFLOPS if gen_nprod == 6 else 2516.6 / gen_nprod  # (reduced modes: fewer plane products)
+            if gen_nprod == 2:
+                kname = "conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 2 fp16 planes, 3 x v_mfma_f32_32x32x16_f16 per product)"
+                peak = SX_F16_PEAK_TFLOPS
+            else:
+                kname = "conv_sx_kernel (implicit-GEMM Conv1d, fp32-exact via 3 bf16 planes, v_mfma_f32_32x32x16_bf16)"
+                peak = SX_PEAK_TFLOPS if gen_nprod == 6 else 2516.6 / gen_nprod  # (reduced modes: fewer plane products)
         else:
             kfl, kms, kn = fl, ms, launches
             kname = "conv_engine_kernel (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)"
@@ -228,11 +235,15 @@ def main():
             "metric": "audio samples/sec (22.05 kHz), batch-32 256-phoneme utterances",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if gen_nprod == 6 else f"f32 + {a.gen_precision} vocoder (reduced precision)",
+            "vs_baseline": None, "dtype": "f32" if gen_nprod in (6, 2) else f"f32 + {a.gen_precision} vocoder (reduced precision)",
             "data": "synthetic",
-            "dtype_note": ("fp32 operands and fp32 accumulation everywhere; the generator's convs evaluate each fp32 product "
-                           "exactly-to-2^-24 as six bf16 MFMA plane products (three bf16 planes per operand)"
-                           if sess_gen_sx else "fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU"),
+            "dtype_note": ("fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU" if not sess_gen_sx else
+                           "fp32 operands and fp32 accumulation everywhere; the generator's convs evaluate each fp32 product "
+                           "as three fp16 MFMA products of its operands' two fp16 planes (h0g0 + h0g1 + h1g0, dropped term "
+                           "<= 2^-24 relative; measured error vs float64 below the f32-MFMA engine's)" if gen_nprod == 2 else
+                           "fp32 operands and fp32 accumulation everywhere; the generator's convs evaluate each fp32 product "
+                           "exactly-to-2^-24 as six bf16 MFMA plane products (three bf16 planes per operand)"),
+            "gen_precision": a.gen_precision,
             "rtf": dt_max / (samples_all / world / 22050.0) if samples_all else None,
             "config": {"workload": f"VITS full pipeline (encoder+duration+flow+HiFi-GAN), preset={a.preset}, "
                                    f"batch={B}/GPU x {T} phoneme ids, scales=[0.667,{scales[1]:.2f},0.8], "

@@ -75,9 +75,12 @@ int vits_meta(vits_handle *h, const char *key, char *buf, size_t n);
 
 /* Derived hyper-parameters: "hidden","inter","filter","n_heads","n_layers","n_vocab",
  * "n_speakers","gin","use_sdp","hop" (= product of upsample rates),"n_ups","resblock",
- * "gen_sx" (1: the generator runs on the split-exact bf16 engine, 0: on the f32 engine),
- * "gen_nprod" (bf16 plane products per fp32 product in the generator: 6 = exact, the default; 3 / 1 with
- * VITSMI_GEN_PRECISION=bf16x3 / bf16 in the environment at open time: BASELINE config 4's "bf16 vocoder"). */
+ * "gen_sx" (1: the generator runs on the split-operand matrix-core engine, 0: on the f32-MFMA engine),
+ * "gen_nprod" (the generator's arithmetic, chosen by VITSMI_GEN_PRECISION in the environment at open time:
+ *   2 = "f16x3", the default: fp32 operands as two fp16 planes, three MFMA products per fp32 product, fp32
+ *       accumulation; error no larger than the f32-MFMA engine's,
+ *   6 = "bf16x6": three bf16 planes, six products, every fp32 product exact to 2^-24,
+ *   3 / 1 = "bf16x3" / "bf16": BASELINE config 4's reduced-precision "bf16 vocoder"). */
 int vits_hparam(vits_handle *h, const char *key, int64_t *out);
 
 /* ---- weight arena (multi-GPU: one rank reads + packs, RCCL broadcasts the bytes) ---- */

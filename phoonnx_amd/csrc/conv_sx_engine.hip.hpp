@@ -48,6 +48,8 @@
 namespace vitsmi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -77,6 +79,7 @@ struct SxArgs {
     int NT, MT, B;        // tiles along time / along rows, utterances   ( " )
     int flags;            // EPI_RES | EPI_ACC | EPI_DIV | DBG_*
     float div, oslope, oslope2;
+    float wscale;         // f16 mode: 1 / (power-of-two scale the packed weights carry), applied to the accumulators
     unsigned long long *prof;  // PROF instantiation only: cycle counters [lgkm wait, vm wait, barrier, DMA issue, loads+MFMA, steps]
 };
 
@@ -144,6 +147,30 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &w0, unsi
     w2 = cvt_pk_bf16(sx, sy);
 }
 
+// ---- f16 mode (NP = 2): an fp32 operand as TWO fp16 planes, round-to-nearest at each step:
+//     v ~ h0 + h1,   h0 = f16(v), h1 = f16(v - h0):   |v - h0 - h1| <= 2^-24 |v|  (11 + 11 bits and the sign of h1)
+// so a product needs only the three MFMAs h0g0 + h0g1 + h1g0 (the dropped h1g1 is <= 2^-24 |v||g|): the same
+// per-product error bound as one fp32 rounding, at half the matrix work of the six bf16 products.  fp16 has 5
+// exponent bits, so the planes are kept in range explicitly:
+//   weights      g = w * 2^k, k per tensor so that max |g| is in [2^14, 2^15); planes g0, g1 and a third one
+//                g0' = g0 * 2^-11 (exact); 2^-k is applied to the accumulators (SxArgs::wscale, exact)
+//   activations  h0 = f16(x) (clamped to +-65504), h1' = f16((x - h0) * 2^11): the low plane is stored 2^11 up, which
+//                keeps it a normal number wherever h0 is one, and meets g0' instead of g0 in its product:
+//                x*g ~ h0*g0 + h0*g1 + h1'*g0'
+// Activations therefore carry ~2^-23 relative error down to |x| = 2^-14 and an absolute floor of 2^-36 below that.
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ void split2h_pair(float x, float y, unsigned &w0, unsigned &w1) {
+    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
+    w0 = cvt_pk_f16(x, y);
+    const f16x2 h = __builtin_bit_cast(f16x2, w0);
+    w1 = cvt_pk_f16((x - (float)h[0]) * 2048.f, (y - (float)h[1]) * 2048.f);
+}
+__device__ __forceinline__ float f16_bits_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+
 // Epilogue description bits beyond EPI_RES / EPI_ACC / EPI_DIV (conv_engine.hip.hpp).  The first group is
 // derived from the arguments by launch_conv_sx; a kernel instantiated with EPI >= 0 has the whole description
 // as a compile-time constant (the common generator epilogues), EPI = -1 reads it at run time.
@@ -166,8 +193,11 @@ constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL 
 template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false, int NP = 6>
 __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     constexpr int BM = MW * WM * 32, BN = NW * WN * 32, MB = BM / 32;
-    static_assert(NP == 6 || NP == 3 || NP == 1, "plane products");
-    constexpr int NPL = NP == 6 ? 3 : (NP == 3 ? 2 : 1);  // planes read per operand
+    static_assert(NP == 6 || NP == 3 || NP == 1 || NP == 2, "plane products");
+    constexpr bool F16 = NP == 2;                          // two fp16 planes, three products
+    constexpr int NPROD = F16 ? 3 : NP;
+    constexpr int NPL = NP == 6 ? 3 : (NP == 1 ? 1 : 2);  // x planes read
+    constexpr int NPLA = F16 ? 3 : NPL;                    // weight planes read (f16: g0, g1, g0 * 2^-11)
     static_assert(WM * WN == 4, "four waves per workgroup");
     static_assert(MW <= 2, "load_a addresses two block rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_sx[];  // two x stages
@@ -203,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             const int row = (int)__umulhi((unsigned)i, a.magic);
             const int col = i - row * LW;
             const int t = t0 - a.padL + col;
-            const bool ok = row < 6 && t >= 0 && t < T;
+            const bool ok = row < 2 * NPL && t >= 0 && t < T;  // (rows of planes this mode does not read stay unloaded)
             const u32x4 *src = ok ? xb + ((row >> 1) * pstride + (int64_t)(2 * chunk + (row & 1)) * T + t)
                                   : reinterpret_cast<const u32x4 *>(a.zeros) + lane;
             lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + xoff + base * 16));
@@ -251,15 +281,20 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
                     u32x4 w0, w1, w2;
                     unsigned p0[4], p1[4], p2[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) split3_pair(v[2 * e], v[2 * e + 1], p0[e], p1[e], p2[e]);
+                    for (int e = 0; e < 4; e++) {
+                        if constexpr (F16) split2h_pair(v[2 * e], v[2 * e + 1], p0[e], p1[e]);
+                        else split3_pair(v[2 * e], v[2 * e + 1], p0[e], p1[e], p2[e]);
+                    }
                     w0 = u32x4{p0[0], p0[1], p0[2], p0[3]};
                     w1 = u32x4{p1[0], p1[1], p1[2], p1[3]};
-                    w2 = u32x4{p2[0], p2[1], p2[2], p2[3]};
                     const uint32_t ad = lds0 + xoff + (uint32_t)(kh * LW + col) * 16u;
                     const uint32_t pb = (uint32_t)(2 * LW) * 16u;
                     ds_write128(ad, w0);
-                    ds_write128(ad + pb, w1);
-                    ds_write128(ad + 2 * pb, w2);
+                    if constexpr (NPL > 1) ds_write128(ad + pb, w1);
+                    if constexpr (!F16 && NPL > 2) {
+                        w2 = u32x4{p2[0], p2[1], p2[2], p2[3]};
+                        ds_write128(ad + 2 * pb, w2);
+                    }
                 }
             }
         });
@@ -314,8 +349,8 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             constexpr int m = decltype(M)::value;
             const uint32_t vo = m == 0 ? voff0 : voff1;
             f.fa[m][0] = global_read128<0>(vo, sb);
-            if constexpr (NPL > 1) f.fa[m][1] = global_read128<1024>(vo, sb);
-            if constexpr (NPL > 2) f.fa[m][2] = global_read128<2048>(vo, sb);
+            if constexpr (NPLA > 1) f.fa[m][1] = global_read128<1024>(vo, sb);
+            if constexpr (NPLA > 2) f.fa[m][2] = global_read128<2048>(vo, sb);
         });
     };
     auto load_b_half = [&](auto H, int chunk, int tap) {
@@ -333,16 +368,23 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
         constexpr int h = decltype(H)::value;
         // plane pairs of combined order <= 2, smallest terms first; consecutive MFMAs hit different accumulators
         // (NP < 6 keeps the LAST NP pairs of the list: the three / one most significant products)
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        // (f16: g1*h0, g0'*h1', g0*h0)
+        constexpr int PA[6] = {2, 1, 0, 1, F16 ? 2 : 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int c = 6 - NP; c < 6; c++)
+        for (int c = 6 - NPROD; c < 6; c++)
 #pragma unroll
             for (int m = 0; m < MW; m++)
 #pragma unroll
-                for (int n = h * NH; n < (h + 1) * NH; n++)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.fa[m][PA[c]]),
-                                                                        __builtin_bit_cast(bf16x8, fb[n][PB[c]]),
-                                                                        acc[m][n], 0, 0, 0);
+                for (int n = h * NH; n < (h + 1) * NH; n++) {
+                    if constexpr (F16)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.fa[m][PA[c]]),
+                                                                           __builtin_bit_cast(f16x8, fb[n][PB[c]]),
+                                                                           acc[m][n], 0, 0, 0);
+                    else
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.fa[m][PA[c]]),
+                                                                            __builtin_bit_cast(bf16x8, fb[n][PB[c]]),
+                                                                            acc[m][n], 0, 0, 0);
+                }
     };
     // LDS reads return in order: "at most NH*3 outstanding" = the older half has landed
     auto wait_lds_older_half = [&]() {  // a half = NH * NPL reads
@@ -479,6 +521,7 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     const bool has_add = (flags & (EPI_RES | EPI_ACC)) != 0;
     const bool two_adds = (flags & EPI_RES) && (flags & EPI_ACC);
     const float oslope = a.oslope, oslope2 = a.oslope2, rdiv = a.div;
+    const float wsc = a.wscale;
     const int64_t plane_elems = (int64_t)CGo * Tout * 8;
     const float *biasp = a.bias ? a.bias : a.zeros;  // a missing bias reads the zero page (no branch per quad)
     const int b_on = a.bias ? 1 : 0;
@@ -521,7 +564,10 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
             for (int q = 0; q < 4; q++) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[m][n][4 * q + e] + bq[q][e];
+                for (int e = 0; e < 4; e++) {
+                    if constexpr (F16) v[e] = __builtin_fmaf(acc[m][n][4 * q + e], wsc, bq[q][e]);  // (power of two: exact)
+                    else v[e] = acc[m][n][4 * q + e] + bq[q][e];
+                }
                 if (has_add) v += ad[j][q];
                 if (two_adds) v += ad2[j][q];
                 if (flags & EPI_DIV) {
@@ -543,10 +589,15 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
                         for (int e = 0; e < 4; e++) o[e] = fmaxf(v[e], v[e] * oslope2);
                     }
                     unsigned wa[3], wb[3];
-                    split3_pair(o[0], o[1], wa[0], wa[1], wa[2]);
-                    split3_pair(o[2], o[3], wb[0], wb[1], wb[2]);
+                    if constexpr (F16) {
+                        split2h_pair(o[0], o[1], wa[0], wa[1]);
+                        split2h_pair(o[2], o[3], wb[0], wb[1]);
+                    } else {
+                        split3_pair(o[0], o[1], wa[0], wa[1], wa[2]);
+                        split3_pair(o[2], o[3], wb[0], wb[1], wb[2]);
+                    }
 #pragma unroll
-                    for (int pl = 0; pl < 3; pl++)
+                    for (int pl = 0; pl < (F16 ? 2 : 3); pl++)
                         *reinterpret_cast<u32x2 *>(plb + pl * plane_elems + cell[j][q]) = u32x2{wa[pl], wb[pl]};
                 }
             }
@@ -583,29 +634,29 @@ constexpr int kSxEpiFirst = EPI_RES | SX_HAS_RAW;                               
 constexpr int kSxEpiAccum = EPI_RES | EPI_ACC | SX_HAS_RAW;                          // xs += block output
 constexpr int kSxEpiRaw = SX_HAS_RAW;                                                // raw only (raw-format stages)
 
-template <int MW, int NW, int WM, int WN>
+template <int MW, int NW, int WM, int WN, int NP = 6>
 inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
-    if (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) return launch_conv_sx_k<MW, NW, WM, WN>(a, grid, lds, stream);
+    if (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, NP>(a, grid, lds, stream);
     switch (epi) {
-        case kSxEpiPlanes: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiPlanes>(a, grid, lds, stream);
-        case kSxEpiUp: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiUp>(a, grid, lds, stream);
-        case kSxEpiInner: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiInner>(a, grid, lds, stream);
-        case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst>(a, grid, lds, stream);
-        case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum>(a, grid, lds, stream);
-        case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw>(a, grid, lds, stream);  // flow WN convs
-        default: return launch_conv_sx_k<MW, NW, WM, WN>(a, grid, lds, stream);
+        case kSxEpiPlanes: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiPlanes, false, false, NP>(a, grid, lds, stream);
+        case kSxEpiUp: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiUp, false, false, NP>(a, grid, lds, stream);
+        case kSxEpiInner: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiInner, false, false, NP>(a, grid, lds, stream);
+        case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst, false, false, NP>(a, grid, lds, stream);
+        case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum, false, false, NP>(a, grid, lds, stream);
+        case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw, false, false, NP>(a, grid, lds, stream);  // flow WN convs
+        default: return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, NP>(a, grid, lds, stream);
     }
 }
 
 // raw-input kernels (tensors of <= 64 channels): outputs are raw only
-template <int MW, int NW, int WM, int WN>
+template <int MW, int NW, int WM, int WN, int NP = 6>
 inline hipError_t launch_conv_sx_rawin(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
-    if (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) return launch_conv_sx_k<MW, NW, WM, WN, -1, false, true>(a, grid, lds, stream);
+    if (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) return launch_conv_sx_k<MW, NW, WM, WN, -1, false, true, NP>(a, grid, lds, stream);
     switch (epi) {
-        case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw, false, true>(a, grid, lds, stream);
-        case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst, false, true>(a, grid, lds, stream);
-        case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum, false, true>(a, grid, lds, stream);
-        default: return launch_conv_sx_k<MW, NW, WM, WN, -1, false, true>(a, grid, lds, stream);
+        case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw, false, true, NP>(a, grid, lds, stream);
+        case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst, false, true, NP>(a, grid, lds, stream);
+        case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum, false, true, NP>(a, grid, lds, stream);
+        default: return launch_conv_sx_k<MW, NW, WM, WN, -1, false, true, NP>(a, grid, lds, stream);
     }
 }
 
@@ -623,7 +674,9 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     a.LW = BN + (a.K - 1) * a.dil;
     a.magic = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
     // an x stage is padded to whole DMA rounds (256 cells = 4 KiB), so that every wave issues the same count
-    a.x_bytes = (unsigned)(((size_t)6 * a.LW * 16 + 4095) / 4096 * 4096);
+    // (rows = 2 channel-group halves x the planes the mode reads: 3 bf16 planes, 2 in the fp16 / bf16x3 modes, 1 in bf16)
+    const int xrows = nprod == 6 ? 6 : (nprod == 1 ? 2 : 4);
+    a.x_bytes = (unsigned)(((size_t)xrows * a.LW * 16 + 4095) / 4096 * 4096);
     const size_t lds = 2 * (size_t)a.x_bytes;  // two x stages; the weights never touch LDS
     // (pack_conv_sx pads narrower kernels to 3 taps; model.cpp sx_supported() mirrors the size limits)
     if (lds > 160 * 1024 || a.x_bytes > 12 * 4096 || a.K < 3) return hipErrorInvalidValue;
@@ -648,6 +701,17 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     if ((epi & EPI_RES) && !a.res) return hipErrorInvalidValue;
     if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
     a.flags = (a.flags & ~kSxEpiMask) | epi;
+    if (nprod == 2) {  // two fp16 planes, three products (fp32-grade): the same specialised epilogues
+        if (a.wscale == 0.f) a.wscale = 1.f;
+        if (rawin)
+            return cfg == 1 ? launch_conv_sx_rawin<1, 4, 2, 2, 2>(a, epi, grid, lds, stream)
+                            : launch_conv_sx_rawin<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
+        switch (cfg) {
+            case 0: return launch_conv_sx_epi<2, 4, 2, 2, 2>(a, epi, grid, lds, stream);
+            case 1: return launch_conv_sx_epi<1, 4, 2, 2, 2>(a, epi, grid, lds, stream);
+            default: return launch_conv_sx_epi<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
+        }
+    }
     if (nprod != 6) {
         if (nprod != 3 && nprod != 1) return hipErrorInvalidValue;
         if (rawin)
@@ -673,8 +737,9 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
 // ---- layout conversion kernels ------------------------------------------------------------------------
 
 // planar fp32 x[b][c][t] (row pitch `pitch`, optionally masked by t < len[b]) -> planes [3][C/8][T][8]
+// (f16 != 0: two fp16 planes in the same addressing, plane 2 untouched)
 __global__ __launch_bounds__(256) void sx_split_planes_kernel(const float *x, int64_t x_bstride, int pitch, const int *len,
-                                                              uint16_t *out, int C, int T) {
+                                                              uint16_t *out, int C, int T, int f16 = 0) {
     const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
     if (t >= T) return;
     const bool live = !len || t < len[b];
@@ -683,12 +748,19 @@ __global__ __launch_bounds__(256) void sx_split_planes_kernel(const float *x, in
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const float v = live ? xb[(int64_t)e * pitch] : 0.f;
-        split3(v, p[0][e], p[1][e], p[2][e]);
+        if (f16) {
+            const float vc = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+            const _Float16 h0 = (_Float16)vc, h1 = (_Float16)((vc - (float)h0) * 2048.f);
+            p[0][e] = __builtin_bit_cast(unsigned short, h0);
+            p[1][e] = __builtin_bit_cast(unsigned short, h1);
+            p[2][e] = 0;
+        } else
+            split3(v, p[0][e], p[1][e], p[2][e]);
     }
     const int CG = C >> 3;
     uint16_t *ob = out + (int64_t)b * 3 * CG * T * 8;
 #pragma unroll
-    for (int pl = 0; pl < 3; pl++) {
+    for (int pl = 0; pl < (f16 ? 2 : 3); pl++) {
         u32x4 w;
         w.x = (unsigned)p[pl][0] | ((unsigned)p[pl][1] << 16);
         w.y = (unsigned)p[pl][2] | ((unsigned)p[pl][3] << 16);
@@ -711,7 +783,8 @@ __global__ __launch_bounds__(256) void sx_block_kernel(const float *x, int64_t x
 }
 
 // raw fp32 [C/8][T][8] (or, with planes != nullptr, the sum of the three planes) -> planar [C][T]
-__global__ __launch_bounds__(256) void sx_unblock_kernel(const float *raw, const uint16_t *planes, float *out, int C, int T) {
+__global__ __launch_bounds__(256) void sx_unblock_kernel(const float *raw, const uint16_t *planes, float *out, int C, int T,
+                                                         int f16 = 0) {
     const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
     if (t >= T) return;
     const int CG = C >> 3;
@@ -722,7 +795,8 @@ __global__ __launch_bounds__(256) void sx_unblock_kernel(const float *raw, const
             const uint16_t *pb = planes + (int64_t)b * 3 * CG * T * 8;
             const int64_t o = ((int64_t)cg * T + t) * 8 + e, ps = (int64_t)CG * T * 8;
             // same order as the exact reconstruction: small terms first
-            v = (bf16_bits_to_f32(pb[o + 2 * ps]) + bf16_bits_to_f32(pb[o + ps])) + bf16_bits_to_f32(pb[o]);
+            if (f16) v = f16_bits_to_f32(pb[o + ps]) * (1.f / 2048.f) + f16_bits_to_f32(pb[o]);
+            else v = (bf16_bits_to_f32(pb[o + 2 * ps]) + bf16_bits_to_f32(pb[o + ps])) + bf16_bits_to_f32(pb[o]);
         } else
             v = raw[(int64_t)b * C * T + ((int64_t)cg * T + t) * 8 + e];
         out[(int64_t)b * C * T + (int64_t)(cg * 8 + e) * T + t] = v;

@@ -210,6 +210,7 @@ void pick_tiling(int Cin, int Cout, int K, int dil, int padL, int hint, int &cfg
 }
 
 thread_local int t_hint = 0;  // size class of the layers being packed (set by Model::build)
+thread_local bool t_sx_f16 = false;  // pack_conv_sx: two scaled fp16 planes instead of three bf16 planes
 
 // W is addressed through a functor so that permutations / transposed-conv rewrites need no copies:
 // w(co, ci, tap) for co < Cout, ci < Cin, tap < K.
@@ -344,6 +345,23 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     const int64_t kib = int64_t(d.mblocks) * d.nchunks * K * 3;  // 1 KiB = one (block, plane) fragment set
     d.w_off = P.alloc(kib * 256);
     uint16_t *dst = reinterpret_cast<uint16_t *>(P.arena.data() + d.w_off);
+    float wmul = 1.f;
+    if (t_sx_f16) {
+        // per-tensor power of two that lifts the largest weight into [2^14, 2^15): both fp16 planes of every weight
+        // within 2^-18 of the largest are then normal numbers; undone exactly on the accumulators
+        float wmax = 0.f;
+        for (int co = 0; co < Cout; co++)
+            for (int ci = 0; ci < Cin; ci++)
+                for (int tap = 0; tap < Kreal; tap++) {
+                    const float a = std::fabs(w(co, ci, tap));
+                    if (std::isfinite(a) && a > wmax) wmax = a;
+                }
+        int e = 0;
+        if (wmax > 0.f) std::frexp(wmax, &e);  // wmax = m * 2^e, m in [0.5, 1)
+        wmul = std::ldexp(1.f, 15 - e);
+        d.f16 = true;
+        d.wscale = std::ldexp(1.f, e - 15);
+    }
     for (int mb = 0; mb < d.mblocks; mb++)
         for (int chunk = 0; chunk < d.nchunks; chunk++)
             for (int tap = 0; tap < K; tap++) {
@@ -351,7 +369,12 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
                 for (int lane = 0; lane < 64; lane++)
                     for (int i = 0; i < 8; i++) {
                         uint16_t p[3];
-                        split3_host(wz(mb * 32 + (lane & 31), chunk * 16 + 8 * (lane >> 5) + i, tap), p);
+                        const float wv = wz(mb * 32 + (lane & 31), chunk * 16 + 8 * (lane >> 5) + i, tap);
+                        if (t_sx_f16) {
+                            split2h_host(wv * wmul, p);
+                            p[2] = f16_rne(std::ldexp(f16_to_f32(p[0]), -11));  // meets the x planes' scaled low plane
+                        } else
+                            split3_host(wv, p);
                         for (int pl = 0; pl < 3; pl++) dst[(base + pl) * 512 + lane * 8 + i] = p[pl];
                     }
             }
@@ -474,6 +497,57 @@ void split3_host(float v, uint16_t p[3]) {
     p[2] = bf16_rne(r2);
 }
 
+uint16_t f16_rne(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint16_t sign = uint16_t((u >> 16) & 0x8000u);
+    u &= 0x7fffffffu;
+    if (u > 0x7f800000u) return uint16_t(sign | 0x7e00u);   // NaN
+    if (u >= 0x477ff000u) return uint16_t(sign | (u >= 0x7f800000u ? 0x7c00u : 0x7bffu));  // clamp to 65504 (inf stays inf)
+    if (u < 0x33000001u) return sign;                       // |f| <= 2^-25 rounds to zero
+    const int e = int(u >> 23) - 127;                       // unbiased exponent
+    uint32_t m = (u & 0x7fffffu) | 0x800000u;               // 24-bit significand
+    int shift;                                              // bits dropped from m
+    uint32_t base;
+    if (e >= -14) {
+        shift = 13;
+        base = uint32_t(e + 15) << 10;                      // (the hidden bit of m carries into the exponent field)
+        m &= 0x7fffffu;
+    } else {
+        shift = 13 + (-14 - e);                             // subnormal: value = m * 2^(e-23) in units of 2^-24
+        base = 0;
+    }
+    const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    uint32_t r = base + q;
+    if (rem > half || (rem == half && (q & 1u))) r++;       // round to nearest even (may carry into the exponent)
+    return uint16_t(sign | r);
+}
+
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = uint32_t(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 31;
+    const uint32_t m = h & 0x3ffu;
+    float v;
+    if (e == 0) v = std::ldexp(float(m), -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp(float(m | 0x400u), e - 25);
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    u |= sign;
+    std::memcpy(&v, &u, 4);
+    return v;
+}
+
+void split2h_host(float v, uint16_t p[3]) {
+    if (v > 65504.f) v = 65504.f;
+    if (v < -65504.f) v = -65504.f;
+    p[0] = f16_rne(v);
+    p[1] = f16_rne(v - f16_to_f32(p[0]));
+    p[2] = 0;
+}
+
+void set_sx_f16(bool on) { t_sx_f16 = on; }
+
 bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil) {
     if (Cin < 16 || Cin % 16 || Cout_virtual % 32 || Cr % 32 || K < 1 || dil < 1) return false;
     const int cfg = sx_pick_cfg(Cout_virtual);
@@ -532,6 +606,7 @@ std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout
 }
 
 std::string Model::build(const OnnxModel &om) {
+    t_sx_f16 = false;
     try {
         Resolver R;
         resolve(om, R);
@@ -661,9 +736,12 @@ std::string Model::build(const OnnxModel &om) {
                     const char *env = std::getenv("VITSMI_GEN_ENGINE");
                     const bool f32_only = env && std::string(env) == "f32";
                     const int ci = int(w->dims[1]), co = int(w->dims[0]);
-                    if (!f32_only && !sx_raw_format(ci) && co % 64 == 0 && ci % 8 == 0 && sx_supported(ci, co, co, k, dil))
+                    if (!f32_only && !sx_raw_format(ci) && co % 64 == 0 && ci % 8 == 0 && sx_supported(ci, co, co, k, dil)) {
+                        const char *pe = std::getenv("VITSMI_GEN_PRECISION");  // (same arithmetic as the generator)
+                        t_sx_f16 = !pe || !*pe || std::string(pe) == "f16x3";
                         cd.wn[i].in = pack_named_sx(P, R, in, dil, same_pad(k, dil));
-                    else
+                        t_sx_f16 = false;
+                    } else
                         cd.wn[i].in = pack_named(P, R, in, dil, same_pad(k, dil));
                     cd.wn[i].rs = pack_named(P, R, s + ".enc.res_skip_layers." + std::to_string(i), 1, 0);
                     cd.n_wn = i + 1;
@@ -712,7 +790,12 @@ std::string Model::build(const OnnxModel &om) {
                     ok = conv_ok(c1) && (!t1 || conv_ok(rb + ".convs2." + std::to_string(q)));
                 }
             gen_sx = ok;
+            // default: the generator's convs on two fp16 planes / three products per fp32 product (fp32-grade error);
+            // VITSMI_GEN_PRECISION=bf16x6 (exact products, six bf16 plane products), bf16x3 or bf16 pack bf16 planes
+            const char *pe = std::getenv("VITSMI_GEN_PRECISION");
+            gen_f16 = gen_sx && (!pe || !*pe || std::string(pe) == "f16x3");
         }
+        t_sx_f16 = gen_f16;
         auto gconv = [&](const std::string &name, int dil, int padL) {
             return gen_sx ? pack_named_sx(P, R, name, dil, padL) : pack_named(P, R, name, dil, padL);
         };
@@ -753,6 +836,7 @@ std::string Model::build(const OnnxModel &om) {
             }
             ups.push_back(st);
         }
+        t_sx_f16 = false;
         const TRef &pw = R.req("dec.conv_post.weight");
         if (pw.dims[0] != 1) throw std::runtime_error("conv_post must have one output channel");
         if (R.get("dec.conv_post.bias")) throw std::runtime_error("conv_post with bias is unsupported");

@@ -32,6 +32,10 @@ struct ConvDesc {
     // sx only: the input tensor is in the fp32 raw layout and is split into planes inside the kernel (tensors of
     // <= 64 channels, see sx_raw_format); such convs use the 64- or 32-row tiles
     bool rawin = false;
+    // sx only: weights are fp16 planes of g = w * 2^k (k per tensor: max |g| in [2^14, 2^15)) in the same slots:
+    // g0, g1 and g0 * 2^-11; wscale = 2^-k is applied to the accumulators (conv_sx_engine.hip.hpp, f16 mode)
+    bool f16 = false;
+    float wscale = 1.f;
     double macs_per_t = 0;   // algorithmic MACs per input time step (reference definition)
     bool valid() const { return w_off >= 0; }
 };
@@ -118,6 +122,7 @@ struct Model {
     // ---- generator
     ConvDesc conv_pre;
     int C0 = 0;
+    bool gen_f16 = false; // ... in its fp16 two-plane mode (VITSMI_GEN_PRECISION=f16x3)
     bool gen_sx = false;  // generator packed for the split-exact bf16 engine (all channel counts % 32 == 0)
     std::vector<UpStageDesc> ups;
     int64_t post_w = -1;  // [Cin, K] conv_post weight (Cout = 1, no bias)
@@ -146,6 +151,11 @@ std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout
 uint16_t bf16_rne(float f);
 float bf16_to_f32(uint16_t h);
 void split3_host(float v, uint16_t p[3]);
+// ... and of the f16 mode: fp16 round-to-nearest-even (clamped to +-65504), two planes (p[2] = 0)
+uint16_t f16_rne(float f);
+float f16_to_f32(uint16_t h);
+void split2h_host(float v, uint16_t p[3]);
+void set_sx_f16(bool on);  // pack_conv_sx format for the calls that follow on this thread (test hooks)
 // may this conv shape run on the sx engine (channel multiples, LDS budget)?
 bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil);
 // Storage format of a generator tensor with C channels on the sx path: true = fp32 raw only (its consumers

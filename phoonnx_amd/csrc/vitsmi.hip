@@ -70,7 +70,8 @@ struct vits_handle {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int cur_stage = 0;  // 0 enc, 1 dp, 2 flow, 3 dec
     uint64_t run_counter = 0;
-    int gen_nprod = 6;  // bf16 plane products per fp32 product in the generator: 6 exact, 3 / 1 reduced (VITSMI_GEN_PRECISION)
+    int gen_nprod = 2;  // generator arithmetic (VITSMI_GEN_PRECISION): 2 = two fp16 planes / three products (default), 6 = six
+                        // exact bf16 plane products, 3 / 1 = the reduced-precision bf16 modes
 };
 
 namespace {
@@ -245,9 +246,10 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.div = div;
     a.oslope = oslope;
     a.oslope2 = oslope2;
+    a.wscale = d.wscale;
     vits_handle *h = c.h;
     const bool ev = conv_event_begin(c);
-    c.note(launch_conv_sx(a, d.cfg, c.B, c.st, d.rawin, h->cur_stage == 3 ? h->gen_nprod : 6));
+    c.note(launch_conv_sx(a, d.cfg, c.B, c.st, d.rawin, d.f16 ? 2 : (h->cur_stage == 3 ? h->gen_nprod : 6)));
     if (ev) {
         if (h->conv_event_sx.size() < h->conv_events.size()) h->conv_event_sx.resize(h->conv_events.size(), 0);
         h->conv_event_sx[h->conv_events_used] = 1;
@@ -526,7 +528,8 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
         sx_block_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_raw, m.C, F);
         zin = tmp_raw;
     } else {
-        sx_split_planes_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_pl, m.C, F);
+        sx_split_planes_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_pl, m.C, F,
+                                                                                  m.gen_f16 ? 1 : 0);
         zin = tmp_pl;
     }
     c.note(hipGetLastError());
@@ -769,7 +772,8 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
             // x_in = in_layer(h) + g_l ; acts = tanh * sigmoid ; rs = res_skip(acts)
             if (cd.wn[i].in.sx) {
                 // split-exact engine: hx -> three bf16 planes, conv to the raw cell layout, gate reads that layout
-                sx_split_planes_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(hx, sHF, F, nullptr, hx_pl, Hf, F);
+                sx_split_planes_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(hx, sHF, F, nullptr, hx_pl, Hf, F,
+                                                                                         cd.wn[i].in.f16 ? 1 : 0);
                 h->stats.total_launches++;
                 conv_sx(c, cd.wn[i].in, hx_pl, F, a2, nullptr, 0, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr, gc_rows);
                 wn_gate_blocked_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(a2, acts, Hf, F);
@@ -822,15 +826,20 @@ static int open_common(const char *path, vits_handle **out, bool host_only, int 
     }
     h->host_only = host_only;
     {
-        // Declared reduced-precision vocoder modes (BASELINE config 4, "bf16 vocoder"); the default computes every
-        // fp32 product exactly.  They apply to the generator's convs only and need the split-exact engine.
+        // Arithmetic of the generator's convs on the split-exact engine (fp32 operands and results in every mode):
+        //   f16x3  (default) two fp16 planes per operand, three MFMA products: each product within ~3 * 2^-24
+        //   bf16x6 three bf16 planes, six products: each product exact to 2^-24
+        //   bf16x3 / bf16: the declared reduced-precision vocoder modes (BASELINE config 4, "bf16 vocoder")
+        // gen_nprod: 2 = f16x3 (Model::build packed the weights for it), else the number of bf16 plane products.
         const char *pe = std::getenv("VITSMI_GEN_PRECISION");
         const std::string ps = pe ? pe : "";
-        if (ps == "bf16x3") h->gen_nprod = 3;
+        if (ps.empty() || ps == "f16x3") h->gen_nprod = 2;
+        else if (ps == "bf16x6") h->gen_nprod = 6;
+        else if (ps == "bf16x3") h->gen_nprod = 3;
         else if (ps == "bf16") h->gen_nprod = 1;
-        else if (!ps.empty() && ps != "f32") {
+        else {
             delete h;
-            return fail(nullptr, VITS_E_ARG, "VITSMI_GEN_PRECISION must be f32, bf16x3 or bf16 (got '%s')", pe);
+            return fail(nullptr, VITS_E_ARG, "VITSMI_GEN_PRECISION must be f16x3, bf16x6, bf16x3 or bf16 (got '%s')", pe);
         }
         if (!h->model.gen_sx) h->gen_nprod = 6;
     }
@@ -1405,7 +1414,8 @@ static int run_test_conv_sx(const ConvDesc &d, const std::vector<float> &arena, 
     TCHECK(hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice));
     TCHECK(hipMemset(draw, 0, no * 4));
     TCHECK(hipMemset(dop, 0, no * 6));
-    sx_split_planes_kernel<<<dim3((T + 255) / 256, d.Cin / 8, B), 256>>>(dx, (int64_t)d.Cin * T, T, nullptr, dxp, d.Cin, T);
+    sx_split_planes_kernel<<<dim3((T + 255) / 256, d.Cin / 8, B), 256>>>(dx, (int64_t)d.Cin * T, T, nullptr, dxp, d.Cin, T,
+                                                                         d.f16 ? 1 : 0);
     TCHECK(hipMalloc((void **)&dres, nx * 4 + 16));  // x in the raw layout: raw-input operand and residual
     sx_block_kernel<<<dim3((T + 255) / 256, d.Cin / 8, B), 256>>>(dx, (int64_t)d.Cin * T, T, nullptr, dres, d.Cin, T);
     SxArgs a{};
@@ -1422,9 +1432,10 @@ static int run_test_conv_sx(const ConvDesc &d, const std::vector<float> &arena, 
         a.res = dres;
         a.flags |= EPI_RES;
     }
-    const int nprod = ((flags >> 4) & 3) == 1 ? 3 : (((flags >> 4) & 3) == 2 ? 1 : 6);
+    const int nprod = d.f16 ? 2 : (((flags >> 4) & 3) == 1 ? 3 : (((flags >> 4) & 3) == 2 ? 1 : 6));
+    a.wscale = d.wscale;
     TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, nprod));
-    sx_unblock_kernel<<<dim3((To + 255) / 256, Cr / 8, B), 256>>>(draw, (flags & 1) ? dop : nullptr, dout, Cr, To);
+    sx_unblock_kernel<<<dim3((To + 255) / 256, Cr / 8, B), 256>>>(draw, (flags & 1) ? dop : nullptr, dout, Cr, To, d.f16 ? 1 : 0);
     TCHECK(hipGetLastError());
     TCHECK(hipDeviceSynchronize());
     TCHECK(hipMemcpy(out, dout, no * 4, hipMemcpyDeviceToHost));
@@ -1438,7 +1449,9 @@ int vits_test_conv1d_sx(int device_id, const float *x, int B, int Cin, int T, co
     if (int rc = test_dev(device_id)) return rc;
     ConvDesc d;
     std::vector<float> arena;
+    set_sx_f16(((flags >> 4) & 3) == 3);  // precision code 3: two fp16 planes
     std::string e = pack_test_conv(w, bias, Cin, Cout, K, dil, pad_l, 3, &d, &arena);
+    set_sx_f16(false);
     if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
     return run_test_conv_sx(d, arena, x, B, T, flags, slope, out);
 }
@@ -1448,7 +1461,11 @@ int vits_test_conv_transpose1d_sx(int device_id, const float *x, int B, int Cin,
     if (int rc = test_dev(device_id)) return rc;
     ConvDesc d;
     std::vector<float> arena;
+    const bool f16 = stride < 0;  // (test hook convention: negative stride = the fp16 two-plane mode)
+    if (f16) stride = -stride;
+    set_sx_f16(f16);
     std::string e = pack_test_convT(w, bias, Cin, Cout, K, stride, &d, &arena, true);
+    set_sx_f16(false);
     if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
     return run_test_conv_sx(d, arena, x, B, T, 0, 0.f, out);
 }
@@ -1466,7 +1483,9 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
     for (auto &v : x) v = rnd();
     ConvDesc d;
     std::vector<float> arena;
+    set_sx_f16((dbg & 128) != 0);
     std::string e = pack_test_conv(w.data(), nullptr, Cin, Cout, K, dil, dil * (K - 1) / 2, 3, &d, &arena);
+    set_sx_f16(false);
     if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
     float *dA = nullptr, *dx = nullptr, *draw = nullptr, *dres = nullptr;
     uint16_t *dxp = nullptr, *dop = nullptr;
@@ -1480,9 +1499,10 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
     TCHECK(hipMemcpy(dA, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
     TCHECK(hipMemcpy(dx, x.data(), nx * 4, hipMemcpyHostToDevice));
     TCHECK(hipMemset(dres, 0, no * 4));
-    sx_split_planes_kernel<<<dim3((T + 255) / 256, Cin / 8, B), 256>>>(dx, (int64_t)Cin * T, T, nullptr, dxp, Cin, T);
+    sx_split_planes_kernel<<<dim3((T + 255) / 256, Cin / 8, B), 256>>>(dx, (int64_t)Cin * T, T, nullptr, dxp, Cin, T, d.f16 ? 1 : 0);
     SxArgs a{};
     fill_sx_args(a, d, dA, T);
+    a.wscale = d.wscale;
     a.xp = reinterpret_cast<const u32x4 *>(dxp);
     a.out_pl = dop;  // as the generator's inner convs: planes out
     a.oslope2 = 0.1f;
@@ -1507,11 +1527,11 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, (dbg & 32) ? 3 : ((dbg & 64) ? 1 : 6)));
+    for (int i = 0; i < 2; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, d.f16 ? 2 : ((dbg & 32) ? 3 : ((dbg & 64) ? 1 : 6))));
     TCHECK(hipDeviceSynchronize());
     if (dprof) TCHECK(hipMemset(dprof, 0, 64));
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, (dbg & 32) ? 3 : ((dbg & 64) ? 1 : 6)));
+    for (int i = 0; i < iters; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, d.f16 ? 2 : ((dbg & 32) ? 3 : ((dbg & 64) ? 1 : 6))));
     hipEventRecord(e1, nullptr);
     TCHECK(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -408,9 +408,10 @@ def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=
     Cout, _, K = w.shape
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     out = np.empty((B, Cout, T), np.float32)
-    # precision: "f32" = six exact plane products; "bf16x3" / "bf16" = the declared reduced-precision vocoder modes
+    # precision: "f32" = six exact bf16 plane products; "f16x3" = two fp16 planes, three products (fp32-grade);
+    # "bf16x3" / "bf16" = the declared reduced-precision vocoder modes
     flags = (1 if planes_slope is not None else 0) | (4 if residual else 0) | (8 if in_slope is not None else 0)
-    flags |= {"f32": 0, "bf16x3": 1, "bf16": 2}[precision] << 4
+    flags |= {"f32": 0, "bf16x3": 1, "bf16": 2, "f16x3": 3}[precision] << 4
     if in_slope is not None and planes_slope is not None and in_slope != planes_slope:
         raise ValueError("the hook takes one slope value")
     if in_slope is not None and Cin > 64:
@@ -445,8 +446,9 @@ def test_conv_transpose1d(x, w, bias, stride, device_id=0, sx=False):
     b = None if bias is None else np.ascontiguousarray(bias, np.float32)
     out = np.empty((B, Cout, T * stride), np.float32)
     fn = lib.vits_test_conv_transpose1d_sx if sx else lib.vits_test_conv_transpose1d
-    rc = fn(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, stride,
-                                        _ffi.ptr(out))
+    # sx="f16": the split-exact engine in its fp16 two-plane mode (the hook takes it as a negative stride)
+    rc = fn(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, -stride if sx == "f16" else stride,
+            _ffi.ptr(out))
     if rc != 0:
         raise SessionError(_ffi.last_error(None))
     return out

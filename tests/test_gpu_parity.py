@@ -189,6 +189,81 @@ def test_conv_sx_reduced_precision_modes_have_their_declared_error():
     assert 2e-4 < err["bf16"] < 5e-2, err       # measured 1.0e-2
 
 
+@pytest.mark.parametrize("B,Cin,Cout,T,K,dil", SX_CASES)
+def test_conv_sx_f16_mode_matches_oracle(B, Cin, Cout, T, K, dil):
+    # the engine's fp16 two-plane mode (three products per fp32 product, scaled weights): every epilogue / input path
+    from phoonnx_amd.session import test_conv1d_sx
+    from vits_oracle import conv1d
+    rng = np.random.default_rng(B * 1000 + Cin + Cout + T + 1)
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    pad = dil * (K - 1) // 2
+    ref = conv1d(x, w, b, dil=dil, pad_l=pad, pad_r=dil * (K - 1) - pad)
+    kw = dict(dil=dil, pad_l=pad, precision="f16x3")
+    np.testing.assert_allclose(test_conv1d_sx(x, w, b, **kw), ref, atol=2e-5, rtol=1e-5)
+    got = test_conv1d_sx(x, w, b, planes_slope=0.1, **kw)                   # read back from the two fp16 planes
+    np.testing.assert_allclose(got, np.where(ref > 0, ref, ref * np.float32(0.1)), atol=2e-5, rtol=1e-5)
+    if Cin == Cout:
+        np.testing.assert_allclose(test_conv1d_sx(x, w, b, residual=True, **kw), ref + x, atol=2e-5, rtol=1e-5)
+    if Cin <= 64:
+        xa = np.where(x > 0, x, x * np.float32(0.1)).astype(np.float32)
+        ref = conv1d(xa, w, b, dil=dil, pad_l=pad, pad_r=dil * (K - 1) - pad)
+        got = test_conv1d_sx(x, w, b, in_slope=0.1, residual=Cin == Cout, **kw)
+        np.testing.assert_allclose(got, ref + (x if Cin == Cout else 0), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("xscale,wscale", [(1.0, 1.0), (0.05, 1.0), (30.0, 1e-3), (1.0, 40.0), (3e-3, 1.0), (1e-4, 1e-2),
+                                           (1e-6, 1.0)])
+def test_conv_sx_f16_mode_error_is_fp32_grade(xscale, wscale):
+    # against float64, next to the f32-MFMA engine on the same data.  Weights carry a per-tensor power-of-two scale,
+    # so their magnitude must not matter; activations are stored unscaled, their low plane 2^11 up: full precision
+    # down to |x| = 2^-14, an absolute floor of 2^-36 below.
+    from phoonnx_amd.session import test_conv1d, test_conv1d_sx
+    rng = np.random.default_rng(31)
+    B, C, T, K, dil = 1, 128, 640, 7, 3
+    x = (rng.standard_normal((B, C, T)) * xscale).astype(np.float32)
+    w = (rng.standard_normal((C, C, K)) / np.sqrt(C * K) * wscale).astype(np.float32)
+    pad = dil * (K - 1) // 2
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (pad, pad)))
+    ref = sum(np.einsum("oc,bct->bot", w[:, :, k].astype(np.float64), xp[:, :, k * dil:k * dil + T]) for k in range(K))
+    rms = float(np.sqrt((ref ** 2).mean()))
+    e_h = float(np.abs(test_conv1d_sx(x, w, dil=dil, pad_l=pad, precision="f16x3") - ref).max()) / rms
+    e_f32 = float(np.abs(test_conv1d(x, w, dil=dil, pad_l=pad) - ref).max()) / rms
+    e_b3 = float(np.abs(test_conv1d_sx(x, w, dil=dil, pad_l=pad, precision="bf16x3") - ref).max()) / rms
+    print(f"xscale {xscale} wscale {wscale}: f16x3 {e_h:.3g}  f32 engine {e_f32:.3g}  bf16x3 {e_b3:.3g} (max err / output rms)")
+    floor = 2.0 ** -36 / xscale * 30          # the activations' absolute resolution, relative to their magnitude
+    assert e_h <= 1.5 * e_f32 + floor, (e_h, e_f32)
+    if xscale >= 1e-4:
+        assert e_h < e_b3 / 2
+
+
+def test_conv_sx_f16_mode_saturates_instead_of_overflowing():
+    from phoonnx_amd.session import test_conv1d_sx
+    C, T = 32, 64
+    w = np.zeros((C, C, 1), np.float32)
+    w[np.arange(C), np.arange(C), 0] = 1
+    x = np.full((1, C, T), 3.0e5, np.float32)
+    x[0, :, ::2] = -1.0e6
+    x[0, 0, :] = 1234.5678
+    got = test_conv1d_sx(x, w, precision="f16x3")
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got[0, 0], x[0, 0], rtol=3e-7)
+    assert np.array_equal(got[0, 1:], np.clip(x[0, 1:], -65504, 65504))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,u", [(2, 32, 32, 50, 16, 8), (2, 128, 64, 129, 4, 2)])
+def test_conv_transpose_sx_f16_mode_matches_oracle(B, Cin, Cout, T, K, u):
+    from phoonnx_amd.session import test_conv_transpose1d
+    from vits_oracle import conv_transpose1d
+    rng = np.random.default_rng(K * 100 + u + 1)
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, K)) / np.sqrt(Cin * K / u)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    got = test_conv_transpose1d(x, w, b, u, sx="f16")
+    np.testing.assert_allclose(got, conv_transpose1d(x, w, b, u, (K - u) // 2), atol=2e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("B,Cin,Cout,T,K,u", [(2, 32, 32, 50, 16, 8), (1, 64, 32, 37, 8, 4), (2, 128, 64, 129, 4, 2),
                                               (1, 512, 256, 9, 16, 8)])
 def test_conv_transpose_sx_matches_oracle(B, Cin, Cout, T, K, u):
