@@ -16,7 +16,7 @@
 //   planes  bf16 [3][C/8][T][8]   conv inputs; one 16-byte cell = 8 channels of one time step, which is
 //                                 exactly one lane's B operand (8 k-values) of the MFMA
 //   raw     fp32 [C/8][T][8]      residual stream (same cell structure, 32-byte cells)
-//   weights bf16 [m-tile][chunk of 16 ci][tap][32-row block][plane][lane][8]  (model.cpp pack_conv_sx):
+//   weights bf16 [m-tile][chunk of 16 ci][tap][32-row block][plane][lane][8]  (model.cpp pack_conv_sx; fp16 mode: 2 planes):
 //                                 MFMA A-operand lane order, one 1 KiB wave-load per (block row, plane)
 // Tensors of <= 64 channels are HBM-bound layers: they are kept as raw only and the consuming conv (RAWIN
 // instantiation) applies the leaky-ReLU and the split while it loads its tile.
@@ -152,8 +152,8 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &w0, unsi
 // so a product needs only the three MFMAs h0g0 + h0g1 + h1g0 (the dropped h1g1 is <= 2^-24 |v||g|): the same
 // per-product error bound as one fp32 rounding, at half the matrix work of the six bf16 products.  fp16 has 5
 // exponent bits, so the planes are kept in range explicitly:
-//   weights      g = w * 2^k, k per tensor so that max |g| is in [2^14, 2^15); planes g0, g1 and a third one
-//                g0' = g0 * 2^-11 (exact); 2^-k is applied to the accumulators (SxArgs::wscale, exact)
+//   weights      g = w * 2^k, k per tensor so that max |g| is in [2^14, 2^15); planes g0, g1 (packed two per block
+//                row) and g0' = g0 * 2^-11, made in registers; 2^-k is applied to the accumulators (SxArgs::wscale)
 //   activations  h0 = f16(x) (clamped to +-65504), h1' = f16((x - h0) * 2^11): the low plane is stored 2^11 up, which
 //                keeps it a normal number wherever h0 is one, and meets g0' instead of g0 in its product:
 //                x*g ~ h0*g0 + h0*g1 + h1'*g0'
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     constexpr bool F16 = NP == 2;                          // two fp16 planes, three products
     constexpr int NPROD = F16 ? 3 : NP;
     constexpr int NPL = NP == 6 ? 3 : (NP == 1 ? 1 : 2);  // x planes read
-    constexpr int NPLA = F16 ? 3 : NPL;                    // weight planes read (f16: g0, g1, g0 * 2^-11)
+    constexpr int NPLA = NPL;                              // weight planes read (f16: g0, g1; g0 * 2^-11 is made here)
+    constexpr int NPW = F16 ? 2 : 3;                       // weight planes packed per 32-row block
     static_assert(WM * WN == 4, "four waves per workgroup");
     static_assert(MW <= 2, "load_a addresses two block rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_sx[];  // two x stages
@@ -219,10 +220,10 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     const uint32_t XB = a.x_bytes;
     const u32x4 *xb = a.xp + (int64_t)b * a.x_bstride;
     const int64_t pstride = (int64_t)CG * T;  // cells per plane
-    constexpr int STEPBYTES = MB * 3 * 1024;   // packed weights of one step (one tap of one 16-channel chunk)
+    constexpr int STEPBYTES = MB * NPW * 1024;  // packed weights of one step (one tap of one 16-channel chunk)
     // this wave's A rows of step 0 (uniform address: lives in SGPRs)
     const char *wbase = reinterpret_cast<const char *>(a.wp) + (int64_t)mt * a.nchunks * K * STEPBYTES +
-                        wm * (MW * 3 * 1024);
+                        wm * (MW * NPW * 1024);
     const int nit = a.x_bytes >> 12;           // DMA rounds of 256 cells per x tile (the stage is padded to 4 KiB)
 
     // x tile of one chunk -> LDS: rows (plane, channel-group half) x LW cells; every wave issues `nit` DMAs
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     u32x4 fb[NW][3];
     const uint32_t b_lane = lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u;
     const uint32_t plane_b = (uint32_t)(2 * LW) * 16u;
-    const uint32_t voff0 = (uint32_t)lane * 16u, voff1 = voff0 + 3072u;  // second block row: + 3 KiB (13-bit imm)
+    const uint32_t voff0 = (uint32_t)lane * 16u, voff1 = voff0 + NPW * 1024u;  // second block row (13-bit imm offsets)
 
     // A fragments: straight from the packed weights (L2-resident) into registers, one 1 KiB wave-load per
     // (block row, plane); asynchronous like the ds_reads: the consumer waits on vmcnt itself.
@@ -369,17 +370,21 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
         // plane pairs of combined order <= 2, smallest terms first; consecutive MFMAs hit different accumulators
         // (NP < 6 keeps the LAST NP pairs of the list: the three / one most significant products)
         // (f16: g1*h0, g0'*h1', g0*h0)
-        constexpr int PA[6] = {2, 1, 0, 1, F16 ? 2 : 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
         for (int c = 6 - NPROD; c < 6; c++)
 #pragma unroll
             for (int m = 0; m < MW; m++)
 #pragma unroll
                 for (int n = h * NH; n < (h + 1) * NH; n++) {
-                    if constexpr (F16)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.fa[m][PA[c]]),
-                                                                           __builtin_bit_cast(f16x8, fb[n][PB[c]]),
+                    if constexpr (F16) {
+                        // g0' = g0 * 2^-11 (exact, or the correctly rounded subnormal): four packed multiplies per
+                        // fragment instead of a third weight plane
+                        const f16x8 ga = c == 4 ? __builtin_bit_cast(f16x8, f.fa[m][0]) * (_Float16)0.00048828125f
+                                                : __builtin_bit_cast(f16x8, f.fa[m][PA[c]]);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga, __builtin_bit_cast(f16x8, fb[n][PB[c]]),
                                                                            acc[m][n], 0, 0, 0);
+                    }
                     else
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.fa[m][PA[c]]),
                                                                             __builtin_bit_cast(bf16x8, fb[n][PB[c]]),
@@ -706,6 +711,7 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
         if (rawin)
             return cfg == 1 ? launch_conv_sx_rawin<1, 4, 2, 2, 2>(a, epi, grid, lds, stream)
                             : launch_conv_sx_rawin<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
+        if (a.prof && cfg == 0) return launch_conv_sx_k<2, 4, 2, 2, -1, true, false, 2>(a, grid, lds, stream);
         switch (cfg) {
             case 0: return launch_conv_sx_epi<2, 4, 2, 2, 2>(a, epi, grid, lds, stream);
             case 1: return launch_conv_sx_epi<1, 4, 2, 2, 2>(a, epi, grid, lds, stream);

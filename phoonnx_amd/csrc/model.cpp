@@ -342,7 +342,8 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     if (d.rawin && d.cfg == 0) d.cfg = 1;  // the raw-input path exists for the 64- and 32-row tiles only
     d.mblocks = Cout / 32;
     const int MB = sx_tile_m(d.cfg) / 32;
-    const int64_t kib = int64_t(d.mblocks) * d.nchunks * K * 3;  // 1 KiB = one (block, plane) fragment set
+    const int npw = t_sx_f16 ? 2 : 3;                              // planes per 32-row block
+    const int64_t kib = int64_t(d.mblocks) * d.nchunks * K * npw;  // 1 KiB = one (block, plane) fragment set
     d.w_off = P.alloc(kib * 256);
     uint16_t *dst = reinterpret_cast<uint16_t *>(P.arena.data() + d.w_off);
     float wmul = 1.f;
@@ -365,17 +366,14 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     for (int mb = 0; mb < d.mblocks; mb++)
         for (int chunk = 0; chunk < d.nchunks; chunk++)
             for (int tap = 0; tap < K; tap++) {
-                const int64_t base = ((((int64_t)(mb / MB) * d.nchunks + chunk) * K + tap) * MB + (mb % MB)) * 3;
+                const int64_t base = ((((int64_t)(mb / MB) * d.nchunks + chunk) * K + tap) * MB + (mb % MB)) * npw;
                 for (int lane = 0; lane < 64; lane++)
                     for (int i = 0; i < 8; i++) {
                         uint16_t p[3];
                         const float wv = wz(mb * 32 + (lane & 31), chunk * 16 + 8 * (lane >> 5) + i, tap);
-                        if (t_sx_f16) {
-                            split2h_host(wv * wmul, p);
-                            p[2] = f16_rne(std::ldexp(f16_to_f32(p[0]), -11));  // meets the x planes' scaled low plane
-                        } else
-                            split3_host(wv, p);
-                        for (int pl = 0; pl < 3; pl++) dst[(base + pl) * 512 + lane * 8 + i] = p[pl];
+                        if (t_sx_f16) split2h_host(wv * wmul, p);
+                        else split3_host(wv, p);
+                        for (int pl = 0; pl < npw; pl++) dst[(base + pl) * 512 + lane * 8 + i] = p[pl];
                     }
             }
     if (bias_virtual) d.b_off = P.put(bias_virtual, Cout);

@@ -32,8 +32,8 @@ struct ConvDesc {
     // sx only: the input tensor is in the fp32 raw layout and is split into planes inside the kernel (tensors of
     // <= 64 channels, see sx_raw_format); such convs use the 64- or 32-row tiles
     bool rawin = false;
-    // sx only: weights are fp16 planes of g = w * 2^k (k per tensor: max |g| in [2^14, 2^15)) in the same slots:
-    // g0, g1 and g0 * 2^-11; wscale = 2^-k is applied to the accumulators (conv_sx_engine.hip.hpp, f16 mode)
+    // sx only: weights are TWO fp16 planes (per 32-row block) of g = w * 2^k, k per tensor: max |g| in [2^14, 2^15);
+    // wscale = 2^-k is applied to the accumulators (conv_sx_engine.hip.hpp, f16 mode)
     bool f16 = false;
     float wscale = 1.f;
     double macs_per_t = 0;   // algorithmic MACs per input time step (reference definition)

@@ -34,7 +34,8 @@ def main():
     ap.add_argument("--sweep", action="store_true", help="try every tile config / chunk depth that fits")
     ap.add_argument("--ablate", action="store_true", help="time with DMA / epilogue / prologue switched off")
     ap.add_argument("--prof", action="store_true", help="with --sx: per-step cycle breakdown of the 128x128 kernel")
-    ap.add_argument("--sx", action="store_true", help="benchmark the split-exact bf16 engine instead")
+    ap.add_argument("--sx", action="store_true", help="benchmark the split-operand engine instead (f16x3 arithmetic)")
+    ap.add_argument("--bf16x6", action="store_true", help="with --sx: the six-product exact arithmetic")
     a = ap.parse_args()
     lib = _ffi.load()
     F, B = a.frames, a.batch
@@ -57,12 +58,13 @@ def main():
     ]
     if a.sx:  # split-exact bf16 engine: generator shapes only (Cin % 16 == 0, Cout % 32 == 0)
         from phoonnx_amd.session import bench_conv1d_sx
+        mode = 0 if a.bf16x6 else 128
         for name, Cin, Cout, T, K, dil, hint in shapes:
             if hint != 0:
                 continue
             line = f"{name:24s} T={T:7d}"
             for tag, dbg in (("planes", 0), ("res+raw+planes", 8), ("noDMA", 1), ("noEPI", 2), ("none", 3)):
-                ms, cfg = bench_conv1d_sx(B, Cin, Cout, T, K, dil, dbg, a.iters)
+                ms, cfg = bench_conv1d_sx(B, Cin, Cout, T, K, dil, dbg | mode, a.iters)
                 tf = 2.0 * B * Cin * Cout * K * T / (ms * 1e-3) / 1e12
                 if dbg == 0:
                     line += f" sx{cfg} {ms:8.3f} ms"
@@ -72,7 +74,7 @@ def main():
             print(line + "  TF/s fp32-equivalent", flush=True)
             if a.prof and Cout % 128 == 0:
                 for dbg in (16, 16 | 3):
-                    ms, cfg, pc = bench_conv1d_sx(B, Cin, Cout, T, K, dil, dbg, a.iters)
+                    ms, cfg, pc = bench_conv1d_sx(B, Cin, Cout, T, K, dil, dbg | mode, a.iters)
                     print(f"      prof dbg={dbg & 15}: s_memtime ticks/step: lgkm {pc[0]:.0f} vmwait {pc[1]:.0f} barrier {pc[2]:.0f} "
                           f"dma-issue {pc[3]:.0f} loads+mfma {pc[4]:.0f}  (sum {sum(pc[:5]):.0f})  clock {pc[5]:.2f} GHz", flush=True)
         return
