@@ -530,50 +530,75 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
     const int64_t plane_elems = (int64_t)CGo * Tout * 8;
     const float *biasp = a.bias ? a.bias : a.zeros;  // a missing bias reads the zero page (no branch per quad)
     const int b_on = a.bias ? 1 : 0;
-#pragma unroll
-    for (int m = 0; m < MW; m++) {
+    // Rounds: (block row m, pair of block columns n0, n0 + 1).  The residual / accumulate operands of a round are 8
+    // 16-byte loads per lane; with a compile-time epilogue that has ONE such operand they are requested a round ahead
+    // (the A / B fragment registers are dead by now), so only the first round exposes a memory latency.  Loads use a
+    // clamped column (always inside the tensor): no branch per load; stores are predicated on the real column.
+    constexpr int NRND = MW * (NW / 2);
+    constexpr bool PIPE = EPI >= 0 && ((EPI & EPI_RES) != 0) != ((EPI & EPI_ACC) != 0);
+    f32x4 adb[PIPE ? 2 : 1][2][4], ad2[2][4];
+    auto geom = [&](int m, int n, int &co0, int &r, int &t) {
         const int row0 = mt * BM + (wm * MW + m) * 32;
-        if (row0 >= a.Cout) continue;
-        const int r = u == 1 ? 0 : row0 / Cr;
-        const int co0 = row0 - r * Cr;
+        r = u == 1 ? 0 : row0 / Cr;
+        co0 = row0 - r * Cr;
+        t = t0 + (wn * NW + n) * 32 + l31;
+    };
+    auto cell_at = [&](int co0, int r, int t, int q) -> int64_t {
+        return ((int64_t)((co0 >> 3) + q) * Tout + (t * u + r)) * 8 + 4 * hi;  // element offset inside raw / a plane
+    };
+    auto issue_adds = [&](auto R, auto P) {
+        constexpr int rr = decltype(R)::value, pp = decltype(P)::value;
+        constexpr int m = rr / (NW / 2), n0 = (rr % (NW / 2)) * 2;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            int co0, r, t;
+            geom(m, n0 + j, co0, r, t);
+            const int tl = t < T ? t : T - 1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t c = cell_at(co0, r, tl, q);
+                if (has_add) adb[pp][j][q] = *reinterpret_cast<const f32x4 *>(addp + c);
+                if (two_adds) ad2[j][q] = *reinterpret_cast<const f32x4 *>(rawb + c);
+            }
+        }
+    };
+    if constexpr (PIPE) issue_adds(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    static_for<NRND>([&](auto R) {
+        constexpr int rr = decltype(R)::value;
+        constexpr int m = rr / (NW / 2), n0 = (rr % (NW / 2)) * 2;
+        constexpr int pp = PIPE ? (rr & 1) : 0;
+        if constexpr (PIPE) {
+            if constexpr (rr + 1 < NRND) issue_adds(std::integral_constant<int, rr + 1>{}, std::integral_constant<int, (rr + 1) & 1>{});
+        } else
+            issue_adds(R, std::integral_constant<int, 0>{});
+        int co0m, rm, tm;
+        geom(m, n0, co0m, rm, tm);
+        const int row0 = mt * BM + (wm * MW + m) * 32;
         f32x4 bq[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
             if (flags & SX_HAS_BIASB)
-                bq[q] += *reinterpret_cast<const f32x4 *>(a.bias_b + (int64_t)b * a.bias_b_stride + co0 + 8 * q + 4 * hi);
-        }
-        // the residual / accumulate operands of two block columns are requested together (register budget)
-#pragma unroll
-        for (int n0 = 0; n0 < NW; n0 += 2) {
-        f32x4 ad[2][4], ad2[2][4];
-        int64_t cell[2][4];
-        bool okn[2];
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int t = t0 + (wn * NW + n0 + j) * 32 + l31;
-            okn[j] = t < T;
-            const int to = t * u + r;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                cell[j][q] = ((int64_t)((co0 >> 3) + q) * Tout + to) * 8 + 4 * hi;  // element offset inside raw / a plane
-                if (has_add && okn[j]) ad[j][q] = *reinterpret_cast<const f32x4 *>(addp + cell[j][q]);
-                if (two_adds && okn[j]) ad2[j][q] = *reinterpret_cast<const f32x4 *>(rawb + cell[j][q]);
-            }
+                bq[q] += *reinterpret_cast<const f32x4 *>(a.bias_b + (int64_t)b * a.bias_b_stride + co0m + 8 * q + 4 * hi);
         }
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            if (!okn[j]) continue;
+            constexpr int dummy = 0;
+            (void)dummy;
             const int n = n0 + j;
+            int co0, r, t;
+            geom(m, n, co0, r, t);
+            if (t >= T) continue;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                const int64_t cell = cell_at(co0, r, t, q);
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     if constexpr (F16) v[e] = __builtin_fmaf(acc[m][n][4 * q + e], wsc, bq[q][e]);  // (power of two: exact)
                     else v[e] = acc[m][n][4 * q + e] + bq[q][e];
                 }
-                if (has_add) v += ad[j][q];
+                if (has_add) v += adb[pp][j][q];
                 if (two_adds) v += ad2[j][q];
                 if (flags & EPI_DIV) {
 #pragma unroll
@@ -585,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) o[e] = fmaxf(v[e], v[e] * oslope);  // leaky_relu, 0 < slope < 1
                     }
-                    *reinterpret_cast<f32x4 *>(rawb + cell[j][q]) = o;
+                    *reinterpret_cast<f32x4 *>(rawb + cell) = o;
                 }
                 if (flags & SX_HAS_PL) {
                     f32x4 o = v;
@@ -603,12 +628,11 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
                     }
 #pragma unroll
                     for (int pl = 0; pl < (F16 ? 2 : 3); pl++)
-                        *reinterpret_cast<u32x2 *>(plb + pl * plane_elems + cell[j][q]) = u32x2{wa[pl], wb[pl]};
+                        *reinterpret_cast<u32x2 *>(plb + pl * plane_elems + cell) = u32x2{wa[pl], wb[pl]};
                 }
             }
         }
-        }
-    }
+    });
 }
 
 // sx tile configs: index -> (BM, BN, waves WM x WN, blocks per wave MW x NW):
