@@ -191,7 +191,7 @@ constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL 
 // 1 (w0x0, plain bf16) are the declared reduced-precision vocoder modes (VITSMI_GEN_PRECISION, BASELINE config 4):
 // they read only the planes they use.
 template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false, int NP = 6>
-__global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
+__global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxArgs a) {
     constexpr int BM = MW * WM * 32, BN = NW * WN * 32, MB = BM / 32;
     static_assert(NP == 6 || NP == 3 || NP == 1 || NP == 2, "plane products");
     constexpr bool F16 = NP == 2;                          // two fp16 planes, three products
@@ -397,9 +397,10 @@ __global__ __launch_bounds__(256, 2) void conv_sx_kernel(SxArgs a) {
         else if constexpr (NH * NPL == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
         else if constexpr (NH * NPL == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
         else if constexpr (NH * NPL == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else if constexpr (NH * NPL == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     };
-    static_assert(NH == 1 || NH == 2, "lgkmcnt immediates above");
+    static_assert(NH * NPL <= 4 || NH * NPL == 6 || NH * NPL == 8, "lgkmcnt immediates above");
     const std::integral_constant<int, 0> H0{};
     const std::integral_constant<int, 1> H1{};
 
