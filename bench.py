@@ -89,6 +89,9 @@ def main():
                          "f32-MFMA engine's; bf16x6: three bf16 planes, six products, every product exact; bf16x3 / "
                          "bf16: the declared reduced-precision vocoder modes of BASELINE config 4 (reported with their "
                          "dtype, never as the headline number)")
+    ap.add_argument("--no-exact-check", action="store_true",
+                    help="skip the second, shorter measurement of the same workload with the six-product exact arithmetic "
+                         "(bf16x6), which the N=1 line carries next to the headline value")
     ap.add_argument("--parts", type=int, default=2,
                     help="render each batch as this many sub-batches on as many engine handles / HIP streams sharing "
                          "one weight arena (PipelinedSession); 1 = a single handle")
@@ -179,6 +182,8 @@ def main():
         launches = 0
         agg = {}
         n_t = max(3, min(a.steps, 5))
+        step_one()  # (untimed: the first timed run creates the handle's HIP events)
+        sess.stats()
         for _ in range(n_t):
             step_one()
             st = sess.stats()
@@ -222,6 +227,36 @@ def main():
             stage["dec_tflops"] = stage["dec_flops"] / (stage["dec_ms"] * 1e-3) / 1e12
             stage["dec_hbm_frac"] = stage["dec_bytes"] / (stage["dec_ms"] * 1e-3) / 8.0e12
 
+    # The same workload once more with every fp32 product exact (VITSMI_GEN_PRECISION=bf16x6), so that the line
+    # carries both arithmetics of the generator: N=1 only, after (outside) the timed region of the headline value.
+    exact = None
+    if world == 1 and gen_nprod == 2 and not a.no_exact_check:
+        try:
+            os.environ["VITSMI_GEN_PRECISION"] = "bf16x6"
+            pe = PipelinedSession.open(voice, device_id=local_rank, parts=max(1, a.parts))
+            pe.set_seed(1234)
+            ke = max(3, a.steps // 2)
+            for _ in range(max(2, a.warmup)):
+                pe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            ne = 0
+            for _ in range(ke):
+                pe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+                ne += int(pe.last_y_lengths(B).sum()) * hop
+            torch.cuda.synchronize()
+            te = time.perf_counter() - te
+            exact = {"gen_precision": "bf16x6", "gen_nprod": int(pe.hparam("gen_nprod")), "value": ne / te,
+                     "unit": "samples/s", "steps": ke, "ms_per_step": te / ke * 1e3,
+                     "note": "six bf16 plane products per fp32 product (each exact to 2^-24); same batch and handle count, measured "
+                             "right after the headline run (chip already at its power / thermal limit: a standalone "
+                             "`bench.py --gen-precision bf16x6` reads ~10 % higher)"}
+            pe.close()
+        except Exception as e:
+            exact = {"gen_precision": "bf16x6", "value": None, "note": f"failed: {e}"}
+        finally:
+            os.environ["VITSMI_GEN_PRECISION"] = a.gen_precision
+
     cpu = None
     if rank == 0 and not a.no_cpu_baseline:
         try:
@@ -253,7 +288,7 @@ def main():
                        "samples_per_step": samples_all / a.steps,
                        "frames_per_id": samples_all / a.steps / hop / (B * world * T),
                        "weights": "RCCL broadcast of packed arena" if world > 1 else "local"},
-            "roofline": roofline, "cpu_baseline": cpu, "stages": stage,
+            "roofline": roofline, "cpu_baseline": cpu, "exact_arithmetic": exact, "stages": stage,
         }
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = value / world / cpu["value"]

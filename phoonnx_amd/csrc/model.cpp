@@ -319,7 +319,14 @@ ConvDesc pack_convT(Packer &P, const Resolver &R, const std::string &name) {
 // v_mfma_f32_32x32x16_bf16 (lane l: row l&31, k = 8*(l>>5) .. +7 = eight consecutive input channels).
 int sx_tile_m(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
 int sx_tile_n(int) { return 256; }
-int sx_pick_cfg(int Cout) { return Cout % 128 == 0 ? 0 : (Cout % 64 == 0 ? 1 : 2); }
+int sx_pick_cfg(int Cout) {
+    static const int min_cfg = [] {
+        const char *e = std::getenv("VITSMI_SX_MIN_CFG");  // tuning experiments only: 1 = no 128-row tiles
+        return e ? std::atoi(e) : 0;
+    }();
+    const int cfg = Cout % 128 == 0 ? 0 : (Cout % 64 == 0 ? 1 : 2);
+    return cfg < min_cfg ? min_cfg : cfg;
+}
 
 template <class WF>
 ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF w, const float *bias_virtual) {
