@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--parts", type=int, nargs="+", default=[1, 2, 4])
+    ap.add_argument("--threads", action="store_true", help="one host thread per part instead of one for all")
     a = ap.parse_args()
     import torch
     from phoonnx_amd import MiSession
@@ -41,13 +42,21 @@ def main():
         hop = sess[0].hparam("hop")
         bounds = [B * i // parts for i in range(parts + 1)]
 
-        def step():
-            n = 0
-            for i, s in enumerate(sess):
-                b0, b1 = bounds[i], bounds[i + 1]
-                s.run_device(ids[b0:b1].data_ptr(), lens[b0:b1].data_ptr(), b1 - b0, T, scales)
-                n += int(s.last_y_lengths().sum()) * hop
-            return n
+        def one(i):
+            s = sess[i]
+            b0, b1 = bounds[i], bounds[i + 1]
+            s.run_device(ids[b0:b1].data_ptr(), lens[b0:b1].data_ptr(), b1 - b0, T, scales)
+            return int(s.last_y_lengths().sum()) * hop
+
+        if a.threads and parts > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(parts)
+
+            def step():
+                return sum(pool.map(one, range(parts)))
+        else:
+            def step():
+                return sum(one(i) for i in range(parts))
 
         for _ in range(3):
             step()
