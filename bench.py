@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--no-exact-check", action="store_true",
                     help="skip the second, shorter measurement of the same workload with the six-product exact arithmetic "
                          "(bf16x6), which the N=1 line carries next to the headline value")
+    ap.add_argument("--lockstep", action="store_true",
+                    help="enqueue the parts of every step from one host thread and join them per step, instead of one "
+                         "free-running host thread per part (two serving workers)")
     ap.add_argument("--parts", type=int, default=2,
                     help="render each batch as this many sub-batches on as many engine handles / HIP streams sharing "
                          "one weight arena (PipelinedSession); 1 = a single handle")
@@ -147,16 +150,21 @@ def main():
     def step_one():  # the whole batch on the first handle: per-kernel timing for the roofline block
         sess.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
 
-    for _ in range(a.warmup):
-        step()
+    # K steps = K passes of the whole path over the batch.  Default: every part (half batch, own handle and stream) is
+    # driven by its own host thread through its K passes, like two serving workers; --lockstep joins them per step.
+    def run_steps(k):
+        if a.lockstep or len(pipe.parts) == 1:
+            return sum(step() for _ in range(k))
+        return int(pipe.run_device_steps(ids.data_ptr(), lens.data_ptr(), B, T, scales, k).sum()) * hop
+
+    if a.warmup > 0:
+        run_steps(a.warmup)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    samples = 0
-    for _ in range(a.steps):
-        samples += step()
+    samples = run_steps(a.steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -285,6 +293,7 @@ def main():
                                    f"device Philox noise, seeded synthetic weights",
                        "preset": a.preset, "batch_per_gpu": B, "tokens": T, "hop": hop,
                        "pipeline_parts": len(pipe.parts),
+                       "pipeline_host": "lockstep" if (a.lockstep or len(pipe.parts) == 1) else "one free-running host thread per part",
                        "samples_per_step": samples_all / a.steps,
                        "frames_per_id": samples_all / a.steps / hop / (B * world * T),
                        "weights": "RCCL broadcast of packed arena" if world > 1 else "local"},

@@ -340,6 +340,47 @@ class PipelinedSession:
             out.append((b0, nb, r))
         return out
 
+    def run_device_steps(self, ids_ptr, lens_ptr, B, T, scales, steps, sid_ptr=None):
+        """`steps` back-to-back passes over the same device-resident batch with one host thread per part, as two
+        serving workers would run: a part goes on to its next pass without waiting for the other one, and part i
+        starts once part i-1 has handed its first generator to the GPU, so that the small-grid stages of one part
+        keep falling under the generator of the other.  Returns the frame count of every utterance of every pass,
+        int64 [steps, B]; all work has completed on return."""
+        import threading
+        bnd = self.bounds(B)
+        n = len(bnd) - 1
+        out = np.zeros((steps, B), np.int64)
+        started = [threading.Event() for _ in range(n)]
+        errors = []
+
+        def work(i):
+            try:
+                if i > 0:
+                    started[i - 1].wait()
+                b0, nb = bnd[i], bnd[i + 1] - bnd[i]
+                for k in range(steps):
+                    self.parts[i].run_device(ids_ptr + b0 * T * 8, lens_ptr + b0 * 8, nb, T, scales,
+                                             sid_ptr + b0 * 8 if sid_ptr else None)
+                    started[i].set()
+                    out[k, b0:b0 + nb] = self.parts[i].last_y_lengths()
+                self.parts[i].sync()
+            except Exception as e:  # noqa: BLE001 - re-raised on the caller's thread
+                errors.append(e)
+            finally:
+                started[i].set()
+
+        if n == 1:
+            work(0)
+        else:
+            th = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if errors:
+            raise errors[0]
+        return out
+
     def last_y_lengths(self, B) -> np.ndarray:
         n = len(self.bounds(B)) - 1
         return np.concatenate([self.parts[i].last_y_lengths() for i in range(n)])

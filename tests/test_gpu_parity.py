@@ -448,6 +448,34 @@ def test_pipelined_session_equals_plain_session():
     p.close()
 
 
+def test_pipelined_session_free_running_steps():
+    # one host thread per part, several passes back to back: every pass reports the frame counts of a plain run
+    import ctypes as C
+    from phoonnx_amd import PipelinedSession
+    s = _session("tiny_rb1")
+    p = PipelinedSession(s, parts=2)
+    rng = np.random.default_rng(9)
+    B, T = 6, 32
+    ids = rng.integers(1, 200, (B, T)).astype(np.int64)
+    lens = np.full(B, T, np.int64)
+    hip = C.CDLL("libamdhip64.so")    # device copies of the inputs (the engine's own runtime; no torch in the tests)
+    dptr = []
+    for arr in (ids, lens):
+        d = C.c_void_p()
+        assert hip.hipMalloc(C.byref(d), C.c_size_t(arr.nbytes)) == 0
+        assert hip.hipMemcpy(d, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes), 1) == 0
+        dptr.append(d)
+    sc = np.array([0, 1.7, 0], np.float32)   # zero noise: durations are deterministic
+    ref = s.synthesize_batch(ids, lens, sc)["y_lengths"]
+    got = p.run_device_steps(dptr[0].value, dptr[1].value, B, T, sc, steps=4)
+    assert got.shape == (4, B)
+    for k in range(4):
+        assert np.array_equal(got[k], ref)
+    p.close()
+    for d in dptr:
+        hip.hipFree(d)
+
+
 def test_vocoder_only_matches_oracle():
     from vits_oracle import VitsOracle
     for preset in ("tiny_rb1", "tiny_rb2_ms"):
