@@ -663,15 +663,31 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
 
     const int nkb = (L + 31) / 32;
     const int srow = tid >> 5, scol = tid & 31;  // staging: 8 rows x 32 columns per pass
+    // K/V block kb+1 is fetched into registers while block kb is being consumed from LDS (the global latency of a
+    // block would otherwise sit in front of every one of its 2 x DKB x 16 MFMAs)
+    constexpr int NST = DKB * 4;  // rows of a block staged per thread
+    float kreg[NST], vreg[NST];
+    auto fetch = [&](int kb) {
+        const int j = kb * 32 + scol;
+#pragma unroll
+        for (int r = 0; r < NST; r++) {
+            const int d = srow + 8 * r;
+            const bool ok = d < dk && j < T;
+            kreg[r] = ok ? k[(int64_t)d * T + j] : 0.f;
+            vreg[r] = ok ? v[(int64_t)d * T + j] : 0.f;
+        }
+    };
+    if (nkb > 0) fetch(0);
     for (int kb = 0; kb < nkb; kb++) {
         const int j0 = kb * 32;
         __syncthreads();
-        for (int d = srow; d < DKB * 32; d += 8) {
-            const int j = j0 + scol;
-            const bool ok = d < dk && j < T;
-            kt[d * 32 + scol] = ok ? k[(int64_t)d * T + j] : 0.f;
-            vs[d * 33 + scol] = ok ? v[(int64_t)d * T + j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < NST; r++) {
+            const int d = srow + 8 * r;
+            kt[d * 32 + scol] = kreg[r];
+            vs[d * 33 + scol] = vreg[r];
         }
+        if (kb + 1 < nkb) fetch(kb + 1);
         __syncthreads();
         if (!active) continue;
         f32x16 s;
