@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--no-exact-check", action="store_true",
                     help="skip the second, shorter measurement of the same workload with the six-product exact arithmetic "
                          "(bf16x6), which the N=1 line carries next to the headline value")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and broadcast the weight arena even at world size 1 "
+                         "(exercises the N > 1 code path on a one-GPU box; needs the torchrun environment)")
     ap.add_argument("--lockstep", action="store_true",
                     help="enqueue the parts of every step from one host thread and join them per step, instead of one "
                          "free-running host thread per part (two serving workers)")
@@ -109,7 +112,7 @@ def main():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
