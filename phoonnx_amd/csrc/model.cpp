@@ -325,7 +325,12 @@ int sx_pick_cfg(int Cout) {
         const char *e = std::getenv("VITSMI_SX_MIN_CFG");  // tuning experiments only: 1 = no 128-row tiles
         return e ? std::atoi(e) : 0;
     }();
-    const int cfg = Cout % 128 == 0 ? 0 : (Cout % 64 == 0 ? 1 : 2);
+    static const int cfg1_for = [] {
+        const char *e = std::getenv("VITSMI_SX_CFG1_FOR");  // tuning experiments only: this Cout gets 64-row tiles
+        return e ? std::atoi(e) : -1;
+    }();
+    int cfg = Cout % 128 == 0 ? 0 : (Cout % 64 == 0 ? 1 : 2);
+    if (Cout == cfg1_for && cfg == 0) cfg = 1;
     const int lo = min_cfg > t_sx_min_cfg ? min_cfg : t_sx_min_cfg;
     return cfg < lo ? lo : cfg;
 }
