@@ -226,8 +226,49 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
                         wm * (MW * NPW * 1024);
     const int nit = a.x_bytes >> 12;           // DMA rounds of 256 cells per x tile (the stage is padded to 4 KiB)
 
+    // Fast path of the x-tile DMA (fp16 mode, plane input): which cell a lane fetches in round `it`, and whether that
+    // cell lies inside the tensor, does not depend on the chunk - only the channel-group base does, and that is a
+    // scalar.  So the per-lane byte offsets and the validity masks are computed once per tile (the general path spends
+    // ~25 VALU operations, eight of them quarter-rate multiplies, in front of every DMA, next to a saturated matrix
+    // pipe); lanes whose cell is padding are masked off and their LDS cells are zeroed once, below.
+    constexpr int MAXIT = 6;
+    const bool fastx = F16 && !RAWIN && nit <= MAXIT && !(a.flags & DBG_NO_DMA) &&
+                       (2 * pstride + 2 * (int64_t)T) * 16 < (1ll << 32);  // 32-bit byte offsets inside an utterance
+    uint32_t xoffs[MAXIT];
+    bool xok[MAXIT];
+    int nx_issued = 0;  // DMAs this wave really issues per x tile (a round whose 64 cells are all padding is skipped)
+    if constexpr (F16 && !RAWIN) {
+        if (fastx) {
+#pragma unroll
+            for (int it = 0; it < MAXIT; it++) {
+                const int i = it * 256 + wave * 64 + lane;
+                const int row = (int)__umulhi((unsigned)i, a.magic);
+                const int col = i - row * LW;
+                const int t = t0 - a.padL + col;
+                xok[it] = it < nit && row < 2 * NPL && t >= 0 && t < T;
+                xoffs[it] = (uint32_t)(((int64_t)(row >> 1) * pstride + (int64_t)(row & 1) * T + t) * 16);
+                nx_issued += __builtin_amdgcn_ballot_w64(xok[it]) != 0 ? 1 : 0;
+            }
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            for (uint32_t o = (uint32_t)tid * 16u; o < 2u * XB; o += 4096u) ds_write128(lds0 + o, z);
+            __syncthreads();  // the zeros are in place before the first DMA can land on a neighbouring cell
+        }
+    }
     // x tile of one chunk -> LDS: rows (plane, channel-group half) x LW cells; every wave issues `nit` DMAs
     auto issue_x = [&](int chunk, uint32_t xoff) {
+        if constexpr (F16 && !RAWIN) {
+            if (fastx) {
+                const char *cb = reinterpret_cast<const char *>(xb) + (int64_t)(2 * chunk) * T * 16;
+#pragma unroll
+                for (int it = 0; it < MAXIT; it++) {
+                    if (it < nit) {  // (uniform) every wave issues the same count, masked-off rounds included
+                        const int base = it * 256 + wave * 64;
+                        if (xok[it]) lds_dma<16>(cb + xoffs[it], reinterpret_cast<float *>(lds_sx + xoff + base * 16));
+                    }
+                }
+                return;
+            }
+        }
         for (int it = 0; it < nit; it++) {
             const int base = it * 256 + wave * 64;
             const int i = base + lane;
@@ -300,7 +341,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
             }
         });
     };
-    const int nxv = RAWIN ? 2 * nxc : nit;  // vector-memory operations per wave for one x tile
+    const int nxv = RAWIN ? 2 * nxc : (fastx ? nx_issued : nit);  // vector-memory operations per wave for one x tile
 
     // wait until at most n of this wave's vector-memory operations are still in flight (they retire in order)
     auto wait_vm = [&](int n) {
