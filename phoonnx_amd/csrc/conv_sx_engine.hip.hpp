@@ -292,17 +292,28 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
         kh = (i >= LW ? 1 : 0) + (i >= 2 * LW ? 1 : 0);
         col = i - kh * LW;
     };
-    auto xload = [&](int chunk) {
+    // which cell a thread stages, and whether it is padding, does not depend on the chunk: byte offsets from the
+    // chunk's (scalar) base and validity are computed once per tile; padding lanes read the chunk base itself (always
+    // inside the tensor) and are zeroed in xstore
+    uint32_t xroff[NXC];
+    bool xrok[NXC];
+    if constexpr (RAWIN) {
+#pragma unroll
+        for (int it = 0; it < NXC; it++) {
+            int kh, col;
+            xcell(it, kh, col);
+            const int t = t0 - a.padL + col;
+            xrok[it] = it < nxc && kh < 2 && t >= 0 && t < T;
+            xroff[it] = xrok[it] ? (uint32_t)(((int64_t)kh * T + t) * 32) : 0u;
+        }
+    }
+    auto xload = [&](int chunk) {  // (launch_conv_sx keeps T small enough for 32-bit offsets inside a chunk)
+        const float *cbase = xrb + (int64_t)(2 * chunk) * T * 8;
         static_for<NXC>([&](auto I) {
             constexpr int it = decltype(I)::value;
             if (it < nxc) {
-                int kh, col;
-                xcell(it, kh, col);
-                const int t = t0 - a.padL + col;
-                const bool ok = kh < 2 && t >= 0 && t < T;
-                const float *src = ok ? xrb + ((int64_t)(2 * chunk + kh) * T + t) * 8 : a.zeros;
-                xst[it][0] = global_read128_v<0>(src);
-                xst[it][1] = global_read128_v<16>(src);
+                xst[it][0] = global_read128<0>(xroff[it], cbase);
+                xst[it][1] = global_read128<16>(xroff[it], cbase);
             }
         });
     };
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        const float x = __uint_as_float(xst[it][e >> 2][e & 3]);
+                        const float x = xrok[it] ? __uint_as_float(xst[it][e >> 2][e & 3]) : 0.f;  // padding cell
                         v[e] = fmaxf(x, x * isl);  // leaky_relu for 0 < islope <= 1 (1 = none)
                     }
                     u32x4 w0, w1, w2;
@@ -751,7 +762,7 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     const size_t lds = 2 * (size_t)a.x_bytes;  // two x stages; the weights never touch LDS
     // (pack_conv_sx pads narrower kernels to 3 taps; model.cpp sx_supported() mirrors the size limits)
     if (lds > 160 * 1024 || a.x_bytes > 12 * 4096 || a.K < 3) return hipErrorInvalidValue;
-    if (rawin && (cfg == 0 || 2 * a.LW > 768 || !a.xr)) return hipErrorInvalidValue;
+    if (rawin && (cfg == 0 || 2 * a.LW > 768 || !a.xr || (long long)a.T * 64 + 64 >= (1ll << 32))) return hipErrorInvalidValue;
     if (a.oslope == 0.f) a.oslope = 1.f;
     if (a.oslope2 == 0.f) a.oslope2 = 1.f;
     if (a.islope == 0.f) a.islope = 1.f;
