@@ -269,7 +269,7 @@ def main():
             os.environ["VITSMI_GEN_PRECISION"] = a.gen_precision
 
     cpu = None
-    if rank == 0 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:  # (N = 1 only: the other ranks would sit in the final barrier)
         try:
             cpu = cpu_baseline(voice, a.preset, T, scales, 1234)
         except Exception as e:  # the baseline is a report, never the product
