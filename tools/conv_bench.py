@@ -95,7 +95,7 @@ def main():
         if a.sweep:
             best = []
             for c in range(5):
-                for k in (8, 16, 32):
+                for k in (8, 16, 32, 64, 96, 192):
                     rr = bench(lib, B, Cin, Cout, T, K, dil, hint, a.iters, c, k)
                     if rr:
                         best.append((rr[1], c, k))
