@@ -1,41 +1,44 @@
-// conv_sx_engine.hip.hpp — dense Conv1d as an implicit GEMM on the gfx950 bf16 matrix cores with
-// fp32-exact operands ("split-exact", sx): every fp32 operand is carried as THREE bf16 planes
-//     v = p0 + p1 + p2,   p0 = bf16(v), p1 = bf16(v - p0), p2 = bf16(v - p0 - p1)     (exact: 3 x 8 = 24 bits)
-// and a product w*x is evaluated as the six plane products of combined order <= 2
-//     w0x0 + w0x1 + w1x0 + w0x2 + w1x1 + w2x0
-// each of which v_mfma_f32_32x32x16_bf16 forms exactly (8 x 8 significant bits) and accumulates in fp32.
-// The three dropped terms are bounded by 3 * 2^-24 |w||x|, i.e. the result carries the same error
-// bound as an fp32 FMA chain (what the reference's fp32 convolutions and the f32 engine in
-// conv_engine.hip.hpp compute); tests/test_gpu_parity.py checks both engines against float64.
-//
-// Why: the f32 matrix pipe peaks at 157 TFLOP/s (measured 155), the bf16 pipe at 2.5 PFLOP/s; six bf16
-// MFMAs per fp32-equivalent product leave a 419 TFLOP/s ceiling (tools/mfma_bf16x6_probe.hip sustains
-// 340-375 TFLOP/s fp32-equivalent with both operands streaming from LDS).
+// conv_sx_engine.hip.hpp — dense Conv1d as an implicit GEMM on the gfx950 16-bit matrix cores with fp32
+// operands and results: every fp32 operand is carried as a few 16-bit PLANES whose products the MFMA forms
+// exactly and accumulates in fp32 ("split operands", sx).  Two arithmetics (template parameter NP):
+//   f16x3  (NP = 2, the default): two fp16 planes per operand, v ~ h0 + h1, and the three products
+//          h0g0 + h0g1 + h1g0 per fp32 product; per-product error ~3 * 2^-24, i.e. one fp32 rounding.  The
+//          range handling (per-tensor weight scale, low activation plane stored 2^11 up) is described at
+//          split2h_pair below.  Ceiling 2516.6 / 3 = 839 TFLOP/s fp32-equivalent.
+//   bf16x6 (NP = 6): three bf16 planes, v = p0 + p1 + p2 exactly (3 x 8 = 24 bits), and the six plane products
+//          of combined order <= 2, w0x0 + w0x1 + w1x0 + w0x2 + w1x1 + w2x0; the dropped terms are below
+//          3 * 2^-24 |w||x|.  Ceiling 2516.6 / 6 = 419 TFLOP/s (tools/mfma_bf16x6_probe.hip sustains 340-375 with
+//          both operands streaming from LDS).
+//   NP = 3 / 1: three / one bf16 product, the declared reduced-precision vocoder modes.
+// Both full-precision modes carry the error bound of an fp32 FMA chain (what the reference's fp32 convolutions
+// and the f32 engine in conv_engine.hip.hpp compute); tests/test_gpu_parity.py checks them against float64.
+// Why: the f32 matrix pipe peaks at 157 TFLOP/s (measured 155), the f16 / bf16 pipe at 2.5 PFLOP/s.
 //
 // Layouts (T = time steps of the tensor, C % 16 == 0 on inputs, C % 32 == 0 on outputs):
-//   planes  bf16 [3][C/8][T][8]   conv inputs; one 16-byte cell = 8 channels of one time step, which is
-//                                 exactly one lane's B operand (8 k-values) of the MFMA
+//   planes  16-bit [3 slots][C/8][T][8]   conv inputs; one 16-byte cell = 8 channels of one time step, which is
+//                                 exactly one lane's B operand (8 k-values) of the MFMA (f16x3 uses 2 slots)
 //   raw     fp32 [C/8][T][8]      residual stream (same cell structure, 32-byte cells)
-//   weights bf16 [m-tile][chunk of 16 ci][tap][32-row block][plane][lane][8]  (model.cpp pack_conv_sx; fp16 mode: 2 planes):
-//                                 MFMA A-operand lane order, one 1 KiB wave-load per (block row, plane)
+//   weights 16-bit [m-tile][chunk of 16 ci][tap][32-row block][plane][lane][8]  (model.cpp pack_conv_sx; 3 planes,
+//                                 f16x3: 2): MFMA A-operand lane order, one 1 KiB wave-load per (block row, plane)
 // Tensors of <= 64 channels are HBM-bound layers: they are kept as raw only and the consuming conv (RAWIN
 // instantiation) applies the leaky-ReLU and the split while it loads its tile.
-// Pipeline: one step = one tap of one 16-channel chunk = 6*MW*NW MFMAs per wave.
+// Pipeline: one step = one tap of one 16-channel chunk = 3*MW*NW MFMAs per wave (bf16x6: 6*MW*NW).
 //   A (weights): global_load straight into registers (L2-resident, no LDS), two register sets, one step ahead.
-//   B (x tile):  [3 planes][2 channel-group halves][BN + halo] cells in LDS, double-buffered per chunk, brought
-//                by 16-byte LDS-DMA (zero padding = out-of-range cells read a zero page) or, RAWIN, through
-//                registers; one barrier per chunk; B fragments are re-read in two halves, half a step ahead.
+//   B (x tile):  [planes][2 channel-group halves][BN + halo] cells in LDS, double-buffered per chunk, brought
+//                by 16-byte LDS-DMA (f16x3: per-tile lane offsets and masks, padding cells zeroed once; else
+//                out-of-range cells read a zero page) or, RAWIN, through registers; one barrier per chunk; B
+//                fragments are re-read in two halves, half a step ahead.
 //   Waits are counted (`vmcnt(n)` / `lgkmcnt(n)`, raw `s_barrier`): a `__syncthreads()` would drain the
 //   prefetches in flight.
 // Epilogue: bias, per-utterance bias, residual, multi-receptive-field accumulate and /n, leaky-ReLU,
 // pixel shuffle of the transposed conv (virtual rows are r-major: row = r*Cr + co), then an fp32 raw
-// store and/or a split into the three planes the next conv reads; the common combinations are compile-time
+// store and/or a split into the planes the next conv reads; the common combinations are compile-time
 // specialisations (EPI template parameter).
 // What shaped it (tools/conv_bench.py --sx --prof, profiles/): LDS-DMA and global loads cost 60-180 issue
 // cycles per 1 KiB wave-instruction next to a saturated matrix pipe, so the design minimises their count per
 // MFMA (256-column tiles: one A load serves 4 block columns); a mid-loop `break` in the unrolled step pair
 // makes hipcc copy all accumulators every step; at this load the chip runs at 1.7-1.9 GHz (power), so the
-// matrix pipe's busy share (60-66 % on the 128-row tiles), not the nominal 2.4 GHz peak, is the honest gauge.
+// matrix pipe's busy share (55-63 % on the 128-row tiles), not the nominal 2.4 GHz peak, is the honest gauge.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
