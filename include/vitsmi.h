@@ -188,14 +188,15 @@ int vits_bench_conv1d(int device_id, int B, int Cin, int Cout, int T, int K, int
 /* out[B,Cout,T*stride] = conv_transpose1d(x, w[Cin,Cout,K], bias, stride, pad=(K-stride)/2). */
 int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, int T, const float *w,
                                const float *bias, int Cout, int K, int stride, float *out);
-/* The same three hooks through the split-exact bf16 engine the generator runs on when all of its channel counts
+/* The same three hooks through the split-operand engine the generator runs on when all of its channel counts
  * are multiples of 32 (csrc/conv_sx_engine.hip.hpp); needs Cin % 16 == 0 and Cout % 32 == 0.
- * vits_test_conv1d_sx flags: bit0 -> out = leaky_relu(conv, slope) read back from the three bf16 output planes
+ * vits_test_conv1d_sx flags: bit0 -> out = leaky_relu(conv, slope) read back from the 16-bit output planes
  * (else the fp32 raw output), bit2 -> residual epilogue with res = x (Cin == Cout), bit3 -> leaky_relu(slope) on the
- * input (raw-input kernels, Cin <= 64), bits 4-5 -> precision mode: 0 exact (six plane products), 1 bf16x3, 2 bf16
- * (the declared reduced-precision vocoder modes of VITSMI_GEN_PRECISION; vits_bench_conv1d_sx: dbg bits 32 / 64).
+ * input (raw-input kernels, Cin <= 64), bits 4-5 -> arithmetic: 0 bf16x6 (six exact bf16 plane products), 1 bf16x3,
+ * 2 bf16 (the declared reduced-precision vocoder modes), 3 f16x3 (two fp16 planes, three products: the generator's
+ * default, VITSMI_GEN_PRECISION).  vits_test_conv_transpose1d_sx: a negative stride selects f16x3.
  * vits_bench_conv1d_sx dbg bits: 1 no DMA after the first step, 2 no epilogue, 8 residual epilogue, 16 in-kernel
- * cycle breakdown (128-row tiles only).  ms_out holds 8 floats: [0] ms per launch, [1] tile config, [3..7] with
+ * cycle breakdown (128-row tiles only), 32 / 64 bf16x3 / bf16, 128 f16x3.  ms_out holds 8 floats: [0] ms per launch, [1] tile config, [3..7] with
  * bit 16: s_memtime ticks per pipeline step spent in {LDS wait, DMA wait, barrier, DMA issue, loads + MFMA}. */
 int vits_test_conv1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
                         int Cout, int K, int dil, int pad_l, int flags, float slope, float *out);
