@@ -616,8 +616,12 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
                                                                int dk, int win) {
     // 4 wavefronts = 4 consecutive 32-query blocks of one (utterance, head); every 32-key block of K and V
     // is staged ONCE in LDS (coalesced 128-byte rows) and shared by the four waves.
-    __shared__ float kt[DKB * 32 * 32];
-    __shared__ float vs[DKB * 32 * 33];
+    // K block transposed: kt[key j][d], d contiguous (row pitch KP), so that a lane's A values of four consecutive
+    // k-steps (d = 2 st + hi) are one 32-byte read; V block vs[d][key j] (row pitch VP): the four keys a lane needs
+    // per accumulator quad are one 16-byte read.  Pitches = 4 mod 32 floats: 16-byte reads of 8 lanes tile the banks.
+    constexpr int KP = DKB * 32 + 4, VP = 36;
+    __shared__ __attribute__((aligned(16))) float kt[32 * KP];
+    __shared__ __attribute__((aligned(16))) float vs[DKB * 32 * VP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
     const int L = len[b] < T ? len[b] : T;
@@ -628,26 +632,34 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
     float *o = out + ((int64_t)b * Hc + (int64_t)h * dk) * T;
     constexpr int STEPS = DKB * 16;
     const bool active = i0 < L;  // a fully padded query block only helps staging and writes zeros
-    const float sq = sqrtf((float)dk);
+    const float rsq = 1.f / sqrtf((float)dk);
     float qf[STEPS];
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
         int d = 2 * s + hi;
-        qf[s] = (active && d < dk && i < T) ? q[(int64_t)d * T + i] / sq : 0.f;
+        qf[s] = (active && d < dk && i < T) ? q[(int64_t)d * T + i] * rsq : 0.f;
     }
-    // relative-key logits of this lane's query: rq[m] = q_i . E_k[m]
+    // relative-key logits of this lane's query: rq[m] = q_i . E_k[m]   (E_k staged once per workgroup: the nine
+    // dk-vectors would otherwise be 9 x STEPS dependent global loads per lane in front of the first key block)
     float rq[9];
     const int nrel = 2 * win + 1;
+    float *relk_s = vs;  // (vs is not in use yet; DKB * 32 * VP >= 9 * DKB * 32 floats)
+    for (int e = tid; e < nrel * DKB * 32; e += 256) {
+        const int m = e / (DKB * 32), d = e - m * (DKB * 32);
+        relk_s[e] = d < dk ? relk[m * dk + d] : 0.f;
+    }
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < 9; m++) {
-        float s = 0.f;
+        float s0 = 0.f, s1 = 0.f;
         if (m < nrel) {
 #pragma unroll
-            for (int st = 0; st < STEPS; st++) {
-                int d = 2 * st + hi;
-                if (d < dk) s += qf[st] * relk[m * dk + d];
+            for (int st = 0; st < STEPS; st += 2) {
+                s0 += qf[st] * relk_s[m * (DKB * 32) + 2 * st + hi];
+                s1 += qf[st + 1] * relk_s[m * (DKB * 32) + 2 * st + 2 + hi];
             }
         }
+        float s = s0 + s1;
         s += __shfl_xor(s, 32);
         rq[m] = s;
     }
@@ -684,20 +696,28 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
 #pragma unroll
         for (int r = 0; r < NST; r++) {
             const int d = srow + 8 * r;
-            kt[d * 32 + scol] = kreg[r];
-            vs[d * 33 + scol] = vreg[r];
+            kt[scol * KP + d] = kreg[r];
+            vs[d * VP + scol] = vreg[r];
         }
         if (kb + 1 < nkb) fetch(kb + 1);
         __syncthreads();
         if (!active) continue;
-        f32x16 s;
+        // two accumulators: the STEPS MFMAs are one dependent chain otherwise (16 passes each)
+        f32x16 s, s2;
 #pragma unroll
-        for (int r = 0; r < 16; r++) s[r] = 0.f;
+        for (int r = 0; r < 16; r++) s[r] = s2[r] = 0.f;
 #pragma unroll
-        for (int st = 0; st < STEPS; st++) {
-            const float a = kt[(2 * st + hi) * 32 + l31];
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qf[st], s, 0, 0, 0);
+        for (int g = 0; g < STEPS / 4; g++) {  // eight d-values = four k-steps per 32-byte read
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(&kt[l31 * KP + 8 * g]);
+            const f32x4 up = *reinterpret_cast<const f32x4 *>(&kt[l31 * KP + 8 * g + 4]);
+            const float a0 = hi ? lo[1] : lo[0], a1 = hi ? lo[3] : lo[2], a2 = hi ? up[1] : up[0], a3 = hi ? up[3] : up[2];
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, qf[4 * g], s, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, qf[4 * g + 1], s2, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, qf[4 * g + 2], s, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, qf[4 * g + 3], s2, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] += s2[r];
         const bool near = (j0 + 31 >= i0 - win) && (j0 <= i0 + 31 + win);
         float bm = -INFINITY;
 #pragma unroll
@@ -716,11 +736,11 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
         }
         bm = fmaxf(bm, __shfl_xor(bm, 32));
         const float mnew = fmaxf(mrun, bm);
-        const float alpha = expf(mrun - mnew);
+        const float alpha = __expf(mrun - mnew);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            float p = expf(s[r] - mnew);
+            float p = __expf(s[r] - mnew);
             s[r] = p;
             psum += p;
         }
@@ -744,15 +764,27 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int jj = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        for (int q4 = 0; q4 < 4; q4++) {  // keys 8 q4 + 4 hi .. + 3: one 16-byte read per V row block
+            f32x4 av[DKB];
 #pragma unroll
-            for (int db = 0; db < DKB; db++) {
-                float a = vs[(db * 32 + l31) * 33 + jj];
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s[r], oacc[db], 0, 0, 0);
-            }
+            for (int db = 0; db < DKB; db++)
+                av[db] = *reinterpret_cast<const f32x4 *>(&vs[(db * 32 + l31) * VP + 8 * q4 + 4 * hi]);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int db = 0; db < DKB; db++)
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[db][e], s[4 * q4 + e], oacc[db], 0, 0, 0);
         }
     }
+    // relative-value embeddings E_v staged once (as E_k was): nine values per output element otherwise come as
+    // dependent global loads in the epilogue
+    __syncthreads();
+    float *relv_s = kt;  // (32 * KP >= 9 * DKB * 32 floats)
+    for (int e = tid; e < nrel * DKB * 32; e += 256) {
+        const int m = e / (DKB * 32), d = e - m * (DKB * 32);
+        relv_s[e] = d < dk ? relv[m * dk + d] : 0.f;
+    }
+    __syncthreads();
     if (!active) {
         for (int d = hi; d < dk; d += 2)
             if (i < T) o[(int64_t)d * T + i] = 0.f;
@@ -761,6 +793,7 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
 #pragma unroll
     for (int m = 0; m < 9; m++) wrel[m] += __shfl_xor(wrel[m], 32);
     const bool qvalid = i < L;
+    const float rl = 1.f / lrun;
 #pragma unroll
     for (int db = 0; db < DKB; db++)
 #pragma unroll
@@ -770,8 +803,8 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
                 float val = oacc[db][r];
 #pragma unroll
                 for (int m = 0; m < 9; m++)
-                    if (m < nrel) val += wrel[m] * relv[m * dk + d];
-                o[(int64_t)d * T + i] = qvalid ? val / lrun : 0.f;
+                    if (m < nrel) val += wrel[m] * relv_s[m * (DKB * 32) + d];
+                o[(int64_t)d * T + i] = qvalid ? val * rl : 0.f;
             }
         }
 }
