@@ -128,10 +128,41 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
     const float4 *aslab0 = reinterpret_cast<const float4 *>(a.wp) + (int64_t)blockIdx.y * a.nchunks * (MB * spc * 64) + lane;
     const int na = MB * spc;
 
+    // Which element of the [CK rows][LW columns] x tile a lane fetches in DMA round s, and whether its column lies inside
+    // the sequence, depends on the tile only; with every chunk full (Cin % CK == 0) the chunk just moves a scalar base.
+    // So the per-lane element offsets are computed once (instead of a umulhi / 64-bit multiply chain in front of every
+    // DMA: most layers on this engine have K loops too short to hide that behind their few MFMAs).
+    constexpr int MAXS = 4;
+    const bool fastx = nxs <= MAXS && a.Cin % CK == 0;
+    int xoff[MAXS];
+    bool xok[MAXS];
+    if (fastx) {
+#pragma unroll
+        for (int s = 0; s < MAXS; s++) {
+            const int e = (s * 256 + tid) * VEC;
+            const int r = (int)__umulhi((unsigned)e, a.magic);
+            const int c = e - r * LW;
+            const int t = t0 - a.padLa + c;
+            xok[s] = s < nxs && r < CK && t >= 0 && t < in_lim;
+            xoff[s] = r * a.x_cstride + t;  // (launch_conv keeps CK * x_cstride inside 31 bits)
+        }
+    }
+
     auto issue = [&](int chunk, float *stage) {
         const float4 *src = aslab0 + (int64_t)chunk * (na * 64);
         float *ab = stage + XS;
         for (int i = wave; i < na; i += 4) lds_dma<16>(src + i * 64, ab + i * 256);
+        if (fastx) {
+            const float *xc = xb + (int64_t)chunk * CK * a.x_cstride;
+#pragma unroll
+            for (int s = 0; s < MAXS; s++) {
+                if (s < nxs) {
+                    const float *src_x = xok[s] ? xc + xoff[s] : a.zeros + lane * VEC;
+                    lds_dma<VEC * 4>(src_x, stage + (s * 256 + wave * 64) * VEC);
+                }
+            }
+            return;
+        }
         // x tile: CK rows x LW columns, linear in LDS; out-of-range lanes read the zero page
         const int rows_valid = (a.Cin - chunk * CK) < CK ? (a.Cin - chunk * CK) : CK;
         const float *xc = xb + (int64_t)chunk * CK * a.x_cstride;
@@ -444,6 +475,7 @@ inline hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
     a.stage_floats = (int)((stage + 63) / 64 * 64);
     const size_t lds = 2 * (size_t)a.stage_floats * sizeof(float);
     if ((int64_t)a.Cout * (a.ups == 1 ? a.out_cstride : a.T) >= (int64_t)1 << 31) return hipErrorInvalidValue;  // 32-bit element offsets per utterance
+    if ((int64_t)a.CK * a.x_cstride + a.T >= (int64_t)1 << 31) return hipErrorInvalidValue;  // ... and inside a chunk of the input
     switch (cfg) {
         case 0: return launch_conv_t<1, 4, 1, 4>(a, grid, vec4, act, lds, stream);
         case 1: return launch_conv_t<2, 2, 1, 4>(a, grid, vec4, act, lds, stream);
