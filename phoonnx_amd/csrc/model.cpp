@@ -316,7 +316,7 @@ ConvDesc pack_convT(Packer &P, const Resolver &R, const std::string &name) {
     return d;
 }
 
-// ---- split-exact (sx) packing: weights as three bf16 planes in the A-operand lane order of
+// ---- split-operand (sx) packing: weights as three bf16 planes (or two scaled fp16 planes) in the A-operand lane order of
 // v_mfma_f32_32x32x16_bf16 (lane l: row l&31, k = 8*(l>>5) .. +7 = eight consecutive input channels).
 int sx_tile_m(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
 int sx_tile_n(int) { return 256; }
@@ -781,7 +781,7 @@ std::string Model::build(const OnnxModel &om) {
             nrb++;
         if (!nups || nrb % nups) throw std::runtime_error("unexpected generator structure");
         const int nk = nrb / nups;
-        // Engine choice for the whole generator (its tensors change layout with the engine): split-exact bf16
+        // Engine choice for the whole generator (its tensors change layout with the engine): split-operand
         // when every conv qualifies, else the f32 engine.  VITSMI_GEN_ENGINE=f32 forces the latter (A/B runs).
         {
             const char *env = std::getenv("VITSMI_GEN_ENGINE");

@@ -25,7 +25,7 @@ struct ConvDesc {
     int mblocks = 0;      // packed 32-row blocks (padded to the tile config)
     int ups = 1;          // pixel-shuffle factor (transposed conv), real Cout = Cout/ups
     int cfg = 0;          // tile: 0: 32x512, 1: 64x256, 2: 128x128, 3: 64x64, 4: 32x128
-    // sx = packed for the split-exact bf16 engine (conv_sx_engine.hip.hpp) instead: weights as three bf16
+    // sx = packed for the split-operand engine (conv_sx_engine.hip.hpp) instead: weights as three bf16
     // planes [m-tile][chunk of 16 ci][tap][32-row block][plane][lane][8]; cfg then indexes the sx tiles
     // (0: 128x256, 1: 64x256, 2: 32x256) and a transposed conv's virtual rows are r-major (r*Cr + co).
     bool sx = false;
@@ -123,7 +123,7 @@ struct Model {
     ConvDesc conv_pre;
     int C0 = 0;
     bool gen_f16 = false; // ... in its fp16 two-plane mode (VITSMI_GEN_PRECISION=f16x3)
-    bool gen_sx = false;  // generator packed for the split-exact bf16 engine (all channel counts % 32 == 0)
+    bool gen_sx = false;  // generator packed for the split-operand engine (all channel counts % 32 == 0)
     std::vector<UpStageDesc> ups;
     int64_t post_w = -1;  // [Cin, K] conv_post weight (Cout = 1, no bias)
     int post_cin = 0, post_k = 7;
@@ -159,7 +159,7 @@ void set_sx_f16(bool on);  // pack_conv_sx format for the calls that follow on t
 // may this conv shape run on the sx engine (channel multiples, LDS budget)?
 bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil);
 // Storage format of a generator tensor with C channels on the sx path: true = fp32 raw only (its consumers
-// split it on the fly; layers this narrow are HBM-bound), false = bf16 planes (+ raw where it is a residual).
+// split it on the fly; layers this narrow are HBM-bound), false = 16-bit planes (+ raw where it is a residual).
 inline bool sx_raw_format(int C) {
     static const int maxc = [] {
         const char *e = std::getenv("VITSMI_SX_RAW_MAXC");  // tuning experiments only

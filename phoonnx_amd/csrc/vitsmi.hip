@@ -209,7 +209,7 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
     conv_account(c, d, T);
 }
 
-// One conv through the split-exact bf16 engine (conv_sx_engine.hip.hpp).  Tensors are whole utterance
+// One conv through the split-operand engine (conv_sx_engine.hip.hpp; 16-bit planes: fp16 x 2 by default, bf16 x 3).  Tensors are whole utterance
 // batches in the engine's layouts: input planes [B][3][Cin/8][T][8], outputs raw [B][Cr/8][T*u][8] and/or
 // planes [B][3][Cr/8][T*u][8]; `res` has the raw layout of the output.
 // `x` is the plane tensor, or (d.rawin) the fp32 raw tensor, to which the kernel applies leaky_relu(islope).
@@ -501,14 +501,14 @@ size_t gen_ws_bytes(const Model &m, int B, int F) {
     return (size_t)(m.gen_sx ? kGenRegionsSx : kGenRegions) * al(gen_region_floats(m, B, F));
 }
 
-// The generator on the split-exact bf16 engine.  Same dataflow as run_generator below; tensors that feed a conv
-// are stored as bf16 planes (already leaky-ReLU'd by their producer), the residual stream as fp32 raw cells.
+// The generator on the split-operand engine.  Same dataflow as run_generator below; tensors that feed a conv
+// are stored as 16-bit planes (already leaky-ReLU'd by their producer), the residual stream as fp32 raw cells.
 int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B,
                      int F, const float *dec_cond, Slab &s) {
     const Model &m = h->model;
     hipStream_t st = h->stream;
     const size_t R = gen_region_floats(m, B, F);
-    const size_t RP = R + R / 2 + 64;  // floats holding R elements as three bf16 planes
+    const size_t RP = R + R / 2 + 64;  // floats holding R elements as three 16-bit plane slots (the fp16 mode uses two)
     auto planes = [&]() { return reinterpret_cast<uint16_t *>(slab_take<float>(s, RP)); };
     uint16_t *stage_in[2] = {planes(), planes()}, *y_pl = planes(), *raa[2] = {planes(), planes()}, *tmp_pl = planes();
     float *y_raw = slab_take<float>(s, R), *ra[2] = {slab_take<float>(s, R), slab_take<float>(s, R)};
@@ -519,7 +519,7 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
     stage_mark(h, 3);
     const float S = 0.1f;  // Generator.LRELU_SLOPE / ResBlock LRELU_SLOPE
     const int nst = (int)m.ups.size();
-    // Tensor formats (model.hpp sx_raw_format): > 64 channels: bf16 planes that already carry the consumer's
+    // Tensor formats (model.hpp sx_raw_format): > 64 channels: 16-bit planes that already carry the consumer's
     // leaky_relu (+ fp32 raw where the tensor is also a residual); <= 64 channels: fp32 raw only, the consuming
     // conv applies the leaky_relu and the split while loading (its `islope`).
     // ---- z * y_mask (models.py:349) in conv_pre's input format
@@ -771,7 +771,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
             const bool last = i == cd.n_wn - 1;
             // x_in = in_layer(h) + g_l ; acts = tanh * sigmoid ; rs = res_skip(acts)
             if (cd.wn[i].in.sx) {
-                // split-exact engine: hx -> three bf16 planes, conv to the raw cell layout, gate reads that layout
+                // split-operand engine: hx -> planes, conv to the raw cell layout, gate reads that layout
                 sx_split_planes_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(hx, sHF, F, nullptr, hx_pl, Hf, F,
                                                                                          cd.wn[i].in.f16 ? 1 : 0);
                 h->stats.total_launches++;
@@ -1382,7 +1382,7 @@ int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, in
     return run_test_conv(d, arena, x, B, T, 0, 0.f, out, (size_t)B * Cout * T * stride, (int64_t)Cout * T * stride);
 }
 
-// ---- the same hooks through the split-exact bf16 engine: planar host tensors are converted to the engine's
+// ---- the same hooks through the split-operand engine: planar host tensors are converted to the engine's
 // plane / raw layouts on the device, the result is converted back.
 static void fill_sx_args(SxArgs &a, const ConvDesc &d, const float *dA, int T) {
     const int Cr = d.Cout / d.ups;

@@ -439,8 +439,8 @@ def test_conv1d(x, w, bias=None, dil=1, pad_l=0, lrelu_slope=None, relu=False, d
 
 def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=False, in_slope=None, device_id=0,
                    precision="f32"):
-    """The split-exact bf16 engine (Cin % 16 == 0, Cout % 32 == 0).  planes_slope: read the result back from
-    the three bf16 output planes, which carry leaky_relu(conv, planes_slope); residual: out = conv(x) + x;
+    """The split-operand engine (Cin % 16 == 0, Cout % 32 == 0).  planes_slope: read the result back from
+    the 16-bit output planes, which carry leaky_relu(conv, planes_slope); residual: out = conv(x) + x;
     in_slope (Cin <= 64 only: the raw-input kernels): out = conv(leaky_relu(x, in_slope))."""
     lib = _ffi.load()
     x = np.ascontiguousarray(x, np.float32)
