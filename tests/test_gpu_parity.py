@@ -116,6 +116,7 @@ SX_CASES = [
     (3, 48, 32, 257, 1, 1),     # k = 1, ragged T
     (1, 64, 64, 5, 7, 1),       # sequence shorter than the kernel (raw-input path, everything is halo)
     (2, 128, 128, 31, 3, 1),    # sequence much shorter than the 256-column tile (plane-input path)
+    (1, 128, 128, 400, 11, 13), # receptive field wider than any VITS layer: 7 DMA rounds per x tile, the general DMA path
 ]
 
 
