@@ -534,36 +534,67 @@ __global__ __launch_bounds__(256) void post_conv_tanh_kernel(const float *x, con
 
 // Same tail for the split-exact generator: x is the fp32 raw layout [C/8][T][8] (conv_sx_engine.hip.hpp).
 // Same (channel, tap) summation order as above.
-__global__ __launch_bounds__(256) void post_conv_tanh_blocked_kernel(const float *x, const float *w, float *out, int C,
-                                                                     int K, int T, float slope) {
-    extern __shared__ float sm[];  // [C][256 + K - 1] staged tile, then weights [C*K]
+// KT: the tap count as a compile-time constant (7 in every VITS voice; 0 = generic): with runtime loop bounds the
+// 32 x 7 LDS reads of a thread are issued and awaited one by one.
+template <int KT>
+__global__ __launch_bounds__(256) void post_conv_tanh_blocked_kernel(const float *x, const float *__restrict__ w, float *out,
+                                                                     int C, int K, int T, float slope) {
+    extern __shared__ float sm[];  // [C][256 + K - 1] staged tile (the weights are uniform: scalar loads, no LDS)
     const int LW = 256 + K - 1;
-    float *ws = sm + (size_t)C * LW;
     int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
     const float *xb = x + (int64_t)b * C * T;
-    for (int i = tid; i < C * K; i += 256) ws[i] = w[i];
     const int pad = (K - 1) / 2;
     // one thread moves a whole cell (8 channels of one time step, 32 contiguous bytes) per round: a wave reads
     // 2 KiB of consecutive addresses
-    for (int i = tid; i < (C / 8) * LW; i += 256) {
-        const int col = i % LW, cg = i / LW;
-        const int t = t0 - pad + col;
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-        if (t >= 0 && t < T) {
-            const float4 *p = reinterpret_cast<const float4 *>(xb + ((int64_t)cg * T + t) * 8);
-            v0 = p[0];
-            v1 = p[1];
-        }
-        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    // (four rounds of loads are requested before the first is consumed: a round trip to HBM per round otherwise,
+    // and a workgroup has only ~5 rounds of work)
+    const int ncell = (C / 8) * LW;
+    for (int i0 = tid; i0 < ncell; i0 += 4 * 256) {
+        float4 v0[4], v1[4];
+        int colr[4], cgr[4];
 #pragma unroll
-        for (int e = 0; e < 8; e++) sm[(cg * 8 + e) * LW + col] = v[e] > 0.f ? v[e] : v[e] * slope;
+        for (int r = 0; r < 4; r++) {
+            const int i = i0 + r * 256;
+            cgr[r] = i / LW;
+            colr[r] = i - cgr[r] * LW;
+            const int t = t0 - pad + colr[r];
+            v0[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v1[r] = v0[r];
+            if (i < ncell && t >= 0 && t < T) {
+                const float4 *p = reinterpret_cast<const float4 *>(xb + ((int64_t)cgr[r] * T + t) * 8);
+                v0[r] = p[0];
+                v1[r] = p[1];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (i0 + r * 256 < ncell) {
+                const float v[8] = {v0[r].x, v0[r].y, v0[r].z, v0[r].w, v1[r].x, v1[r].y, v1[r].z, v1[r].w};
+#pragma unroll
+                for (int e = 0; e < 8; e++) sm[(cgr[r] * 8 + e) * LW + colr[r]] = v[e] > 0.f ? v[e] : v[e] * slope;
+            }
+        }
     }
     __syncthreads();
     int t = t0 + tid;
     if (t >= T) return;
     float acc = 0.f;
-    for (int c = 0; c < C; c++)
-        for (int k = 0; k < K; k++) acc += ws[c * K + k] * sm[c * LW + tid + k];
+    if constexpr (KT > 0) {
+        for (int c0 = 0; c0 < C; c0 += 4) {  // (C % 8 == 0 in this layout) same (channel, tap) summation order
+            float xv[4][KT];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+                for (int k = 0; k < KT; k++) xv[cc][k] = sm[(c0 + cc) * LW + tid + k];
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+                for (int k = 0; k < KT; k++) acc += w[(c0 + cc) * KT + k] * xv[cc][k];
+        }
+    } else {
+        for (int c = 0; c < C; c++)
+            for (int k = 0; k < K; k++) acc += w[c * K + k] * sm[c * LW + tid + k];
+    }
     out[(int64_t)b * T + t] = tanhf(acc);
 }
 

@@ -599,9 +599,13 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
     h->S = T;
     h->d_out = slab_take<float>(s, (size_t)B * T);
     {
-        const size_t lds = ((size_t)m.post_cin * (256 + m.post_k - 1) + (size_t)m.post_cin * m.post_k) * sizeof(float);
-        post_conv_tanh_blocked_kernel<<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out,
-                                                                                 m.post_cin, m.post_k, T, 0.01f);
+        const size_t lds = (size_t)m.post_cin * (256 + m.post_k - 1) * sizeof(float);
+        if (m.post_k == 7)
+            post_conv_tanh_blocked_kernel<7><<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out,
+                                                                                        m.post_cin, m.post_k, T, 0.01f);
+        else
+            post_conv_tanh_blocked_kernel<0><<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out,
+                                                                                        m.post_cin, m.post_k, T, 0.01f);
     }
     c.note(hipGetLastError());
     h->stats.total_launches++;
