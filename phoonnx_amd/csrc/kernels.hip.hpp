@@ -24,15 +24,18 @@ __global__ void lens_to_i32(const int64_t *in, int *out, int B, int T) {
 }
 
 // ---- a1: embedding gather * sqrt(H), transposed to [B,H,T], masked (models.py:199-205) -------
+// grid (T / 64, H / 16, B): a thread writes 16 channels of one token (a loop over all H channels per thread is one
+// long chain of dependent round trips on very few waves)
 __global__ void embed_kernel(const int64_t *ids, const int *len, const float *emb, float *x, int H, int T,
                              int n_vocab, float scale) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
     if (t >= T) return;
     int64_t id = ids[(int64_t)b * T + t];
     bool ok = t < len[b] && id >= 0 && id < n_vocab;
     const float *row = emb + id * H;
     float *o = x + (int64_t)b * H * T + t;
-    for (int c = 0; c < H; c++) o[(int64_t)c * T] = ok ? row[c] * scale : 0.f;
+    const int c0 = blockIdx.y * 16, c1 = c0 + 16 < H ? c0 + 16 : H;
+    for (int c = c0; c < c1; c++) o[(int64_t)c * T] = ok ? row[c] * scale : 0.f;
 }
 
 // ---- LayerNorm over channels (modules.py:14-26), options: GELU, accumulate, mask ------------
@@ -180,15 +183,15 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
 }
 
 // ---- a7: ConvFlow pre (1 -> C) + conditioning add: h = w*z[ch] + b + cond (modules.py:498-499,119)
+// grid (T / 256, C, B): one element per thread (a per-thread loop over the channels is a chain of C dependent
+// load -> store round trips on a handful of waves)
 __global__ void cf_pre_kernel(const float *z, int ch, const float *w, const float *bias, const float *cond,
                               float *h, int C, int T) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
     if (t >= T) return;
-    float z0 = z[((int64_t)b * 2 + ch) * T + t];
-    for (int c = 0; c < C; c++) {
-        int64_t o = ((int64_t)b * C + c) * T + t;
-        h[o] = w[c] * z0 + bias[c] + cond[o];
-    }
+    const float z0 = z[((int64_t)b * 2 + ch) * T + t];
+    const int64_t o = ((int64_t)b * C + c) * T + t;
+    h[o] = w[c] * z0 + bias[c] + cond[o];
 }
 
 // ---- a7: inverse rational-quadratic spline with linear tails (transforms.py:50-98,101-191) ----
@@ -375,7 +378,9 @@ __global__ void expand_prior_strided_kernel(const float *m_p, const float *logs_
                                             const int *len, const int *y_len, const float *noise,
                                             int64_t noise_stride, float noise_scale, float *z_p, int C, int T, int F,
                                             int Fnoise) {
-    int f = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    // grid (F / 64, C / 16, B): 16 channels of one frame per thread (the token search is repeated per channel group:
+    // eight steps, against 16 x 3 loads)
+    int f = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.z;
     if (f >= F) return;
     const int *cb = cum + (int64_t)b * T;
     int tok = -1;
@@ -389,7 +394,8 @@ __global__ void expand_prior_strided_kernel(const float *m_p, const float *logs_
         if (lo < T && lo < len[b]) tok = lo;
     }
     const float *mb = m_p + (int64_t)b * bstride, *lb = logs_p + (int64_t)b * bstride;
-    for (int c = 0; c < C; c++) {
+    const int c0 = blockIdx.y * 16, c1 = c0 + 16 < C ? c0 + 16 : C;
+    for (int c = c0; c < c1; c++) {
         float mp = 0.f, lp = 0.f;
         if (tok >= 0) {
             mp = mb[(int64_t)c * T + tok];

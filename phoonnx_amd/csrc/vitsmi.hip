@@ -358,7 +358,7 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     const int *len = h->d_len;
     h->cur_stage = 0;
     stage_mark(h, 0);
-    embed_kernel<<<dim3((T + 63) / 64, B), 64, 0, st>>>(d_ids, len, c.P(m.emb), x, H, T, m.n_vocab,
+    embed_kernel<<<dim3((T + 63) / 64, (H + 15) / 16, B), 64, 0, st>>>(d_ids, len, c.P(m.emb), x, H, T, m.n_vocab,
                                                         (float)std::sqrt((double)H));
     h->stats.total_launches += 2;
     const int64_t sHT = (int64_t)H * T;
@@ -436,7 +436,7 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
             swapped ^= 1;  // Flip (modules.py:384-391)
             const auto &cf = m.cf[f];
             int ch0 = swapped, ch1 = swapped ^ 1;
-            cf_pre_kernel<<<dim3((T + 63) / 64, B), 64, 0, st>>>(z, ch0, c.P(cf.pre_w), c.P(cf.pre_b), cond, h2, Cd, T);
+            cf_pre_kernel<<<dim3((T + 255) / 256, Cd, B), 256, 0, st>>>(z, ch0, c.P(cf.pre_w), c.P(cf.pre_b), cond, h2, Cd, T);
             h->stats.total_launches++;
             ddsconv(c, cf.convs, h2, y, y2, len, Cd, T);
             conv(c, cf.proj, h2, sC, T, pr, (int64_t)cf.proj.Cout * T, EPI_MASK, len);
@@ -746,7 +746,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
         }
     }
     // m_p / logs_p are the two halves of the proj output: channel stride T, batch stride 2*C*T
-    expand_prior_strided_kernel<<<dim3((F + 63) / 64, B), 64, 0, st>>>(h->d_mp, h->d_logs, (int64_t)2 * C * T, h->d_cum,
+    expand_prior_strided_kernel<<<dim3((F + 63) / 64, (C + 15) / 16, B), 64, 0, st>>>(h->d_mp, h->d_logs, (int64_t)2 * C * T, h->d_cum,
                                                                        len, ylen, nz, nzs, noise_scale, zp, C, T, F,
                                                                        nz == d_noise_z ? Freal : F);
     h->stats.total_launches++;
