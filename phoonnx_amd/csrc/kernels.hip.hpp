@@ -670,11 +670,26 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
     constexpr int STEPS = DKB * 16;
     const bool active = i0 < L;  // a fully padded query block only helps staging and writes zeros
     const float rsq = 1.f / sqrtf((float)dk);
+    // dk a whole number of 32-row blocks (every VITS voice: dk = 96): loads need no per-element predicate - clamped
+    // token indices keep them inside the tensor, padded keys are masked by their -1e4 logits, padded queries by the
+    // predicated store - and their addresses step by a constant (one 64-bit add per load instead of ~15 operations
+    // and a branch: the kernel is issue-bound, one wave per SIMD)
+    const bool full = dk == DKB * 32;
     float qf[STEPS];
+    if (full) {
+        const float *qp = q + (int64_t)hi * T + (i < T ? i : T - 1);
+        const int64_t two_t = 2 * (int64_t)T;
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) {
-        int d = 2 * s + hi;
-        qf[s] = (active && d < dk && i < T) ? q[(int64_t)d * T + i] * rsq : 0.f;
+        for (int s = 0; s < STEPS; s++) {
+            qf[s] = *qp * rsq;
+            qp += two_t;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            int d = 2 * s + hi;
+            qf[s] = (active && d < dk && i < T) ? q[(int64_t)d * T + i] * rsq : 0.f;
+        }
     }
     // relative-key logits of this lane's query: rq[m] = q_i . E_k[m]   (E_k staged once per workgroup: the nine
     // dk-vectors would otherwise be 9 x STEPS dependent global loads per lane in front of the first key block)
@@ -718,6 +733,18 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
     float kreg[NST], vreg[NST];
     auto fetch = [&](int kb) {
         const int j = kb * 32 + scol;
+        if (full) {
+            const int64_t off = (int64_t)srow * T + (j < T ? j : T - 1), eight_t = 8 * (int64_t)T;
+            const float *kp = k + off, *vp = v + off;
+#pragma unroll
+            for (int r = 0; r < NST; r++) {
+                kreg[r] = *kp;
+                vreg[r] = *vp;
+                kp += eight_t;
+                vp += eight_t;
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < NST; r++) {
             const int d = srow + 8 * r;
@@ -831,12 +858,13 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
     for (int m = 0; m < 9; m++) wrel[m] += __shfl_xor(wrel[m], 32);
     const bool qvalid = i < L;
     const float rl = 1.f / lrun;
+    if (i >= T) return;  // (no barrier follows)
 #pragma unroll
     for (int db = 0; db < DKB; db++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (d < dk && i < T) {
+            if (full || d < dk) {
                 float val = oacc[db][r];
 #pragma unroll
                 for (int m = 0; m < 9; m++)
