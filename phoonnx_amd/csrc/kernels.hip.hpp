@@ -132,7 +132,17 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
         const int c = cg + 8 * i;
         float x = 0.f;
         if (c < C && tv) {
-            if (DW) {
+            if (DW > 1) {
+                // tap count known at compile time (DW = K; 3 in every DDSConv): the loads of all taps and channels are
+                // in flight together instead of one round trip per (channel, tap)
+                x = dw_b[c];
+#pragma unroll
+                for (int k = 0; k < DW; k++) {
+                    const int tt = t + k * dil - pad;
+                    const float xv = (tt >= 0 && tt < T && tt < L) ? p[(int64_t)c * T + tt] : 0.f;
+                    x += dw_w[c * DW + k] * xv;
+                }
+            } else if (DW) {
                 x = dw_b[c];
                 for (int k = 0; k < K; k++) {
                     const int tt = t + k * dil - pad;

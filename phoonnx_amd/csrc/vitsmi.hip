@@ -300,7 +300,10 @@ void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const 
 void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const int *len, int C, int T) {
     for (int l = 0; l < d.n_layers; l++) {
         const auto &L = d.l[l];
-        if (C <= 256)
+        if (C <= 256 && d.K == 3)
+            ln_tile_kernel<3><<<dim3((T + 31) / 32, c.B), 256, 0, c.st>>>(hbuf, y, c.P(L.ln1_g), c.P(L.ln1_b), len, C, T,
+                                                                          LN_GELU, c.P(L.dw_w), c.P(L.dw_b), d.K, L.dil);
+        else if (C <= 256)
             ln_tile_kernel<1><<<dim3((T + 31) / 32, c.B), 256, 0, c.st>>>(hbuf, y, c.P(L.ln1_g), c.P(L.ln1_b), len, C, T,
                                                                           LN_GELU, c.P(L.dw_w), c.P(L.dw_b), d.K, L.dil);
         else
