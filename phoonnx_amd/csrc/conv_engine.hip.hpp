@@ -422,7 +422,13 @@ inline int conv_tile_n(int cfg) {
 }
 
 // largest pipeline stage (floats) a layer may use: 38 KiB (two workgroups per CU)
-inline int conv_stage_floats(int cfg) { return cfg <= 2 ? 9728 : 4864; }
+inline int conv_stage_floats(int cfg) {
+    static const int cap3 = [] {
+        const char *e = std::getenv("VITSMI_STAGE_CAP_SMALL");  // tuning experiments only (model.cpp stage_capacity)
+        return e ? std::atoi(e) : 4864;
+    }();
+    return cfg <= 2 ? 9728 : cap3;
+}
 
 template <int MW, int NW, int WM, int WN, int VEC, int ACT>
 inline hipError_t launch_conv_k(const ConvArgs &a, dim3 grid, size_t lds, hipStream_t stream) {

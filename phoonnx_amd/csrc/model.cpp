@@ -169,7 +169,13 @@ size_t stage_floats(int cfg, int K, int dil, int padL, int CK) {
     const size_t as = size_t(BM / 32) * size_t(K * CK / 8) * 256;
     return xs + as;
 }
-size_t stage_capacity(int cfg) { return cfg <= 2 ? 9728 : 4864; }  // conv_engine.hip.hpp ConvTile::STAGE_FLOATS
+size_t stage_capacity(int cfg) {  // conv_engine.hip.hpp conv_stage_floats
+    static const long cap3 = [] {
+        const char *e = std::getenv("VITSMI_STAGE_CAP_SMALL");  // tuning experiments only
+        return e ? std::atol(e) : 4864l;
+    }();
+    return cfg <= 2 ? 9728 : size_t(cap3);
+}
 
 // hint: 0 = frame/sample domain (generator), 1 = frame domain (flow), 2 = token domain (encoder, durations)
 thread_local int t_cfg_override = -1, t_ck_override = -1;  // kernel tuning only (tools/conv_bench.py)
