@@ -252,9 +252,11 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
                 xoffs[it] = (uint32_t)(((int64_t)(row >> 1) * pstride + (int64_t)(row & 1) * T + t) * 16);
                 nx_issued += __builtin_amdgcn_ballot_w64(xok[it]) != 0 ? 1 : 0;
             }
-            const u32x4 z = {0u, 0u, 0u, 0u};
-            for (uint32_t o = (uint32_t)tid * 16u; o < 2u * XB; o += 4096u) ds_write128(lds0 + o, z);
-            __syncthreads();  // the zeros are in place before the first DMA can land on a neighbouring cell
+            if (t0 - a.padL < 0 || t0 - a.padL + LW > T) {  // (uniform) only edge tiles have padding columns
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                for (uint32_t o = (uint32_t)tid * 16u; o < 2u * XB; o += 4096u) ds_write128(lds0 + o, z);
+                __syncthreads();  // the zeros are in place before the first DMA can land on a neighbouring cell
+            }
         }
     }
     // x tile of one chunk -> LDS: rows (plane, channel-group half) x LW cells; every wave issues `nit` DMAs
