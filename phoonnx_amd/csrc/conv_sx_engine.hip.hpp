@@ -470,13 +470,17 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     const bool dbg_nodma = a.flags & DBG_NO_DMA;
     ASet f0, f1;
     if constexpr (RAWIN) {
+        // the first weights are requested behind the first x tile and travel while that tile is converted (these
+        // tiles have short K loops: a second exposed round trip in the prologue is a tenth of a 32-channel k = 3 tile)
         xload(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        load_a(f0, 0);
+        wait_vm(MW * NPLA);  // in-order return: the x loads have landed, A(0) may still be in flight
         xstore(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the barrier of step 0 publishes it
-    } else
+    } else {
         issue_x(0, 0);
-    load_a(f0, 0);
+        load_a(f0, 0);
+    }
     int chunk = 0, tap = 0;
     // PROF: where a step's cycles go (s_memtime stamps; tools/conv_bench.py --sx --prof)
     unsigned long long pt = 0;
