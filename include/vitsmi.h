@@ -37,7 +37,7 @@ enum {
     VITS_E_NOMEM = -5
 };
 
-/* Stage taps for parity tests ("x","m_p","logs_p","logw","w_ceil","z_p","z"). */
+/* Stage taps for parity tests ("emb","x","m_p","logs_p","logw","w_ceil","z_p","z"). */
 #define VITS_MAX_DIMS 4
 
 /* ---- lifetime ------------------------------------------------------------------- */
@@ -145,8 +145,9 @@ int vits_last_pcm16(vits_handle *h, int normalize, float volume, int16_t *out, s
  * float32, already masked; output as vits_run. */
 int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t *sid, vits_output *out);
 
-/* Copy a stage tensor of the LAST run to host: name in {"x","m_p","logs_p","logw",
- * "w_ceil","z_p","z"}.  dims receives the shape (rank returned). buf may be NULL to
+/* Copy a stage tensor of the LAST run to host: name in {"emb","x","m_p","logs_p","logw",
+ * "w_ceil","z_p","z"}; "emb" is emb[ids] * sqrt(hidden) * mask as [B,hidden,T] (models.py:199): the integer
+ * gather, bit-exact.  dims receives the shape (rank returned). buf may be NULL to
  * query the shape only. */
 int vits_tap(vits_handle *h, const char *name, float *buf, size_t buf_elems, int64_t dims[VITS_MAX_DIMS]);
 

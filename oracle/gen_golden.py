@@ -53,6 +53,22 @@ PRESETS = {
         resblock_dilation_sizes=((1, 2), (2, 6)),
         upsample_rates=(4, 4), upsample_initial_channel=16,
         upsample_kernel_sizes=(8, 8), n_speakers=1, gin_channels=0, use_sdp=False),
+    # Generators whose channel counts are all multiples of 32: these run on the split-operand matrix-core engine
+    # (conv_sx_kernel, `vits_hparam "gen_sx"` = 1) that every full-size voice uses.  sx_rb1: a 128-channel stage in the
+    # 16-bit plane format (ResBlock1 conv pairs: planes -> planes -> residual) followed by 64- and 32-channel stages in
+    # the fp32 raw format.  sx_rb2_ms: ResBlock2 with the speaker path (dec.cond bias into conv_pre).
+    "sx_rb1": dict(
+        inter_channels=32, hidden_channels=32, filter_channels=64, n_heads=2, n_layers=2,
+        resblock="1", resblock_kernel_sizes=(3, 7),
+        resblock_dilation_sizes=((1, 3, 5), (1, 3, 5)),
+        upsample_rates=(4, 4, 2), upsample_initial_channel=256,
+        upsample_kernel_sizes=(8, 8, 4), n_speakers=1, gin_channels=0, use_sdp=True),
+    "sx_rb2_ms": dict(
+        inter_channels=32, hidden_channels=32, filter_channels=64, n_heads=2, n_layers=2,
+        resblock="2", resblock_kernel_sizes=(3, 5, 7),
+        resblock_dilation_sizes=((1, 2), (2, 6), (3, 12)),
+        upsample_rates=(4, 4, 2), upsample_initial_channel=256,
+        upsample_kernel_sizes=(8, 8, 4), n_speakers=4, gin_channels=16, use_sdp=True),
     # full-size presets (not committed; --big only)
     "medium": dict(
         resblock="2", resblock_kernel_sizes=(3, 5, 7),
@@ -70,6 +86,10 @@ PRESETS = {
         upsample_rates=(8, 8, 4), upsample_initial_channel=256,
         upsample_kernel_sizes=(16, 16, 8), n_speakers=4, gin_channels=512),
 }
+
+# metadata_props["phoneme_id_map"] of the sx_* fixtures (export_onnx.py:335-345 writes the voice's map there): a voice
+# that loads from the .onnx alone, no JSON next to it (tests: TTSVoice.load -> synthesize on the GPU)
+META_ID_MAP = {"_": 0, "^": 1, "$": 2, " ": 3, **{chr(97 + i): 4 + i for i in range(26)}, ".": 30, ",": 31, "?": 32}
 
 BASE = dict(  # lightning.py:86-106 defaults
     n_vocab=256, spec_channels=513, segment_size=32, inter_channels=192,
@@ -123,7 +143,7 @@ def build_model(torch, models, name, seed=1234):
     return m, kw
 
 
-def export_onnx(torch, m, kw, path):
+def export_onnx(torch, m, kw, path, name=""):
     """Mirror of export_onnx.py:250-327 (this container has no `onnx` package;
     the legacy exporter's only use of it is a post-step that is a no-op here)."""
     from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
@@ -158,7 +178,8 @@ def export_onnx(torch, m, kw, path):
     # metadata_props (export_onnx.py:335-350): ModelProto field 14, appended
     meta = {"model_type": "vits", "n_speakers": kw["n_speakers"], "n_vocab": kw["n_vocab"],
             "sample_rate": 22050, "alphabet": "ipa", "phoneme_type": "raw",
-            "phonemizer_model": "", "phoneme_id_map": json.dumps({}), "has_espeak": False}
+            "phonemizer_model": "", "phoneme_id_map": json.dumps(META_ID_MAP if name.startswith("sx_") else {}),
+            "has_espeak": False}
 
     def vint(v):
         out = b""
@@ -295,7 +316,7 @@ def main():
         print("preset", name)
         m, kw = build_model(torch, models, name)
         path = os.path.join(out, f"{name}.onnx")
-        export_onnx(torch, m, kw, path)
+        export_onnx(torch, m, kw, path, name)
         print("   wrote", path, os.path.getsize(path), "bytes")
         rng = np.random.default_rng(4321)
         cases = make_cases(torch, m, kw, rng, big=bool(a.big))

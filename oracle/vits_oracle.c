@@ -415,6 +415,10 @@ static int text_encoder(vo_model *m, const int64_t *ids, const int64_t *len, int
             for (int c = 0; c < H; c++)
                 x[((int64_t)b * H + c) * T + t] = t < len[b] ? emb->data[id * H + c] * sq : 0.f;
         }
+    { /* tap "emb": the integer gather itself (bit-exact row lookup, one fp32 multiply), before any float pipeline */
+        int64_t de[3] = {B, H, T};
+        memcpy(put_result(m, "emb", 3, de), x, sizeof(float) * B * H * T);
+    }
     int L = 0;
     while (T_opt(m, "enc_p.encoder.attn_layers.%d.conv_q.weight", L)) L++;
     for (int l = 0; l < L; l++) {

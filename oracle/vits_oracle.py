@@ -159,7 +159,7 @@ class VitsOracle:
         if rc != 0:
             raise RuntimeError(self.lib.vo_error(self.h).decode())
         out = {k: self._result(k) for k in
-               ("x", "m_p", "logs_p", "logw", "w_ceil", "y_lengths", "z_p", "z", "output")}
+               ("emb", "x", "m_p", "logs_p", "logw", "w_ceil", "y_lengths", "z_p", "z", "output")}
         out["y_lengths"] = out["y_lengths"].astype(np.int64)
         return out
 

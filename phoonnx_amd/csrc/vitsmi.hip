@@ -56,7 +56,7 @@ struct vits_handle {
     // last-run state (for taps / outputs)
     int B = 0, T = 0, F = 0, S = 0;
     int Fpitch = 0;  // row pitch of the frame-domain flow tensors (F rounded up to 4)
-    float *d_x = nullptr, *d_mp = nullptr, *d_logs = nullptr, *d_logw = nullptr, *d_wceil = nullptr;
+    float *d_emb = nullptr, *d_x = nullptr, *d_mp = nullptr, *d_logs = nullptr, *d_logw = nullptr, *d_wceil = nullptr;
     float *d_zp = nullptr, *d_z = nullptr, *d_out = nullptr;
     int *d_len = nullptr, *d_ylen = nullptr, *d_cum = nullptr;
     int64_t *d_ylen64 = nullptr;
@@ -331,7 +331,7 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     const size_t nHT = (size_t)B * H * T;
     const int Cdp = m.use_sdp ? m.dp_pre.Cout : m.dpp_F;
     size_t need = 0;
-    need += al(nHT) * 3;                                   // x, attn out, spare
+    need += al(nHT) * 4;                                   // x, attn out, embedding, spare
     need += al((size_t)B * 3 * H * T);                     // qkv
     need += al((size_t)B * m.FF * T);                      // ffn hidden
     need += al((size_t)B * 2 * C * T) + 2 * al((size_t)B * C * T);  // stats, m_p, logs_p
@@ -350,6 +350,10 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     h->d_ylen64 = slab_take<int64_t>(s, B);
     h->d_cum = slab_take<int>(s, (size_t)B * T);
     float *x = slab_take<float>(s, nHT), *att = slab_take<float>(s, nHT);
+    // the embedded ids keep their own buffer (tap "emb": the integer gather, checked bit for bit); layer 0 reads it
+    // and writes `x`, so nothing is copied
+    float *xe = slab_take<float>(s, nHT);
+    h->d_emb = xe;
     float *qkv = slab_take<float>(s, (size_t)B * 3 * H * T);
     float *ffh = slab_take<float>(s, (size_t)B * m.FF * T);
     float *stats = slab_take<float>(s, (size_t)B * 2 * C * T);
@@ -361,13 +365,14 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     const int *len = h->d_len;
     h->cur_stage = 0;
     stage_mark(h, 0);
-    embed_kernel<<<dim3((T + 63) / 64, (H + 15) / 16, B), 64, 0, st>>>(d_ids, len, c.P(m.emb), x, H, T, m.n_vocab,
+    embed_kernel<<<dim3((T + 63) / 64, (H + 15) / 16, B), 64, 0, st>>>(d_ids, len, c.P(m.emb), xe, H, T, m.n_vocab,
                                                         (float)std::sqrt((double)H));
     h->stats.total_launches += 2;
     const int64_t sHT = (int64_t)H * T;
+    const float *xin = xe;  // layer input: the embedding for layer 0, x afterwards
     for (auto &L : m.enc) {
         // q|k|v = 1x1 convs (attentions.py:216-218), fused into one [3H,H] GEMM
-        conv(c, L.qkv, x, sHT, T, qkv, 3 * sHT, 0);
+        conv(c, L.qkv, xin, sHT, T, qkv, 3 * sHT, 0);
         dim3 ag((T + 127) / 128, m.n_heads, B);
         int dkb = (m.dk + 31) / 32;
         switch (dkb) {
@@ -380,7 +385,8 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
         h->stats.total_launches++;
         h->stats.enc_flops += 2.0 * B * m.n_heads * (2.0 * m.dk * T * (double)T);
         // x = LN(x + conv_o(att))  (attentions.py:66-68)
-        conv(c, L.o, att, sHT, T, x, sHT, EPI_RES, nullptr, x, sHT);
+        conv(c, L.o, att, sHT, T, x, sHT, EPI_RES, nullptr, xin, sHT);
+        xin = x;
         // Padded positions never reach valid ones (keys are masked, every other op is per-position or reads
         // x*mask), so masking the LayerNorm outputs changes no observable value and lets the FFN convs read
         // their input without a ragged mask (16-byte LDS-DMA path).
@@ -1199,6 +1205,7 @@ int vits_tap(vits_handle *h, const char *name, float *buf, size_t buf_elems, int
     int64_t bstride = 0;
     int nd = 3, C = 0, L = 0, cstride = 0;
     if (k == "x") { src = h->d_x; C = m.H; L = T; bstride = (int64_t)C * L; }
+    else if (k == "emb") { src = h->d_emb; C = m.H; L = T; bstride = (int64_t)C * L; }
     else if (k == "m_p") { src = h->d_mp; C = m.C; L = T; bstride = (int64_t)2 * C * L; }
     else if (k == "logs_p") { src = h->d_logs; C = m.C; L = T; bstride = (int64_t)2 * C * L; }
     else if (k == "logw") { src = h->d_logw; C = 1; L = T; bstride = L; }

@@ -9,6 +9,10 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 TINY_PRESETS = ("tiny_rb1", "tiny_rb2_ms", "tiny_dp")
+# reference-generated voices whose generator channel counts are all multiples of 32: these run on conv_sx_kernel,
+# the split-operand matrix-core engine of every full-size voice (vits_hparam "gen_sx" == 1)
+SX_PRESETS = ("sx_rb1", "sx_rb2_ms")
+ALL_PRESETS = TINY_PRESETS + SX_PRESETS
 
 
 def pytest_configure(config):

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, TINY_PRESETS, case_get, golden_cases
+from conftest import ALL_PRESETS, GOLDEN, SX_PRESETS, TINY_PRESETS, case_get, golden_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -343,6 +343,79 @@ def test_pipeline_matches_reference_goldens(preset):
         assert r["output"].shape == ref.shape and r["output"].dtype == np.float32
         np.testing.assert_allclose(r["output"], ref, atol=WAVE_TOL, rtol=0, err_msg=f"{preset}/{c}/output")
         assert np.abs(r["output"] - ref).max() < 5e-5, "fp32 path should sit far inside the 1e-3 budget"
+    s.close()
+
+
+@pytest.mark.parametrize("precision,nprod", [("f16x3", 2), ("bf16x6", 6)])
+@pytest.mark.parametrize("preset", SX_PRESETS)
+def test_sx_generator_matches_reference_goldens(monkeypatch, preset, precision, nprod):
+    """The headline kernel pinned to the reference: these fixtures come from the reference's own PyTorch graph
+    (oracle/gen_golden.py) and their generators (256 -> 128 -> 64 -> 32 channels) run on conv_sx_kernel - plane-format
+    ResBlock pairs at 128 channels, raw-format stages below, pixel-shuffled upsamplers, the speaker bias - in BOTH
+    arithmetics.  A break in conv_sx_kernel or pack_conv_sx fails here against numbers the reference produced."""
+    monkeypatch.setenv("VITSMI_GEN_PRECISION", precision)
+    s = _session(preset)
+    assert s.hparam("gen_sx") == 1 and s.hparam("gen_nprod") == nprod
+    g = np.load(os.path.join(GOLDEN, preset + ".npz"))
+    worst = 0.0
+    for c in golden_cases(g):
+        r = s.synthesize_batch(case_get(g, c, "ids"), case_get(g, c, "lens"), case_get(g, c, "scales"),
+                               case_get(g, c, "sid"), case_get(g, c, "noise_dp"), case_get(g, c, "noise_z"), taps=TAPS)
+        assert np.array_equal(r["w_ceil"], case_get(g, c, "out_w_ceil")), (preset, c)
+        assert np.array_equal(r["y_lengths"], case_get(g, c, "out_y_lengths")), (preset, c)
+        for k in ("x", "m_p", "logs_p", "logw", "z_p", "z"):
+            np.testing.assert_allclose(r[k], case_get(g, c, "out_" + k), atol=STAGE_TOL, rtol=0, err_msg=f"{preset}/{c}/{k}")
+        ref = case_get(g, c, "out_output")
+        assert r["output"].shape == ref.shape and r["output"].dtype == np.float32
+        assert np.abs(ref).max() > 0.05                       # the comparison is not vacuous
+        err = float(np.abs(r["output"] - ref).max())
+        worst = max(worst, err)
+        assert err < WAVE_TOL, (preset, c, err)
+        assert err < 5e-5, "both full-precision arithmetics sit far inside the 1e-3 budget"
+    print(f"{preset} {precision}: worst waveform error vs the reference fixture {worst:.3g}")
+    assert s.stats()["sx_launches"] > 0                          # ... and it really ran on the sx engine
+    s.close()
+
+
+@pytest.mark.parametrize("preset", SX_PRESETS)
+def test_sx_vocoder_only_matches_reference_z(preset):
+    """BASELINE config 2 (vocoder only) on an sx voice: feed the reference's own z (already masked) to
+    vits_run_vocoder and compare with the reference's waveform."""
+    s = _session(preset)
+    g = np.load(os.path.join(GOLDEN, preset + ".npz"))
+    for c in ("b1_zero", "b3_noise"):
+        z = case_get(g, c, "out_z")
+        ylen = case_get(g, c, "out_y_lengths")
+        mask = (np.arange(z.shape[2])[None, :] < ylen[:, None]).astype(np.float32)[:, None, :]
+        got = s.vocoder(z * mask, case_get(g, c, "sid"))
+        ref = case_get(g, c, "out_output")
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, atol=5e-5, rtol=0)
+    s.close()
+
+
+@pytest.mark.parametrize("preset", ALL_PRESETS)
+def test_embedding_lookup_is_bit_exact(preset):
+    """north_star: integer phoneme id -> embedding lookup bit-exact.  Tap "emb" is emb[ids] * sqrt(hidden) * mask
+    (models.py:199): a row gather and ONE fp32 multiply, so the GPU must reproduce NumPy bit for bit."""
+    from vits_oracle import VitsOracle
+    s = _session(preset)
+    o = VitsOracle(os.path.join(GOLDEN, preset + ".onnx"))
+    emb = o.tensors["enc_p.emb.weight"]
+    V, H = emb.shape
+    rng = np.random.default_rng(77)
+    B, T = 3, 50
+    ids = rng.integers(0, V, (B, T)).astype(np.int64)
+    ids[0, :4] = [0, V - 1, 1, V - 2]                          # table edges
+    lens = np.array([T, 31, 1], np.int64)
+    sid = np.zeros(B, np.int64) if s.hparam("n_speakers") > 1 else None
+    r = s.synthesize_batch(ids, lens, np.array([0, 1, 0], np.float32), sid, taps=("emb",))
+    want = (emb[ids] * np.float32(np.sqrt(H))).transpose(0, 2, 1)
+    want = want * (np.arange(T)[None, None, :] < lens[:, None, None])
+    assert r["emb"].shape == (B, H, T) and r["emb"].dtype == np.float32
+    assert np.array_equal(r["emb"], want.astype(np.float32))
+    ro = o.infer(ids, lens, [0, 1, 0], sid)
+    assert np.array_equal(ro["emb"], r["emb"])                  # the oracle agrees bit for bit as well
     s.close()
 
 
