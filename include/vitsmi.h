@@ -34,7 +34,10 @@ enum {
     VITS_E_FORMAT = -2,    /* not a VITS graph this engine understands */
     VITS_E_ARG = -3,       /* invalid argument (shape, id out of range, missing sid, ...) */
     VITS_E_DEVICE = -4,    /* HIP error / no gfx950 device */
-    VITS_E_NOMEM = -5
+    VITS_E_NOMEM = -5,
+    VITS_E_RANGE = -6      /* f16x3 arithmetic only: an activation left the range of the fp16 operand planes (|x| > 65504,
+                              or a non-finite value entered the generator); the engine reports it instead of returning
+                              clamped audio.  Reopen with gen_precision "bf16x6" (fp32 range). */
 };
 
 /* Stage taps for parity tests ("emb","x","m_p","logs_p","logw","w_ceil","z_p","z"). */
@@ -48,8 +51,10 @@ enum {
 int vits_open(const char *onnx_path, int device_id, vits_handle **out);
 
 /* Same, but the packed weight arena is supplied by the caller (already resident on the
- * device, e.g. received by an RCCL broadcast from the rank that read the file).
- * `arena_dev` must stay valid for the life of the handle.  See vits_arena_* below. */
+ * device, e.g. received by an RCCL broadcast from the rank that read the file, or owned by
+ * another handle on the same GPU).  The file is parsed for the model description and the arena
+ * LAYOUT only: no weight is packed again.  `arena_dev` must stay valid for the life of the
+ * handle.  See vits_arena_* below. */
 int vits_open_with_arena(const char *onnx_path, int device_id, void *arena_dev, size_t arena_bytes,
                          vits_handle **out);
 
@@ -57,6 +62,23 @@ int vits_open_with_arena(const char *onnx_path, int device_id, void *arena_dev, 
  * metadata / arena / hparam calls work on such a handle.  Used by CPU-side tests and
  * by non-root ranks that only need the arena size. */
 int vits_open_host(const char *onnx_path, vits_handle **out);
+
+/* Host-only and layout-only: the model description and the arena layout (vits_arena_bytes, vits_hparam,
+ * vits_meta) without packing a single weight - exactly what vits_open_with_arena computes before it adopts the
+ * caller's device arena.  vits_arena_host() is NULL on such a handle. */
+int vits_open_layout(const char *onnx_path, vits_handle **out);
+
+/* Everything above in one call, with the generator's arithmetic chosen explicitly instead of through
+ * VITSMI_GEN_PRECISION in the environment. */
+typedef struct {
+    int device_id;
+    const char *gen_precision;  /* NULL / "": environment or default ("f16x3"); "f16x3", "bf16x6", "bf16x3", "bf16" */
+    void *arena_dev;            /* as vits_open_with_arena, or NULL */
+    size_t arena_bytes;
+    int host_only;              /* as vits_open_host */
+    int layout_only;            /* as vits_open_layout (with host_only) */
+} vits_open_options;
+int vits_open_opts(const char *onnx_path, const vits_open_options *opts, vits_handle **out);
 
 void vits_close(vits_handle *h);
 
@@ -67,7 +89,10 @@ const char *vits_last_error(vits_handle *h);
 /* ---- model description (session.get_inputs(), metadata_props) ---------------------- */
 
 int vits_num_inputs(vits_handle *h);                 /* 3, or 4 with "sid" */
-const char *vits_input_name(vits_handle *h, int i);  /* "input","input_lengths","scales"[,"sid"] */
+/* "input","input_lengths","scales"[,"sid"]; a third-party graph may also declare "langid" (voice.py:369): it is
+ * listed here so that the caller's feed filter (voice.py:373) keeps it, and ignored by the engine (a graph that
+ * really consumes a language table is rejected at open). */
+const char *vits_input_name(vits_handle *h, int i);
 
 /* metadata_props written by export_onnx.py:335-350 (sample_rate, n_speakers, ...).
  * Returns the value length, or VITS_E_ARG if the key is absent. */
@@ -76,6 +101,7 @@ int vits_meta(vits_handle *h, const char *key, char *buf, size_t n);
 /* Derived hyper-parameters: "hidden","inter","filter","n_heads","n_layers","n_vocab",
  * "n_speakers","gin","use_sdp","hop" (= product of upsample rates),"n_ups","resblock",
  * "gen_sx" (1: the generator runs on the split-operand matrix-core engine, 0: on the f32-MFMA engine),
+ * "gen_rf_frames" (one-sided receptive field of the generator in frames: the context chunked rendering adds),
  * "gen_nprod" (the generator's arithmetic, chosen by VITSMI_GEN_PRECISION in the environment at open time:
  *   2 = "f16x3", the default: fp32 operands as two fp16 planes, three MFMA products per fp32 product, fp32
  *       accumulation; error no larger than the f32-MFMA engine's,
@@ -86,7 +112,8 @@ int vits_hparam(vits_handle *h, const char *key, int64_t *out);
 /* ---- weight arena (multi-GPU: one rank reads + packs, RCCL broadcasts the bytes) ---- */
 
 size_t vits_arena_bytes(vits_handle *h);
-/* Host copy of the packed arena (valid until vits_close). */
+/* Host copy of the packed arena (valid until vits_close); NULL for a handle opened with
+ * vits_open_with_arena, which never materialises one. */
 const void *vits_arena_host(vits_handle *h);
 /* Device copy (NULL for a host-only handle). */
 void *vits_arena_device(vits_handle *h);
@@ -129,7 +156,27 @@ void vits_free_output(vits_handle *h, vits_output *out);
  * (max frame count) has completed; call vits_sync() before reading `out`. */
 int vits_run_device(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T,
                     const float scales[3], const int64_t *sid, const vits_noise *noise, vits_output *out);
+/* Waits for the handle's stream; VITS_E_RANGE if the run it completes left the fp16 planes' range. */
 int vits_sync(vits_handle *h);
+
+/* Chunked (streaming) rendering - SURVEY §8 f1; the reference renders a text sentence by sentence and hands each
+ * sentence's audio on as soon as it exists (voice.py:261-269); this does the same INSIDE an utterance batch.
+ * Encoder, duration predictor and flow run once; the generator (models.py:348-368) then renders `chunk_frames`
+ * frames at a time, each chunk together with vits_hparam "gen_rf_frames" frames of context on either side (the
+ * generator's receptive field), of which only the interior is kept: every sample is bit-identical to the one an
+ * unchunked vits_run returns.  `fn` is called once per chunk, in order, from the calling thread, while the next chunk
+ * renders: samples is host memory [B][n_samples] (row b = utterance b, valid during the call), covering samples
+ * [first_sample, first_sample + n_samples) of each row of the [B,1,1,total_samples] output; rows shorter than the
+ * longest utterance carry the generator's rendering of their padding, as in vits_run.  A non-zero return stops the
+ * run early.  Frame counts: vits_last_y_lengths().  The generator workspace is sized by the chunk, not by the
+ * utterance. */
+typedef int (*vits_chunk_fn)(void *user, const float *samples, int B, int64_t first_sample, int64_t n_samples,
+                             int64_t total_samples);
+int vits_run_chunked(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
+                     const int64_t *sid, const vits_noise *noise, int chunk_frames, vits_chunk_fn fn, void *user);
+/* ... and for the vocoder-only entry (z as in vits_run_vocoder). */
+int vits_run_vocoder_chunked(vits_handle *h, const float *z, int B, int F, const int64_t *sid, int chunk_frames,
+                             vits_chunk_fn fn, void *user);
 
 /* Frame counts of the last run, from the host copy made by the mid-pipeline readback
  * (no synchronisation).  Writes min(n, B) values, returns B. */
@@ -165,6 +212,12 @@ typedef struct {
     double sx_flops;
     float sx_ms;
     int sx_launches;
+    /* f16x3 range guard (valid after vits_sync / vits_get_stats): every launch that splits fp32 values into fp16
+     * operand planes records the largest magnitude it split.  f16_peak_max: the largest over the run (above 65504 =
+     * clamped -> f16_saturated = 1 and VITS_E_RANGE); f16_peak_min: the smallest per-launch peak (a whole tensor below
+     * ~2^-12 would lose relative precision: planes resolve 2^-36 absolute); f16_tracked: launches recorded. */
+    float f16_peak_max, f16_peak_min;
+    int f16_tracked, f16_saturated;
 } vits_stats;
 
 /* Enable per-stage HIP-event timing (adds event records on the handle's stream). */

@@ -25,11 +25,25 @@ class VitsStats(C.Structure):
                 ("dec_bytes", C.c_double), ("flow_flops", C.c_double), ("enc_flops", C.c_double),
                 ("dp_flops", C.c_double), ("conv_ms", C.c_float), ("dec_ms", C.c_float), ("flow_ms", C.c_float),
                 ("enc_ms", C.c_float), ("dp_ms", C.c_float), ("total_ms", C.c_float), ("conv_launches", C.c_int),
-                ("total_launches", C.c_int), ("sx_flops", C.c_double), ("sx_ms", C.c_float), ("sx_launches", C.c_int)]
+                ("total_launches", C.c_int), ("sx_flops", C.c_double), ("sx_ms", C.c_float), ("sx_launches", C.c_int),
+                ("f16_peak_max", C.c_float), ("f16_peak_min", C.c_float), ("f16_tracked", C.c_int),
+                ("f16_saturated", C.c_int)]
+
+
+class VitsOpenOptions(C.Structure):
+    _fields_ = [("device_id", C.c_int), ("gen_precision", C.c_char_p), ("arena_dev", C.c_void_p),
+                ("arena_bytes", C.c_size_t), ("host_only", C.c_int), ("layout_only", C.c_int)]
+
+
+# int fn(void *user, const float *samples, int B, int64 first_sample, int64 n_samples, int64 total_samples)
+CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_int64, C.c_int64)
+
+VITS_E_RANGE = -6
 
 
 EXPORTS = [
-    "vits_open", "vits_open_with_arena", "vits_open_host", "vits_close", "vits_last_error", "vits_num_inputs",
+    "vits_open", "vits_open_with_arena", "vits_open_host", "vits_open_layout", "vits_open_opts", "vits_close",
+    "vits_run_chunked", "vits_run_vocoder_chunked", "vits_last_error", "vits_num_inputs",
     "vits_input_name", "vits_meta", "vits_hparam", "vits_arena_bytes", "vits_arena_host", "vits_arena_device",
     "vits_run", "vits_free_output", "vits_run_device", "vits_sync", "vits_last_y_lengths", "vits_last_pcm16", "vits_run_vocoder",
     "vits_tap",
@@ -56,6 +70,10 @@ def load():
     lib.vits_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     lib.vits_open_with_arena.argtypes = [C.c_char_p, C.c_int, vp, C.c_size_t, C.POINTER(vp)]
     lib.vits_open_host.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.vits_open_layout.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.vits_open_opts.argtypes = [C.c_char_p, C.POINTER(VitsOpenOptions), C.POINTER(vp)]
+    lib.vits_run_chunked.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(VitsNoise), C.c_int, CHUNK_FN, vp]
+    lib.vits_run_vocoder_chunked.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, CHUNK_FN, vp]
     lib.vits_close.argtypes = [vp]
     lib.vits_close.restype = None
     lib.vits_last_error.argtypes = [vp]

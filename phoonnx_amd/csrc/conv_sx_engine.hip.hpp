@@ -84,7 +84,15 @@ struct SxArgs {
     float div, oslope, oslope2;
     float wscale;         // f16 mode: 1 / (power-of-two scale the packed weights carry), applied to the accumulators
     unsigned long long *prof;  // PROF instantiation only: cycle counters [lgkm wait, vm wait, barrier, DMA issue, loads+MFMA, steps]
+    // f16 mode range guard: 64 slots (float bits, atomicMax) that receive the largest |value| this launch splits into
+    // fp16 planes - its plane outputs and, RAWIN, its inputs after the leaky-ReLU.  nullptr = not tracked (test hooks).
+    // A peak above 65504 (or inf) means split2h_pair clamped: the run is then reported as out of range instead of
+    // returning plausible-looking audio (vits_stats::f16_peak_max / f16_saturated, VITS_E_RANGE).
+    unsigned *peak;
 };
+
+constexpr int kSxPeakSlots = 64;
+constexpr float kF16Max = 65504.f;
 
 template <int OFF>
 __device__ __forceinline__ u32x4 ds_read128(uint32_t addr) {
@@ -172,6 +180,22 @@ __device__ __forceinline__ void split2h_pair(float x, float y, unsigned &w0, uns
     const f16x2 h = __builtin_bit_cast(f16x2, w0);
     w1 = cvt_pk_f16((x - (float)h[0]) * 2048.f, (y - (float)h[1]) * 2048.f);
 }
+// ... the same, recording the largest magnitude seen (one v_max3_f32 per pair)
+__device__ __forceinline__ void split2h_pair_pk(float x, float y, unsigned &w0, unsigned &w1, float &pk) {
+    pk = __builtin_fmaxf(pk, __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y)));
+    split2h_pair(x, y, w0, w1);
+}
+// publish a wave's peak (all 64 lanes must call): wave-wide max, then one atomicMax on slot `slot` - skipped when
+// the slot already holds as much (after the first waves of a launch nearly always)
+__device__ __forceinline__ void sx_publish_peak(unsigned *slots, int slot_idx, float pk) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pk = __builtin_fmaxf(pk, __shfl_xor(pk, o, 64));
+    if ((threadIdx.x & 63) == 0) {
+        unsigned *slot = slots + (slot_idx & (kSxPeakSlots - 1));
+        const unsigned bits = __float_as_uint(pk);  // (non-negative floats order like their bit patterns; inf on top)
+        if (bits > __builtin_nontemporal_load(slot)) atomicMax(slot, bits);
+    }
+}
 __device__ __forceinline__ float f16_bits_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
 
 // Epilogue description bits beyond EPI_RES / EPI_ACC / EPI_DIV (conv_engine.hip.hpp).  The first group is
@@ -228,6 +252,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     const char *wbase = reinterpret_cast<const char *>(a.wp) + (int64_t)mt * a.nchunks * K * STEPBYTES +
                         wm * (MW * NPW * 1024);
     const int nit = a.x_bytes >> 12;           // DMA rounds of 256 cells per x tile (the stage is padded to 4 KiB)
+    float pk = 0.f;                            // f16 mode: largest |value| this thread split into fp16 planes
 
     // Fast path of the x-tile DMA (fp16 mode, plane input): which cell a lane fetches in round `it`, and whether that
     // cell lies inside the tensor, does not depend on the chunk - only the channel-group base does, and that is a
@@ -340,7 +365,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
                     unsigned p0[4], p1[4], p2[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        if constexpr (F16) split2h_pair(v[2 * e], v[2 * e + 1], p0[e], p1[e]);
+                        if constexpr (F16) split2h_pair_pk(v[2 * e], v[2 * e + 1], p0[e], p1[e], pk);
                         else split3_pair(v[2 * e], v[2 * e + 1], p0[e], p1[e], p2[e]);
                     }
                     w0 = u32x4{p0[0], p0[1], p0[2], p0[3]};
@@ -682,8 +707,8 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
                     }
                     unsigned wa[3], wb[3];
                     if constexpr (F16) {
-                        split2h_pair(o[0], o[1], wa[0], wa[1]);
-                        split2h_pair(o[2], o[3], wb[0], wb[1]);
+                        split2h_pair_pk(o[0], o[1], wa[0], wa[1], pk);
+                        split2h_pair_pk(o[2], o[3], wb[0], wb[1], pk);
                     } else {
                         split3_pair(o[0], o[1], wa[0], wa[1], wa[2]);
                         split3_pair(o[2], o[3], wb[0], wb[1], wb[2]);
@@ -695,6 +720,9 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
             }
         }
     });
+    if constexpr (F16) {
+        if (a.peak) sx_publish_peak(a.peak, (int)blockIdx.x, pk);  // (uniform branch)
+    }
 }
 
 // sx tile configs: index -> (BM, BN, waves WM x WN, blocks per wave MW x NW):
@@ -830,48 +858,60 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
 
 // planar fp32 x[b][c][t] (row pitch `pitch`, optionally masked by t < len[b]) -> planes [3][C/8][T][8]
 // (f16 != 0: two fp16 planes in the same addressing, plane 2 untouched)
+// peak (f16 only, may be nullptr): 64 range-guard slots as in SxArgs::peak.  This is where tensors ENTER the split
+// engine (the generator's z, the flow's WN input), so non-finite values are caught here too: NaN counts as inf.
 __global__ __launch_bounds__(256) void sx_split_planes_kernel(const float *x, int64_t x_bstride, int pitch, const int *len,
-                                                              uint16_t *out, int C, int T, int f16 = 0) {
+                                                              uint16_t *out, int C, int T, int f16 = 0, unsigned *peak = nullptr) {
     const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
-    if (t >= T) return;
-    const bool live = !len || t < len[b];
-    const float *xb = x + (int64_t)b * x_bstride + (int64_t)cg * 8 * pitch + t;
-    unsigned short p[3][8];
+    float pk = 0.f;
+    if (t < T) {
+        const bool live = !len || t < len[b];
+        const float *xb = x + (int64_t)b * x_bstride + (int64_t)cg * 8 * pitch + t;
+        unsigned short p[3][8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const float v = live ? xb[(int64_t)e * pitch] : 0.f;
-        if (f16) {
-            const float vc = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
-            const _Float16 h0 = (_Float16)vc, h1 = (_Float16)((vc - (float)h0) * 2048.f);
-            p[0][e] = __builtin_bit_cast(unsigned short, h0);
-            p[1][e] = __builtin_bit_cast(unsigned short, h1);
-            p[2][e] = 0;
-        } else
-            split3(v, p[0][e], p[1][e], p[2][e]);
-    }
-    const int CG = C >> 3;
-    uint16_t *ob = out + (int64_t)b * 3 * CG * T * 8;
+        for (int e = 0; e < 8; e++) {
+            const float v = live ? xb[(int64_t)e * pitch] : 0.f;
+            if (f16) {
+                pk = !(__builtin_fabsf(v) <= kF16Max) ? __builtin_inff() : __builtin_fmaxf(pk, __builtin_fabsf(v));
+                const float vc = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+                const _Float16 h0 = (_Float16)vc, h1 = (_Float16)((vc - (float)h0) * 2048.f);
+                p[0][e] = __builtin_bit_cast(unsigned short, h0);
+                p[1][e] = __builtin_bit_cast(unsigned short, h1);
+                p[2][e] = 0;
+            } else
+                split3(v, p[0][e], p[1][e], p[2][e]);
+        }
+        const int CG = C >> 3;
+        uint16_t *ob = out + (int64_t)b * 3 * CG * T * 8;
 #pragma unroll
-    for (int pl = 0; pl < (f16 ? 2 : 3); pl++) {
-        u32x4 w;
-        w.x = (unsigned)p[pl][0] | ((unsigned)p[pl][1] << 16);
-        w.y = (unsigned)p[pl][2] | ((unsigned)p[pl][3] << 16);
-        w.z = (unsigned)p[pl][4] | ((unsigned)p[pl][5] << 16);
-        w.w = (unsigned)p[pl][6] | ((unsigned)p[pl][7] << 16);
-        *reinterpret_cast<u32x4 *>(ob + (((int64_t)pl * CG + cg) * T + t) * 8) = w;
+        for (int pl = 0; pl < (f16 ? 2 : 3); pl++) {
+            u32x4 w;
+            w.x = (unsigned)p[pl][0] | ((unsigned)p[pl][1] << 16);
+            w.y = (unsigned)p[pl][2] | ((unsigned)p[pl][3] << 16);
+            w.z = (unsigned)p[pl][4] | ((unsigned)p[pl][5] << 16);
+            w.w = (unsigned)p[pl][6] | ((unsigned)p[pl][7] << 16);
+            *reinterpret_cast<u32x4 *>(ob + (((int64_t)pl * CG + cg) * T + t) * 8) = w;
+        }
     }
+    if (f16 && peak) sx_publish_peak(peak, (int)(blockIdx.x + blockIdx.y + blockIdx.z), pk);  // (uniform: whole waves)
 }
 
 // planar fp32 x[b][c][t] (row pitch `pitch`, optionally masked by t < len[b]) -> raw fp32 [C/8][T][8]
 __global__ __launch_bounds__(256) void sx_block_kernel(const float *x, int64_t x_bstride, int pitch, const int *len,
-                                                       float *raw, int C, int T) {
+                                                       float *raw, int C, int T, unsigned *peak = nullptr) {
     const int t = blockIdx.x * 256 + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
-    if (t >= T) return;
-    const bool live = !len || t < len[b];
-    const float *xb = x + (int64_t)b * x_bstride + (int64_t)cg * 8 * pitch + t;
+    float pk = 0.f;  // range guard of the f16 arithmetic (see sx_split_planes_kernel): this tensor enters a raw-input conv
+    if (t < T) {
+        const bool live = !len || t < len[b];
+        const float *xb = x + (int64_t)b * x_bstride + (int64_t)cg * 8 * pitch + t;
 #pragma unroll
-    for (int e = 0; e < 8; e++)
-        raw[(int64_t)b * C * T + ((int64_t)cg * T + t) * 8 + e] = live ? xb[(int64_t)e * pitch] : 0.f;
+        for (int e = 0; e < 8; e++) {
+            const float v = live ? xb[(int64_t)e * pitch] : 0.f;
+            pk = !(__builtin_fabsf(v) <= kF16Max) ? __builtin_inff() : __builtin_fmaxf(pk, __builtin_fabsf(v));
+            raw[(int64_t)b * C * T + ((int64_t)cg * T + t) * 8 + e] = v;
+        }
+    }
+    if (peak) sx_publish_peak(peak, (int)(blockIdx.x + blockIdx.y + blockIdx.z), pk);  // (uniform: whole waves)
 }
 
 // raw fp32 [C/8][T][8] (or, with planes != nullptr, the sum of the three planes) -> planar [C][T]

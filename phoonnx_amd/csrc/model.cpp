@@ -33,6 +33,14 @@ struct Resolver {
 
     void put(const std::string &name, const OnnxTensor *ot) {
         if (!ot || !ot->data() || t.count(name)) return;
+        // every parameter is finite: with that, a NaN / inf can only enter a run through its inputs, where the engine
+        // checks for it (the f16 range guard of the generator relies on this)
+        {
+            const float *p = ot->data();
+            const int64_t n = ot->numel();
+            for (int64_t i = 0; i < n; i++)
+                if (!std::isfinite(p[i])) throw std::runtime_error("non-finite value in parameter " + name);
+        }
         TRef r;
         r.p = ot->data();
         r.dims = ot->dims;
@@ -46,6 +54,24 @@ struct Resolver {
         auto it = t.find(name);
         if (it == t.end()) throw std::runtime_error("parameter not found in graph: " + name);
         return it->second;
+    }
+    // a required tensor whose shape is checked before anything indexes dims[] or copies `numel` floats out of it:
+    // shapes in a downloaded voice file are untrusted input
+    const TRef &need(const std::string &name, size_t rank, int64_t want_numel = -1) const {
+        const TRef &r = req(name);
+        if (r.dims.size() != rank) throw std::runtime_error(name + ": expected rank " + std::to_string(rank));
+        for (auto d : r.dims)
+            if (d <= 0) throw std::runtime_error(name + ": empty dimension");
+        if (want_numel >= 0 && r.numel() != want_numel)
+            throw std::runtime_error(name + ": expected " + std::to_string(want_numel) + " values, file has " +
+                                     std::to_string(r.numel()));
+        return r;
+    }
+    // optional bias of `n` values
+    const TRef *bias_of(const std::string &name, int64_t n) const {
+        const TRef *b = get(name);
+        if (b && b->numel() != n) throw std::runtime_error(name + ": expected " + std::to_string(n) + " values");
+        return b;
     }
     int64_t geti(const std::string &k, int64_t d) const {
         auto it = ints.find(k);
@@ -137,17 +163,23 @@ void resolve(const OnnxModel &om, Resolver &R) {
 
 // ---------------------------------------------------------------------------------- packing
 
+// `dry`: lay the arena out (offsets, descriptors, total size) without materialising a single weight: what a handle
+// needs when the packed bytes already sit on its GPU (vits_open_with_arena: RCCL-broadcast weights, or a second
+// handle sharing the first one's arena).
 struct Packer {
     std::vector<float> &arena;
-    explicit Packer(std::vector<float> &a) : arena(a) {}
+    const bool dry;
+    int64_t size = 0;  // floats laid out so far (== arena.size() unless dry)
+    explicit Packer(std::vector<float> &a, bool dry_ = false) : arena(a), dry(dry_), size(int64_t(a.size())) {}
     int64_t alloc(int64_t n) {
-        int64_t off = int64_t((arena.size() + 63) / 64 * 64);  // 256-byte alignment
-        arena.resize(size_t(off + n), 0.f);
+        int64_t off = (size + 63) / 64 * 64;  // 256-byte alignment
+        size = off + n;
+        if (!dry) arena.resize(size_t(size), 0.f);
         return off;
     }
     int64_t put(const float *p, int64_t n) {
         int64_t off = alloc(n);
-        std::memcpy(arena.data() + off, p, size_t(n) * 4);
+        if (!dry) std::memcpy(arena.data() + off, p, size_t(n) * 4);
         return off;
     }
     int64_t put(const TRef &r) { return put(r.p, r.numel()); }
@@ -236,6 +268,9 @@ ConvDesc pack_conv(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF w,
     d.mblocks = (Cout + bm - 1) / bm * (bm / 32);
     int64_t per_block = int64_t(d.nchunks * K * d.CK / 8) * 64 * 4;  // float4 groups x lanes x 4
     d.w_off = P.alloc(per_block * d.mblocks);
+    if (bias_virtual) d.b_off = P.put(bias_virtual, Cout);
+    d.macs_per_t = double(Cin) * Cout * K;
+    if (P.dry) return d;
     float *dst = P.arena.data() + d.w_off;
     int half = d.CK / 2;
     // Layout: Wp[m-tile][chunk][block-in-tile][group][lane][4]: the A slab one workgroup needs for one
@@ -254,19 +289,18 @@ ConvDesc pack_conv(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF w,
                         g[lane * 4] = (co < Cout && ci < Cin) ? w(co, ci, tap) : 0.f;
                     }
                 }
-    if (bias_virtual) d.b_off = P.put(bias_virtual, Cout);
-    d.macs_per_t = double(Cin) * Cout * K;
     return d;
 }
 
 // plain Conv1d module "<name>": weight [Cout, Cin, K]
 ConvDesc pack_named(Packer &P, const Resolver &R, const std::string &name, int dil, int padL,
                     const std::vector<int> *in_perm = nullptr, const std::vector<int> *out_perm = nullptr) {
-    const TRef &w = R.req(name + ".weight");
-    if (w.dims.size() != 3) throw std::runtime_error(name + ".weight is not rank 3");
+    const TRef &w = R.need(name + ".weight", 3);
     int Cout = int(w.dims[0]), Cin = int(w.dims[1]), K = int(w.dims[2]);
     if (R.geti(name + ".group", 1) != 1) throw std::runtime_error(name + ": grouped conv not expected here");
-    const TRef *b = R.get(name + ".bias");
+    const TRef *b = R.bias_of(name + ".bias", Cout);
+    if ((in_perm && int(in_perm->size()) != Cin) || (out_perm && int(out_perm->size()) != Cout))
+        throw std::runtime_error(name + ": channel count does not match the coupling layer's half width");
     const float *wp = w.p;
     auto wf = [&](int co, int ci, int tap) {
         int so = out_perm ? (*out_perm)[co] : co;
@@ -286,7 +320,7 @@ ConvDesc pack_named(Packer &P, const Resolver &R, const std::string &name, int d
 // ConvTranspose1d [Cin, Cout, K], stride u, padding p  ->  dense conv with Cout*u virtual
 // channels (co' = co*u + r) over taps o_min..o_max and a pixel-shuffle store.
 ConvDesc pack_convT(Packer &P, const Resolver &R, const std::string &name) {
-    const TRef &w = R.req(name + ".weight");
+    const TRef &w = R.need(name + ".weight", 3);
     int Cin = int(w.dims[0]), Cout = int(w.dims[1]), K = int(w.dims[2]);
     int u = int(R.geti(name + ".stride", -1));
     int p = int(R.geti(name + ".pad", -1));
@@ -311,7 +345,7 @@ ConvDesc pack_convT(Packer &P, const Resolver &R, const std::string &name) {
         return wp[(int64_t(ci) * Cout + co) * K + j];
     };
     std::vector<float> bv;
-    const TRef *b = R.get(name + ".bias");
+    const TRef *b = R.bias_of(name + ".bias", Cout);
     if (b) {
         bv.resize(size_t(Cout) * u);
         for (int c = 0; c < Cout * u; c++) bv[c] = b->p[c / u];
@@ -365,7 +399,8 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     const int npw = t_sx_f16 ? 2 : 3;                              // planes per 32-row block
     const int64_t kib = int64_t(d.mblocks) * d.nchunks * K * npw;  // 1 KiB = one (block, plane) fragment set
     d.w_off = P.alloc(kib * 256);
-    uint16_t *dst = reinterpret_cast<uint16_t *>(P.arena.data() + d.w_off);
+    if (bias_virtual) d.b_off = P.put(bias_virtual, Cout);
+    d.macs_per_t = double(Cin) * Cout * Kreal;
     float wmul = 1.f;
     if (t_sx_f16) {
         // per-tensor power of two that lifts the largest weight into [2^14, 2^15): both fp16 planes of every weight
@@ -383,6 +418,8 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
         d.f16 = true;
         d.wscale = std::ldexp(1.f, e - 15);
     }
+    if (P.dry) return d;
+    uint16_t *dst = reinterpret_cast<uint16_t *>(P.arena.data() + d.w_off);
     for (int mb = 0; mb < d.mblocks; mb++)
         for (int chunk = 0; chunk < d.nchunks; chunk++)
             for (int tap = 0; tap < K; tap++) {
@@ -396,17 +433,14 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
                         for (int pl = 0; pl < npw; pl++) dst[(base + pl) * 512 + lane * 8 + i] = p[pl];
                     }
             }
-    if (bias_virtual) d.b_off = P.put(bias_virtual, Cout);
-    d.macs_per_t = double(Cin) * Cout * Kreal;
     return d;
 }
 
 ConvDesc pack_named_sx(Packer &P, const Resolver &R, const std::string &name, int dil, int padL) {
-    const TRef &w = R.req(name + ".weight");
-    if (w.dims.size() != 3) throw std::runtime_error(name + ".weight is not rank 3");
+    const TRef &w = R.need(name + ".weight", 3);
     int Cout = int(w.dims[0]), Cin = int(w.dims[1]), K = int(w.dims[2]);
     if (R.geti(name + ".group", 1) != 1) throw std::runtime_error(name + ": grouped conv not expected here");
-    const TRef *b = R.get(name + ".bias");
+    const TRef *b = R.bias_of(name + ".bias", Cout);
     const float *wp = w.p;
     auto wf = [&](int co, int ci, int tap) { return wp[(int64_t(co) * Cin + ci) * K + tap]; };
     return pack_conv_sx(P, Cin, Cout, K, dil, padL, wf, b ? b->p : nullptr);
@@ -417,7 +451,7 @@ struct ConvTGeom {
     int Cin, Cout, K, u, p, o_min, o_max;
 };
 ConvTGeom convt_geom(const Resolver &R, const std::string &name) {
-    const TRef &w = R.req(name + ".weight");
+    const TRef &w = R.need(name + ".weight", 3);
     ConvTGeom g;
     g.Cin = int(w.dims[0]);
     g.Cout = int(w.dims[1]);
@@ -453,7 +487,7 @@ ConvDesc pack_convT_sx(Packer &P, const Resolver &R, const std::string &name) {
         return wp[(int64_t(ci) * g.Cout + co) * g.K + j];
     };
     std::vector<float> bv;
-    const TRef *b = R.get(name + ".bias");
+    const TRef *b = R.bias_of(name + ".bias", g.Cout);
     if (b) {
         bv.resize(size_t(g.Cout) * g.u);
         for (int c = 0; c < g.Cout * g.u; c++) bv[c] = b->p[c % g.Cout];
@@ -471,21 +505,24 @@ DDSDesc pack_dds(Packer &P, const Resolver &R, const std::string &pfx) {
     DDSDesc d;
     for (int l = 0; l < 4; l++) {
         std::string s = pfx + ".convs_sep." + std::to_string(l);
-        const TRef *w = R.get(s + ".weight");
-        if (!w) break;
+        if (!R.get(s + ".weight")) break;
+        const TRef *w = &R.need(s + ".weight", 3);  // depthwise [C, 1, K]
+        if (w->dims[1] != 1) throw std::runtime_error(s + ": depthwise conv expected");
+        const int64_t Cd = w->dims[0];
         d.n_layers = l + 1;
         d.K = int(w->dims[2]);
         auto &L = d.l[l];
         L.dw_w = P.put(*w);
-        L.dw_b = P.put(R.req(s + ".bias"));
+        L.dw_b = P.put(R.need(s + ".bias", 1, Cd));
         int dil = 1;
         for (int i = 0; i < l; i++) dil *= d.K;  // modules.py:101
         L.dil = int(R.geti(s + ".dilation", dil));
-        L.ln1_g = P.put(R.req(pfx + ".norms_1." + std::to_string(l) + ".gamma"));
-        L.ln1_b = P.put(R.req(pfx + ".norms_1." + std::to_string(l) + ".beta"));
-        L.ln2_g = P.put(R.req(pfx + ".norms_2." + std::to_string(l) + ".gamma"));
-        L.ln2_b = P.put(R.req(pfx + ".norms_2." + std::to_string(l) + ".beta"));
+        L.ln1_g = P.put(R.need(pfx + ".norms_1." + std::to_string(l) + ".gamma", 1, Cd));
+        L.ln1_b = P.put(R.need(pfx + ".norms_1." + std::to_string(l) + ".beta", 1, Cd));
+        L.ln2_g = P.put(R.need(pfx + ".norms_2." + std::to_string(l) + ".gamma", 1, Cd));
+        L.ln2_b = P.put(R.need(pfx + ".norms_2." + std::to_string(l) + ".beta", 1, Cd));
         L.pw = pack_named(P, R, pfx + ".convs_1x1." + std::to_string(l), 1, 0);
+        if (L.pw.Cin != Cd || L.pw.Cout != Cd) throw std::runtime_error(pfx + ": 1x1 conv does not match the depthwise width");
     }
     if (!d.n_layers) throw std::runtime_error("no DDSConv layers under " + pfx);
     return d;
@@ -566,6 +603,18 @@ void split2h_host(float v, uint16_t p[3]) {
 
 void set_sx_f16(bool on) { t_sx_f16 = on; }
 
+// Arithmetic of the split-operand convs for the opens that follow on this thread: an explicit choice
+// (vits_open_opts) wins over VITSMI_GEN_PRECISION in the environment; nullptr / "" = the default (f16x3).
+thread_local std::string t_precision_override;
+thread_local bool t_precision_set = false;
+void set_gen_precision_override(const char *name) {
+    t_precision_set = name != nullptr;
+    t_precision_override = name ? name : "";
+}
+const char *gen_precision_name() {
+    return t_precision_set ? t_precision_override.c_str() : std::getenv("VITSMI_GEN_PRECISION");
+}
+
 bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil) {
     if (Cin < 16 || Cin % 16 || Cout_virtual % 32 || Cr % 32 || K < 1 || dil < 1) return false;
     const int cfg = sx_pick_cfg(Cout_virtual);
@@ -623,19 +672,29 @@ std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout
     return "";
 }
 
-std::string Model::build(const OnnxModel &om) {
+std::string Model::build(const OnnxModel &om, bool layout_only) {
     t_sx_f16 = false;
     try {
         Resolver R;
         resolve(om, R);
-        Packer P(arena);
+        arena.clear();
+        Packer P(arena, layout_only);
         zeros_off = P.alloc(1024);  // zero page: padding source of the conv engine's LDS-DMA
         input_names = om.inputs;
         meta = om.meta;
+        // Graph inputs (voice.py:347-373 filters its feed by these names).  "langid" appears in third-party
+        // multi-lingual exports (voice.py:369): it is accepted when nothing in the graph consumes a language table
+        // this engine would have to apply; anything else is not a graph this engine understands.
+        for (const auto &n : input_names)
+            if (n != "input" && n != "input_lengths" && n != "scales" && n != "sid" && n != "langid")
+                throw std::runtime_error("unsupported graph input '" + n + "'");
+        for (const auto &kv : R.t)
+            if (kv.first.find("emb_l") != std::string::npos || kv.first.find("emb_lang") != std::string::npos)
+                throw std::runtime_error("language-embedding conditioned voices are not supported (" + kv.first + ")");
 
         // ---------------- text encoder (models.py:168-209, attentions.py)
         t_hint = 2;
-        const TRef &embw = R.req("enc_p.emb.weight");
+        const TRef &embw = R.need("enc_p.emb.weight", 2);
         n_vocab = int(embw.dims[0]);
         H = int(embw.dims[1]);
         emb = P.put(embw);
@@ -643,10 +702,13 @@ std::string Model::build(const OnnxModel &om) {
             std::string a = "enc_p.encoder.attn_layers." + std::to_string(l);
             if (!R.get(a + ".conv_q.weight")) break;
             EncLayerDesc L;
-            const TRef &wq = R.req(a + ".conv_q.weight"), &wk = R.req(a + ".conv_k.weight"),
-                       &wv = R.req(a + ".conv_v.weight");
-            const TRef &bq = R.req(a + ".conv_q.bias"), &bk = R.req(a + ".conv_k.bias"), &bv = R.req(a + ".conv_v.bias");
-            if (wq.dims[2] != 1) throw std::runtime_error("attention projections must be 1x1");
+            const int64_t HH = int64_t(H) * H;
+            const TRef &wq = R.need(a + ".conv_q.weight", 3, HH), &wk = R.need(a + ".conv_k.weight", 3, HH),
+                       &wv = R.need(a + ".conv_v.weight", 3, HH);
+            const TRef &bq = R.need(a + ".conv_q.bias", 1, H), &bk = R.need(a + ".conv_k.bias", 1, H),
+                       &bv = R.need(a + ".conv_v.bias", 1, H);
+            if (wq.dims[0] != H || wq.dims[2] != 1 || wk.dims[0] != H || wv.dims[0] != H)
+                throw std::runtime_error("attention projections must be 1x1 convs of the hidden width");
             // fused q|k|v projection: one [3H, H, 1] conv
             const float *ws[3] = {wq.p, wk.p, wv.p};
             int Hh = H;
@@ -657,32 +719,41 @@ std::string Model::build(const OnnxModel &om) {
             std::memcpy(b3.data() + 2 * H, bv.p, size_t(H) * 4);
             L.qkv = pack_conv(P, H, 3 * H, 1, 1, 0, wf, b3.data());
             L.o = pack_named(P, R, a + ".conv_o", 1, 0);
-            const TRef &rk = R.req(a + ".emb_rel_k"), &rv = R.req(a + ".emb_rel_v");
+            const TRef &rk = R.need(a + ".emb_rel_k", 3);
             if (rk.dims[0] != 1) throw std::runtime_error("per-head relative embeddings are unsupported");
-            window = int(rk.dims[1] - 1) / 2;
-            dk = int(rk.dims[2]);
+            if (rk.dims[1] % 2 != 1) throw std::runtime_error(a + ".emb_rel_k: expected 2*window+1 rows");
+            const int dk_l = int(rk.dims[2]), window_l = int(rk.dims[1] - 1) / 2;
+            if (dk_l <= 0 || H % dk_l) throw std::runtime_error(a + ": head width does not divide the hidden width");
+            if (l > 0 && (dk_l != dk || window_l != window)) throw std::runtime_error(a + ": attention layers differ in shape");
+            const TRef &rv = R.need(a + ".emb_rel_v", 3, rk.numel());
+            window = window_l;
+            dk = dk_l;
             n_heads = H / dk;
             L.rel_k = P.put(rk);
             L.rel_v = P.put(rv);
-            L.ln1_g = P.put(R.req("enc_p.encoder.norm_layers_1." + std::to_string(l) + ".gamma"));
-            L.ln1_b = P.put(R.req("enc_p.encoder.norm_layers_1." + std::to_string(l) + ".beta"));
-            L.ln2_g = P.put(R.req("enc_p.encoder.norm_layers_2." + std::to_string(l) + ".gamma"));
-            L.ln2_b = P.put(R.req("enc_p.encoder.norm_layers_2." + std::to_string(l) + ".beta"));
+            L.ln1_g = P.put(R.need("enc_p.encoder.norm_layers_1." + std::to_string(l) + ".gamma", 1, H));
+            L.ln1_b = P.put(R.need("enc_p.encoder.norm_layers_1." + std::to_string(l) + ".beta", 1, H));
+            L.ln2_g = P.put(R.need("enc_p.encoder.norm_layers_2." + std::to_string(l) + ".gamma", 1, H));
+            L.ln2_b = P.put(R.need("enc_p.encoder.norm_layers_2." + std::to_string(l) + ".beta", 1, H));
+            if (L.o.Cin != H || L.o.Cout != H) throw std::runtime_error(a + ".conv_o: unexpected shape");
             std::string f = "enc_p.encoder.ffn_layers." + std::to_string(l);
-            const TRef &w1 = R.req(f + ".conv_1.weight");
+            const TRef &w1 = R.need(f + ".conv_1.weight", 3);
             int fk = int(w1.dims[2]);
             FF = int(w1.dims[0]);
             L.ffn1 = pack_named(P, R, f + ".conv_1", 1, (fk - 1) / 2);  // attentions.py:419-427
             L.ffn2 = pack_named(P, R, f + ".conv_2", 1, (fk - 1) / 2);
+            if (L.ffn1.Cin != H || L.ffn2.Cin != FF || L.ffn2.Cout != H) throw std::runtime_error(f + ": unexpected FFN shape");
             enc.push_back(L);
         }
         n_layers = int(enc.size());
         if (!n_layers) throw std::runtime_error("no encoder attention layers found");
         enc_proj = pack_named(P, R, "enc_p.proj", 1, 0);
+        if (enc_proj.Cin != H || enc_proj.K != 1 || enc_proj.Cout % 2) throw std::runtime_error("enc_p.proj: unexpected shape");
         C = enc_proj.Cout / 2;
 
         // ---------------- speaker embedding (models.py:614-615)
-        if (const TRef *eg = R.get("emb_g.weight")) {
+        if (R.get("emb_g.weight")) {
+            const TRef *eg = &R.need("emb_g.weight", 2);
             n_speakers = int(eg->dims[0]);
             gin = int(eg->dims[1]);
             emb_g = P.put(*eg);
@@ -697,32 +768,45 @@ std::string Model::build(const OnnxModel &om) {
             int order[3] = {7, 5, 3};  // models.py:109-110
             for (int i = 0; i < 3; i++) {
                 std::string s = "dp.flows." + std::to_string(order[i]);
-                cf[i].pre_w = P.put(R.req(s + ".pre.weight"));
-                cf[i].pre_b = P.put(R.req(s + ".pre.bias"));
+                const int Cd = dp_pre.Cout;
+                cf[i].pre_w = P.put(R.need(s + ".pre.weight", 3, Cd));  // Conv1d(1, C, 1)
+                cf[i].pre_b = P.put(R.need(s + ".pre.bias", 1, Cd));
                 cf[i].convs = pack_dds(P, R, s + ".convs");
                 cf[i].proj = pack_named(P, R, s + ".proj", 1, 0);
+                if (cf[i].proj.Cin != Cd || cf[i].convs.l[0].pw.Cin != Cd || (cf[i].proj.Cout + 1) % 3)
+                    throw std::runtime_error(s + ": unexpected ConvFlow shape");
                 cf[i].nb = (cf[i].proj.Cout + 1) / 3;
-                if (cf[i].nb > 16) throw std::runtime_error("spline with more than 16 bins is unsupported");
+                if (cf[i].nb < 1 || cf[i].nb > 16) throw std::runtime_error("spline with more than 16 bins is unsupported");
             }
+            if (dp_pre.Cin != H || dp_proj.Cin != dp_pre.Cout || dp_proj.Cout != dp_pre.Cout ||
+                dp_convs.l[0].pw.Cin != dp_pre.Cout)
+                throw std::runtime_error("dp: unexpected stochastic duration predictor shape");
+            if (R.req("dp.flows.0.m").numel() < 1 || R.req("dp.flows.0.logs").numel() < 1)
+                throw std::runtime_error("dp.flows.0: empty ElementwiseAffine parameters");
             ea_m0 = R.req("dp.flows.0.m").p[0];
             ea_logs0 = R.req("dp.flows.0.logs").p[0];
         } else {
-            const TRef &w1 = R.req("dp.conv_1.weight");
+            const TRef &w1 = R.need("dp.conv_1.weight", 3);
             int k = int(w1.dims[2]);
             dpp_F = int(w1.dims[0]);
             dpp_conv1 = pack_named(P, R, "dp.conv_1", 1, k / 2);  // models.py:138-144
             dpp_conv2 = pack_named(P, R, "dp.conv_2", 1, k / 2);
             dpp_proj = pack_named(P, R, "dp.proj", 1, 0);
-            dpp_n1_g = P.put(R.req("dp.norm_1.gamma"));
-            dpp_n1_b = P.put(R.req("dp.norm_1.beta"));
-            dpp_n2_g = P.put(R.req("dp.norm_2.gamma"));
-            dpp_n2_b = P.put(R.req("dp.norm_2.beta"));
+            dpp_n1_g = P.put(R.need("dp.norm_1.gamma", 1, dpp_F));
+            dpp_n1_b = P.put(R.need("dp.norm_1.beta", 1, dpp_F));
+            dpp_n2_g = P.put(R.need("dp.norm_2.gamma", 1, dpp_F));
+            dpp_n2_b = P.put(R.need("dp.norm_2.beta", 1, dpp_F));
+            if (dpp_conv1.Cin != H || dpp_conv2.Cin != dpp_F || dpp_conv2.Cout != dpp_F || dpp_proj.Cin != dpp_F ||
+                dpp_proj.Cout != 1)
+                throw std::runtime_error("dp: unexpected duration predictor shape");
         }
         if (gin) {
-            const TRef &cw = R.req("dp.cond.weight");
+            const TRef &cw = R.need("dp.cond.weight", 3);
             dp_cond_rows = int(cw.dims[0]);
+            if (cw.dims[1] != gin || cw.dims[2] != 1 || dp_cond_rows != (use_sdp ? dp_pre.Cout : H))
+                throw std::runtime_error("dp.cond: unexpected shape");
             dp_cond_w = P.put(cw);
-            dp_cond_b = P.put(R.req("dp.cond.bias"));
+            dp_cond_b = P.put(R.need("dp.cond.bias", 1, dp_cond_rows));
         }
 
         // ---------------- flow (models.py:212-254), Flip folded into channel permutations
@@ -742,20 +826,25 @@ std::string Model::build(const OnnxModel &om) {
                 cd.pre = pack_named(P, R, s + ".pre", 1, 0, cd.swapped ? &rev : nullptr, nullptr);
                 cd.post = pack_named(P, R, s + ".post", 1, 0, nullptr, cd.swapped ? &rev : nullptr);
                 if (cd.post.Cout != half) throw std::runtime_error("only mean_only coupling layers are supported");
+                if (cd.pre.Cin != half || cd.pre.K != 1 || cd.post.K != 1 || cd.post.Cin != cd.pre.Cout ||
+                    (e > 0 && cd.pre.Cout != flow_H))
+                    throw std::runtime_error(s + ": unexpected coupling layer shape");
                 flow_H = cd.pre.Cout;
                 for (int i = 0; i < 8; i++) {
                     std::string in = s + ".enc.in_layers." + std::to_string(i);
-                    const TRef *w = R.get(in + ".weight");
-                    if (!w) break;
+                    if (!R.get(in + ".weight")) break;
+                    const TRef *w = &R.need(in + ".weight", 3);
+                    if (w->dims[0] != 2 * flow_H || w->dims[1] != flow_H) throw std::runtime_error(in + ": unexpected WN shape");
                     int k = int(w->dims[2]);
                     int dil = int(R.geti(in + ".dilation", 1));
+                    if (dil < 1) throw std::runtime_error(in + ": bad dilation");
                     // the WN dilated conv carries 83 % of the flow's FLOPs: split-exact engine when the shape allows
                     // (plane input, 128/64-row tiles); VITSMI_GEN_ENGINE=f32 keeps everything on the f32 engine
                     const char *env = std::getenv("VITSMI_GEN_ENGINE");
                     const bool f32_only = env && std::string(env) == "f32";
                     const int ci = int(w->dims[1]), co = int(w->dims[0]);
                     if (!f32_only && !sx_raw_format(ci) && co % 64 == 0 && ci % 8 == 0 && sx_supported(ci, co, co, k, dil)) {
-                        const char *pe = std::getenv("VITSMI_GEN_PRECISION");  // (same arithmetic as the generator)
+                        const char *pe = gen_precision_name();  // (same arithmetic as the generator)
                         t_sx_f16 = !pe || !*pe || std::string(pe) == "f16x3";
                         // frame-domain tensors are short (F ~ 3 T): 64-row tiles give the grid twice the workgroups
                         // (288 -> 576 at batch 32), measured 3.04 -> 2.87 ms for the flow
@@ -766,11 +855,19 @@ std::string Model::build(const OnnxModel &om) {
                     } else
                         cd.wn[i].in = pack_named(P, R, in, dil, same_pad(k, dil));
                     cd.wn[i].rs = pack_named(P, R, s + ".enc.res_skip_layers." + std::to_string(i), 1, 0);
+                    if (cd.wn[i].rs.Cin != flow_H || cd.wn[i].rs.K != 1 ||
+                        (cd.wn[i].rs.Cout != flow_H && cd.wn[i].rs.Cout != 2 * flow_H))
+                        throw std::runtime_error(s + ": unexpected res_skip shape");
                     cd.n_wn = i + 1;
                 }
+                if (!cd.n_wn || cd.wn[cd.n_wn - 1].rs.Cout != flow_H)
+                    throw std::runtime_error(s + ": WN stack must end in a skip-only layer");
+                for (int i = 0; i + 1 < cd.n_wn; i++)
+                    if (cd.wn[i].rs.Cout != 2 * flow_H) throw std::runtime_error(s + ": unexpected res_skip shape");
                 if (gin) {
-                    cd.cond_w = P.put(R.req(s + ".enc.cond_layer.weight"));
-                    cd.cond_b = P.put(R.req(s + ".enc.cond_layer.bias"));
+                    const int64_t rows = int64_t(2) * flow_H * cd.n_wn;
+                    cd.cond_w = P.put(R.need(s + ".enc.cond_layer.weight", 3, rows * gin));
+                    cd.cond_b = P.put(R.need(s + ".enc.cond_layer.bias", 1, rows));
                 }
                 flow.push_back(cd);
             }
@@ -814,18 +911,22 @@ std::string Model::build(const OnnxModel &om) {
             gen_sx = ok;
             // default: the generator's convs on two fp16 planes / three products per fp32 product (fp32-grade error);
             // VITSMI_GEN_PRECISION=bf16x6 (exact products, six bf16 plane products), bf16x3 or bf16 pack bf16 planes
-            const char *pe = std::getenv("VITSMI_GEN_PRECISION");
+            const char *pe = gen_precision_name();
             gen_f16 = gen_sx && (!pe || !*pe || std::string(pe) == "f16x3");
         }
         t_sx_f16 = gen_f16;
         auto gconv = [&](const std::string &name, int dil, int padL) {
             return gen_sx ? pack_named_sx(P, R, name, dil, padL) : pack_named(P, R, name, dil, padL);
         };
-        conv_pre = gconv("dec.conv_pre", 1, 3);
+        {
+            const TRef &wpre = R.need("dec.conv_pre.weight", 3);
+            if (wpre.dims[1] != C) throw std::runtime_error("dec.conv_pre: input width differs from the flow's");
+            conv_pre = gconv("dec.conv_pre", 1, int(wpre.dims[2] - 1) / 2);
+        }
         C0 = conv_pre.Cout;
         if (gin) {
-            dec_cond_w = P.put(R.req("dec.cond.weight"));
-            dec_cond_b = P.put(R.req("dec.cond.bias"));
+            dec_cond_w = P.put(R.need("dec.cond.weight", 3, int64_t(C0) * gin));
+            dec_cond_b = P.put(R.need("dec.cond.bias", 1, C0));
         }
         hop = 1;
         for (int i = 0; i < nups; i++) {
@@ -833,6 +934,7 @@ std::string Model::build(const OnnxModel &om) {
             st.up = gen_sx ? pack_convT_sx(P, R, "dec.ups." + std::to_string(i)) : pack_convT(P, R, "dec.ups." + std::to_string(i));
             st.u = st.up.ups;
             st.C = st.up.Cout / st.u;
+            if (st.up.Cin != (i == 0 ? C0 : ups.back().C)) throw std::runtime_error("dec.ups: channel chain is broken");
             hop *= st.u;
             for (int j = 0; j < nk; j++) {
                 std::string rb = "dec.resblocks." + std::to_string(i * nk + j);
@@ -840,16 +942,18 @@ std::string Model::build(const OnnxModel &om) {
                 rd.type1 = R.get(rb + ".convs1.0.weight") != nullptr;
                 for (int q = 0; q < 4; q++) {
                     std::string c1 = rb + (rd.type1 ? ".convs1." : ".convs.") + std::to_string(q);
-                    const TRef *w = R.get(c1 + ".weight");
-                    if (!w) break;
+                    if (!R.get(c1 + ".weight")) break;
+                    const TRef *w = &R.need(c1 + ".weight", 3);
                     int k = int(w->dims[2]);
                     int dil = int(R.geti(c1 + ".dilation", 1));
+                    if (dil < 1 || w->dims[0] != st.C || w->dims[1] != st.C) throw std::runtime_error(c1 + ": unexpected shape");
                     rd.c1[q] = gconv(c1, dil, same_pad(k, dil));
                     if (rd.type1) {
                         std::string c2 = rb + ".convs2." + std::to_string(q);
-                        const TRef &w2 = R.req(c2 + ".weight");
+                        const TRef &w2 = R.need(c2 + ".weight", 3);
                         int k2 = int(w2.dims[2]);
                         int d2 = int(R.geti(c2 + ".dilation", 1));
+                        if (d2 < 1 || w2.dims[0] != st.C || w2.dims[1] != st.C) throw std::runtime_error(c2 + ": unexpected shape");
                         rd.c2[q] = gconv(c2, d2, same_pad(k2, d2));
                     }
                     rd.n = q + 1;
@@ -859,8 +963,9 @@ std::string Model::build(const OnnxModel &om) {
             ups.push_back(st);
         }
         t_sx_f16 = false;
-        const TRef &pw = R.req("dec.conv_post.weight");
+        const TRef &pw = R.need("dec.conv_post.weight", 3);
         if (pw.dims[0] != 1) throw std::runtime_error("conv_post must have one output channel");
+        if (ups.empty() || pw.dims[1] != ups.back().C) throw std::runtime_error("conv_post: input width differs from the last stage");
         if (R.get("dec.conv_post.bias")) throw std::runtime_error("conv_post with bias is unsupported");
         post_cin = int(pw.dims[1]);
         post_k = int(pw.dims[2]);
@@ -898,10 +1003,36 @@ std::string Model::build(const OnnxModel &om) {
             for (auto &L : enc) em += L.qkv.macs_per_t + L.o.macs_per_t + L.ffn1.macs_per_t + L.ffn2.macs_per_t;
             enc_macs_per_token = em;  // attention contraction added at run time (depends on T)
         }
+        // One-sided receptive field of the generator in input frames (chunked rendering discards this much on either
+        // side of a chunk; models.py:348-368): conv_pre, then per stage the transposed conv's reach (in its input steps)
+        // and the widest ResBlock of the multi-receptive-field bank, each divided by the cumulative upsampling.
+        {
+            double r = double(conv_pre.K - 1 - conv_pre.padL > conv_pre.padL ? conv_pre.K - 1 - conv_pre.padL : conv_pre.padL);
+            double rate = 1;
+            for (auto &st : ups) {
+                const int right = st.up.K - 1 - st.up.padL;  // dense-conv form of the transposed conv: taps -padL .. right
+                r += double(right > st.up.padL ? right : st.up.padL) / rate;
+                rate *= st.u;
+                double widest = 0;
+                for (auto &rb : st.rbs) {
+                    double w = 0;
+                    for (int q = 0; q < rb.n; q++) {
+                        // (sx packing pads narrow kernels to 3 taps with zeros: padL is still the real left reach)
+                        w += double(rb.c1[q].padL);
+                        if (rb.type1) w += double(rb.c2[q].padL);
+                    }
+                    widest = w > widest ? w : widest;
+                }
+                r += widest / rate;
+            }
+            r += double(post_k / 2) / rate;
+            gen_rf_frames = int(std::ceil(r)) + 1;
+        }
         if (input_names.empty()) {
             input_names = {"input", "input_lengths", "scales"};
             if (gin) input_names.push_back("sid");
         }
+        arena_floats = P.size;
     } catch (const std::exception &e) {
         return e.what();
     }

@@ -127,13 +127,16 @@ struct Model {
     std::vector<UpStageDesc> ups;
     int64_t post_w = -1;  // [Cin, K] conv_post weight (Cout = 1, no bias)
     int post_cin = 0, post_k = 7;
+    int gen_rf_frames = 0;  // one-sided receptive field of the whole generator, in input frames (rounded up, + 1)
 
-    // ---- packed arena (host copy)
+    // ---- packed arena (host copy; empty after a layout-only build)
     std::vector<float> arena;
+    int64_t arena_floats = 0;  // size of the packed arena, materialised or not
     int64_t zeros_off = 0;  // >= 1024 zero floats
 
-    // Build from a parsed file.  Returns "" or an error message.
-    std::string build(const OnnxModel &om);
+    // Build from a parsed file.  Returns "" or an error message.  layout_only: compute every offset and descriptor
+    // but materialise no weight (the packed bytes already live on the device: vits_open_with_arena).
+    std::string build(const OnnxModel &om, bool layout_only = false);
 
     // reference-definition work per unit: MACs per frame / per token
     double dec_macs_per_frame = 0, flow_macs_per_frame = 0, enc_macs_per_token = 0, dp_macs_per_token = 0;
@@ -156,6 +159,10 @@ uint16_t f16_rne(float f);
 float f16_to_f32(uint16_t h);
 void split2h_host(float v, uint16_t p[3]);
 void set_sx_f16(bool on);  // pack_conv_sx format for the calls that follow on this thread (test hooks)
+// generator arithmetic for the Model::build calls that follow on this thread: explicit name, or nullptr = take
+// VITSMI_GEN_PRECISION from the environment (default f16x3)
+void set_gen_precision_override(const char *name);
+const char *gen_precision_name();
 // may this conv shape run on the sx engine (channel multiples, LDS budget)?
 bool sx_supported(int Cin, int Cout_virtual, int Cr, int K, int dil);
 // Storage format of a generator tensor with C channels on the sx path: true = fp32 raw only (its consumers

@@ -14,11 +14,22 @@ struct Span {
 };
 
 struct Field {
-    uint32_t num;
-    int wire;
-    uint64_t val;  // wire 0/1/5
-    Span sub;      // wire 2
+    uint32_t num = 0;
+    int wire = -1;
+    uint64_t val = 0;              // wire 0/1/5
+    Span sub{nullptr, nullptr};    // wire 2
 };
+
+// A string / bytes / sub-message field must arrive length-delimited: a damaged or hostile file can send the same
+// field number with wire type 0/1/5, in which case `sub` holds nothing of this field (never read it then).
+const Span &ld(const Field &f, const char *what) {
+    if (f.wire != 2) throw std::runtime_error(std::string("field '") + what + "' is not length-delimited");
+    return f.sub;
+}
+uint64_t scalar(const Field &f, const char *what) {
+    if (f.wire == 2) throw std::runtime_error(std::string("field '") + what + "' is not a scalar");
+    return f.val;
+}
 
 uint64_t varint(Span &s) {
     uint64_t r = 0;
@@ -38,6 +49,8 @@ bool next(Span &s, Field &f) {
     uint64_t key = varint(s);
     f.num = uint32_t(key >> 3);
     f.wire = int(key & 7);
+    f.val = 0;
+    f.sub = {nullptr, nullptr};
     switch (f.wire) {
         case 0: f.val = varint(s); break;
         case 1:
@@ -82,12 +95,14 @@ OnnxTensor tensor(Span s) {
     while (next(s, f)) {
         switch (f.num) {
             case 1: ints_of(f, t.dims); break;
-            case 2: t.dtype = int(f.val); break;
-            case 8: t.name = str(f.sub); break;
-            case 9:
-                t.raw = f.sub.p;
-                t.raw_bytes = size_t(f.sub.e - f.sub.p);
+            case 2: t.dtype = int(scalar(f, "TensorProto.data_type")); break;
+            case 8: t.name = str(ld(f, "TensorProto.name")); break;
+            case 9: {
+                const Span &r = ld(f, "TensorProto.raw_data");
+                t.raw = r.p;
+                t.raw_bytes = size_t(r.e - r.p);
                 break;
+            }
             case 4:  // float_data, packed or not
                 if (f.wire == 2) {
                     size_t n = size_t(f.sub.e - f.sub.p) / 4;
@@ -118,19 +133,19 @@ OnnxNode node(Span s) {
     Field f;
     while (next(s, f)) {
         switch (f.num) {
-            case 1: n.inputs.push_back(str(f.sub)); break;
-            case 2: n.outputs.push_back(str(f.sub)); break;
-            case 3: n.name = str(f.sub); break;
-            case 4: n.op = str(f.sub); break;
+            case 1: n.inputs.push_back(str(ld(f, "NodeProto.input"))); break;
+            case 2: n.outputs.push_back(str(ld(f, "NodeProto.output"))); break;
+            case 3: n.name = str(ld(f, "NodeProto.name")); break;
+            case 4: n.op = str(ld(f, "NodeProto.op_type")); break;
             case 5: {  // AttributeProto
-                Span a = f.sub;
+                Span a = ld(f, "NodeProto.attribute");
                 Field g;
                 std::string an;
                 std::vector<int64_t> iv;
                 bool has = false;
                 while (next(a, g)) {
-                    if (g.num == 1) an = str(g.sub);
-                    else if (g.num == 3) { iv.push_back(int64_t(g.val)); has = true; }
+                    if (g.num == 1) an = str(ld(g, "AttributeProto.name"));
+                    else if (g.num == 3) { iv.push_back(int64_t(scalar(g, "AttributeProto.i"))); has = true; }
                     else if (g.num == 8) { ints_of(g, iv); has = true; }
                 }
                 if (has) n.ints[an] = iv;
@@ -169,15 +184,15 @@ std::string OnnxModel::load(const std::string &path) {
                 Field g;
                 std::string k, v;
                 while (next(s, g)) {
-                    if (g.num == 1) k = str(g.sub);
-                    else if (g.num == 2) v = str(g.sub);
+                    if (g.num == 1) k = str(ld(g, "metadata key"));
+                    else if (g.num == 2) v = str(ld(g, "metadata value"));
                 }
                 meta[k] = v;
             } else if (f.num == 8 && f.wire == 2) {
                 Span s = f.sub;
                 Field g;
                 while (next(s, g))
-                    if (g.num == 2) opset = int64_t(g.val);
+                    if (g.num == 2 && g.wire != 2) opset = int64_t(g.val);
             }
         }
         if (!graph.p) return "no GraphProto in " + path;

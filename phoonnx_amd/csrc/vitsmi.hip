@@ -72,7 +72,29 @@ struct vits_handle {
     uint64_t run_counter = 0;
     int gen_nprod = 2;  // generator arithmetic (VITSMI_GEN_PRECISION): 2 = two fp16 planes / three products (default), 6 = six
                         // exact bf16 plane products, 3 / 1 = the reduced-precision bf16 modes
+    // f16 range guard: every launch that splits values into fp16 planes publishes the largest magnitude it saw into its
+    // own 64 slots of d_range; range_reduce_kernel folds them at the end of a run into d_range_res = {max, min over
+    // launches of the per-launch peak, launches tracked}, copied to the pinned h_range (read after the next sync).
+    unsigned *d_range = nullptr;
+    float *d_range_res = nullptr;
+    float *h_range = nullptr;
+    int range_launch = 0;
+    bool range_pending = false;   // h_range holds the result of a run that has not been checked yet
+    bool range_failed = false;    // the last run saturated (sticky until the next run starts)
+    // chunked rendering: two pinned host buffers the finished chunks are copied into, with their completion events
+    char *ring[2] = {nullptr, nullptr};
+    size_t ring_cap = 0;
+    hipEvent_t ring_ev[2] = {nullptr, nullptr};
 };
+
+// chunked rendering (vits_run_chunked / vits_run_vocoder_chunked): where the audio goes
+struct ChunkSink {
+    int chunk_frames;
+    vits_chunk_fn fn;
+    void *user;
+};
+
+constexpr int kMaxRangeLaunches = 512;
 
 namespace {
 
@@ -85,6 +107,74 @@ int fail(vits_handle *h, int code, const char *fmt, ...) {
     if (h) h->err = buf;
     else g_open_error = buf;
     return code;
+}
+
+// this launch's slots of the f16 range guard (nullptr when the arithmetic has no fp16 planes)
+unsigned *range_slots(vits_handle *h, bool f16) {
+    if (!f16 || !h->d_range) return nullptr;
+    const int i = h->range_launch < kMaxRangeLaunches ? h->range_launch : kMaxRangeLaunches - 1;
+    h->range_launch++;
+    return h->d_range + (size_t)i * kSxPeakSlots;
+}
+
+// per launch: peak = max over its 64 slots; out = {max over launches, min over launches, launches}
+__global__ void range_reduce_kernel(const unsigned *slots, int launches, float *out) {
+    __shared__ float smax[256], smin[256];
+    float mx = 0.f, mn = __builtin_inff();
+    for (int l = threadIdx.x; l < launches; l += 256) {
+        unsigned b = 0;
+        for (int i = 0; i < kSxPeakSlots; i++) b = max(b, slots[(size_t)l * kSxPeakSlots + i]);
+        const float pk = __uint_as_float(b);
+        mx = fmaxf(mx, pk);
+        mn = fminf(mn, pk);
+    }
+    smax[threadIdx.x] = mx;
+    smin[threadIdx.x] = mn;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+            smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = smax[0];
+        out[1] = launches ? smin[0] : 0.f;
+        out[2] = (float)launches;
+    }
+}
+
+void range_begin(vits_handle *h) {
+    h->range_launch = 0;
+    if (h->d_range) hipMemsetAsync(h->d_range, 0, (size_t)kMaxRangeLaunches * kSxPeakSlots * sizeof(unsigned), h->stream);
+}
+
+// fold the slots and start the 12-byte copy to the host; evaluated by range_check() after the next synchronisation
+void range_end(vits_handle *h) {
+    if (!h->d_range) return;
+    const int n = h->range_launch < kMaxRangeLaunches ? h->range_launch : kMaxRangeLaunches;
+    range_reduce_kernel<<<1, 256, 0, h->stream>>>(h->d_range, n, h->d_range_res);
+    hipMemcpyAsync(h->h_range, h->d_range_res, 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    h->range_pending = true;
+}
+
+// after a synchronisation: did the last run leave the fp16 planes' range?
+int range_check(vits_handle *h) {
+    if (!h->range_pending) return 0;
+    h->range_pending = false;
+    h->stats.f16_peak_max = h->h_range[0];
+    h->stats.f16_peak_min = h->h_range[1];
+    h->stats.f16_tracked = (int)h->h_range[2];
+    h->stats.f16_saturated = !(h->h_range[0] <= kF16Max) ? 1 : 0;
+    h->range_failed = h->stats.f16_saturated != 0;
+    if (h->stats.f16_saturated)
+        return fail(h, VITS_E_RANGE,
+                    "an activation of magnitude %g (or a non-finite value) left the range of the generator's fp16 operand "
+                    "planes (65504): the f16x3 arithmetic would clamp it.  Open the voice with gen_precision \"bf16x6\" "
+                    "(VITSMI_GEN_PRECISION=bf16x6), whose bf16 planes have the fp32 range",
+                    (double)h->h_range[0]);
+    return 0;
 }
 
 #define HIPCHECK(h, expr)                                                                       \
@@ -248,6 +338,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.oslope2 = oslope2;
     a.wscale = d.wscale;
     vits_handle *h = c.h;
+    a.peak = range_slots(h, d.f16);
     const bool ev = conv_event_begin(c);
     c.note(launch_conv_sx(a, d.cfg, c.B, c.st, d.rawin, d.f16 ? 2 : (h->cur_stage == 3 ? h->gen_nprod : 6)));
     if (ev) {
@@ -336,7 +427,10 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     need += al((size_t)B * m.FF * T);                      // ffn hidden
     need += al((size_t)B * 2 * C * T) + 2 * al((size_t)B * C * T);  // stats, m_p, logs_p
     need += al((size_t)B * Cdp * T) * 5;                   // dp buffers
-    need += al((size_t)B * 32 * T) + al((size_t)B * 2 * T) * 2 + al((size_t)B * T) * 4;
+    int pr_rows = 32;  // spline parameters per position: 3 * bins - 1 (29 for the reference's 10 bins, up to 47)
+    if (m.use_sdp)
+        for (const auto &cfd : m.cf) pr_rows = cfd.proj.Cout > pr_rows ? cfd.proj.Cout : pr_rows;
+    need += al((size_t)B * pr_rows * T) + al((size_t)B * 2 * T) * 2 + al((size_t)B * T) * 4;
     need += al((size_t)B * (m.gin + m.dp_cond_rows + m.C0 + 16)) + (1 << 16);
     for (auto &cd : m.flow) need += al((size_t)B * 2 * m.flow_H * cd.n_wn);
     if (int rc = slab_reserve(h, h->tok, need)) return rc;
@@ -423,7 +517,7 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
         float *hb = slab_take<float>(s, (size_t)B * Cd * T), *y = slab_take<float>(s, (size_t)B * Cd * T);
         float *y2 = slab_take<float>(s, (size_t)B * Cd * T), *cond = slab_take<float>(s, (size_t)B * Cd * T);
         float *h2 = slab_take<float>(s, (size_t)B * Cd * T);
-        float *pr = slab_take<float>(s, (size_t)B * 32 * T);
+        float *pr = slab_take<float>(s, (size_t)B * pr_rows * T);
         float *z = slab_take<float>(s, (size_t)B * 2 * T);
         // h = pre(x) [+ cond(g)] ; DDSConv ; cond = proj(h)*mask (models.py:65-70)
         conv(c, m.dp_pre, x, sHT, T, hb, sC, 0, nullptr, nullptr, 0, dp_cond, m.dp_cond_rows);
@@ -484,6 +578,12 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     h->h_ylen.resize(B);
     HIPCHECK(h, hipMemcpyAsync(h->h_ylen.data(), h->d_ylen, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     HIPCHECK(h, hipStreamSynchronize(st));  // the one data-dependent readback: output length
+    if (h->range_pending) {  // an earlier asynchronous run whose range verdict nobody has looked at
+        const vits_stats keep = h->stats;
+        const int rr = range_check(h);
+        h->stats = keep;
+        if (rr) return fail(h, VITS_E_RANGE, "the previous run on this handle left the range of the fp16 operand planes");
+    }
     int F = 1;
     for (int b = 0; b < B; b++) F = h->h_ylen[b] > F ? h->h_ylen[b] : F;
     h->F = F;
@@ -534,11 +634,12 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
     // ---- z * y_mask (models.py:349) in conv_pre's input format
     const void *zin;
     if (sx_raw_format(m.C)) {
-        sx_block_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_raw, m.C, F);
+        sx_block_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_raw, m.C, F,
+                                                                           range_slots(h, m.gen_f16));
         zin = tmp_raw;
     } else {
         sx_split_planes_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_pl, m.C, F,
-                                                                                  m.gen_f16 ? 1 : 0);
+                                                                                  m.gen_f16 ? 1 : 0, range_slots(h, m.gen_f16));
         zin = tmp_pl;
     }
     c.note(hipGetLastError());
@@ -713,8 +814,78 @@ int run_generator(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int
     return 0;
 }
 
+__global__ void chunk_len_kernel(const int *ylen, int *out, int B, int lo, int n) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        const int v = ylen ? ylen[b] - lo : n;  // (no lengths: every frame of the chunk is valid)
+        out[b] = v < 0 ? 0 : (v > n ? n : v);
+    }
+}
+
+// Frames [0, F) of z rendered in chunks of sink->chunk_frames: each chunk is rendered together with gen_rf_frames of
+// context on either side (clipped at the utterance ends, where the generator really sees zero padding) and only its
+// interior is kept, so every sample equals the one an unchunked run produces (the convolutions accumulate in the same
+// order wherever a column sits in a tile).  Finished chunks go to the host through two pinned buffers; the callback
+// for chunk i runs while chunk i + 1 renders.
+int render_chunks(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B, int F,
+                  const float *dec_cond, Slab &s, const ChunkSink &sink) {
+    const Model &m = h->model;
+    hipStream_t st = h->stream;
+    const int ov = m.gen_rf_frames, hop = m.hop;
+    const int chunk = sink.chunk_frames;
+    const size_t need = (size_t)B * chunk * hop * sizeof(float);
+    if (need > h->ring_cap) {
+        for (auto &r : h->ring) {
+            if (r) hipHostFree(r);
+            r = nullptr;
+        }
+        h->ring_cap = 0;
+        for (auto &r : h->ring)
+            if (hipHostMalloc((void **)&r, need) != hipSuccess) return fail(h, VITS_E_NOMEM, "pinned chunk buffer (%zu bytes)", need);
+        h->ring_cap = need;
+    }
+    for (auto &e : h->ring_ev)
+        if (!e) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    // per-chunk valid lengths, ALWAYS passed: a chunk is a window into rows whose neighbours are real data, and only a
+    // length mask makes the conv engines bound their reads by the chunk instead of by the row pitch
+    int *yl = slab_take<int>(s, B);
+    const size_t mark = s.used;
+    const int64_t total = (int64_t)F * hop;
+    int64_t pend_first = 0, pend_n = 0;
+    int pend = -1, k = 0, stop = 0;
+    auto deliver = [&]() -> int {  // hand the pending chunk to the caller
+        if (pend < 0) return 0;
+        if (hipEventSynchronize(h->ring_ev[pend]) != hipSuccess) return fail(h, VITS_E_DEVICE, "chunk copy failed");
+        stop = sink.fn ? sink.fn(sink.user, reinterpret_cast<const float *>(h->ring[pend]), B, pend_first, pend_n, total) : 0;
+        pend = -1;
+        return 0;
+    };
+    for (int f0 = 0; f0 < F && !stop; f0 += chunk, k ^= 1) {
+        const int f1 = f0 + chunk < F ? f0 + chunk : F;
+        const int lo = f0 - ov > 0 ? f0 - ov : 0, hi = f1 + ov < F ? f1 + ov : F, n = hi - lo;
+        s.used = mark;  // the previous chunk's workspace (its copy-out precedes this chunk on the stream)
+        chunk_len_kernel<<<(B + 63) / 64, 64, 0, st>>>(ylen, yl, B, lo, n);
+        if (int rc = run_generator(h, c, z + lo, z_bstride, z_cstride, yl, B, n, dec_cond, s)) return rc;
+        if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
+        const int64_t ns = (int64_t)(f1 - f0) * hop;
+        // interior of this chunk: samples [(f0 - lo) * hop, (f1 - lo) * hop) of every row -> ring[k] as [B, ns]
+        HIPCHECK(h, hipMemcpy2DAsync(h->ring[k], (size_t)ns * 4, h->d_out + (int64_t)(f0 - lo) * hop, (size_t)h->S * 4,
+                                     (size_t)ns * 4, B, hipMemcpyDeviceToHost, st));
+        HIPCHECK(h, hipEventRecord(h->ring_ev[k], st));
+        if (int rc = deliver()) return rc;  // (the previous chunk, while this one renders)
+        pend = k;
+        pend_first = (int64_t)f0 * hop;
+        pend_n = ns;
+    }
+    if (!stop)
+        if (int rc = deliver()) return rc;
+    h->S = (int)total;
+    h->d_out = nullptr;  // (no whole waveform exists on the device after a chunked run)
+    return 0;
+}
+
 int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t *d_sid, const float *d_noise_z,
-               int64_t noise_z_stride, uint64_t seed) {
+               int64_t noise_z_stride, uint64_t seed, const ChunkSink *sink = nullptr) {
     const Model &m = h->model;
     const int C = m.C, Freal = h->F, Hf = m.flow_H;
     if (d_noise_z && noise_z_stride < Freal)
@@ -726,7 +897,9 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     const int F = (Freal + 3) & ~3;
     h->Fpitch = F;
     const size_t nCF = (size_t)B * C * F, nHF = (size_t)B * Hf * F;
-    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + al(nHF * 2) + gen_ws_bytes(m, B, F) + (1 << 16);
+    // frames the generator renders at a time: everything, or one chunk with its context
+    const int Fgen = sink && sink->chunk_frames + 2 * m.gen_rf_frames < F ? sink->chunk_frames + 2 * m.gen_rf_frames : F;
+    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + al(nHF * 2) + gen_ws_bytes(m, B, Fgen) + (1 << 16);
     for (auto &cd : m.flow) need += al((size_t)B * 2 * Hf * cd.n_wn);
     need += al((size_t)B * m.C0);
     if (int rc = slab_reserve(h, h->frm, need)) return rc;
@@ -786,7 +959,8 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
             if (cd.wn[i].in.sx) {
                 // split-operand engine: hx -> planes, conv to the raw cell layout, gate reads that layout
                 sx_split_planes_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(hx, sHF, F, nullptr, hx_pl, Hf, F,
-                                                                                         cd.wn[i].in.f16 ? 1 : 0);
+                                                                                         cd.wn[i].in.f16 ? 1 : 0,
+                                                                                         range_slots(h, cd.wn[i].in.f16));
                 h->stats.total_launches++;
                 conv_sx(c, cd.wn[i].in, hx_pl, F, a2, nullptr, 0, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr, gc_rows);
                 wn_gate_blocked_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(a2, acts, Hf, F);
@@ -811,6 +985,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
                                                                     c.P(m.dec_cond_b), dec_cond, m.C0, m.gin);
         h->stats.total_launches++;
     }
+    if (sink) return render_chunks(h, c, z, sCF, F, ylen, B, Freal, dec_cond, s, *sink);
     if (int rc = run_generator(h, c, z, sCF, F, ylen, B, Freal, dec_cond, s)) return rc;
     if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
     return 0;
@@ -821,14 +996,15 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
 // ================================================================================== C ABI
 
 static int open_common(const char *path, vits_handle **out, bool host_only, int device, void *ext_arena,
-                       size_t ext_bytes) {
+                       size_t ext_bytes, bool layout_only = false) {
     if (!out || !path) return fail(nullptr, VITS_E_ARG, "null argument");
     *out = nullptr;
     OnnxModel om;
     std::string e = om.load(path);
     if (!e.empty()) return fail(nullptr, e.rfind("cannot open", 0) == 0 ? VITS_E_IO : VITS_E_FORMAT, "%s", e.c_str());
     vits_handle *h = new vits_handle();
-    e = h->model.build(om);
+    // a handle that adopts a resident arena only needs the layout (offsets, descriptors): no weight is re-packed
+    e = h->model.build(om, /*layout_only=*/ext_arena != nullptr || layout_only);
     if (!e.empty()) {
         delete h;
         return fail(nullptr, VITS_E_FORMAT, "%s: %s", path, e.c_str());
@@ -844,7 +1020,7 @@ static int open_common(const char *path, vits_handle **out, bool host_only, int 
         //   bf16x6 three bf16 planes, six products: each product exact to 2^-24
         //   bf16x3 / bf16: the declared reduced-precision vocoder modes (BASELINE config 4, "bf16 vocoder")
         // gen_nprod: 2 = f16x3 (Model::build packed the weights for it), else the number of bf16 plane products.
-        const char *pe = std::getenv("VITSMI_GEN_PRECISION");
+        const char *pe = gen_precision_name();
         const std::string ps = pe ? pe : "";
         if (ps.empty() || ps == "f16x3") h->gen_nprod = 2;
         else if (ps == "bf16x6") h->gen_nprod = 6;
@@ -869,7 +1045,7 @@ static int open_common(const char *path, vits_handle **out, bool host_only, int 
             delete h;
             return fail(nullptr, VITS_E_DEVICE, "cannot create stream on device %d", device);
         }
-        size_t bytes = h->model.arena.size() * 4;
+        size_t bytes = (size_t)h->model.arena_floats * 4;
         if (ext_arena) {
             if (ext_bytes != bytes) {
                 delete h;
@@ -885,6 +1061,16 @@ static int open_common(const char *path, vits_handle **out, bool host_only, int 
             h->arena_owned = true;
         }
         for (auto &e2 : h->ev) hipEventCreate(&e2);
+        {  // range guard of the fp16 operand planes (generator and / or the flow's WN convs)
+            const size_t nb = (size_t)kMaxRangeLaunches * kSxPeakSlots * sizeof(unsigned);
+            if (hipMalloc((void **)&h->d_range, nb + 64) != hipSuccess || hipHostMalloc((void **)&h->h_range, 64) != hipSuccess) {
+                vits_close(h);
+                return fail(nullptr, VITS_E_NOMEM, "cannot allocate the range-guard buffers");
+            }
+            h->d_range_res = reinterpret_cast<float *>(reinterpret_cast<char *>(h->d_range) + nb);
+            hipMemset(h->d_range, 0, nb + 64);
+            std::memset(h->h_range, 0, 64);
+        }
     }
     *out = h;
     return VITS_OK;
@@ -898,6 +1084,17 @@ int vits_open_with_arena(const char *p, int dev, void *arena, size_t bytes, vits
     return open_common(p, out, false, dev, arena, bytes);
 }
 int vits_open_host(const char *p, vits_handle **out) { return open_common(p, out, true, -1, nullptr, 0); }
+int vits_open_layout(const char *p, vits_handle **out) { return open_common(p, out, true, -1, nullptr, 0, true); }
+
+int vits_open_opts(const char *p, const vits_open_options *o, vits_handle **out) {
+    if (!o) return fail(nullptr, VITS_E_ARG, "null options");
+    if (o->arena_dev && o->host_only) return fail(nullptr, VITS_E_ARG, "host_only excludes arena_dev");
+    set_gen_precision_override(o->gen_precision && *o->gen_precision ? o->gen_precision : nullptr);
+    const int rc = open_common(p, out, o->host_only != 0, o->host_only ? -1 : o->device_id, o->arena_dev, o->arena_bytes,
+                               o->layout_only != 0);
+    set_gen_precision_override(nullptr);
+    return rc;
+}
 
 void vits_close(vits_handle *h) {
     if (!h) return;
@@ -909,6 +1106,12 @@ void vits_close(vits_handle *h) {
         if (h->frm.base) hipFree(h->frm.base);
         if (h->io.base) hipFree(h->io.base);
         if (h->pin.base) hipHostFree(h->pin.base);
+        if (h->d_range) hipFree(h->d_range);
+        if (h->h_range) hipHostFree(h->h_range);
+        for (auto &r : h->ring)
+            if (r) hipHostFree(r);
+        for (auto &e : h->ring_ev)
+            if (e) hipEventDestroy(e);
         for (auto &p : h->conv_events) {
             hipEventDestroy(p.first);
             hipEventDestroy(p.second);
@@ -959,6 +1162,7 @@ int vits_hparam(vits_handle *h, const char *key, int64_t *out) {
     else if (k == "n_ups") *out = (int64_t)m.ups.size();
     else if (k == "resblock") *out = m.ups.empty() || m.ups[0].rbs.empty() ? 0 : (m.ups[0].rbs[0].type1 ? 1 : 2);
     else if (k == "window") *out = m.window;
+    else if (k == "gen_rf_frames") *out = m.gen_rf_frames;
     else if (k == "upsample_initial_channel") *out = m.C0;
     else if (k == "dec_macs_per_frame") *out = (int64_t)m.dec_macs_per_frame;
     else if (k == "flow_macs_per_frame") *out = (int64_t)m.flow_macs_per_frame;
@@ -968,8 +1172,8 @@ int vits_hparam(vits_handle *h, const char *key, int64_t *out) {
     return VITS_OK;
 }
 
-size_t vits_arena_bytes(vits_handle *h) { return h ? h->model.arena.size() * 4 : 0; }
-const void *vits_arena_host(vits_handle *h) { return h ? h->model.arena.data() : nullptr; }
+size_t vits_arena_bytes(vits_handle *h) { return h ? (size_t)h->model.arena_floats * 4 : 0; }
+const void *vits_arena_host(vits_handle *h) { return h && !h->model.arena.empty() ? h->model.arena.data() : nullptr; }
 void *vits_arena_device(vits_handle *h) { return h ? h->arena_dev : nullptr; }
 void *vits_stream(vits_handle *h) { return h ? (void *)h->stream : nullptr; }
 
@@ -987,27 +1191,35 @@ static int check_dev(vits_handle *h) {
 }
 
 static int run_device_locked(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T,
-                             const float scales[3], const int64_t *sid, const vits_noise *noise, vits_output *out) {
+                             const float scales[3], const int64_t *sid, const vits_noise *noise, vits_output *out,
+                             const ChunkSink *sink = nullptr) {
     if (B <= 0 || T <= 0) return fail(h, VITS_E_ARG, "empty batch or sequence (B=%d, T=%d)", B, T);
-    if (!ids || !lens || !scales || !out) return fail(h, VITS_E_ARG, "null argument");
+    if (!ids || !lens || !scales || (!out && !sink)) return fail(h, VITS_E_ARG, "null argument");
     if (h->model.gin && !sid) return fail(h, VITS_E_ARG, "Missing speaker id");
     std::memset(&h->stats, 0, sizeof h->stats);
     h->conv_events_used = 0;
     h->B = B;
     h->T = T;
+    h->range_failed = false;
     uint64_t seed = noise ? noise->seed : 0;
     seed = seed * 0x9E3779B97F4A7C15ull + (++h->run_counter);
+    // (run_tokens' one synchronisation also completes the previous run on this handle: its range verdict, if nobody
+    // asked for it yet, is looked at there, before this run's guard slots are cleared)
     if (int rc = run_tokens(h, ids, lens, B, T, scales, sid, noise ? noise->noise_dp : nullptr, seed)) return rc;
+    range_begin(h);
     if (int rc = run_frames(h, B, T, scales, sid, noise ? noise->noise_z : nullptr, noise ? noise->noise_z_stride : 0,
-                            seed))
+                            seed, sink))
         return rc;
     ylen_to_i64<<<(B + 63) / 64, 64, 0, h->stream>>>(h->d_ylen, h->d_ylen64, B);
-    out->data = h->d_out;
-    out->dims[0] = B;
-    out->dims[1] = 1;
-    out->dims[2] = 1;
-    out->dims[3] = h->S;
-    out->y_lengths = h->d_ylen64;
+    range_end(h);
+    if (out) {
+        out->data = h->d_out;
+        out->dims[0] = B;
+        out->dims[1] = 1;
+        out->dims[2] = 1;
+        out->dims[3] = h->S;
+        out->y_lengths = h->d_ylen64;
+    }
     return VITS_OK;
 }
 
@@ -1015,6 +1227,7 @@ int vits_run_device(vits_handle *h, const int64_t *ids, const int64_t *lens, int
                     const int64_t *sid, const vits_noise *noise, vits_output *out) {
     if (int rc = check_dev(h)) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
+    if (!out) return fail(h, VITS_E_ARG, "null argument");
     return run_device_locked(h, ids, lens, B, T, scales, sid, noise, out);
 }
 
@@ -1027,16 +1240,24 @@ int vits_last_y_lengths(vits_handle *h, int64_t *buf, int n) {
 
 int vits_sync(vits_handle *h) {
     if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
     HIPCHECK(h, hipStreamSynchronize(h->stream));
+    if (int rc = range_check(h)) return rc;
+    if (h->range_failed) return fail(h, VITS_E_RANGE, "the last run left the range of the fp16 operand planes (see vits_get_stats)");
     return VITS_OK;
 }
 
-int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
-             const int64_t *sid, const vits_noise *noise, vits_output *out) {
-    if (int rc = check_dev(h)) return rc;
-    std::lock_guard<std::mutex> lk(h->mu);
+// vits_run / vits_run_chunked: validate the host inputs and stage them on the device (one slab, reused across calls)
+struct Staged {
+    int64_t *d_ids = nullptr, *d_lens = nullptr, *d_sid = nullptr;
+    vits_noise dn{};
+    bool has_noise = false;
+};
+
+static int stage_inputs(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const int64_t *sid,
+                        const vits_noise *noise, Staged &sg) {
     if (B <= 0 || T <= 0) return fail(h, VITS_E_ARG, "empty batch or sequence (B=%d, T=%d)", B, T);
-    if (!ids || !lens || !scales) return fail(h, VITS_E_ARG, "null argument");  // (out == NULL: run only)
+    if (!ids || !lens) return fail(h, VITS_E_ARG, "null argument");
     const Model &m = h->model;
     for (int b = 0; b < B; b++) {
         if (lens[b] < 0 || lens[b] > T)
@@ -1051,13 +1272,14 @@ int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int
             return fail(h, VITS_E_ARG, "sid[%d]=%lld is out of range [0,%d)", b, (long long)sid[b], m.n_speakers);
     }
     if (m.gin && !sid) return fail(h, VITS_E_ARG, "Missing speaker id");
-    // stage host inputs on the device
     size_t nb = (size_t)B * T * 8 + (size_t)B * 16 + 1024;
     size_t ndp = noise && noise->noise_dp ? (size_t)B * 2 * T * 4 : 0;
     size_t nz = noise && noise->noise_z ? (size_t)B * m.C * (size_t)noise->noise_z_stride * 4 : 0;
     if (int rc0 = slab_reserve(h, h->io, nb + ndp + nz + 1024)) return rc0;
     char *stage = h->io.base;
-    int64_t *d_ids = (int64_t *)stage, *d_lens = d_ids + (size_t)B * T, *d_sid = d_lens + B;
+    sg.d_ids = (int64_t *)stage;
+    sg.d_lens = sg.d_ids + (size_t)B * T;
+    int64_t *d_sid = sg.d_lens + B;
     float *d_ndp = (float *)(stage + ((nb + 255) & ~size_t(255)));
     float *d_nz = (float *)((char *)d_ndp + ((ndp + 255) & ~size_t(255)));
     hipStream_t st = h->stream;
@@ -1066,27 +1288,43 @@ int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int
         if (rc == VITS_OK && hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st) != hipSuccess)
             rc = fail(h, VITS_E_DEVICE, "host-to-device copy failed");
     };
-    cp(d_ids, ids, (size_t)B * T * 8);
-    cp(d_lens, lens, (size_t)B * 8);
-    if (sid) cp(d_sid, sid, (size_t)B * 8);
-    vits_noise dn{};
+    cp(sg.d_ids, ids, (size_t)B * T * 8);
+    cp(sg.d_lens, lens, (size_t)B * 8);
+    if (sid) {
+        cp(d_sid, sid, (size_t)B * 8);
+        sg.d_sid = d_sid;
+    }
     if (noise) {
-        dn = *noise;
+        sg.has_noise = true;
+        sg.dn = *noise;
         if (noise->noise_dp) {
             cp(d_ndp, noise->noise_dp, ndp);
-            dn.noise_dp = d_ndp;
+            sg.dn.noise_dp = d_ndp;
         }
         if (noise->noise_z) {
             cp(d_nz, noise->noise_z, nz);
-            dn.noise_z = d_nz;
+            sg.dn.noise_z = d_nz;
         }
     }
+    return rc;
+}
+
+int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
+             const int64_t *sid, const vits_noise *noise, vits_output *out) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!scales) return fail(h, VITS_E_ARG, "null argument");  // (out == NULL: run only)
+    Staged sg;
+    int rc = stage_inputs(h, ids, lens, B, T, sid, noise, sg);
+    hipStream_t st = h->stream;
     vits_output dev{};
-    if (rc == VITS_OK) rc = run_device_locked(h, d_ids, d_lens, B, T, scales, sid ? d_sid : nullptr, noise ? &dn : nullptr, &dev);
+    if (rc == VITS_OK) rc = run_device_locked(h, sg.d_ids, sg.d_lens, B, T, scales, sg.d_sid, sg.has_noise ? &sg.dn : nullptr, &dev);
     if (rc == VITS_OK && !out) {
         // run only: the caller fetches what it needs afterwards (vits_last_pcm16, vits_last_y_lengths, vits_tap)
         if (hipStreamSynchronize(st) != hipSuccess)
             rc = fail(h, VITS_E_DEVICE, "synchronisation failed: %s", hipGetErrorString(hipGetLastError()));
+        else
+            rc = range_check(h);
     } else if (rc == VITS_OK) {
         // one pinned block: [samples | frame counts]
         const size_t n = (size_t)B * h->S, ybase = (n * 4 + 63) & ~size_t(63);
@@ -1097,6 +1335,8 @@ int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int
                  hipStreamSynchronize(st) != hipSuccess) {
             pinned_put(h, host);
             rc = fail(h, VITS_E_DEVICE, "device-to-host copy failed: %s", hipGetErrorString(hipGetLastError()));
+        } else if ((rc = range_check(h)) != VITS_OK) {
+            pinned_put(h, host);  // clamped audio is not handed out
         } else {
             int64_t *hy = (int64_t *)(host + ybase);
             for (int b = 0; b < B; b++) hy[b] = h->h_ylen[b];
@@ -1106,6 +1346,23 @@ int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int
         }
     }
     if (rc != VITS_OK) hipStreamSynchronize(st);  // the staging slab is reused by the next call
+    return rc;
+}
+
+int vits_run_chunked(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
+                     const int64_t *sid, const vits_noise *noise, int chunk_frames, vits_chunk_fn fn, void *user) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!scales || chunk_frames < 1) return fail(h, VITS_E_ARG, "bad chunked-run arguments");
+    Staged sg;
+    int rc = stage_inputs(h, ids, lens, B, T, sid, noise, sg);
+    const ChunkSink sink{chunk_frames, fn, user};
+    if (rc == VITS_OK)
+        rc = run_device_locked(h, sg.d_ids, sg.d_lens, B, T, scales, sg.d_sid, sg.has_noise ? &sg.dn : nullptr, nullptr, &sink);
+    if (hipStreamSynchronize(h->stream) != hipSuccess && rc == VITS_OK)
+        rc = fail(h, VITS_E_DEVICE, "synchronisation failed: %s", hipGetErrorString(hipGetLastError()));
+    // (chunks are handed out as they finish; a range violation is therefore reported after the fact)
+    if (rc == VITS_OK) rc = range_check(h);
     return rc;
 }
 
@@ -1146,16 +1403,22 @@ int vits_last_pcm16(vits_handle *h, int normalize, float volume, int16_t *out, s
     return VITS_OK;
 }
 
-int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t *sid, vits_output *out) {
-    if (int rc = check_dev(h)) return rc;
-    std::lock_guard<std::mutex> lk(h->mu);
+// vocoder-only entry points: z (host, [B, inter, F], already masked) -> device, speaker bias; then either the whole
+// waveform or chunks
+static int vocoder_common(vits_handle *h, const float *z, int B, int F, const int64_t *sid, vits_output *out,
+                          const ChunkSink *sink) {
     const Model &m = h->model;
-    if (!z || !out || B <= 0 || F <= 0) return fail(h, VITS_E_ARG, "bad vocoder arguments");
+    if (!z || (!out && !sink) || B <= 0 || F <= 0) return fail(h, VITS_E_ARG, "bad vocoder arguments");
     if (m.gin && !sid) return fail(h, VITS_E_ARG, "Missing speaker id");
+    for (int b = 0; sid && m.gin && b < B; b++)
+        if (sid[b] < 0 || sid[b] >= m.n_speakers)
+            return fail(h, VITS_E_ARG, "sid[%d]=%lld is out of range [0,%d)", b, (long long)sid[b], m.n_speakers);
     std::memset(&h->stats, 0, sizeof h->stats);
     h->conv_events_used = 0;
+    h->range_failed = false;
     const size_t nCF = (size_t)B * m.C * F;
-    size_t need = al(nCF) + gen_ws_bytes(m, B, F) + al((size_t)B * m.C0) + (1 << 16);
+    const int Fgen = sink && sink->chunk_frames + 2 * m.gen_rf_frames < F ? sink->chunk_frames + 2 * m.gen_rf_frames : F;
+    size_t need = al(nCF) + gen_ws_bytes(m, B, Fgen) + al((size_t)B * m.C0) + (1 << 16);
     if (int rc = slab_reserve(h, h->frm, need)) return rc;
     Slab &s = h->frm;
     s.used = 0;
@@ -1174,8 +1437,18 @@ int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t
     }
     h->B = B;
     h->F = F;
-    if (int rc = run_generator(h, c, dz, (int64_t)m.C * F, F, nullptr, B, F, dec_cond, s)) return rc;
+    h->d_ylen = nullptr;  // (no frame counts: vits_last_pcm16 does not apply to a vocoder-only run)
+    range_begin(h);
+    int rc;
+    if (sink) rc = render_chunks(h, c, dz, (int64_t)m.C * F, F, nullptr, B, F, dec_cond, s, *sink);
+    else rc = run_generator(h, c, dz, (int64_t)m.C * F, F, nullptr, B, F, dec_cond, s);
+    if (rc) return rc;
     if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
+    range_end(h);
+    if (sink) {
+        HIPCHECK(h, hipStreamSynchronize(st));
+        return range_check(h);
+    }
     size_t n = (size_t)B * h->S;
     float *host = (float *)pinned_get(h, n * 4 + 64);
     if (!host) return fail(h, VITS_E_NOMEM, "pinned alloc failed");
@@ -1185,6 +1458,10 @@ int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t
         pinned_put(h, host);
         return fail(h, VITS_E_DEVICE, "device-to-host copy failed: %s", hipGetErrorString(ce));
     }
+    if (int rr = range_check(h)) {
+        pinned_put(h, host);
+        return rr;
+    }
     out->data = host;
     out->dims[0] = B;
     out->dims[1] = 1;
@@ -1192,6 +1469,22 @@ int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t
     out->dims[3] = h->S;
     out->y_lengths = nullptr;
     return VITS_OK;
+}
+
+int vits_run_vocoder(vits_handle *h, const float *z, int B, int F, const int64_t *sid, vits_output *out) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!out) return fail(h, VITS_E_ARG, "bad vocoder arguments");
+    return vocoder_common(h, z, B, F, sid, out, nullptr);
+}
+
+int vits_run_vocoder_chunked(vits_handle *h, const float *z, int B, int F, const int64_t *sid, int chunk_frames,
+                             vits_chunk_fn fn, void *user) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (chunk_frames < 1) return fail(h, VITS_E_ARG, "bad vocoder arguments");
+    const ChunkSink sink{chunk_frames, fn, user};
+    return vocoder_common(h, z, B, F, sid, nullptr, &sink);
 }
 
 int vits_tap(vits_handle *h, const char *name, float *buf, size_t buf_elems, int64_t dims[VITS_MAX_DIMS]) {
@@ -1234,6 +1527,7 @@ int vits_get_stats(vits_handle *h, vits_stats *out) {
     if (!h->host_only) {
         hipSetDevice(h->device);
         hipStreamSynchronize(h->stream);
+        range_check(h);  // fills stats.f16_*; a violation stays on record for vits_sync (range_failed)
         if (h->timing) {
             float ms = 0.f, tot = 0.f, tot_sx = 0.f;
             for (size_t i = 0; i < h->conv_events_used; i++) {

@@ -22,6 +22,13 @@ class SessionError(RuntimeError):
     InvalidArgument/RuntimeException at voice.py:374; callers there do not catch either)."""
 
 
+class RangeError(SessionError):
+    """VITS_E_RANGE: the f16x3 generator arithmetic met an activation beyond the range of its fp16 operand planes
+    (|x| > 65504) or a non-finite value.  The engine reports this instead of returning clamped audio; `MiSession`
+    (range_fallback=True, the default) then reopens the voice with the bf16x6 arithmetic (fp32 range) and repeats the
+    call, so user code only sees this when the fallback is switched off or impossible (borrowed weight arena)."""
+
+
 @dataclass
 class NodeArg:
     name: str
@@ -34,6 +41,7 @@ _INPUT_SPECS = {
     "input_lengths": ("tensor(int64)", ["batch_size"]),
     "scales": ("tensor(float)", [3]),
     "sid": ("tensor(int64)", ["batch_size"]),
+    "langid": ("tensor(int64)", ["batch_size"]),  # third-party exports (voice.py:369); accepted, validated, unused
 }
 
 
@@ -46,7 +54,11 @@ class ModelMeta:
 
 class MiSession:
     def __init__(self, path_or_bytes, sess_options=None, providers=None, provider_options=None, device_id: int = 0,
-                 arena_device_ptr: Optional[int] = None, arena_bytes: int = 0, host_only: bool = False, **kwargs):
+                 arena_device_ptr: Optional[int] = None, arena_bytes: int = 0, host_only: bool = False,
+                 gen_precision: Optional[str] = None, range_fallback: bool = True, layout_only: bool = False, **kwargs):
+        """gen_precision: arithmetic of the generator's convs - None (VITSMI_GEN_PRECISION or the default "f16x3"),
+        "f16x3", "bf16x6", "bf16x3", "bf16".  range_fallback: on a RangeError of the f16x3 arithmetic, reopen with
+        "bf16x6" and repeat the call (never silently clamped audio)."""
         if not isinstance(path_or_bytes, (str, bytes)) or isinstance(path_or_bytes, bytes):
             if isinstance(path_or_bytes, bytes):
                 raise SessionError("MiSession loads a model from a file path, not from serialized bytes")
@@ -55,21 +67,43 @@ class MiSession:
         self._h = C.c_void_p()
         self.path = path_or_bytes
         self.device_id = device_id
-        self.host_only = host_only
-        p = path_or_bytes.encode()
-        if host_only:
-            rc = self._lib.vits_open_host(p, C.byref(self._h))
-        elif arena_device_ptr is not None:
-            rc = self._lib.vits_open_with_arena(p, device_id, C.c_void_p(arena_device_ptr), arena_bytes,
-                                                C.byref(self._h))
-        else:
-            rc = self._lib.vits_open(p, device_id, C.byref(self._h))
+        self.host_only = host_only or layout_only
+        self.range_fallback = bool(range_fallback) and arena_device_ptr is None
+        self._open_args = dict(arena_device_ptr=arena_device_ptr, arena_bytes=arena_bytes, host_only=self.host_only,
+                               layout_only=layout_only)
+        self._seed = 0
+        self._open(gen_precision)
+
+    def _open(self, gen_precision):
+        a = self._open_args
+        o = _ffi.VitsOpenOptions()
+        o.device_id = self.device_id
+        o.gen_precision = gen_precision.encode() if gen_precision else None
+        o.arena_dev = a["arena_device_ptr"]
+        o.arena_bytes = a["arena_bytes"] if a["arena_device_ptr"] is not None else 0
+        o.host_only = 1 if a["host_only"] else 0
+        o.layout_only = 1 if a["layout_only"] else 0
+        h = C.c_void_p()
+        rc = self._lib.vits_open_opts(self.path.encode(), C.byref(o), C.byref(h))
         if rc != 0:
-            self._h = C.c_void_p()
-            raise SessionError(f"vits_open({path_or_bytes!r}) failed [{rc}]: {_ffi.last_error(None)}")
+            raise SessionError(f"vits_open({self.path!r}) failed [{rc}]: {_ffi.last_error(None)}")
+        self._h = h
+        self.gen_precision = gen_precision
         n = self._lib.vits_num_inputs(self._h)
         self._input_names = [self._lib.vits_input_name(self._h, i).decode() for i in range(n)]
-        self._seed = 0
+
+    def _raise(self, what, rc):
+        cls = RangeError if rc == _ffi.VITS_E_RANGE else SessionError
+        raise cls(f"{what} failed [{rc}]: {self._err()}")
+
+    def _fall_back_to_bf16x6(self, exc):
+        """After a RangeError: reopen this voice with the exact six-product arithmetic (bf16 planes: fp32 range)."""
+        import logging
+        if not self.range_fallback or self.hparam("gen_nprod") != 2:
+            raise exc
+        logging.getLogger(__name__).warning("%s: %s - reopening with gen_precision='bf16x6'", self.path, exc)
+        self.close()
+        self._open("bf16x6")
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -114,8 +148,12 @@ class MiSession:
         for k in self._input_names:
             if k not in input_feed:
                 raise SessionError(f"Required input {k} is missing")
-        out = self.synthesize_batch(input_feed["input"], input_feed["input_lengths"], input_feed["scales"],
-                                    input_feed.get("sid"))
+        if "langid" in input_feed:  # declared by the graph, consumed by nothing this engine runs: validate, then ignore
+            lg = np.asarray(input_feed["langid"])
+            if lg.dtype != np.int64 or lg.shape != (np.asarray(input_feed["input"]).shape[0],):
+                raise SessionError("Unexpected input: 'langid' must be int64 of shape [batch_size]")
+        scales = input_feed["scales"] if "scales" in self._input_names else np.array([0.667, 1.0, 0.8], np.float32)
+        out = self.synthesize_batch(input_feed["input"], input_feed["input_lengths"], scales, input_feed.get("sid"))
         return [out["output"]]
 
     # ------------------------------------------------------------------ extensions
@@ -157,8 +195,14 @@ class MiSession:
         out = _ffi.VitsOutput()
         rc = self._lib.vits_run(self._h, _ffi.ptr(ids), _ffi.ptr(lens), B, T, _ffi.ptr(scales), _ffi.ptr(sid),
                                 C.byref(noise), C.byref(out))
+        if rc == _ffi.VITS_E_RANGE:
+            try:
+                self._raise("vits_run", rc)
+            except RangeError as exc:
+                self._fall_back_to_bf16x6(exc)
+            return self.synthesize_batch(ids, lens, scales, sid, noise_dp, noise_z, taps)
         if rc != 0:
-            raise SessionError(f"vits_run failed [{rc}]: {self._err()}")
+            self._raise("vits_run", rc)
         try:
             dims = tuple(out.dims[i] for i in range(4))
             n = int(np.prod(dims))
@@ -179,13 +223,86 @@ class MiSession:
         sid = None if sid is None else np.ascontiguousarray(sid, np.int64)
         out = _ffi.VitsOutput()
         rc = self._lib.vits_run_vocoder(self._h, _ffi.ptr(z), B, F, _ffi.ptr(sid), C.byref(out))
+        if rc == _ffi.VITS_E_RANGE:
+            try:
+                self._raise("vits_run_vocoder", rc)
+            except RangeError as exc:
+                self._fall_back_to_bf16x6(exc)
+            return self.vocoder(z, sid)
         if rc != 0:
-            raise SessionError(f"vits_run_vocoder failed [{rc}]: {self._err()}")
+            self._raise("vits_run_vocoder", rc)
         try:
             dims = tuple(out.dims[i] for i in range(4))
             return np.ctypeslib.as_array(out.data, shape=(int(np.prod(dims)),)).reshape(dims).copy()
         finally:
             self._lib.vits_free_output(self._h, C.byref(out))
+
+    # ------------------------------------------------------------------ chunked (streaming) rendering, SURVEY §8 f1
+    def _stream(self, start):
+        """Run `start(callback)` (a blocking C call) on a worker thread and yield (first_sample, samples [B, n]) as the
+        engine hands chunks over: the consumer works on chunk i while chunk i + 1 renders."""
+        import queue
+        import threading
+        q = queue.Queue()
+
+        @_ffi.CHUNK_FN
+        def on_chunk(user, samples, B, first, n, total):
+            q.put((int(first), np.ctypeslib.as_array(samples, shape=(B * n,)).reshape(B, n).copy(), int(total)))
+            return 0
+
+        def work():
+            try:
+                rc = start(on_chunk)
+                q.put(None if rc == 0 else (rc, self._err()))
+            except BaseException as e:  # noqa: BLE001 - re-raised on the consumer's thread
+                q.put(e)
+
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            if len(item) == 2:
+                cls = RangeError if item[0] == _ffi.VITS_E_RANGE else SessionError
+                raise cls(f"chunked run failed [{item[0]}]: {item[1]}")
+            yield item
+        t.join()
+
+    def synthesize_stream(self, ids, lens, scales, sid=None, chunk_frames: int = 64, noise_dp=None, noise_z=None):
+        """The whole path with the waveform delivered in chunks of `chunk_frames` frames (hop samples each): yields
+        (first_sample, float32 [B, n], total_samples).  Concatenated, the chunks are bit-identical to
+        synthesize_batch(...)["output"][:, 0, 0, :]; frame counts afterwards from last_y_lengths()."""
+        ids = np.ascontiguousarray(ids, np.int64)
+        lens = np.ascontiguousarray(lens, np.int64)
+        scales = np.ascontiguousarray(scales, np.float32)
+        B, T = ids.shape
+        sid = None if sid is None else np.ascontiguousarray(sid, np.int64)
+        noise = _ffi.VitsNoise()
+        noise.seed = self._seed
+        keep = []
+        if noise_dp is not None:
+            keep.append(np.ascontiguousarray(noise_dp, np.float32))
+            noise.noise_dp = keep[-1].ctypes.data
+        if noise_z is not None:
+            keep.append(np.ascontiguousarray(noise_z, np.float32))
+            noise.noise_z = keep[-1].ctypes.data
+            noise.noise_z_stride = keep[-1].shape[2]
+        return self._stream(lambda cb: self._lib.vits_run_chunked(
+            self._h, _ffi.ptr(ids), _ffi.ptr(lens), B, T, _ffi.ptr(scales), _ffi.ptr(sid), C.byref(noise),
+            int(chunk_frames), cb, None))
+
+    def vocoder_stream(self, z, sid=None, chunk_frames: int = 64):
+        """Vocoder only, chunked: yields (first_sample, float32 [B, n], total_samples)."""
+        z = np.ascontiguousarray(z, np.float32)
+        B, Cc, F = z.shape
+        if Cc != self.hparam("inter"):
+            raise SessionError(f"z must have {self.hparam('inter')} channels")
+        sid = None if sid is None else np.ascontiguousarray(sid, np.int64)
+        return self._stream(lambda cb: self._lib.vits_run_vocoder_chunked(self._h, _ffi.ptr(z), B, F, _ffi.ptr(sid),
+                                                                          int(chunk_frames), cb, None))
 
     def tap(self, name):
         dims = (C.c_int64 * 4)()
@@ -224,6 +341,8 @@ class MiSession:
     def arena_host(self) -> np.ndarray:
         n = self.arena_bytes()
         p = self._lib.vits_arena_host(self._h)
+        if not p:
+            raise SessionError("this handle holds no host copy of the weight arena (opened with a device arena / layout only)")
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,))
 
     def arena_device(self) -> int:
@@ -245,7 +364,7 @@ class MiSession:
         rc = self._lib.vits_run_device(self._h, C.c_void_p(ids_ptr), C.c_void_p(lens_ptr), B, T, _ffi.ptr(scales),
                                        C.c_void_p(sid_ptr) if sid_ptr else None, C.byref(noise), C.byref(out))
         if rc != 0:
-            raise SessionError(f"vits_run_device failed [{rc}]: {self._err()}")
+            self._raise("vits_run_device", rc)
         dims = tuple(out.dims[i] for i in range(4))
         return {"data_ptr": C.cast(out.data, C.c_void_p).value, "dims": dims,
                 "y_lengths_ptr": C.cast(out.y_lengths, C.c_void_p).value}
@@ -291,8 +410,9 @@ class MiSession:
         return self.last_pcm16(normalize, volume, shape=(B, S)), ylen
 
     def sync(self):
-        if self._lib.vits_sync(self._h) != 0:
-            raise SessionError(self._err())
+        rc = self._lib.vits_sync(self._h)
+        if rc != 0:
+            self._raise("vits_sync", rc)
 
 
 class PipelinedSession:

@@ -147,8 +147,9 @@ def hparams(preset="medium", **over):
     return hp
 
 
-def write_voice(path, preset="medium", seed=1234, **over):
-    """Write `<path>` (.onnx) and `<path>.json` (voice config).  Returns the hyper-parameter dict."""
+def write_voice(path, preset="medium", seed=1234, extra_inputs=(), **over):
+    """Write `<path>` (.onnx) and `<path>.json` (voice config).  Returns the hyper-parameter dict.
+    extra_inputs: further graph input names to declare (e.g. "langid", as third-party exports do, voice.py:369)."""
     hp = hparams(preset, **over)
     rng = np.random.default_rng(seed)
     g = _Graph(rng)
@@ -253,7 +254,7 @@ def write_voice(path, preset="medium", seed=1234, **over):
     g.conv("dec.conv_post", wp * np.float32(hp.get("post_gain", 1.0)), None)
 
     # ---- ModelProto
-    inputs = ["input", "input_lengths", "scales"] + (["sid"] if gin else [])
+    inputs = ["input", "input_lengths", "scales"] + (["sid"] if gin else []) + list(extra_inputs)
     graph = b"".join(g.nodes) + _ld(2, b"main_graph") + b"".join(g.inits)
     graph += b"".join(_ld(11, _ld(1, n.encode())) for n in inputs) + _ld(12, _ld(1, b"output"))
     meta = {"model_type": "vits", "n_speakers": hp["n_speakers"], "n_vocab": V, "sample_rate": 22050,

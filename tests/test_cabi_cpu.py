@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT, TINY_PRESETS
+from conftest import ALL_PRESETS, GOLDEN, ROOT, TINY_PRESETS
 
 from phoonnx_amd import MiSession, SessionError, _ffi
 
@@ -117,3 +117,148 @@ def test_work_counts_match_survey_formulas():
             macs += t * ch * ch * rk * len(rd) * 2
     macs += t * ch * 7
     assert s.hparam("dec_macs_per_frame") == macs
+
+
+@pytest.mark.parametrize("preset", ALL_PRESETS)
+@pytest.mark.parametrize("precision", [None, "bf16x6"])
+def test_layout_only_open_equals_full_pack(preset, precision):
+    """vits_open_with_arena (a rank that received the weights by broadcast, a second handle on one GPU) lays the arena
+    out without packing a weight: same size, same description as the full pack, and no host copy."""
+    path = os.path.join(GOLDEN, preset + ".onnx")
+    full = MiSession(path, host_only=True, gen_precision=precision)
+    lay = MiSession(path, layout_only=True, gen_precision=precision)
+    assert lay.arena_bytes() == full.arena_bytes() > 0
+    for k in ("hidden", "inter", "filter", "n_heads", "n_layers", "n_vocab", "n_speakers", "gin", "gen_sx", "gen_nprod",
+              "use_sdp", "hop", "n_ups", "resblock", "window", "upsample_initial_channel", "dec_macs_per_frame",
+              "flow_macs_per_frame", "enc_macs_per_token", "gen_rf_frames"):
+        assert lay.hparam(k) == full.hparam(k), k
+    assert [i.name for i in lay.get_inputs()] == [i.name for i in full.get_inputs()]
+    with pytest.raises(SessionError):
+        lay.arena_host()
+    assert full.arena_host().size == full.arena_bytes()
+    lay.close()
+    full.close()
+
+
+def test_gen_precision_option_and_fixture_runs_on_sx():
+    path = os.path.join(GOLDEN, "sx_rb1.onnx")
+    for name, nprod in (("f16x3", 2), ("bf16x6", 6), ("bf16x3", 3), ("bf16", 1), (None, 2)):
+        s = MiSession(path, host_only=True, gen_precision=name)
+        assert s.hparam("gen_sx") == 1 and s.hparam("gen_nprod") == nprod
+        s.close()
+    with pytest.raises(SessionError, match="VITSMI_GEN_PRECISION|precision"):
+        MiSession(path, host_only=True, gen_precision="fp8")
+    tiny = MiSession(os.path.join(GOLDEN, "tiny_rb1.onnx"), host_only=True)   # channels < 32: the f32-MFMA engine
+    assert tiny.hparam("gen_sx") == 0
+    tiny.close()
+
+
+def test_generator_receptive_field():
+    """gen_rf_frames = what chunked rendering discards on either side of a chunk.  LJSpeech-size generator
+    (models.py:299-368): conv_pre 3 + per stage (transposed-conv reach / rate_in + widest ResBlock / rate_out) + conv_post."""
+    from phoonnx_amd.synth import write_voice
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "v.onnx")
+        write_voice(p, "small", seed=1)
+        s = MiSession(p, layout_only=True)
+        # small: ups (8,4,2), k (16,8,4), ResBlock2 k (3,5,7) d ((1,2),(2,6),(3,12)): widest = 3*3 + 3*12 = 45 samples
+        r = 3 + 1 / 1 + 45 / 8 + 1 / 8 + 45 / 32 + 1 / 32 + 45 / 64 + 3 / 64
+        assert s.hparam("gen_rf_frames") == int(np.ceil(r)) + 1
+        s.close()
+
+
+def test_langid_input_is_listed_and_unknown_inputs_are_rejected(tmp_path):
+    """voice.py:369 offers `langid` to graphs that declare it.  A graph that declares it without consuming a language
+    table loads (the name is listed so the caller's feed filter keeps it); unknown inputs are not a VITS graph."""
+    from phoonnx_amd.synth import write_voice
+    p = str(tmp_path / "lang.onnx")
+    write_voice(p, "small", seed=2, extra_inputs=("langid",))
+    s = MiSession(p, host_only=True)
+    assert [i.name for i in s.get_inputs()] == ["input", "input_lengths", "scales", "langid"]
+    s.close()
+    q = str(tmp_path / "odd.onnx")
+    write_voice(q, "small", seed=2, extra_inputs=("prosody",))
+    with pytest.raises(SessionError, match="unsupported graph input"):
+        MiSession(q, host_only=True)
+
+
+def _tensor_spans(buf):
+    """(dims byte offsets, name) of every TensorProto whose layout is dims* data_type name raw_data (what the
+    exporter and synth.py write): 08 d .. 10 01 42 len name."""
+    out = []
+    i = 0
+    while True:
+        i = buf.find(b"\x10\x01\x42", i)
+        if i < 0:
+            return out
+        n = buf[i + 3]
+        name = bytes(buf[i + 4:i + 4 + n])
+        j, dims = i, []
+        while j >= 2 and buf[j - 2] == 0x08 and buf[j - 1] < 0x80:
+            dims.append(j - 1)
+            j -= 2
+        if dims and name.isascii() and b"." in name:
+            out.append((dims[::-1], name.decode()))
+        i += 3
+
+
+def test_targeted_shape_and_wire_type_damage_is_rejected(tmp_path):
+    """random byte flips rarely hit a key byte or a dims field.  Targeted damage: (a) every parameter's dims
+    rewritten (0, 1, swapped, rank dropped), (b) the key byte of name / raw_data / node strings / metadata switched to
+    another wire type.  Each file must load or raise SessionError - in a child process, so a crash fails only this."""
+    import subprocess
+    import sys
+    src = bytearray(open(os.path.join(GOLDEN, "tiny_rb2_ms.onnx"), "rb").read())
+    spans = _tensor_spans(src)
+    assert len(spans) > 40
+    cases = []
+    rng = np.random.default_rng(5)
+    for dims, name in spans:
+        for kind in range(4):
+            b = bytearray(src)
+            if kind == 0:
+                b[dims[int(rng.integers(len(dims)))]] = 0
+            elif kind == 1:
+                b[dims[int(rng.integers(len(dims)))]] = int(rng.integers(1, 120))
+            elif kind == 2 and len(dims) > 1:
+                b[dims[0]], b[dims[-1]] = b[dims[-1]], b[dims[0]]
+            elif kind == 3:
+                b[dims[0] - 1] = 0x18   # the first dims key becomes an unknown varint field: rank drops by one
+            else:
+                continue
+            cases.append(bytes(b))
+    for key, repl in ((b"\x10\x01\x42", b"\x10\x01\x40"), (b"\x10\x01\x42", b"\x10\x01\x45")):
+        pos = [m for m in range(len(src) - 3) if src[m:m + 3] == key][:25]
+        for m in pos:
+            b = bytearray(src)
+            b[m:m + 3] = repl
+            cases.append(bytes(b))
+    cases.append(bytes([0x3a, 0x04, 0x2a, 0x02, 0x40, 0x01]))     # graph{initializer{key 0x40 (name as varint), 1}}
+    cases.append(bytes([0x3a, 0x04, 0x2a, 0x02, 0x48, 0x01]))     # ... raw_data as varint
+    cases.append(bytes([0x3a, 0x04, 0x0a, 0x02, 0x18, 0x01]))     # graph{node{name as varint}}
+    cases.append(bytes([0x72, 0x02, 0x08, 0x01]))                 # metadata key as varint
+    blob = tmp_path / "cases.bin"
+    with open(blob, "wb") as f:
+        for c in cases:
+            f.write(len(c).to_bytes(4, "little") + c)
+    code = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+from phoonnx_amd import MiSession, SessionError
+data = open(sys.argv[2], "rb").read()
+i = ok = err = 0
+while i < len(data):
+    n = int.from_bytes(data[i:i + 4], "little"); i += 4
+    open(sys.argv[3], "wb").write(data[i:i + n]); i += n
+    try:
+        MiSession(sys.argv[3], host_only=True).close(); ok += 1
+    except SessionError:
+        err += 1
+print("survived", ok, err)
+'''
+    r = subprocess.run([sys.executable, "-c", code, ROOT, str(blob), str(tmp_path / "c.onnx")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "survived" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-500:])
+    n_ok, n_err = (int(v) for v in r.stdout.split()[-2:])
+    assert n_ok + n_err == len(cases) and n_err > len(cases) // 2, (n_ok, n_err)

@@ -24,7 +24,11 @@ int main(int argc, char **argv) {
     return 0;
 }
 EOF
-g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer \
+# -ftrivial-auto-var-init=pattern: ASan does not see reads of uninitialised locals; with pattern-initialised stack
+# variables such a read turns into a wild pointer / absurd length that ASan or the reader's own checks then catch
+CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}   # (g++ 11 lacks -ftrivial-auto-var-init)
+"$CXX" -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer \
+    -ftrivial-auto-var-init=pattern \
     -I"$R/phoonnx_amd/csrc" "$W/drv.cpp" "$R/phoonnx_amd/csrc/model.cpp" "$R/phoonnx_amd/csrc/onnx_reader.cpp" -o "$W/drv"
 python3 - "$R" "$W" "$N" <<'EOF'
 import random, sys
@@ -39,6 +43,23 @@ for i in range(n):
         for _ in range(rng.randrange(1, 12)):
             b[rng.randrange(len(b))] = rng.randrange(256)
     open(f"{w}/d{i}.onnx", "wb").write(bytes(b))
+# targeted damage (what random flips rarely hit): key bytes switched to another wire type, dims fields rewritten
+k = 0
+pos = [m for m in range(len(src) - 3) if src[m:m + 3] == b"\x10\x01\x42"]
+for m in pos[::3]:
+    for repl in (b"\x10\x01\x40", b"\x10\x01\x45", b"\x10\x01\x41"):
+        b = bytearray(src); b[m:m + 3] = repl
+        open(f"{w}/dk{k}.onnx", "wb").write(bytes(b)); k += 1
+    j = m
+    while j >= 2 and src[j - 2] == 0x08 and src[j - 1] < 0x80:
+        for v in (0, 1, 97):
+            b = bytearray(src); b[j - 1] = v
+            open(f"{w}/dk{k}.onnx", "wb").write(bytes(b)); k += 1
+        j -= 2
+for blob in (bytes([0x3a, 4, 0x2a, 2, 0x40, 1]), bytes([0x3a, 4, 0x2a, 2, 0x48, 1]), bytes([0x3a, 4, 0x0a, 2, 0x18, 1]),
+             bytes([0x72, 2, 0x08, 1])):
+    open(f"{w}/dk{k}.onnx", "wb").write(blob); k += 1
+print("targeted cases", k)
 EOF
 "$W/drv" "$R"/tests/golden/*.onnx "$W"/d*.onnx
 rm -rf "$W"
