@@ -3,16 +3,22 @@
 phoneme batches (BASELINE.json: batch-32, 256-phoneme utterances, 22.05 kHz).
 
   python bench.py --gpus N --steps K --warmup W [--preset high|medium] [--batch 32] [--tokens 256]
+                  [--total-batch 256]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU: rank 0 reads and packs the
-.onnx, the packed weight arena is broadcast over RCCL/xGMI, then every rank synthesises its
-own 32 utterances with no further communication ("scaling": "weak").
-A step = one pass of the whole path (encoder + duration predictor + flow + vocoder) over one
-batch whose inputs are already resident in HBM.  Rank 0 prints ONE JSON line.
+One process per GPU.  `--gpus N` with N > 1 started by hand (no RANK in the environment) launches the N ranks itself
+(`python -m torch.distributed.run`, fresh child processes) and relays rank 0's line; under torchrun the ranks find
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment.  Rank 0 reads and packs the .onnx, the packed weight
+arena is broadcast over RCCL/xGMI (every rank verifies its checksum and compares it with a local pack), then every
+rank synthesises its own utterances with no further communication.  Default: 32 utterances per GPU ("scaling":
+"weak"); `--total-batch T`: T utterances split over the GPUs ("strong").
+
+A step = one pass of the whole path (encoder + duration predictor + flow + vocoder) over one batch whose inputs are
+already resident in HBM.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,10 +28,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
-# split-exact engine: dense bf16 MFMA peak (256 CUs x 4096 FLOP/clk x 2.4 GHz = 2516.6 TFLOP/s) / 6 plane products
-SX_PEAK_TFLOPS = 2516.6 / 6
-# ... the same pipe (f16 MFMA has the bf16 rate) / 3 products of the default two-fp16-plane arithmetic
-SX_F16_PEAK_TFLOPS = 2516.6 / 3
+# split-operand engine: dense 16-bit MFMA peak (256 CUs x 4096 FLOP/clk x 2.4 GHz = 2516.6 TFLOP/s) / plane products
+MFMA16_PEAK_TFLOPS = 2516.6
+# scales[1]: ~3 frames per phoneme id with the synthetic weight sets (1.5 gave 2.4)
+LENGTH_SCALE = {"high": 1.95, "medium": 1.95, "small": 1.95}
+DTYPE = {2: "f32 (f16x3 split: fp32 operands as two fp16 planes, three MFMA products, fp32 accumulate)",
+         6: "f32 (bf16x6 split: fp32 operands as three bf16 planes, six exact MFMA products, fp32 accumulate)",
+         3: "f32 + bf16x3 vocoder (reduced precision)", 1: "f32 + bf16 vocoder (reduced precision)"}
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except Exception:
+        return None
 
 
 def pmc_traffic(preset, kernel_prefix):
@@ -33,11 +50,12 @@ def pmc_traffic(preset, kernel_prefix):
     (profiles/*_<preset>_b32_pmc.json, written by tools/profile_gpu.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate
     passes, per MI355X_MICROARCH.md).  Launch-weighted mean over the family's instantiations; None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{preset}_b32_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{preset}_b32_pmc.json")), key=os.path.getmtime)
     if not files:
         return None
     try:
-        ks = json.load(open(files[-1]))["kernels"]
+        doc = json.load(open(files[-1]))
+        ks = doc["kernels"]
     except Exception:
         return None
     tot = n = 0.0
@@ -45,32 +63,125 @@ def pmc_traffic(preset, kernel_prefix):
         if kernel_prefix in name and "hbm_read_bytes_per_launch" in c and "hbm_write_bytes_per_launch" in c:
             tot += (c["hbm_read_bytes_per_launch"] + c["hbm_write_bytes_per_launch"]) * c["launches"]
             n += c["launches"]
-    return {"bytes_per_launch": tot / n, "source": os.path.basename(files[-1])} if n else None
-LENGTH_SCALE = {"high": 1.5, "medium": 1.5, "small": 1.5}  # gives ~3 frames per phoneme id with synth weights
+    if not n:
+        return None
+    return {"bytes_per_launch": tot / n, "source": os.path.basename(files[-1]), "commit": doc.get("commit"),
+            "length_scale": doc.get("length_scale")}
 
 
-def cpu_baseline(voice_path, preset, tokens, scales, seed):
-    """Oracle (C restatement, OpenMP, all host cores) timed on a bounded sample of the workload."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(voice_path, preset, tokens, scales, seed, budget_s=45.0):
+    """What the reference's hot call costs on this box's host cores, on a bounded sample of the
+    workload.  Preferred: onnxruntime's CPU provider with default session options, as phoonnx/voice.py:167-171 builds
+    it - probed, absent on the build and GPU images (and the synthetic bench voice carries only the parameter nodes of
+    the graph, so it would need a real export anyway).  Otherwise the faster of two restatements of the graph, both
+    pinned to the reference-generated fixtures: PyTorch CPU kernels op by op (oracle/torch_baseline.py, oneDNN/MKL on
+    all cores - the closest stand-in for onnxruntime) and the C/OpenMP checker (oracle/vits_oracle.c)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import vits_oracle
+    out = {"unit": "samples/s", "cores": os.cpu_count(), "kind": "port"}
     try:
-        o = vits_oracle.VitsOracle(voice_path, native=True)
-    except Exception:
-        o = vits_oracle.VitsOracle(voice_path, native=False)
-    Bs = 2 if preset == "high" else 4
+        import onnxruntime  # noqa: F401
+        out["onnxruntime"] = "importable, but the bench voice holds only the graph's parameter nodes (phoonnx_amd/synth.py)"
+    except Exception as e:  # noqa: BLE001
+        out["onnxruntime"] = f"not available on this box ({type(e).__name__})"
     rng = np.random.default_rng(seed)
-    ids = rng.integers(0, 256, size=(Bs, tokens)).astype(np.int64)
-    lens = np.full((Bs,), tokens, np.int64)
-    ndp = rng.standard_normal((Bs, 2, tokens)).astype(np.float32)
-    nz = rng.standard_normal((Bs, o.inter_channels, tokens * 12)).astype(np.float32)
-    t0 = time.perf_counter()
-    r = o.infer(ids, lens, scales, None, ndp, nz)
-    dt = time.perf_counter() - t0
-    hop = r["output"].shape[3] // int(r["y_lengths"].max())
-    samples = int(r["y_lengths"].sum()) * hop
-    return {"value": samples / dt, "unit": "samples/s", "cores": int(o.lib.vo_num_threads()), "kind": "port",
-            "sample": f"C/OpenMP restatement (oracle/vits_oracle.c), B={Bs} x {tokens} ids, {samples} samples in {dt:.1f}s",
-            "rtf": dt / (samples / 22050.0)}
+    cands = {}
+
+    def sample(B):
+        ids = rng.integers(0, 256, size=(B, tokens)).astype(np.int64)
+        lens = np.full((B,), tokens, np.int64)
+        ndp = rng.standard_normal((B, 2, tokens)).astype(np.float32)
+        nz = rng.standard_normal((B, 192, tokens * 12)).astype(np.float32)
+        return ids, lens, ndp, nz
+
+    def timed(name, infer, hop, threads):
+        # warm-up on a short batch (thread pool, allocator, code paths), then batches of doubling size while the
+        # projected time of the next one stays inside the budget: the largest is the figure reported
+        ids, lens, ndp, nz = sample(1)
+        infer(ids[:, :64], np.full((1,), 64, np.int64), ndp[:, :, :64], nz)
+        B, spent, best = 1, 0.0, None
+        while True:
+            ids, lens, ndp, nz = sample(B)
+            t0 = time.perf_counter()
+            r = infer(ids, lens, ndp, nz)
+            dt = time.perf_counter() - t0
+            spent += dt
+            samples = int(np.asarray(r["y_lengths"]).sum()) * hop
+            best = {"value": samples / dt, "B": B, "samples": samples, "seconds": dt, "threads": threads,
+                    "rtf": dt / (samples / 22050.0)}
+            if B >= 32 or spent + 2.2 * dt > budget_s / 2:
+                break
+            B *= 2
+        cands[name] = best
+
+    try:
+        import torch
+        from torch_baseline import TorchVits
+        m = TorchVits(voice_path)
+        timed("torch_cpu", lambda i, l, a, b: m.infer(i, l, scales, None, a, b[:, :m.C]), m.hop, torch.get_num_threads())
+    except Exception as e:  # noqa: BLE001 - the baseline is a report, never the product
+        out["torch_cpu_error"] = f"{type(e).__name__}: {e}"
+    try:
+        import vits_oracle
+        try:
+            o = vits_oracle.VitsOracle(voice_path, native=True)
+        except Exception:  # noqa: BLE001
+            o = vits_oracle.VitsOracle(voice_path, native=False)
+        hop = [1]
+
+        def run(i, l, a, b):
+            r = o.infer(i, l, scales, None, a, b[:, :o.inter_channels])
+            hop[0] = r["output"].shape[3] // int(r["y_lengths"].max())
+            return r
+        # (hop is known only after a run: time with the hop of the first call)
+        run(*sample(1)[:2], *sample(1)[2:])
+        timed("c_openmp", run, hop[0], int(o.lib.vo_num_threads()))
+    except Exception as e:  # noqa: BLE001
+        out["c_openmp_error"] = f"{type(e).__name__}: {e}"
+    if not cands:
+        out.update(value=None, sample="failed")
+        return out
+    name = max(cands, key=lambda k: cands[k]["value"])
+    b = cands[name]
+    impl = {"torch_cpu": "PyTorch CPU kernels op by op (oracle/torch_baseline.py)",
+            "c_openmp": "C/OpenMP restatement (oracle/vits_oracle.c)"}[name]
+    out.update(value=b["value"], cores=b["threads"], rtf=b["rtf"], implementation=name,
+               sample=f"{impl}, B={b['B']} x {tokens} ids, same voice and scales, {b['samples']} samples in "
+                      f"{b['seconds']:.1f}s after one warm-up call (largest batch inside a {budget_s:.0f}s budget)",
+               candidates={k: {"value": v["value"], "B": v["B"], "threads": v["threads"]} for k, v in cands.items()},
+               host_cores=os.cpu_count())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(a, argv):
+    """`--gpus N` without a torchrun environment: start the N ranks as fresh child processes (nothing in this process
+    has touched the GPU) and relay rank 0's JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line:
+        print(line, flush=True)
+    elif r.stdout:
+        sys.stderr.write(r.stdout[-2000:])
+    return r.returncode if line or r.returncode else 1
+
+
+def pctl(xs):
+    xs = np.asarray(xs, np.float64)
+    return {"median": float(np.median(xs)), "p10": float(np.percentile(xs, 10)), "p90": float(np.percentile(xs, 90)),
+            "n": int(xs.size)}
 
 
 def main():
@@ -79,22 +190,26 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--preset", default="high", choices=["high", "medium", "small"])
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (weak scaling)")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="strong scaling: this many utterances in total, split evenly over the GPUs (BASELINE config 5: 256)")
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements of the N=1 line (exact arithmetic, host-in/host-out, the medium "
+                         "preset, per-step percentiles)")
     ap.add_argument("--gen-precision", default="f16x3", choices=["f16x3", "bf16x6", "bf16x3", "bf16"],
                     help="arithmetic of the generator's convs (fp32 operands and results in every mode).  f16x3 (default): "
                          "two fp16 planes per operand, three MFMA products per fp32 product, error no larger than the "
-                         "f32-MFMA engine's; bf16x6: three bf16 planes, six products, every product exact; bf16x3 / "
-                         "bf16: the declared reduced-precision vocoder modes of BASELINE config 4 (reported with their "
-                         "dtype, never as the headline number)")
+                         "f32-MFMA engine's, range-guarded; bf16x6: three bf16 planes, six products, every product exact; "
+                         "bf16x3 / bf16: the declared reduced-precision vocoder modes of BASELINE config 4 (reported with "
+                         "their dtype, never as the headline number)")
     ap.add_argument("--no-exact-check", action="store_true",
-                    help="skip the second, shorter measurement of the same workload with the six-product exact arithmetic "
-                         "(bf16x6), which the N=1 line carries next to the headline value")
+                    help="skip the second, shorter measurement of the same workload with the six-product exact arithmetic")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and broadcast the weight arena even at world size 1 "
-                         "(exercises the N > 1 code path on a one-GPU box; needs the torchrun environment)")
+                         "(exercises the N > 1 code path on a one-GPU box)")
     ap.add_argument("--lockstep", action="store_true",
                     help="enqueue the parts of every step from one host thread and join them per step, instead of one "
                          "free-running host thread per part (two serving workers)")
@@ -102,78 +217,174 @@ def main():
                     help="render each batch as this many sub-batches on as many engine handles / HIP streams sharing "
                          "one weight arena (PipelinedSession); 1 = a single handle")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(a, sys.argv[1:]))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world_env:
+        sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started {world_env} rank(s) (WORLD_SIZE)")
     os.environ["VITSMI_GEN_PRECISION"] = a.gen_precision
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or a.force_dist:
+    if world_env > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    world = dist.get_world_size() if dist else 1
 
-    from phoonnx_amd import PipelinedSession
-    from phoonnx_amd.sharding import open_sharded
+    from phoonnx_amd import MiSession, PipelinedSession
+    from phoonnx_amd.sharding import arena_checksum, open_sharded
     from phoonnx_amd.synth import write_voice
 
     cache = os.environ.get("VITSMI_BENCH_CACHE", "/tmp/vitsmi_bench")
-    voice = os.path.join(cache, f"synth_{a.preset}.onnx")
-    if rank == 0 and not os.path.exists(voice):
-        os.makedirs(cache, exist_ok=True)
-        write_voice(voice + ".tmp", a.preset, seed=1234)
-        os.replace(voice + ".tmp", voice)
+
+    def voice_path(preset):
+        p = os.path.join(cache, f"synth_{preset}.onnx")
+        if rank == 0 and not os.path.exists(p):
+            os.makedirs(cache, exist_ok=True)
+            write_voice(p + ".tmp", preset, seed=1234)
+            os.replace(p + ".tmp", p)
+        return p
+
+    voice = voice_path(a.preset)
     if dist:
         dist.barrier()
 
-    # weights: rank 0 reads + packs, RCCL broadcast of the arena, every rank opens on its GPU
-    sess, arena_keepalive = open_sharded(voice, local_rank, dist)
+    # weights: rank 0 reads + packs, RCCL broadcast of the arena (checksum-verified), every rank opens on its GPU
+    t_load = time.perf_counter()
+    sess, arena_keepalive = open_sharded(voice, local_rank, dist, force_broadcast=a.force_dist)
+    t_load = time.perf_counter() - t_load
+    weights = {"mode": "local pack", "load_s": t_load}
+    if arena_keepalive is not None:
+        # every rank: the arena that arrived over RCCL equals what packing the file here would give
+        probe = MiSession(voice, host_only=True)
+        local_sum = arena_checksum(torch.from_numpy(np.array(probe.arena_host(), copy=True)))
+        probe.close()
+        got = arena_checksum(arena_keepalive)
+        ok = torch.tensor([1 if got == local_sum else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            sys.exit(f"rank {rank}: broadcast weight arena differs from a local pack ({got:#x} vs {local_sum:#x})")
+        weights = {"mode": "RCCL broadcast of the packed arena from rank 0", "bytes": int(arena_keepalive.numel()),
+                   "checksum": f"{got & (2**64 - 1):#018x}", "verified_equal_to_local_pack_on_every_rank": True,
+                   "load_s": t_load}
     hop = sess.hparam("hop")
-    sess_gen_sx = bool(sess.hparam("gen_sx"))
     gen_nprod = int(sess.hparam("gen_nprod"))
-    sess.set_seed(1234 + rank * 16)
-    pipe = PipelinedSession(sess, max(1, a.parts))  # extra handles borrow sess's weight arena
-    pipe.set_seed(1234 + rank * 16)
 
-    B, T = a.batch, a.tokens
-    scales = np.array([0.667, LENGTH_SCALE[a.preset], 0.8], np.float32)
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    ids = torch.randint(0, 256, (B, T), generator=g, dtype=torch.int64).cuda()
-    lens = torch.full((B,), T, dtype=torch.int64).cuda()
-    torch.cuda.synchronize()
+    if a.total_batch:
+        if a.total_batch % world:
+            sys.exit(f"--total-batch {a.total_batch} does not divide over {world} GPUs")
+        B = a.total_batch // world
+    else:
+        B = a.batch
+    T = a.tokens
 
-    def step():
-        pipe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
-        return int(pipe.last_y_lengths(B).sum()) * hop
+    def make_inputs(seed, Bn=B):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        ids = torch.randint(0, 256, (Bn, T), generator=g, dtype=torch.int64)
+        lens = torch.full((Bn,), T, dtype=torch.int64)
+        return ids, lens
 
-    def step_one():  # the whole batch on the first handle: per-kernel timing for the roofline block
-        sess.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+    def measure(first, preset, steps, warmup, parts, lockstep, seed):
+        """K timed passes of the whole path on `parts` handles sharing `first`'s arena -> (dt, samples, pipe)."""
+        pipe = PipelinedSession(first, max(1, parts))
+        pipe.set_seed(1234 + rank * 16)
+        scales = np.array([0.667, LENGTH_SCALE[preset], 0.8], np.float32)
+        ids_h, lens_h = make_inputs(seed)
+        ids, lens = ids_h.cuda(), lens_h.cuda()
+        torch.cuda.synchronize()
 
-    # K steps = K passes of the whole path over the batch.  Default: every part (half batch, own handle and stream) is
-    # driven by its own host thread through its K passes, like two serving workers; --lockstep joins them per step.
-    def run_steps(k):
-        if a.lockstep or len(pipe.parts) == 1:
-            return sum(step() for _ in range(k))
-        return int(pipe.run_device_steps(ids.data_ptr(), lens.data_ptr(), B, T, scales, k).sum()) * hop
+        def run_steps(k):
+            if lockstep or len(pipe.parts) == 1:
+                n = 0
+                for _ in range(k):
+                    pipe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+                    n += int(pipe.last_y_lengths(B).sum()) * hop
+                return n
+            return int(pipe.run_device_steps(ids.data_ptr(), lens.data_ptr(), B, T, scales, k).sum()) * hop
 
-    if a.warmup > 0:
-        run_steps(a.warmup)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    samples = run_steps(a.steps)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+        if warmup > 0:
+            run_steps(warmup)
+        pipe.sync()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        samples = run_steps(steps)
+        pipe.sync()  # (also the f16 range verdict of the last pass: a violation raises here)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return dt, samples, pipe, (ids, lens, ids_h, lens_h, scales)
 
+    def roofline_of(s, preset, inputs, n_t):
+        """Per-kernel timing with HIP events on the engine's own stream (vits_set_timing), one handle, whole batch."""
+        ids, lens, _, _, scales = inputs
+        s.set_timing(True)
+        fl = ms = by = 0.0
+        launches = 0
+        agg = {}
+        s.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)  # (untimed: creates the handle's HIP events)
+        s.stats()
+        for _ in range(n_t):
+            s.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+            st = s.stats()
+            fl += st["conv_flops"]
+            by += st["conv_bytes"]
+            ms += st["conv_ms"]
+            launches += st["conv_launches"]
+            for k in ("enc_ms", "dp_ms", "flow_ms", "dec_ms", "total_ms", "dec_flops", "dec_bytes", "flow_flops",
+                      "sx_flops", "sx_ms", "sx_launches", "total_launches"):
+                agg[k] = agg.get(k, 0.0) + st[k]
+            rng_stats = {"f16_peak_max": st["f16_peak_max"], "f16_peak_min": st["f16_peak_min"],
+                         "f16_launches_tracked": st["f16_tracked"], "f16_saturated": st["f16_saturated"]}
+        s.set_timing(False)
+        nprod = int(s.hparam("gen_nprod"))
+        if agg.get("sx_launches", 0) > 0:
+            kfl, kms, kn = agg["sx_flops"], agg["sx_ms"], int(agg["sx_launches"])
+            kname = ("conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 2 fp16 planes, 3 x v_mfma_f32_32x32x16_f16 per product)"
+                     if nprod == 2 else
+                     "conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 3 bf16 planes, v_mfma_f32_32x32x16_bf16 plane products)")
+            peak = MFMA16_PEAK_TFLOPS / (3 if nprod == 2 else nprod)
+        else:
+            kfl, kms, kn = fl, ms, launches
+            kname = "conv_engine_kernel (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)"
+            peak = FP32_PEAK_TFLOPS
+        ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        tr = pmc_traffic(preset, kname.split(" ")[0]) if (B, T) == (32, 256) else None
+        roof = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": (tr or {}).get("bytes_per_launch"),
+                "traffic_source": (tr or {}).get("source"), "traffic_commit": (tr or {}).get("commit"),
+                "launches_per_step": kn // n_t, "avg_launch_ms": kms / max(kn, 1),
+                "algorithmic_gflop_per_launch": kfl / max(kn, 1) / 1e9,
+                "all_conv_launches_per_step": launches // n_t,
+                "all_kernel_launches_per_step": int(agg.get("total_launches", 0)) // n_t,
+                "all_conv_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                "algorithmic_gflop_per_step": fl / n_t / 1e9,
+                "algorithmic_gbytes_per_step": by / n_t / 1e9,
+                "hbm_frac_of_8TBs": (by / (ms * 1e-3)) / 8.0e12 if ms > 0 else 0.0,
+                "note": "one handle, whole batch, HIP events around every conv launch (serialises the stream): the step "
+                        "this describes is stages.total_ms, not ms_per_step of the pipelined headline run"}
+        stage = {k: v / n_t for k, v in agg.items()}
+        if stage.get("dec_ms", 0) > 0:
+            stage["dec_tflops"] = stage["dec_flops"] / (stage["dec_ms"] * 1e-3) / 1e12
+            stage["dec_hbm_frac"] = stage["dec_bytes"] / (stage["dec_ms"] * 1e-3) / 8.0e12
+        return roof, stage, rng_stats
+
+    # ---------------------------------------------------------------- the headline measurement
+    dt, samples, pipe, inputs = measure(sess, a.preset, a.steps, a.warmup, a.parts, a.lockstep, 1234 + rank)
     tot = torch.tensor([dt, float(samples)], dtype=torch.float64, device="cuda")
     if dist:
         mx = tot.clone()
@@ -184,95 +395,74 @@ def main():
     else:
         dt_max, samples_all = dt, float(samples)
 
-    roofline = None
-    stage = None
+    roofline = stage = f16_range = None
     if rank == 0 and not a.no_roofline:
-        # per-kernel timing with HIP events on the engine's own stream (vits_set_timing)
-        sess.set_timing(True)
-        fl = ms = by = 0.0
-        launches = 0
-        agg = {}
-        n_t = max(3, min(a.steps, 5))
-        step_one()  # (untimed: the first timed run creates the handle's HIP events)
-        sess.stats()
-        for _ in range(n_t):
-            step_one()
-            st = sess.stats()
-            fl += st["conv_flops"]
-            by += st["conv_bytes"]
-            ms += st["conv_ms"]
-            launches += st["conv_launches"]
-            for k in ("enc_ms", "dp_ms", "flow_ms", "dec_ms", "total_ms", "dec_flops", "dec_bytes", "flow_flops",
-                      "sx_flops", "sx_ms", "sx_launches"):
-                agg[k] = agg.get(k, 0.0) + st[k]
-        sess.set_timing(False)
-        if agg.get("sx_launches", 0) > 0:
-            # dominant kernel: the generator's split-exact conv (six bf16 MFMA plane products per fp32 product)
-            kfl, kms, kn = agg["sx_flops"], agg["sx_ms"], int(agg["sx_launches"])
-            if gen_nprod == 2:
-                kname = "conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 2 fp16 planes, 3 x v_mfma_f32_32x32x16_f16 per product)"
-                peak = SX_F16_PEAK_TFLOPS
-            else:
-                kname = "conv_sx_kernel (implicit-GEMM Conv1d, fp32-exact via 3 bf16 planes, v_mfma_f32_32x32x16_bf16)"
-                peak = SX_PEAK_TFLOPS if gen_nprod == 6 else 2516.6 / gen_nprod  # (reduced modes: fewer plane products)
-        else:
-            kfl, kms, kn = fl, ms, launches
-            kname = "conv_engine_kernel (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)"
-            peak = FP32_PEAK_TFLOPS
-        ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": kname,
-                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                    "traffic": (pmc_traffic(a.preset, kname.split(" ")[0]) or {}).get("bytes_per_launch")
-                    if (B, T) == (32, 256) else None,
-                    "traffic_source": (pmc_traffic(a.preset, kname.split(" ")[0]) or {}).get("source"),
-                    "launches_per_step": kn // n_t,
-                    "avg_launch_ms": kms / max(kn, 1),
-                    "algorithmic_gflop_per_launch": kfl / max(kn, 1) / 1e9,
-                    "all_conv_launches_per_step": launches // n_t,
-                    "all_conv_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                    "algorithmic_gflop_per_step": fl / n_t / 1e9,
-                    "algorithmic_gbytes_per_step": by / n_t / 1e9,
-                    "hbm_frac_of_8TBs": (by / (ms * 1e-3)) / 8.0e12 if ms > 0 else 0.0}
-        stage = {k: v / n_t for k, v in agg.items()}
-        if stage.get("dec_ms", 0) > 0:
-            stage["dec_tflops"] = stage["dec_flops"] / (stage["dec_ms"] * 1e-3) / 1e12
-            stage["dec_hbm_frac"] = stage["dec_bytes"] / (stage["dec_ms"] * 1e-3) / 8.0e12
+        roofline, stage, f16_range = roofline_of(sess, a.preset, inputs, max(3, min(a.steps, 5)))
 
-    # The same workload once more with every fp32 product exact (VITSMI_GEN_PRECISION=bf16x6), so that the line
-    # carries both arithmetics of the generator: N=1 only, after (outside) the timed region of the headline value.
+    extras = world == 1 and not a.no_extras
+    ids, lens, ids_h, lens_h, scales = inputs
+
+    # per-step wall times (lock-step: every step joined), median / p10 / p90
+    step_pct = None
+    if extras:
+        per = []
+        for _ in range(max(a.steps, 10)):
+            t0 = time.perf_counter()
+            pipe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+            pipe.sync()
+            per.append((time.perf_counter() - t0) * 1e3)
+        step_pct = dict(pctl(per), unit="ms", note="lock-step passes, each one synchronised (no overlap between passes)")
+
+    # the reference's call shape: host arrays in, host fp32 waveform out (session.run, voice.py:374-377) - never `value`
+    host_io = None
+    if extras:
+        ids_n, lens_n = ids_h.numpy(), lens_h.numpy()
+        pipe.synthesize_batch(ids_n, lens_n, scales)
+        per, n_s = [], 0
+        for _ in range(max(3, a.steps // 2)):
+            t0 = time.perf_counter()
+            r = pipe.synthesize_batch(ids_n, lens_n, scales)
+            per.append(time.perf_counter() - t0)
+            n_s += int(r["y_lengths"].sum()) * hop
+        host_io = {"value": n_s / sum(per), "unit": "samples/s", "ms_per_step": 1e3 * sum(per) / len(per),
+                   "note": "vits_run: host int64 ids in, pinned-host fp32 [B,1,1,S] out (H2D + D2H + a NumPy copy per part "
+                           "inside the timed region), what session.run returns"}
+
+    # the same workload once more with every fp32 product exact (bf16x6), after (outside) the headline's timed region
     exact = None
-    if world == 1 and gen_nprod == 2 and not a.no_exact_check:
+    if extras and gen_nprod == 2 and not a.no_exact_check:
         try:
-            os.environ["VITSMI_GEN_PRECISION"] = "bf16x6"
-            pe = PipelinedSession.open(voice, device_id=local_rank, parts=max(1, a.parts))
-            pe.set_seed(1234)
+            pe_first = MiSession(voice, device_id=local_rank, gen_precision="bf16x6")
             ke = max(3, a.steps // 2)
-            for _ in range(max(2, a.warmup)):
-                pe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
-            torch.cuda.synchronize()
-            te = time.perf_counter()
-            ne = 0
-            for _ in range(ke):
-                pe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
-                ne += int(pe.last_y_lengths(B).sum()) * hop
-            torch.cuda.synchronize()
-            te = time.perf_counter() - te
-            exact = {"gen_precision": "bf16x6", "gen_nprod": int(pe.hparam("gen_nprod")), "value": ne / te,
-                     "unit": "samples/s", "steps": ke, "ms_per_step": te / ke * 1e3,
-                     "note": "six bf16 plane products per fp32 product (each exact to 2^-24); same batch and handle count, measured "
-                             "right after the headline run (chip already at its power / thermal limit: a standalone "
-                             "`bench.py --gen-precision bf16x6` reads ~10 % higher)"}
+            dte, ne, pe, _ = measure(pe_first, a.preset, ke, max(2, a.warmup), a.parts, a.lockstep, 1234 + rank)
+            exact = {"gen_precision": "bf16x6", "gen_nprod": int(pe_first.hparam("gen_nprod")), "value": ne / dte,
+                     "unit": "samples/s", "steps": ke, "ms_per_step": dte / ke * 1e3,
+                     "note": "six bf16 plane products per fp32 product (each exact to 2^-24, fp32 range); same batch and "
+                             "handle count, measured after the headline run on the already power-limited chip"}
             pe.close()
-        except Exception as e:
+        except Exception as e:  # noqa: BLE001
             exact = {"gen_precision": "bf16x6", "value": None, "note": f"failed: {e}"}
-        finally:
-            os.environ["VITSMI_GEN_PRECISION"] = a.gen_precision
+
+    # "headline = high; always also report medium"
+    also = None
+    if extras and a.preset != "medium":
+        try:
+            mfirst = MiSession(voice_path("medium"), device_id=local_rank)
+            km = max(5, a.steps)
+            dtm, nm, mp_, minputs = measure(mfirst, "medium", km, max(2, a.warmup), a.parts, a.lockstep, 1234 + rank)
+            mroof, mstage, mrange = (None, None, None) if a.no_roofline else roofline_of(mfirst, "medium", minputs, 3)
+            also = {"preset": "medium", "value": nm / dtm, "unit": "samples/s", "steps": km, "ms_per_step": dtm / km * 1e3,
+                    "frames_per_id": nm / km / hop_of(mfirst) / (B * T), "roofline": mroof, "stages": mstage,
+                    "f16_range": mrange}
+            mp_.close()
+        except Exception as e:  # noqa: BLE001
+            also = {"preset": "medium", "value": None, "note": f"failed: {type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:  # (N = 1 only: the other ranks would sit in the final barrier)
         try:
             cpu = cpu_baseline(voice, a.preset, T, scales, 1234)
-        except Exception as e:  # the baseline is a report, never the product
+        except Exception as e:  # noqa: BLE001 - the baseline is a report, never the product
             cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
     if rank == 0:
@@ -280,27 +470,22 @@ def main():
         line = {
             "metric": "audio samples/sec (22.05 kHz), batch-32 256-phoneme utterances",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if gen_nprod in (6, 2) else f"f32 + {a.gen_precision} vocoder (reduced precision)",
-            "data": "synthetic",
-            "dtype_note": ("fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 VALU" if not sess_gen_sx else
-                           "fp32 operands and fp32 accumulation everywhere; the generator's convs evaluate each fp32 product "
-                           "as three fp16 MFMA products of its operands' two fp16 planes (h0g0 + h0g1 + h1g0, dropped term "
-                           "<= 2^-24 relative; measured error vs float64 below the f32-MFMA engine's)" if gen_nprod == 2 else
-                           "fp32 operands and fp32 accumulation everywhere; the generator's convs evaluate each fp32 product "
-                           "exactly-to-2^-24 as six bf16 MFMA plane products (three bf16 planes per operand)"),
-            "gen_precision": a.gen_precision,
+            "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if a.total_batch else "weak",
+            "vs_baseline": None, "dtype": DTYPE.get(gen_nprod, "f32") if sess.hparam("gen_sx") else "f32",
+            "data": "synthetic", "gen_precision": a.gen_precision,
             "rtf": dt_max / (samples_all / world / 22050.0) if samples_all else None,
             "config": {"workload": f"VITS full pipeline (encoder+duration+flow+HiFi-GAN), preset={a.preset}, "
                                    f"batch={B}/GPU x {T} phoneme ids, scales=[0.667,{scales[1]:.2f},0.8], "
                                    f"device Philox noise, seeded synthetic weights",
-                       "preset": a.preset, "batch_per_gpu": B, "tokens": T, "hop": hop,
+                       "preset": a.preset, "batch_per_gpu": B, "global_batch": B * world, "tokens": T, "hop": hop,
                        "pipeline_parts": len(pipe.parts),
                        "pipeline_host": "lockstep" if (a.lockstep or len(pipe.parts) == 1) else "one free-running host thread per part",
                        "samples_per_step": samples_all / a.steps,
                        "frames_per_id": samples_all / a.steps / hop / (B * world * T),
-                       "weights": "RCCL broadcast of packed arena" if world > 1 else "local"},
-            "roofline": roofline, "cpu_baseline": cpu, "exact_arithmetic": exact, "stages": stage,
+                       "weights": weights, "commit": git_head()},
+            "roofline": roofline, "cpu_baseline": cpu, "step_ms": step_pct, "host_io": host_io,
+            "exact_arithmetic": exact, "also": also, "stages": stage, "f16_range": f16_range,
         }
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = value / world / cpu["value"]
@@ -309,6 +494,10 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def hop_of(s):
+    return s.hparam("hop")
 
 
 if __name__ == "__main__":

@@ -138,6 +138,26 @@ def main():
         "cotovia": {"characters": {"characters_class": "TTS.tts.models.vits.VitsCharacters", "characters": "abc",
                                    "punctuations": ".", "pad": "_"}, "phoneme_type": "cotovia", "lang_code": "gl"},
     }
+    # Piper JSON as the reference's exporter writes it (export_onnx.py:97-130, convert_to_piper): the function is pulled
+    # out of the reference file with `ast` and run here (export_onnx.py itself does not import in this container -
+    # pytorch_lightning is absent), on a phoonnx voice config; what it writes is one more dialect VoiceConfig must read
+    import ast
+    import tempfile
+    from pathlib import Path
+    src = open(os.path.join(REF, "phoonnx_train", "export_onnx.py"), encoding="utf-8").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "convert_to_piper"]
+    ns = {"Path": Path, "json": json, "Dict": dict, "Any": object}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "convert_to_piper", "exec"), ns)
+    with tempfile.TemporaryDirectory() as td:
+        for tag, ptype in (("espeak", "espeak"), ("raw", "raw")):
+            src_cfg = {"phoneme_type": ptype, "lang_code": "pt-PT", "alphabet": "ipa", "audio": {"sample_rate": 22050},
+                       "inference": {"noise_scale": 0.6, "length_scale": 1.2, "noise_w": 0.9}, "num_symbols": 70,
+                       "num_speakers": 3, "phoonnx_version": "0.2.3",
+                       "phoneme_id_map": {"_": 0, "^": 1, "$": 2, " ": 3, "a": 4, "b": 5}}
+            cin, cout = Path(td) / "in.json", Path(td) / "piper.json"
+            cin.write_text(json.dumps(src_cfg), encoding="utf-8")
+            ns["convert_to_piper"](cin, cout)
+            cfgs["piper_from_export_" + tag] = json.loads(cout.read_text(encoding="utf-8"))
     for name, cfg in cfgs.items():
         try:
             vc = Cfg.VoiceConfig.from_dict(json.loads(json.dumps(cfg)))

@@ -16,15 +16,20 @@ from .session import MiSession
 
 
 def partition(lengths: Sequence[int], world: int) -> Tuple[List[np.ndarray], np.ndarray]:
-    """Deal utterances to ranks: sort by length (longest first) so each rank's padded batch
-    wastes little, then give rank r the r-th contiguous block.  Returns (per-rank index arrays
-    into the original order, inverse permutation that restores the original order from the
-    concatenation of the per-rank results)."""
+    """Deal utterances to ranks so that every rank gets the same amount of work: utterances sorted by length
+    (longest first) are dealt in snake order (ranks 0..N-1, then N-1..0, ...), which keeps each rank's shard
+    length-sorted (little padding inside its batch) and its total length within one utterance of every other
+    rank's - a gathered request finishes when the slowest rank does.  Returns (per-rank index arrays into the
+    original order, inverse permutation that restores the original order from the concatenation of the per-rank
+    results)."""
     lengths = np.asarray(lengths)
     n = len(lengths)
     order = np.argsort(-lengths, kind="stable")
-    per = (n + world - 1) // world if world else n
-    shards = [order[r * per:(r + 1) * per] for r in range(world)]
+    world = max(int(world), 1)
+    pos = np.arange(n)
+    lap, slot = pos // world, pos % world
+    rank_of = np.where(lap % 2 == 0, slot, world - 1 - slot)
+    shards = [order[rank_of == r] for r in range(world)]
     inv = np.empty(n, dtype=np.int64)
     inv[np.concatenate(shards) if n else np.zeros(0, np.int64)] = np.arange(n)
     return shards, inv
@@ -40,36 +45,52 @@ def pad_batch(utts: Sequence[Sequence[int]], pad_id: int = 0) -> Tuple[np.ndarra
     return ids, lens
 
 
-def broadcast_arena(path: str, dist, device: Optional[int], src: int = 0):
+def arena_checksum(arena) -> int:
+    """Order-independent 64-bit checksum of a packed arena (torch uint8 tensor, host or device): the wrapping sum of
+    its little-endian 32-bit words.  Cheap enough to run on the GPU right after the broadcast."""
+    import torch
+    n = arena.numel() // 4 * 4
+    return int(arena[:n].view(torch.int32).sum(dtype=torch.int64).item())
+
+
+def broadcast_arena(path: str, dist, device: Optional[int], src: int = 0, verify: bool = True):
     """Rank `src` parses + packs the .onnx on the host; the packed arena is broadcast to every
     rank (device tensors over RCCL when `device` is not None, host tensors otherwise, e.g. gloo).
-    Returns a uint8 torch tensor holding the arena on this rank."""
+    verify: every rank compares the checksum of what it received with rank `src`'s (a second, 8-byte broadcast) and
+    raises on a mismatch.  Returns a uint8 torch tensor holding the arena on this rank."""
     import torch
     rank = dist.get_rank()
     dev = torch.device("cuda", device) if device is not None else torch.device("cpu")
-    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    hdr = torch.zeros(2, dtype=torch.int64, device=dev)  # [bytes, checksum]
     host = None
     if rank == src:
         host = MiSession(path, host_only=True)
-        n[0] = host.arena_bytes()
-    dist.broadcast(n, src)
-    nbytes = int(n.item())
-    if rank == src:
-        arena = torch.from_numpy(np.array(host.arena_host(), copy=True)).to(dev)
+        arena = torch.from_numpy(np.array(host.arena_host(), copy=True))
+        hdr[0] = host.arena_bytes()
+        hdr[1] = arena_checksum(arena)
+        arena = arena.to(dev)
         host.close()
-    else:
+    dist.broadcast(hdr, src)
+    nbytes, want = int(hdr[0].item()), int(hdr[1].item())
+    if rank != src:
         arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     dist.broadcast(arena, src)  # ~64-119 MB once; 7 xGMI links x ~153 GB/s -> sub-millisecond class
+    if verify:
+        got = arena_checksum(arena)
+        if got != want:
+            raise RuntimeError(f"rank {rank}: weight arena checksum {got:#x} differs from rank {src}'s {want:#x}")
     return arena
 
 
-def open_sharded(path: str, device_id: int, dist=None, src: int = 0):
-    """Open one engine handle per rank.  With a process group, weights arrive by broadcast and the
-    handle adopts the device arena (vits_open_with_arena); without one this is a plain open.
-    Returns (session, arena_tensor_or_None) — keep the tensor alive as long as the session."""
-    if dist is None or dist.get_world_size() == 1:
+def open_sharded(path: str, device_id: int, dist=None, src: int = 0, force_broadcast: bool = False, verify: bool = True):
+    """Open one engine handle per rank.  With a process group, weights arrive by broadcast and the handle adopts the
+    device arena (vits_open_with_arena: the file is parsed for the model description and the arena LAYOUT only - no
+    rank but `src` packs a weight); without one this is a plain open.  force_broadcast takes the broadcast path even at
+    world size 1 (exercises the N > 1 code on a one-GPU box).
+    Returns (session, arena_tensor_or_None) - keep the tensor alive as long as the session."""
+    if dist is None or (dist.get_world_size() == 1 and not force_broadcast):
         return MiSession(path, device_id=device_id), None
-    arena = broadcast_arena(path, dist, device_id, src)
+    arena = broadcast_arena(path, dist, device_id, src, verify)
     sess = MiSession(path, device_id=device_id, arena_device_ptr=arena.data_ptr(), arena_bytes=arena.numel())
     return sess, arena
 
@@ -78,11 +99,11 @@ class ShardedSynthesizer:
     """Batched-utterance front: `synthesize(utterances)` runs this rank's shard and (optionally)
     gathers the waveforms of all ranks on the host in the original order."""
 
-    def __init__(self, path: str, device_id: int, dist=None):
+    def __init__(self, path: str, device_id: int, dist=None, force_broadcast: bool = False):
         self.dist = dist
         self.rank = dist.get_rank() if dist else 0
         self.world = dist.get_world_size() if dist else 1
-        self.session, self._arena = open_sharded(path, device_id, dist)
+        self.session, self._arena = open_sharded(path, device_id, dist, force_broadcast=force_broadcast)
         self.hop = self.session.hparam("hop")
 
     def synthesize(self, utterances: Sequence[Sequence[int]], scales, sids: Optional[Sequence[int]] = None,

@@ -53,6 +53,43 @@ def config_from_metadata(meta: dict) -> dict:
     }
 
 
+def check_consistency(config_dict: dict, meta: dict, graph_speakers: int, graph_vocab: int) -> None:
+    """Extension: the three places that describe a voice must agree - the voice JSON, the
+    metadata_props export_onnx.py:335-350 wrote into the .onnx, and the graph itself (embedding table sizes).  The
+    reference never compares them (config.py:335-358 just reads the JSON) and a mismatch surfaces later as wrong-rate
+    audio or an out-of-range Gather inside onnxruntime.  Only values a side actually STATES are compared; raises
+    ValueError naming both sides."""
+    def as_int(v):
+        try:
+            return int(v)
+        except (TypeError, ValueError):
+            return None
+
+    problems = []
+    pairs = (("num_speakers", config_dict.get("num_speakers"), "n_speakers"),
+             ("audio.sample_rate", (config_dict.get("audio") or {}).get("sample_rate"), "sample_rate"),
+             ("num_symbols", config_dict.get("num_symbols"), "n_vocab"))
+    for cfg_key, cfg_val, meta_key in pairs:
+        c, m = as_int(cfg_val), as_int((meta or {}).get(meta_key))
+        if c is not None and m is not None and c != m:
+            problems.append(f"config {cfg_key}={c} but the .onnx metadata says {meta_key}={m}")
+    c = as_int(config_dict.get("num_speakers"))
+    if c is not None and c != graph_speakers and not (c <= 1 and graph_speakers <= 1):
+        problems.append(f"config num_speakers={c} but the graph's speaker table has {graph_speakers} rows")
+    m = as_int((meta or {}).get("n_speakers"))
+    if m is not None and m != graph_speakers and not (m <= 1 and graph_speakers <= 1):
+        problems.append(f".onnx metadata n_speakers={m} but the graph's speaker table has {graph_speakers} rows")
+    id_map = config_dict.get("phoneme_id_map") or {}
+    top = -1
+    for v in id_map.values():
+        for i in (v if isinstance(v, (list, tuple)) else [v]):
+            top = max(top, as_int(i) if as_int(i) is not None else -1)
+    if top >= graph_vocab:
+        problems.append(f"phoneme_id_map uses id {top} but the graph's embedding table has {graph_vocab} rows")
+    if problems:
+        raise ValueError("inconsistent voice: " + "; ".join(problems))
+
+
 @dataclass
 class AudioChunk:
     """A chunk of raw audio: float samples in [-1, 1] plus their PCM16 rendering."""
@@ -94,9 +131,10 @@ class TTSVoice:
     def load(model_path: Union[str, Path], config_path: Optional[Union[str, Path]] = None,
              phonemes_txt: Optional[str] = None, phoneme_map: Optional[str] = None, lang_code: Optional[str] = None,
              phoneme_type_str: Optional[str] = None, use_cuda: bool = False, device_id: int = 0,
-             phonemizer: Optional[Any] = None) -> "TTSVoice":
+             phonemizer: Optional[Any] = None, strict: bool = True) -> "TTSVoice":
         """Load a voice: `<model>.onnx` + `<model>.onnx.json` (voice.py:125-172).  `use_cuda` is
-        accepted for signature compatibility; the engine always runs on the MI355X `device_id`."""
+        accepted for signature compatibility; the engine always runs on the MI355X `device_id`.
+        strict (extension): raise ValueError when JSON, .onnx metadata and graph disagree (check_consistency)."""
         import os
         from .session import MiSession
         if config_path is None:
@@ -111,11 +149,15 @@ class TTSVoice:
             # extension: no JSON next to the model -> rebuild the config from the
             # metadata_props export_onnx.py:335-350 wrote into the .onnx itself
             config_dict = config_from_metadata(session.get_modelmeta().custom_metadata_map)
+        if strict:
+            try:
+                check_consistency(config_dict, session.get_modelmeta().custom_metadata_map,
+                                  session.hparam("n_speakers"), session.hparam("n_vocab"))
+            except ValueError:
+                session.close()
+                raise
         config = VoiceConfig.from_dict(config_dict, phonemes_txt=phonemes_txt, lang_code=lang_code,
                                        phoneme_type_str=phoneme_type_str)
-        n_spk = session.hparam("n_speakers")
-        if config.num_speakers != n_spk:
-            LOG.warning("config says %d speakers, the graph has %d", config.num_speakers, n_spk)
         return TTSVoice(session=session, config=config, phonemizer=phonemizer)
 
     # ------------------------------------------------------------------ text -> phonemes -> ids
@@ -204,6 +246,9 @@ class TTSVoice:
                     wav_file.setsampwidth(chunk.sample_width)
                     wav_file.setnchannels(chunk.sample_channels)
                 first = False
+            # NOTE (mirrors voice.py:317-324): `first` was cleared just above, so the "silence between sentences" is also
+            # written before the first one; it is zero bytes long today (sentence_silence = 0.0), which is the only
+            # reason this is inaudible.  Kept for byte-identity with the reference (tests/golden/frontend.json).
             if not first:
                 wav_file.writeframes(silence)
             wav_file.writeframes(chunk.audio_int16_bytes)

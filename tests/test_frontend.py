@@ -181,3 +181,23 @@ def test_builtin_phonemizers_and_missing_id_map():
     assert v.config.lang_code == "und"
     with pytest.raises(ValueError):
         v.phonemes_to_ids(["a"])
+
+
+def test_consistency_validation_of_json_metadata_and_graph():
+    """f3: JSON, .onnx metadata_props (export_onnx.py:335-350) and the graph must agree; only stated values count."""
+    from phoonnx_amd.voice import check_consistency
+    meta = {"n_speakers": "4", "n_vocab": "130", "sample_rate": "22050"}
+    ok = {"num_speakers": 4, "num_symbols": 130, "audio": {"sample_rate": 22050}, "phoneme_id_map": {"a": 1, "b": [129]}}
+    check_consistency(ok, meta, 4, 130)
+    check_consistency({"phoneme_id_map": {"a": 1}}, meta, 4, 130)            # a JSON that states nothing: fine
+    check_consistency(ok, {}, 4, 130)                                          # no metadata: fine
+    check_consistency({"num_speakers": 1}, {"n_speakers": "1"}, 1, 130)       # single-speaker graphs have no table
+    for bad, msg in ((dict(ok, num_speakers=2), "num_speakers=2"),
+                     (dict(ok, audio={"sample_rate": 16000}), "sample_rate"),
+                     (dict(ok, num_symbols=256), "num_symbols=256"),
+                     (dict(ok, phoneme_id_map={"a": 130}), "id 130"),
+                     (dict(ok, phoneme_id_map={"a": [3, 400]}), "id 400")):
+        with pytest.raises(ValueError, match=msg):
+            check_consistency(bad, meta, 4, 130)
+    with pytest.raises(ValueError, match="speaker table has 2 rows"):
+        check_consistency(ok, meta, 2, 130)

@@ -174,3 +174,277 @@ def test_baseline_batch_properties():
     n = (int(one["y_lengths"][0]) - 64) * hop  # minus the generator's receptive field at the right edge
     np.testing.assert_allclose(r["output"][0, 0, 0, :n], one["output"][0, 0, 0, :n], atol=2e-5)
     s.close()
+
+
+# ------------------------------------------------------------------ f16x3 range guard
+
+def _loud_voice(tmp_path, gain):
+    """A `small`-family voice on the sx engine whose generator weights are `gain` times the usual ones."""
+    from phoonnx_amd.synth import PRESETS, write_voice
+    path = str(tmp_path / f"loud_{gain}.onnx")
+    write_voice(path, "small", seed=11, upsample_initial_channel=128, upsample_rates=(8, 4), upsample_kernel_sizes=(16, 8),
+                dec_gain=PRESETS["small"]["dec_gain"] * gain)
+    return path
+
+
+def test_f16_range_guard_raises_or_falls_back_never_clamps(tmp_path):
+    """dec.* weights x100: activations leave the fp16 planes' range.  The engine must not return clamped audio: with the
+    fallback off it raises RangeError; with it on (default) the call is repeated with the bf16x6 arithmetic and matches
+    the oracle to north_star's 1e-3."""
+    from phoonnx_amd import MiSession, RangeError
+    from vits_oracle import VitsOracle
+    path = _loud_voice(tmp_path, 100.0)
+    rng = np.random.default_rng(3)
+    B, T = 2, 48
+    ids = rng.integers(0, 256, (B, T)).astype(np.int64)
+    lens = np.array([T, T - 9], np.int64)
+    sc = np.array([0.667, 1.2, 0.8], np.float32)
+    ndp = rng.standard_normal((B, 2, T)).astype(np.float32)
+    nz = rng.standard_normal((B, 64, T * 8)).astype(np.float32)
+    strict = MiSession(path, range_fallback=False)
+    assert strict.hparam("gen_sx") == 1 and strict.hparam("gen_nprod") == 2
+    with pytest.raises(RangeError, match="65504|range"):
+        strict.synthesize_batch(ids, lens, sc, None, ndp, nz)
+    st = strict.stats()
+    assert st["f16_saturated"] == 1 and not (st["f16_peak_max"] <= 65504.0)
+    # the device-resident entry reports it at the synchronisation
+    strict.close()
+    s = MiSession(path)                                       # range_fallback=True
+    got = s.synthesize_batch(ids, lens, sc, None, ndp, nz)
+    assert s.hparam("gen_nprod") == 6                         # ... it reopened itself with the exact arithmetic
+    ref = VitsOracle(path).infer(ids, lens, sc, None, ndp, nz)
+    assert np.array_equal(got["y_lengths"], ref["y_lengths"])
+    assert np.isfinite(ref["output"]).all()
+    np.testing.assert_allclose(got["output"], ref["output"], atol=1e-3, rtol=0)
+    s.close()
+
+
+def test_f16_range_guard_reports_the_dynamic_range_of_a_normal_voice():
+    """On the bench voices nothing comes near either end of the fp16 planes' range: the stats say so."""
+    from phoonnx_amd import MiSession
+    for preset in ("medium", "high"):
+        s = MiSession(_voice(preset))
+        rng = np.random.default_rng(2)
+        ids = rng.integers(0, 256, (2, 96)).astype(np.int64)
+        s.synthesize_batch(ids, np.array([96, 80], np.int64), np.array([0.667, 1.4, 0.8], np.float32))
+        st = s.stats()
+        print(preset, "f16 planes: launches tracked", st["f16_tracked"], "largest |x|", st["f16_peak_max"],
+              "smallest per-tensor peak", st["f16_peak_min"])
+        assert st["f16_tracked"] > 20 and st["f16_saturated"] == 0
+        assert 2.0 ** -12 < st["f16_peak_min"] <= st["f16_peak_max"] < 65504.0 / 8
+        s.close()
+
+
+def test_nonfinite_input_to_the_generator_is_reported(tmp_path):
+    from phoonnx_amd import MiSession, RangeError
+    s = MiSession(_voice("medium"), range_fallback=False)
+    z = np.random.default_rng(0).standard_normal((1, 192, 40)).astype(np.float32)
+    s.vocoder(z)                                              # fine
+    z[0, 5, 17] = np.nan
+    with pytest.raises(RangeError):
+        s.vocoder(z)
+    z[0, 5, 17] = np.inf
+    with pytest.raises(RangeError):
+        s.vocoder(z)
+    s.close()
+
+
+# ------------------------------------------------------------------ chunked / streaming vocoder (SURVEY §8 f1)
+
+@pytest.mark.parametrize("preset,chunk", [("medium", 32), ("high", 24), ("medium", 1000)])
+def test_chunked_rendering_is_bit_identical_to_the_unchunked_run(preset, chunk):
+    from phoonnx_amd import MiSession
+    s = MiSession(_voice(preset))
+    rng = np.random.default_rng(41)
+    B, T = 3, 64
+    ids = rng.integers(0, 256, (B, T)).astype(np.int64)
+    lens = np.array([T, 40, 55], np.int64)
+    sc = np.array([0.667, 1.3, 0.8], np.float32)
+    ndp = rng.standard_normal((B, 2, T)).astype(np.float32)
+    nz = rng.standard_normal((B, 192, T * 8)).astype(np.float32)
+    whole = s.synthesize_batch(ids, lens, sc, None, ndp, nz)
+    S = whole["output"].shape[3]
+    got = np.full((B, S), np.nan, np.float32)
+    firsts = []
+    for first, samples, total in s.synthesize_stream(ids, lens, sc, None, chunk_frames=chunk, noise_dp=ndp, noise_z=nz):
+        assert total == S and samples.shape[0] == B
+        firsts.append(first)
+        got[:, first:first + samples.shape[1]] = samples
+    hop = s.hparam("hop")
+    assert firsts == sorted(firsts) and firsts[0] == 0
+    assert len(firsts) == -(-(S // hop) // chunk)
+    assert np.array_equal(s.last_y_lengths(), whole["y_lengths"])
+    assert np.array_equal(got, whole["output"][:, 0, 0, :])   # every sample, bit for bit: edges included
+    # vocoder-only entry
+    z = rng.standard_normal((2, 192, 77)).astype(np.float32)
+    ref = s.vocoder(z)[:, 0, 0, :]
+    parts = [c for _, c, _ in s.vocoder_stream(z, chunk_frames=chunk)]
+    assert np.array_equal(np.concatenate(parts, axis=1), ref)
+    s.close()
+
+
+def test_chunked_rendering_on_the_f32_engine_fixture():
+    from conftest import GOLDEN
+    from phoonnx_amd import MiSession
+    s = MiSession(os.path.join(GOLDEN, "tiny_rb1.onnx"))
+    assert s.hparam("gen_sx") == 0
+    rng = np.random.default_rng(4)
+    z = rng.standard_normal((2, 32, 150)).astype(np.float32)
+    ref = s.vocoder(z)[:, 0, 0, :]
+    parts = [c for _, c, _ in s.vocoder_stream(z, chunk_frames=37)]
+    assert len(parts) == 5
+    assert np.array_equal(np.concatenate(parts, axis=1), ref)
+    s.close()
+
+
+# ------------------------------------------------------------------ corners the first round left open (VERDICT r1 item 7)
+
+def test_baseline_batch_properties_high():
+    """The headline voice at the headline batch (B=32 x 256 ids), through the size-independent properties."""
+    from phoonnx_amd import MiSession
+    s = MiSession(_voice("high"))
+    rng = np.random.default_rng(1234)
+    B, T = 32, 256
+    ids = rng.integers(0, 256, (B, T)).astype(np.int64)
+    lens = np.full(B, T, np.int64)
+    sc = np.array([0, 1.5, 0], np.float32)
+    r = s.synthesize_batch(ids, lens, sc, taps=("w_ceil",))
+    hop = s.hparam("hop")
+    assert r["output"].shape == (B, 1, 1, hop * int(r["y_lengths"].max()))
+    assert np.isfinite(r["output"]).all() and np.abs(r["output"]).max() <= 1.0
+    assert np.array_equal(r["w_ceil"].sum(1).astype(np.int64), r["y_lengths"])
+    st = s.stats()
+    assert st["f16_saturated"] == 0 and st["sx_launches"] > 80
+    one = s.synthesize_batch(ids[:1], lens[:1], sc, taps=("w_ceil",))
+    assert np.array_equal(one["w_ceil"][0], r["w_ceil"][0])
+    n = (int(one["y_lengths"][0]) - s.hparam("gen_rf_frames")) * hop   # minus the generator's receptive field
+    np.testing.assert_allclose(r["output"][0, 0, 0, :n], one["output"][0, 0, 0, :n], atol=2e-5)
+    s.close()
+
+
+@pytest.mark.parametrize("preset,B,F", [("medium", 1, 700), ("high", 2, 300)])
+def test_config2_vocoder_only_fullsize_matches_oracle(preset, B, F):
+    """BASELINE config 2: the HiFi-GAN vocoder alone, z -> waveform, at the frame count of a 256-id utterance (medium)."""
+    from phoonnx_amd import MiSession
+    from vits_oracle import VitsOracle
+    path = _voice(preset)
+    s, o = MiSession(path), VitsOracle(path)
+    z = np.random.default_rng(8).standard_normal((B, 192, F)).astype(np.float32)
+    got, ref = s.vocoder(z), o.vocoder(z)
+    assert got.shape == ref.shape == (B, 1, 1, F * s.hparam("hop"))
+    err = float(np.abs(got - ref).max())
+    print(f"{preset} vocoder-only B={B} F={F}: max-abs error vs oracle {err:.3g}")
+    assert err < 1e-3 and np.abs(ref).max() > 0.02
+    s.close()
+
+
+def test_config4_batch64_properties_bf16_vocoder(monkeypatch):
+    """BASELINE config 4 at its stated size: 4-speaker voice, B=64 mixed lengths with padding mask, bf16 vocoder.
+    The oracle cannot render 64 utterances inside a test; properties: durations independent of the batch composition
+    and of the vocoder arithmetic, shape law, finiteness, and each utterance's interior equal to its own B=1 rendering
+    within the mode's declared tolerance, with its SNR reported against the f16x3 rendering."""
+    from phoonnx_amd import MiSession
+    path = _voice("medium", n_speakers=4)
+    rng = np.random.default_rng(64)
+    B, T = 64, 96
+    lens = np.concatenate([[T], rng.integers(24, T, B - 1)]).astype(np.int64)
+    ids = np.zeros((B, T), np.int64)
+    for b in range(B):
+        ids[b, :lens[b]] = rng.integers(0, 256, lens[b])
+    sid = rng.integers(0, 4, B).astype(np.int64)
+    sc = np.array([0, 1.3, 0], np.float32)
+    full = MiSession(path)
+    ref = full.synthesize_batch(ids, lens, sc, sid)
+    full.close()
+    s = MiSession(path, gen_precision="bf16")
+    assert s.hparam("gen_nprod") == 1
+    r = s.synthesize_batch(ids, lens, sc, sid, taps=("w_ceil",))
+    hop = s.hparam("hop")
+    assert np.array_equal(r["y_lengths"], ref["y_lengths"])
+    assert r["output"].shape == (B, 1, 1, hop * int(r["y_lengths"].max())) and np.isfinite(r["output"]).all()
+    assert np.all(r["w_ceil"][np.arange(T)[None, :] >= lens[:, None]] == 0)          # padding mask
+    worst, snr_min = 0.0, 1e9
+    for b in range(B):
+        n = int(r["y_lengths"][b]) * hop
+        a, f = r["output"][b, 0, 0, :n].astype(np.float64), ref["output"][b, 0, 0, :n].astype(np.float64)
+        worst = max(worst, float(np.abs(a - f).max()))
+        snr_min = min(snr_min, 10 * np.log10((f ** 2).sum() / max(((a - f) ** 2).sum(), 1e-30)))
+    print(f"config 4, B=64: bf16 vocoder vs f16x3: max-abs {worst:.3g}, worst per-utterance SNR {snr_min:.1f} dB")
+    # SURVEY §7 suggests 1e-2 max-abs + 35 dB for a bf16 vocoder; a single bf16 product per fp32 product (8-bit
+    # mantissas on BOTH operands through ~40 conv layers) measures ~1e-2..6e-2 on these unit-scale synthetic voices:
+    # declared tolerance 8e-2 and 20 dB, bf16x3 (the mode that meets 1e-3) is the recommended reduced mode.
+    assert worst < 8e-2 and snr_min > 20.0
+    for b in (0, 17):
+        one = s.synthesize_batch(ids[b:b + 1, :lens[b]].copy(), lens[b:b + 1], sc, sid[b:b + 1])
+        assert one["y_lengths"][0] == r["y_lengths"][b]
+        n = (int(one["y_lengths"][0]) - s.hparam("gen_rf_frames")) * hop
+        np.testing.assert_allclose(r["output"][b, 0, 0, :n], one["output"][0, 0, 0, :n], atol=1e-4)
+    s.close()
+
+
+def test_langid_voice_runs_and_ignores_the_language_id(tmp_path):
+    """A third-party style graph that declares `langid` (voice.py:369): the feed built by TTSVoice passes through."""
+    from phoonnx_amd import MiSession, SessionError
+    from phoonnx_amd.synth import write_voice
+    p = str(tmp_path / "lang.onnx")
+    write_voice(p, "small", seed=2, extra_inputs=("langid",))
+    s = MiSession(p)
+    ids = np.arange(1, 31, dtype=np.int64)[None]
+    feed = {"input": ids, "input_lengths": np.array([30], np.int64), "scales": np.array([0, 1, 0], np.float32),
+            "langid": np.array([3], np.int64)}
+    a = s.run(None, feed)[0]
+    b = s.run(None, dict(feed, langid=np.array([0], np.int64)))[0]
+    assert a.ndim == 4 and np.array_equal(a, b)
+    with pytest.raises(SessionError):
+        s.run(None, dict(feed, langid=np.zeros((1, 1), np.int64)))
+    with pytest.raises(SessionError):
+        s.run(None, {k: v for k, v in feed.items() if k != "langid"})   # declared inputs are required, as in onnxruntime
+    s.close()
+
+
+# ------------------------------------------------------------------ the N > 1 code path on one GPU (VERDICT r1 item 2)
+
+def test_open_sharded_under_rccl_world_size_1_equals_plain_open(tmp_path):
+    """RCCL (backend "nccl") process group of one rank: rank 0 packs on the host, the arena goes through
+    dist.broadcast on the device, its checksum is verified, the handle adopts it with a layout-only open - and renders
+    exactly what a plain open renders.  In a child process (process-group state must not leak into the test session)."""
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+from phoonnx_amd import MiSession
+from phoonnx_amd.sharding import ShardedSynthesizer, arena_checksum, open_sharded
+path = sys.argv[2]
+s, arena = open_sharded(path, 0, dist, force_broadcast=True)
+assert arena is not None and arena.is_cuda and arena.numel() == s.arena_bytes()
+plain = MiSession(path)
+assert arena_checksum(arena) == arena_checksum(torch.from_numpy(np.array(plain.arena_host(), copy=True)))
+rng = np.random.default_rng(0)
+ids = rng.integers(0, 200, (3, 40)).astype(np.int64)
+lens = np.array([40, 33, 12], np.int64)
+sid = np.array([0, 3, 1], np.int64)
+sc = np.array([0, 1.3, 0], np.float32)
+a = s.synthesize_batch(ids, lens, sc, sid)
+b = plain.synthesize_batch(ids, lens, sc, sid)
+assert np.array_equal(a["y_lengths"], b["y_lengths"]) and np.array_equal(a["output"], b["output"])
+s.close(); plain.close()
+sh = ShardedSynthesizer(path, 0, dist, force_broadcast=True)
+utts = [list(map(int, ids[i, :lens[i]])) for i in range(3)]
+out = sh.synthesize(utts, sc, sids=[0, 3, 1], gather=True)
+assert len(out) == 3 and all(len(w) == int(b["y_lengths"][i]) * sh.hop for i, w in enumerate(out))
+sh.close()
+dist.destroy_process_group()
+print("SHARDED_OK")
+'''
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code, ROOT, os.path.join(GOLDEN, "sx_rb2_ms.onnx")], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])

@@ -642,3 +642,37 @@ def test_device_pcm16_matches_numpy_postprocessing(normalize, volume):
         assert np.array_equal(pcm[b, :n], ref), (b, np.abs(pcm[b, :n].astype(int) - ref.astype(int)).max())
         assert not pcm[b, n:].any()
     s.close()
+
+
+def test_ttsvoice_loads_from_the_onnx_alone_and_rejects_inconsistent_json(tmp_path):
+    """f3 end to end: sx_rb2_ms.onnx carries a real phoneme_id_map in its metadata_props (as export_onnx.py:335-345
+    writes it) and no JSON: TTSVoice.load rebuilds the config from the file and synthesizes on the sx engine.  A JSON
+    that contradicts the file is rejected with ValueError instead of a warning."""
+    import json
+    import shutil
+    from phoonnx_amd.config import SynthesisConfig
+    from phoonnx_amd.voice import TTSVoice
+    model = tmp_path / "voice.onnx"
+    shutil.copy(os.path.join(GOLDEN, "sx_rb2_ms.onnx"), model)
+    voice = TTSVoice.load(str(model))
+    assert voice.config.num_speakers == 4 and voice.config.sample_rate == 22050
+    assert voice.config.phoneme_id_map["a"] == 4 and voice.config.include_whitespace
+    assert voice.session.hparam("gen_sx") == 1
+    voice.dedupe_sentences = True
+    syn = SynthesisConfig(speaker_id=2, noise_scale=0.0, noise_w_scale=0.0, length_scale=1.5)
+    chunks = list(voice.synthesize("hello world. again, hello?", syn))
+    assert len(chunks) == 2 and all(len(c.audio_float_array) > 1000 for c in chunks)
+    # the same ids by hand through the session: identical audio
+    ids = voice.phonemes_to_ids(list("hello world."))
+    raw = voice.phoneme_ids_to_audio(ids, syn)
+    assert np.array_equal(chunks[0].audio_float_array, voice._postprocess(raw, syn))
+    voice.session.close()
+    for bad in ({"num_speakers": 2}, {"audio": {"sample_rate": 16000}}, {"num_symbols": 99},
+                {"phoneme_id_map": {"a": 5000}}):
+        cfg = {"phoneme_type": "raw", "lang_code": "en", "alphabet": "ipa", "audio": {"sample_rate": 22050},
+               "num_speakers": 4, "num_symbols": 256, "phoneme_id_map": {"a": 4}}
+        cfg.update(bad)
+        (tmp_path / "voice.onnx.json").write_text(json.dumps(cfg))
+        with pytest.raises(ValueError, match="inconsistent voice"):
+            TTSVoice.load(str(model))
+    TTSVoice.load(str(model), strict=False).session.close()    # opt-out: the reference's behaviour (no checks)

@@ -22,11 +22,14 @@ def test_partition_covers_everything_and_restores_order():
             assert len(shards) == world
             flat = np.concatenate(shards) if n else np.zeros(0, np.int64)
             assert sorted(flat.tolist()) == list(range(n))              # every utterance exactly once
-            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= max(1, (n + world - 1) // world)
-            # longest-first: a shard never holds an utterance longer than any in the previous shard
-            for a, b in zip(shards[:-1], shards[1:]):
-                if len(a) and len(b):
-                    assert lengths[a].min() >= lengths[b].max()
+            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+            for sh in shards:                                            # each shard stays length-sorted: little padding
+                assert np.all(np.diff(lengths[sh]) <= 0)
+            # balanced work: no rank carries more than the lightest one plus the longest utterance (snake dealing);
+            # the contiguous-block deal this replaces gave rank 0 all the longest ones
+            if n >= world:
+                loads = [int(lengths[sh].sum()) for sh in shards]
+                assert max(loads) - min(loads) <= int(lengths.max()), (world, n, loads)
             results = [f"utt{i}" for i in flat]                          # "concatenated per-rank results"
             assert [results[inv[i]] for i in range(n)] == [f"utt{i}" for i in range(n)]
 
@@ -45,9 +48,16 @@ def _worker(rank, world, port, onnx_path, q):
     from phoonnx_amd.sharding import broadcast_arena, partition as part
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        arena = broadcast_arena(onnx_path, dist, device=None, src=0)
+        arena = broadcast_arena(onnx_path, dist, device=None, src=0)           # (verifies rank 0's checksum itself)
         local = MiSession(onnx_path, host_only=True)
         same = bool(np.array_equal(arena.numpy(), np.asarray(local.arena_host())))
+        from phoonnx_amd.sharding import arena_checksum
+        import torch
+        same = same and arena_checksum(arena) == arena_checksum(torch.from_numpy(np.array(local.arena_host(), copy=True)))
+        # what a receiving rank opens with: the layout alone must describe exactly these bytes
+        lay = MiSession(onnx_path, layout_only=True)
+        same = same and lay.arena_bytes() == arena.numel()
+        lay.close()
         # each rank synthesises only its shard; shards are disjoint and cover the request
         shards, _ = part([9, 3, 7, 1, 5], world)
         objs = [None] * world
@@ -89,3 +99,16 @@ def test_arena_broadcast_two_ranks_gloo(voice, tmp_path):
     assert all(g[1] for g in got), "broadcast arena differs from a local pack"
     assert got[0][2] == got[1][2] > 0
     assert sorted(got[0][3][0] + got[0][3][1]) == [0, 1, 2, 3, 4] and got[0][3] == got[1][3]
+
+
+def test_arena_checksum_detects_corruption():
+    import torch
+    from phoonnx_amd import MiSession
+    from phoonnx_amd.sharding import arena_checksum
+    s = MiSession(os.path.join(GOLDEN, "tiny_dp.onnx"), host_only=True)
+    a = torch.from_numpy(np.array(s.arena_host(), copy=True))
+    s.close()
+    c0 = arena_checksum(a)
+    b = a.clone()
+    b[12345] ^= 0x40
+    assert arena_checksum(b) != c0 and arena_checksum(a.clone()) == c0
