@@ -38,9 +38,17 @@ DTYPE = {2: "f32 (f16x3 split: fp32 operands as two fp16 planes, three MFMA prod
 
 
 def git_head():
+    """Commit of this tree: from git where there is one, else from the build stamp (the GPU box receives no .git)."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
-                              timeout=5).stdout.strip() or None
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                           timeout=5).stdout.strip()
+        if h:
+            return h
+    except Exception:
+        pass
+    try:
+        info = json.load(open(os.path.join(ROOT, "phoonnx_amd", "_build_info.json")))
+        return info["commit"] + ("+dirty" if info.get("dirty") else "")
     except Exception:
         return None
 
@@ -70,7 +78,7 @@ def pmc_traffic(preset, kernel_prefix):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(voice_path, preset, tokens, scales, seed, budget_s=45.0):
+def cpu_baseline(voice_path, preset, tokens, scales, seed, hop, budget_s=70.0):
     """What the reference's hot call costs on this box's host cores, on a bounded sample of the
     workload.  Preferred: onnxruntime's CPU provider with default session options, as phoonnx/voice.py:167-171 builds
     it - probed, absent on the build and GPU images (and the synthetic bench voice carries only the parameter nodes of
@@ -95,24 +103,22 @@ def cpu_baseline(voice_path, preset, tokens, scales, seed, budget_s=45.0):
         return ids, lens, ndp, nz
 
     def timed(name, infer, hop, threads):
-        # warm-up on a short batch (thread pool, allocator, code paths), then batches of doubling size while the
-        # projected time of the next one stays inside the budget: the largest is the figure reported
+        # one short warm-up call (thread pool, allocator, code paths), one utterance to learn the rate, then ONE batch
+        # sized to fill what is left of this implementation's share of the budget (at most the bench batch, 32)
         ids, lens, ndp, nz = sample(1)
         infer(ids[:, :64], np.full((1,), 64, np.int64), ndp[:, :, :64], nz)
-        B, spent, best = 1, 0.0, None
-        while True:
+        t0 = time.perf_counter()
+        r = infer(ids, lens, ndp, nz)
+        t1 = time.perf_counter() - t0
+        B = int(max(1, min(32, (budget_s / 2 - t1) / max(t1, 1e-3) * 0.8)))
+        if B > 1:
             ids, lens, ndp, nz = sample(B)
             t0 = time.perf_counter()
             r = infer(ids, lens, ndp, nz)
-            dt = time.perf_counter() - t0
-            spent += dt
-            samples = int(np.asarray(r["y_lengths"]).sum()) * hop
-            best = {"value": samples / dt, "B": B, "samples": samples, "seconds": dt, "threads": threads,
-                    "rtf": dt / (samples / 22050.0)}
-            if B >= 32 or spent + 2.2 * dt > budget_s / 2:
-                break
-            B *= 2
-        cands[name] = best
+            t1 = time.perf_counter() - t0
+        samples = int(np.asarray(r["y_lengths"]).sum()) * hop
+        cands[name] = {"value": samples / t1, "B": B, "samples": samples, "seconds": t1, "threads": threads,
+                       "rtf": t1 / (samples / 22050.0)}
 
     try:
         import torch
@@ -127,15 +133,8 @@ def cpu_baseline(voice_path, preset, tokens, scales, seed, budget_s=45.0):
             o = vits_oracle.VitsOracle(voice_path, native=True)
         except Exception:  # noqa: BLE001
             o = vits_oracle.VitsOracle(voice_path, native=False)
-        hop = [1]
-
-        def run(i, l, a, b):
-            r = o.infer(i, l, scales, None, a, b[:, :o.inter_channels])
-            hop[0] = r["output"].shape[3] // int(r["y_lengths"].max())
-            return r
-        # (hop is known only after a run: time with the hop of the first call)
-        run(*sample(1)[:2], *sample(1)[2:])
-        timed("c_openmp", run, hop[0], int(o.lib.vo_num_threads()))
+        timed("c_openmp", lambda i, l, a, b: o.infer(i, l, scales, None, a, b[:, :o.inter_channels]), hop,
+              int(o.lib.vo_num_threads()))
     except Exception as e:  # noqa: BLE001
         out["c_openmp_error"] = f"{type(e).__name__}: {e}"
     if not cands:
@@ -147,7 +146,7 @@ def cpu_baseline(voice_path, preset, tokens, scales, seed, budget_s=45.0):
             "c_openmp": "C/OpenMP restatement (oracle/vits_oracle.c)"}[name]
     out.update(value=b["value"], cores=b["threads"], rtf=b["rtf"], implementation=name,
                sample=f"{impl}, B={b['B']} x {tokens} ids, same voice and scales, {b['samples']} samples in "
-                      f"{b['seconds']:.1f}s after one warm-up call (largest batch inside a {budget_s:.0f}s budget)",
+                      f"{b['seconds']:.1f}s after a warm-up call (batch sized to a {budget_s / 2:.0f}s share of the budget)",
                candidates={k: {"value": v["value"], "B": v["B"], "threads": v["threads"]} for k, v in cands.items()},
                host_cores=os.cpu_count())
     return out
@@ -461,7 +460,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:  # (N = 1 only: the other ranks would sit in the final barrier)
         try:
-            cpu = cpu_baseline(voice, a.preset, T, scales, 1234)
+            cpu = cpu_baseline(voice, a.preset, T, scales, 1234, hop)
         except Exception as e:  # noqa: BLE001 - the baseline is a report, never the product
             cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
@@ -489,11 +488,18 @@ def main():
         }
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = value / world / cpu["value"]
-        print(json.dumps(line), flush=True)
     pipe.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio: flush it first, so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 def hop_of(s):

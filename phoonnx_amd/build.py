@@ -25,7 +25,25 @@ def stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def write_build_info():
+    """phoonnx_amd/_build_info.json: the commit this tree was built from (the GPU box receives no .git)."""
+    import json
+    import time
+    root = os.path.dirname(HERE)
+    try:
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5)
+        if head.returncode != 0 or not head.stdout.strip():
+            return
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], capture_output=True,
+                               text=True, timeout=10).stdout.strip() != ""
+        with open(os.path.join(HERE, "_build_info.json"), "w") as f:
+            json.dump({"commit": head.stdout.strip(), "dirty": dirty, "time": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}, f)
+    except Exception:
+        pass
+
+
 def build(force=False, verbose=False):
+    write_build_info()
     if not force and not stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",

@@ -206,9 +206,15 @@ enum : int {
     SX_HAS_PL = 1 << 10,    // out_pl is written
     SX_RAW_ACT = 1 << 11,   // oslope != 1
     SX_PL_ACT = 1 << 12,    // oslope2 != 1
-    SX_HAS_BIASB = 1 << 13  // per-utterance bias
+    SX_HAS_BIASB = 1 << 13, // per-utterance bias
+    // RAWIN kernels whose residual IS their input tensor (ResBlock2: x = conv(lrelu(x)) + x, modules.py:355-364): the
+    // residual is requested in the prologue, next to the first x tile that covers the same lines, and waits in
+    // registers.  Requested in the epilogue it is a second HBM read of the tensor (measured: 1.40 GB read per launch
+    // against a 0.71 GB tensor; the tile's lines are gone from the 4 MB L2 by then), requested here the two reads of a
+    // line merge in the L2.
+    SX_RES_EARLY = 1 << 14
 };
-constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB;
+constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB | SX_RES_EARLY;
 
 // One 256-thread workgroup = 4 waves arranged WM x WN, each owning MW x NW 32x32 accumulator blocks.
 // RAWIN: the input is the fp32 raw tensor itself; each x tile is loaded into registers, leaky-ReLU'd (islope) and
@@ -506,6 +512,27 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
         issue_x(0, 0);
         load_a(f0, 0);
     }
+    // SX_RES_EARLY: all residual operands of this wave, requested now (same addressing as the epilogue's issue_adds)
+    constexpr bool PRE = RAWIN && EPI >= 0 && (EPI & SX_RES_EARLY) != 0;
+    constexpr int NRND_ = MW * (NW / 2);
+    f32x4 pre[PRE ? NRND_ : 1][2][4];
+    if constexpr (PRE) {
+        const int Tout_ = T * a.ups;  // (ups == 1 here: a residual conv)
+        const float *resb_ = a.res + (int64_t)b * a.raw_bstride;
+        static_for<NRND_>([&](auto R) {
+            constexpr int rr = decltype(R)::value;
+            constexpr int m = rr / (NW / 2), n0 = (rr % (NW / 2)) * 2;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int row0 = mt * BM + (wm * MW + m) * 32;
+                const int t = t0 + (wn * NW + n0 + j) * 32 + l31;
+                const int tl = t < T ? t : T - 1;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    pre[rr][j][q] = *reinterpret_cast<const f32x4 *>(resb_ + ((int64_t)((row0 >> 3) + q) * Tout_ + tl) * 8 + 4 * hi);
+            }
+        });
+    }
     int chunk = 0, tap = 0;
     // PROF: where a step's cycles go (s_memtime stamps; tools/conv_bench.py --sx --prof)
     unsigned long long pt = 0;
@@ -609,9 +636,11 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     float *rawb = a.out_raw + (int64_t)b * a.raw_bstride;     // (only dereferenced when the flags say so)
     uint16_t *plb = a.out_pl + (int64_t)b * a.pl_bstride;
     const float *resb = a.res + (int64_t)b * a.raw_bstride;
-    const float *addp = (flags & EPI_RES) ? resb : rawb;
-    const bool has_add = (flags & (EPI_RES | EPI_ACC)) != 0;
-    const bool two_adds = (flags & EPI_RES) && (flags & EPI_ACC);
+    // operands still to be loaded here: the residual (unless it was requested in the prologue) and / or the accumulate
+    const bool res_epi = (flags & EPI_RES) && !PRE;
+    const float *addp = res_epi ? resb : rawb;
+    const bool has_add = res_epi || (flags & EPI_ACC);
+    const bool two_adds = res_epi && (flags & EPI_ACC);
     const float oslope = a.oslope, oslope2 = a.oslope2, rdiv = a.div;
     const float wsc = a.wscale;
     const int64_t plane_elems = (int64_t)CGo * Tout * 8;
@@ -622,7 +651,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     // (the A / B fragment registers are dead by now), so only the first round exposes a memory latency.  Loads use a
     // clamped column (always inside the tensor): no branch per load; stores are predicated on the real column.
     constexpr int NRND = MW * (NW / 2);
-    constexpr bool PIPE = EPI >= 0 && ((EPI & EPI_RES) != 0) != ((EPI & EPI_ACC) != 0);
+    constexpr bool PIPE = EPI >= 0 && ((EPI & EPI_RES) != 0 && !PRE) != ((EPI & EPI_ACC) != 0);
     f32x4 adb[PIPE ? 2 : 1][2][4], ad2[2][4];
     auto geom = [&](int m, int n, int &co0, int &r, int &t) {
         const int row0 = mt * BM + (wm * MW + m) * 32;
@@ -685,6 +714,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
                     if constexpr (F16) v[e] = __builtin_fmaf(acc[m][n][4 * q + e], wsc, bq[q][e]);  // (power of two: exact)
                     else v[e] = acc[m][n][4 * q + e] + bq[q][e];
                 }
+                if constexpr (PRE) v += pre[rr][j][q];
                 if (has_add) v += adb[pp][j][q];
                 if (two_adds) v += ad2[j][q];
                 if (flags & EPI_DIV) {
@@ -775,7 +805,21 @@ inline hipError_t launch_conv_sx_rawin(const SxArgs &a, int epi, dim3 grid, size
         case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw, false, true, NP>(a, grid, lds, stream);
         case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst, false, true, NP>(a, grid, lds, stream);
         case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum, false, true, NP>(a, grid, lds, stream);
-        default: return launch_conv_sx_k<MW, NW, WM, WN, -1, false, true, NP>(a, grid, lds, stream);
+        default: break;
+    }
+    if constexpr (NP == 2 || NW == 2) {  // ResBlock2 (residual == input): the residual is requested in the prologue
+        switch (epi) {
+            case kSxEpiFirst | SX_RES_EARLY:
+                return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst | SX_RES_EARLY, false, true, NP>(a, grid, lds, stream);
+            case kSxEpiAccum | SX_RES_EARLY:
+                return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum | SX_RES_EARLY, false, true, NP>(a, grid, lds, stream);
+            case kSxEpiAccum | EPI_DIV | SX_RES_EARLY:
+                return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum | EPI_DIV | SX_RES_EARLY, false, true, NP>(a, grid, lds, stream);
+            default: break;
+        }
+    }
+    {
+        return launch_conv_sx_k<MW, NW, WM, WN, -1, false, true, NP>(a, grid, lds, stream);
     }
 }
 
@@ -817,6 +861,12 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     if (a.out_raw && !(a.flags & SX_NO_RAW_STORE)) epi |= SX_HAS_RAW | (a.oslope != 1.f ? SX_RAW_ACT : 0);
     if (a.out_pl) epi |= SX_HAS_PL | (a.oslope2 != 1.f ? SX_PL_ACT : 0);
     if (a.bias_b) epi |= SX_HAS_BIASB;
+    // (SX_RES_EARLY has compile-time instantiations only: where none matches, the residual is read in the epilogue)
+    // (bf16x6 on the 64-row tile has no registers left for it: 256 VGPRs and a spill)
+    const bool early_ok = rawin && (nprod == 2 || (nprod == 6 && cfg == 2)) && (a.flags & EPI_RES) && !(a.flags & (DBG_NO_DMA | DBG_NO_EPI)) &&
+                          a.res == a.xr && a.ups == 1 && a.out_raw && !(a.flags & SX_NO_RAW_STORE) && !a.out_pl && !a.bias_b &&
+                          a.oslope == 1.f && (!(a.flags & EPI_DIV) || (a.flags & EPI_ACC));
+    if (early_ok) epi |= SX_RES_EARLY;
     if ((epi & EPI_RES) && !a.res) return hipErrorInvalidValue;
     if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
     a.flags = (a.flags & ~kSxEpiMask) | epi;

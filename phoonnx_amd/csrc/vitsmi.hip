@@ -126,7 +126,7 @@ __global__ void range_reduce_kernel(const unsigned *slots, int launches, float *
         for (int i = 0; i < kSxPeakSlots; i++) b = max(b, slots[(size_t)l * kSxPeakSlots + i]);
         const float pk = __uint_as_float(b);
         mx = fmaxf(mx, pk);
-        mn = fminf(mn, pk);
+        if (b) mn = fminf(mn, pk);  // (an all-zero tensor - e.g. a fully masked batch row set - says nothing about range)
     }
     smax[threadIdx.x] = mx;
     smin[threadIdx.x] = mn;
@@ -140,7 +140,7 @@ __global__ void range_reduce_kernel(const unsigned *slots, int launches, float *
     }
     if (threadIdx.x == 0) {
         out[0] = smax[0];
-        out[1] = launches ? smin[0] : 0.f;
+        out[1] = smin[0] <= smax[0] ? smin[0] : 0.f;
         out[2] = (float)launches;
     }
 }
@@ -338,7 +338,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.oslope2 = oslope2;
     a.wscale = d.wscale;
     vits_handle *h = c.h;
-    a.peak = range_slots(h, d.f16);
+    a.peak = range_slots(h, d.f16 && (d.rawin || out_pl));  // launches that split values into fp16 planes
     const bool ev = conv_event_begin(c);
     c.note(launch_conv_sx(a, d.cfg, c.B, c.st, d.rawin, d.f16 ? 2 : (h->cur_stage == 3 ? h->gen_nprod : 6)));
     if (ev) {
@@ -1061,7 +1061,8 @@ static int open_common(const char *path, vits_handle **out, bool host_only, int 
             h->arena_owned = true;
         }
         for (auto &e2 : h->ev) hipEventCreate(&e2);
-        {  // range guard of the fp16 operand planes (generator and / or the flow's WN convs)
+        if (!std::getenv("VITSMI_NO_RANGE_GUARD")) {  // range guard of the fp16 operand planes (generator, flow WN convs);
+                                                     // the switch exists for A/B timing of its cost only
             const size_t nb = (size_t)kMaxRangeLaunches * kSxPeakSlots * sizeof(unsigned);
             if (hipMalloc((void **)&h->d_range, nb + 64) != hipSuccess || hipHostMalloc((void **)&h->h_range, 64) != hipSuccess) {
                 vits_close(h);

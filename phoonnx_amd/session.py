@@ -427,9 +427,11 @@ class PipelinedSession:
         if parts < 1:
             raise SessionError("parts must be >= 1")
         self.parts = [first]
+        # the borrowed arena is packed for `first`'s arithmetic: the other handles must lay it out the same way
+        precision = {2: "f16x3", 6: "bf16x6", 3: "bf16x3", 1: "bf16"}[int(first.hparam("gen_nprod"))]
         for _ in range(parts - 1):
             self.parts.append(MiSession(first.path, device_id=first.device_id, arena_device_ptr=first.arena_device(),
-                                        arena_bytes=first.arena_bytes()))
+                                        arena_bytes=first.arena_bytes(), gen_precision=precision))
         self.set_seed(first._seed)
 
     @classmethod

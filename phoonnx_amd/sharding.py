@@ -91,6 +91,7 @@ def open_sharded(path: str, device_id: int, dist=None, src: int = 0, force_broad
     if dist is None or (dist.get_world_size() == 1 and not force_broadcast):
         return MiSession(path, device_id=device_id), None
     arena = broadcast_arena(path, dist, device_id, src, verify)
+    # (every rank resolves the arithmetic the same way rank `src` did when it packed: VITSMI_GEN_PRECISION / default)
     sess = MiSession(path, device_id=device_id, arena_device_ptr=arena.data_ptr(), arena_bytes=arena.numel())
     return sess, arena
 

@@ -14,10 +14,11 @@ OUT=$R/gpurun_out/prof_${TAG}_${PRESET}
 mkdir -p "$OUT" "$R/profiles"
 cd /tmp && export TMPDIR=/tmp
 # (--parts 1: one handle / stream, as in the roofline block of the bench line, so that kernels do not overlap in the trace)
-BENCH="python3 $R/bench.py --preset $PRESET --steps 3 --warmup 1 --no-cpu-baseline --no-exact-check --parts 1"
+BENCH="python3 $R/bench.py --preset $PRESET --steps 3 --warmup 1 --no-cpu-baseline --no-extras --parts 1"
 T="timeout -k 10 240"
 $T rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o s -- $BENCH > "$OUT/stats.log" 2>&1
 $T rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc1" -o p -- $BENCH > "$OUT/pmc1.log" 2>&1
 $T rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc2" -o p -- $BENCH > "$OUT/pmc2.log" 2>&1
 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc3" -o p -- $BENCH > "$OUT/pmc3.log" 2>&1
-python3 "$R/tools/rocprof_summary.py" "$OUT" "$R/profiles/${TAG}_${PRESET}_b32" --preset "$PRESET"
+python3 "$R/tools/rocprof_summary.py" "$OUT" "$R/profiles/${TAG}_${PRESET}_b32" --preset "$PRESET" --length-scale 1.95
+cp "$R/profiles/${TAG}_${PRESET}_b32_kernel_stats.csv" "$R/profiles/${TAG}_${PRESET}_b32_pmc.json" "$R/gpurun_out/" 2>/dev/null

@@ -53,6 +53,7 @@ def main():
     ap.add_argument("outdir")
     ap.add_argument("prefix")
     ap.add_argument("--preset", default="")
+    ap.add_argument("--length-scale", type=float, default=None, help="scales[1] of the profiled bench command")
     a = ap.parse_args()
 
     # ---- pass "stats": kernel trace -> per-kernel time
@@ -82,7 +83,14 @@ def main():
         if sub == "pmc1":
             for k, d in dispatches(p):
                 kdur[k] += d
-    out = {"preset": a.preset,
+    commit = None
+    try:
+        info = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "phoonnx_amd",
+                                           "_build_info.json")))
+        commit = info["commit"] + ("+dirty" if info.get("dirty") else "")
+    except Exception:
+        pass
+    out = {"preset": a.preset, "commit": commit, "length_scale": a.length_scale,
            "source": "rocprofv3 --kernel-trace --pmc <set>, one counter set per run (tools/profile_gpu.sh); sums over all "
                      "dispatches of the run unless a key says per_launch",
            "kernels": {}}
@@ -95,8 +103,11 @@ def main():
             # GRBM_GUI_ACTIVE is the sum over the 8 XCDs
             d["MfmaUtil_pct"] = 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
             if kdur.get(k):
-                d["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / kdur[k]
                 d["avg_duration_ms_under_pmc"] = kdur[k] / n / 1e6
+                # (GRBM_GUI_ACTIVE also counts the dispatch's ramp-up and drain: for launches under ~100 us the ratio
+                # says nothing about the shader clock - it read 3-10 "GHz" there - so it is only derived for long ones)
+                if kdur[k] / n >= 100e3:
+                    d["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / kdur[k]
         if "FETCH_SIZE" in c:
             d["hbm_read_bytes_per_launch"] = c["FETCH_SIZE"] * 1024.0 * 2.0 / n
         if "WRITE_SIZE" in c:
