@@ -185,13 +185,20 @@ __device__ __forceinline__ void split2h_pair_pk(float x, float y, unsigned &w0, 
     pk = __builtin_fmaxf(pk, __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y)));
     split2h_pair(x, y, w0, w1);
 }
-// publish a wave's peak (all 64 lanes must call): wave-wide max, then one atomicMax on slot `slot` - skipped when
-// the slot already holds as much (after the first waves of a launch nearly always)
+// Publish a workgroup's peak (all 256 threads must call, uniformly): wave-wide max, the four wave maxima through LDS,
+// then ONE atomicMax on one of the launch's 64 slots - each slot on its own 128-byte line, and skipped when the slot
+// already holds as much (nearly always, after the first workgroups of a launch).  A first version with one atomic
+// per WAVE on 64 adjacent words made the 10 us split kernel take 200 us: atomics on one cache line serialise in the L2.
+constexpr int kSxPeakStride = 32;  // uints between slots: one 128-byte line each
 __device__ __forceinline__ void sx_publish_peak(unsigned *slots, int slot_idx, float pk) {
+    __shared__ float s_pk[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) pk = __builtin_fmaxf(pk, __shfl_xor(pk, o, 64));
-    if ((threadIdx.x & 63) == 0) {
-        unsigned *slot = slots + (slot_idx & (kSxPeakSlots - 1));
+    if ((threadIdx.x & 63) == 0) s_pk[threadIdx.x >> 6] = pk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pk = __builtin_fmaxf(__builtin_fmaxf(s_pk[0], s_pk[1]), __builtin_fmaxf(s_pk[2], s_pk[3]));
+        unsigned *slot = slots + (slot_idx & (kSxPeakSlots - 1)) * kSxPeakStride;
         const unsigned bits = __float_as_uint(pk);  // (non-negative floats order like their bit patterns; inf on top)
         if (bits > __builtin_nontemporal_load(slot)) atomicMax(slot, bits);
     }

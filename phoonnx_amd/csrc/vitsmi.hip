@@ -79,6 +79,8 @@ struct vits_handle {
     float *d_range_res = nullptr;
     float *h_range = nullptr;
     int range_launch = 0;
+    int range_used = -1;          // slots groups the last run wrote (-1: unknown, clear all)
+    int h_range_launches = 0;     // launches behind the values in h_range
     bool range_pending = false;   // h_range holds the result of a run that has not been checked yet
     bool range_failed = false;    // the last run saturated (sticky until the next run starts)
     // chunked rendering: two pinned host buffers the finished chunks are copied into, with their completion events
@@ -114,48 +116,41 @@ unsigned *range_slots(vits_handle *h, bool f16) {
     if (!f16 || !h->d_range) return nullptr;
     const int i = h->range_launch < kMaxRangeLaunches ? h->range_launch : kMaxRangeLaunches - 1;
     h->range_launch++;
-    return h->d_range + (size_t)i * kSxPeakSlots;
+    return h->d_range + (size_t)i * kSxPeakSlots * kSxPeakStride;
 }
 
-// per launch: peak = max over its 64 slots; out = {max over launches, min over launches, launches}
-__global__ void range_reduce_kernel(const unsigned *slots, int launches, float *out) {
-    __shared__ float smax[256], smin[256];
-    float mx = 0.f, mn = __builtin_inff();
-    for (int l = threadIdx.x; l < launches; l += 256) {
-        unsigned b = 0;
-        for (int i = 0; i < kSxPeakSlots; i++) b = max(b, slots[(size_t)l * kSxPeakSlots + i]);
-        const float pk = __uint_as_float(b);
-        mx = fmaxf(mx, pk);
-        if (b) mn = fminf(mn, pk);  // (an all-zero tensor - e.g. a fully masked batch row set - says nothing about range)
-    }
-    smax[threadIdx.x] = mx;
-    smin[threadIdx.x] = mn;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
-            smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + o]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        out[0] = smax[0];
-        out[1] = smin[0] <= smax[0] ? smin[0] : 0.f;
-        out[2] = (float)launches;
+// one wave per launch: peak = max over its 64 slots; out[0] = max over launches, out[1] = min over the launches that
+// recorded anything (both as float bit patterns, which order like unsigned integers for non-negative floats; preset
+// to 0 / 0xffffffff by range_end)
+__global__ void range_reduce_kernel(const unsigned *slots, unsigned *out) {
+    unsigned b = slots[((size_t)blockIdx.x * kSxPeakSlots + threadIdx.x) * kSxPeakStride];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, o, 64));
+    if (threadIdx.x == 0 && b) {  // (an all-zero tensor - e.g. fully masked rows - says nothing about range)
+        atomicMax(out, b);
+        atomicMin(out + 1, b);
     }
 }
 
 void range_begin(vits_handle *h) {
     h->range_launch = 0;
-    if (h->d_range) hipMemsetAsync(h->d_range, 0, (size_t)kMaxRangeLaunches * kSxPeakSlots * sizeof(unsigned), h->stream);
+    // (only the slots the previous run used need clearing)
+    if (h->d_range)
+        hipMemsetAsync(h->d_range, 0, (size_t)(h->range_used > 0 ? h->range_used : kMaxRangeLaunches) * kSxPeakSlots *
+                                          kSxPeakStride * sizeof(unsigned), h->stream);
 }
 
 // fold the slots and start the 12-byte copy to the host; evaluated by range_check() after the next synchronisation
 void range_end(vits_handle *h) {
     if (!h->d_range) return;
     const int n = h->range_launch < kMaxRangeLaunches ? h->range_launch : kMaxRangeLaunches;
-    range_reduce_kernel<<<1, 256, 0, h->stream>>>(h->d_range, n, h->d_range_res);
-    hipMemcpyAsync(h->h_range, h->d_range_res, 3 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    h->range_used = n;
+    unsigned *res = reinterpret_cast<unsigned *>(h->d_range_res);
+    hipMemsetAsync(res, 0, 4, h->stream);
+    hipMemsetAsync(res + 1, 0xff, 4, h->stream);
+    if (n > 0) range_reduce_kernel<<<n, kSxPeakSlots, 0, h->stream>>>(h->d_range, res);
+    hipMemcpyAsync(h->h_range, h->d_range_res, 2 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    h->h_range_launches = n;
     h->range_pending = true;
 }
 
@@ -163,17 +158,23 @@ void range_end(vits_handle *h) {
 int range_check(vits_handle *h) {
     if (!h->range_pending) return 0;
     h->range_pending = false;
-    h->stats.f16_peak_max = h->h_range[0];
-    h->stats.f16_peak_min = h->h_range[1];
-    h->stats.f16_tracked = (int)h->h_range[2];
-    h->stats.f16_saturated = !(h->h_range[0] <= kF16Max) ? 1 : 0;
+    unsigned bits[2];
+    std::memcpy(bits, h->h_range, sizeof bits);
+    float pmax, pmin;
+    std::memcpy(&pmax, &bits[0], 4);
+    if (bits[1] == 0xffffffffu) pmin = 0.f;  // nothing recorded
+    else std::memcpy(&pmin, &bits[1], 4);
+    h->stats.f16_peak_max = pmax;
+    h->stats.f16_peak_min = pmin;
+    h->stats.f16_tracked = h->h_range_launches;
+    h->stats.f16_saturated = !(pmax <= kF16Max) ? 1 : 0;
     h->range_failed = h->stats.f16_saturated != 0;
     if (h->stats.f16_saturated)
         return fail(h, VITS_E_RANGE,
                     "an activation of magnitude %g (or a non-finite value) left the range of the generator's fp16 operand "
                     "planes (65504): the f16x3 arithmetic would clamp it.  Open the voice with gen_precision \"bf16x6\" "
                     "(VITSMI_GEN_PRECISION=bf16x6), whose bf16 planes have the fp32 range",
-                    (double)h->h_range[0]);
+                    (double)h->stats.f16_peak_max);
     return 0;
 }
 
@@ -1063,7 +1064,7 @@ static int open_common(const char *path, vits_handle **out, bool host_only, int 
         for (auto &e2 : h->ev) hipEventCreate(&e2);
         if (!std::getenv("VITSMI_NO_RANGE_GUARD")) {  // range guard of the fp16 operand planes (generator, flow WN convs);
                                                      // the switch exists for A/B timing of its cost only
-            const size_t nb = (size_t)kMaxRangeLaunches * kSxPeakSlots * sizeof(unsigned);
+            const size_t nb = (size_t)kMaxRangeLaunches * kSxPeakSlots * kSxPeakStride * sizeof(unsigned);
             if (hipMalloc((void **)&h->d_range, nb + 64) != hipSuccess || hipHostMalloc((void **)&h->h_range, 64) != hipSuccess) {
                 vits_close(h);
                 return fail(nullptr, VITS_E_NOMEM, "cannot allocate the range-guard buffers");

@@ -661,7 +661,7 @@ def test_ttsvoice_loads_from_the_onnx_alone_and_rejects_inconsistent_json(tmp_pa
     voice.dedupe_sentences = True
     syn = SynthesisConfig(speaker_id=2, noise_scale=0.0, noise_w_scale=0.0, length_scale=1.5)
     chunks = list(voice.synthesize("hello world. again, hello?", syn))
-    assert len(chunks) == 2 and all(len(c.audio_float_array) > 1000 for c in chunks)
+    assert len(chunks) == 2 and all(len(c.audio_float_array) > 200 for c in chunks)   # (hop 32: short audio)
     # the same ids by hand through the session: identical audio
     ids = voice.phonemes_to_ids(list("hello world."))
     raw = voice.phoneme_ids_to_audio(ids, syn)
