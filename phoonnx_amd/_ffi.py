@@ -49,7 +49,7 @@ EXPORTS = [
     "vits_tap",
     "vits_set_timing", "vits_get_stats", "vits_stream", "vits_test_conv1d", "vits_test_conv_transpose1d",
     "vits_test_attention", "vits_bench_conv1d", "vits_test_conv1d_sx", "vits_test_conv_transpose1d_sx",
-    "vits_bench_conv1d_sx",
+    "vits_bench_conv1d_sx", "vits_test_conv_pair_sx",
 ]
 
 
@@ -112,6 +112,8 @@ def load():
     lib.vits_test_conv1d_sx.argtypes = lib.vits_test_conv1d.argtypes
     lib.vits_test_conv_transpose1d_sx.argtypes = lib.vits_test_conv_transpose1d.argtypes
     lib.vits_bench_conv1d_sx.argtypes = [C.c_int] * 9 + [f32p]
+    lib.vits_test_conv_pair_sx.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
+                                           C.c_float, vp, f32p]
     _LIB = lib
     return lib
 

@@ -190,6 +190,8 @@ __device__ __forceinline__ void split2h_pair_pk(float x, float y, unsigned &w0, 
 // already holds as much (nearly always, after the first workgroups of a launch).  A first version with one atomic
 // per WAVE on 64 adjacent words made the 10 us split kernel take 200 us: atomics on one cache line serialise in the L2.
 constexpr int kSxPeakStride = 32;  // uints between slots: one 128-byte line each
+// (sx_publish_peak's four floats are static LDS: the dynamic part a kernel may ask for is the CU's 160 KiB less that)
+constexpr int kSxMaxDynLds = 160 * 1024 - 256;
 __device__ __forceinline__ void sx_publish_peak(unsigned *slots, int slot_idx, float pk) {
     __shared__ float s_pk[4];
 #pragma unroll
@@ -774,7 +776,7 @@ inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipSt
     auto kern = conv_sx_kernel<MW, NW, WM, WN, EPI, PROF, RAWIN, NP>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
+                                           kSxMaxDynLds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -849,7 +851,7 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     a.x_bytes = (unsigned)(((size_t)xrows * a.LW * 16 + 4095) / 4096 * 4096);
     const size_t lds = 2 * (size_t)a.x_bytes;  // two x stages; the weights never touch LDS
     // (pack_conv_sx pads narrower kernels to 3 taps; model.cpp sx_supported() mirrors the size limits)
-    if (lds > 160 * 1024 || a.x_bytes > 12 * 4096 || a.K < 3) return hipErrorInvalidValue;
+    if (lds > (size_t)kSxMaxDynLds || a.x_bytes > 12 * 4096 || a.K < 3) return hipErrorInvalidValue;
     if (rawin && (cfg == 0 || 2 * a.LW > 768 || !a.xr || (long long)a.T * 64 + 64 >= (1ll << 32))) return hipErrorInvalidValue;
     if (a.oslope == 0.f) a.oslope = 1.f;
     if (a.oslope2 == 0.f) a.oslope2 = 1.f;

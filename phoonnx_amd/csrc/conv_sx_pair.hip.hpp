@@ -1,0 +1,470 @@
+// conv_sx_pair.hip.hpp — one launch for a whole ResBlock1 step on the raw-format stages of the generator
+// (<= 64 channels):   out = c2(lrelu(c1(lrelu(x)))) + x        (phoonnx_train/vits/modules.py:301-314)
+//
+// Why: these layers are HBM-bound (8-20 FLOP/B, 4-5 TB/s measured).  As two launches of conv_sx_kernel a step moves
+// 20 bytes per element: c1 reads x and writes the intermediate, c2 reads the intermediate AND x (the residual) and
+// writes the result.  Here the intermediate never leaves the CU - it is produced as the fp16 operand planes c2 reads,
+// directly into LDS - and x is read once (the residual is requested next to the x tile, cf. SX_RES_EARLY):
+// ~4 * (1 + halo/256) + 4 bytes per element, 2.1-2.3x less.  The matrix work is the same (+ the 2-10 overlap columns
+// of a 256-column tile), so the matrix pipe is about twice as busy as in the two-launch form.
+//
+// Arithmetic: exactly that of two conv_sx_kernel launches in the f16x3 mode (same operand planes, same products, same
+// accumulation order); only the tile boundaries move, which changes no sum.  tests/test_gpu_parity.py compares the
+// fused launch with the two-launch form bit for bit and with the oracle.
+//
+// Structure (one workgroup = 4 waves, all C output channels, 256 columns):
+//   phase 1  c1 over columns [t0 - P2, t0 - P2 + 256): the main loop of conv_sx_kernel's RAWIN f16 instantiation
+//            (x tile global -> registers -> lrelu -> split -> LDS per 16-channel chunk, weights global -> registers);
+//   hand-over  accumulators * 2^-k1 + bias1 -> lrelu -> two fp16 planes -> LDS array Y[chunk][plane][half][col]
+//            (zero where the column lies outside the tensor: c2's zero padding); Y overlays the x stages, hence one
+//            barrier before and one after;
+//   phase 2  c2 over Y: weights global -> registers, B fragments from Y, no DMA and no barriers;
+//   epilogue bias2, residual (from registers), multi-receptive-field accumulate / divide, fp32 raw store of the
+//            256 - 2 P2 interior columns.
+#pragma once
+#include "conv_sx_engine.hip.hpp"
+
+namespace vitsmi {
+
+struct SxPairArgs {
+    const float *xr;          // fp32 raw input [B][C/8][T][8]; also the residual
+    float islope, mslope;     // leaky-ReLU slopes: on x, and between the convs
+    int T;
+    const u32x4 *wp1, *wp2;   // packed weights (pack_conv_sx, two fp16 planes, this tile config)
+    const float *bias1, *bias2;
+    float wscale1, wscale2;
+    float *out_raw;           // fp32 raw output [B][C/8][T][8]
+    const float *zeros;
+    int C, nchunks;           // channels (= Cin = Cout of both convs), C / 16
+    int K1, dil1, pad1;       // c1
+    int K2, pad2;             // c2 (dilation 1)
+    int LW1;                  // x tile width in cells = 256 + (K1 - 1) * dil1
+    unsigned x_bytes;         // one x stage (2 planes x 2 halves x LW1 cells, padded to 4 KiB)
+    int LW2;                  // Y row width in cells
+    unsigned y_chunk_bytes;   // bytes of one chunk of Y = 4 * LW2 * 16
+    int BNo, NT, B;           // kept output columns per tile, tiles along time, utterances
+    int flags;                // EPI_ACC | EPI_DIV (the residual is always added)
+    float div;
+    unsigned *peak;           // f16 range guard slots (SxArgs::peak), may be nullptr
+};
+
+template <int MW, int NW, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, 2) void conv_sx_pair_kernel(SxPairArgs a) {
+    constexpr int BN = NW * WN * 32, NH = NW / 2;
+    static_assert(WM * WN == 4 && MW == 1 && BN == 256, "one block row per wave, 256 columns");
+    constexpr int NPW = 2, STEPBYTES = WM * MW * NPW * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_sx[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wg_xcd = blockIdx.x & 7, wg_seq = blockIdx.x >> 3;
+    const int tile_nb = __builtin_amdgcn_readfirstlane(wg_seq * 8 + wg_xcd);
+    if (tile_nb >= a.NT * a.B) return;
+    const int b = tile_nb / a.NT, t0 = (tile_nb - b * a.NT) * a.BNo;  // first kept output column
+    const int t1 = t0 - a.pad2;                                        // first column phase 1 computes
+    const int T = a.T, LW = a.LW1, K1 = a.K1, K2 = a.K2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds_sx;
+    const uint32_t XB = a.x_bytes;
+    const char *wbase1 = reinterpret_cast<const char *>(a.wp1) + wm * (MW * NPW * 1024);
+    const char *wbase2 = reinterpret_cast<const char *>(a.wp2) + wm * (MW * NPW * 1024);
+    float pk = 0.f;
+
+    // ---- x tile through registers (as conv_sx_kernel<RAWIN>): a thread owns cells i = it*256 + tid of [2][LW]
+    constexpr int NXC = 3;
+    u32x4 xst[NXC][2];
+    const float *xrb = a.xr + (int64_t)b * a.C * T;
+    const int nxc = (2 * LW + 255) >> 8;
+    auto xcell = [&](int it, int &kh, int &col) {
+        const int i = it * 256 + tid;
+        kh = (i >= LW ? 1 : 0) + (i >= 2 * LW ? 1 : 0);
+        col = i - kh * LW;
+    };
+    uint32_t xroff[NXC];
+    bool xrok[NXC];
+#pragma unroll
+    for (int it = 0; it < NXC; it++) {
+        int kh, col;
+        xcell(it, kh, col);
+        const int t = t1 - a.pad1 + col;
+        xrok[it] = it < nxc && kh < 2 && t >= 0 && t < T;
+        xroff[it] = xrok[it] ? (uint32_t)(((int64_t)kh * T + t) * 32) : 0u;
+    }
+    auto xload = [&](int chunk) {
+        const float *cbase = xrb + (int64_t)(2 * chunk) * T * 8;
+        static_for<NXC>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            if (it < nxc) {
+                xst[it][0] = global_read128<0>(xroff[it], cbase);
+                xst[it][1] = global_read128<16>(xroff[it], cbase);
+            }
+        });
+    };
+    auto xstore = [&](uint32_t xoff) {
+        const float isl = a.islope;
+        static_for<NXC>([&](auto I) {
+            constexpr int it = decltype(I)::value;
+            if (it < nxc) {
+                int kh, col;
+                xcell(it, kh, col);
+                if (kh < 2) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const float x = xrok[it] ? __uint_as_float(xst[it][e >> 2][e & 3]) : 0.f;
+                        v[e] = fmaxf(x, x * isl);
+                    }
+                    unsigned p0[4], p1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) split2h_pair_pk(v[2 * e], v[2 * e + 1], p0[e], p1[e], pk);
+                    const uint32_t ad = lds0 + xoff + (uint32_t)(kh * LW + col) * 16u;
+                    ds_write128(ad, u32x4{p0[0], p0[1], p0[2], p0[3]});
+                    ds_write128(ad + (uint32_t)(2 * LW) * 16u, u32x4{p1[0], p1[1], p1[2], p1[3]});
+                }
+            }
+        });
+    };
+    const int nxv = 2 * nxc;
+    auto wait_vm = [&](int n) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        }
+    };
+
+    f32x16 acc[NW];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int n = 0; n < NW; n++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
+    };
+    zero_acc();
+
+    struct ASet {
+        u32x4 fa[2];
+    };
+    u32x4 fb[NW][2];
+    const uint32_t voff0 = (uint32_t)lane * 16u;
+    auto load_a = [&](ASet &f, const char *wb, int step) {
+        const char *sb = wb + (int64_t)step * STEPBYTES;
+        f.fa[0] = global_read128<0>(voff0, sb);
+        f.fa[1] = global_read128<1024>(voff0, sb);
+    };
+    // B fragments of one half (block columns [h*NH, (h+1)*NH)) from the rows at byte address `rows` (plane 0,
+    // half-group `hi` selected by the lane), plane stride `pstride`
+    auto load_b_half = [&](auto H, uint32_t rows, uint32_t pstride) {
+        constexpr int h = decltype(H)::value;
+        static_for<NH>([&](auto N) {
+            constexpr int n = h * NH + decltype(N)::value;
+            fb[n][0] = ds_read128<n * 512>(rows);
+            fb[n][1] = ds_read128<n * 512>(rows + pstride);
+        });
+    };
+    auto mma_half = [&](const ASet &f, auto H) {
+        constexpr int h = decltype(H)::value;
+        // (f16x3: g1*h0, g0'*h1', g0*h0 - the order of conv_sx_kernel)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int n = h * NH; n < (h + 1) * NH; n++) {
+                const f16x8 ga = c == 0 ? __builtin_bit_cast(f16x8, f.fa[1])
+                                        : (c == 1 ? __builtin_bit_cast(f16x8, f.fa[0]) * (_Float16)0.00048828125f
+                                                  : __builtin_bit_cast(f16x8, f.fa[0]));
+                const f16x8 gb = __builtin_bit_cast(f16x8, fb[n][c == 1 ? 1 : 0]);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ga, gb, acc[n], 0, 0, 0);
+            }
+    };
+    auto wait_lds_older_half = [&]() {  // a half = NH * 2 reads
+        if constexpr (NH * 2 == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    };
+    const std::integral_constant<int, 0> H0{};
+    const std::integral_constant<int, 1> H1{};
+
+    // ---- residual operands of this wave (x itself, columns t0 ..): requested now, next to the x tile
+    f32x4 pre[NW / 2][2][4];
+    {
+        static_for<NW / 2>([&](auto R) {
+            constexpr int rr = decltype(R)::value;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int row0 = wm * 32;
+                const int t = t0 + (wn * NW + rr * 2 + j) * 32 + l31;
+                const int tl = t < T ? t : T - 1;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    pre[rr][j][q] = *reinterpret_cast<const f32x4 *>(xrb + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi);
+            }
+        });
+    }
+
+    // =================================================================== phase 1: c1 over columns [t1, t1 + 256)
+    const int nchunks = a.nchunks;
+    const uint32_t b_lane1 = lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u;
+    const uint32_t plane_b1 = (uint32_t)(2 * LW) * 16u;
+    ASet f0, f1;
+    xload(0);
+    load_a(f0, wbase1, 0);
+    wait_vm(2);  // in-order return: the residual and x loads have landed, A(0) may still be in flight
+    xstore(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+        int chunk = 0, tap = 0;
+        const int S = nchunks * K1;
+        auto step = [&](ASet &fc, ASet &fn, int s) {
+            const bool more_x = chunk + 1 < nchunks;
+            const uint32_t rows = b_lane1 + (uint32_t)(chunk & 1) * XB;
+            if (tap == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                load_b_half(H0, rows, plane_b1);
+                load_b_half(H1, rows, plane_b1);
+            } else {
+                if (tap == 1 && more_x) wait_vm(nxv);
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < S) load_a(fn, wbase1, s + 1);
+            if (tap == 0 && more_x) xload(chunk + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool more_taps = tap + 1 < K1;
+            const uint32_t next = rows + (uint32_t)((tap + 1) * a.dil1) * 16u;
+            wait_lds_older_half();
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(fc, H0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more_taps) {
+                load_b_half(H0, next, plane_b1);
+                wait_lds_older_half();
+            } else
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(fc, H1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap == 2 && more_x) xstore(((chunk + 1) & 1) * XB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more_taps) load_b_half(H1, next, plane_b1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (++tap == K1) {
+                tap = 0;
+                chunk++;
+            }
+        };
+        for (int s = 0; s + 1 < S; s += 2) {
+            step(f0, f1, s);
+            step(f1, f0, s + 1);
+        }
+        if (S & 1) step(f0, f1, S - 1);
+    }
+
+    // =================================================================== hand-over: c1's output -> Y (fp16 planes in LDS)
+    // first weights of c2 travel meanwhile (S1 odd: the last step left its weights in f0, so f1 is free either way)
+    ASet g0, g1;
+    load_a(g0, wbase2, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave has finished reading the x stages Y is about to overwrite
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const float wsc = a.wscale1, msl = a.mslope;
+        const float *biasp = a.bias1 ? a.bias1 : a.zeros;
+        const int b_on = a.bias1 ? 1 : 0;
+        const uint32_t YC = a.y_chunk_bytes, LW2 = (uint32_t)a.LW2;
+        const int row0 = wm * 32;
+        f32x4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
+#pragma unroll
+        for (int n = 0; n < NW; n++) {
+            const int col = (wn * NW + n) * 32 + l31;
+            const int t = t1 + col;
+            const bool live = t >= 0 && t < T;  // outside the tensor c2 sees zero padding, not c1 evaluated there
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float v = __builtin_fmaf(acc[n][4 * q + e], wsc, bq[q][e]);
+                    o[e] = live ? fmaxf(v, v * msl) : 0.f;
+                }
+                unsigned wa[2], wb[2];
+                split2h_pair_pk(o[0], o[1], wa[0], wa[1], pk);
+                split2h_pair_pk(o[2], o[3], wb[0], wb[1], pk);
+                // channel group g = 4 * wm + q -> chunk g / 2, half g % 2; 4 channels = 8 bytes of the 16-byte cell
+                const int g = 4 * wm + q;
+                const uint32_t cell = lds0 + (uint32_t)(g >> 1) * YC + ((uint32_t)(g & 1) * LW2 + (uint32_t)col) * 16u + 8u * hi;
+                asm volatile("ds_write_b64 %0, %1" ::"v"(cell), "v"(u32x2{wa[0], wb[0]}) : "memory");
+                asm volatile("ds_write_b64 %0, %1" ::"v"(cell + 2u * LW2 * 16u), "v"(u32x2{wa[1], wb[1]}) : "memory");
+            }
+        }
+    }
+    zero_acc();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // Y is complete
+    __builtin_amdgcn_sched_barrier(0);
+
+    // =================================================================== phase 2: c2 over Y (no DMA, no barriers)
+    {
+        const uint32_t b_lane2 = lds0 + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31) * 16u;
+        const uint32_t plane_b2 = (uint32_t)(2 * a.LW2) * 16u;
+        int chunk = 0, tap = 0;
+        const int S = nchunks * K2;
+        load_b_half(H0, b_lane2, plane_b2);
+        load_b_half(H1, b_lane2, plane_b2);
+        auto step = [&](ASet &fc, ASet &fn, int s) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A(s)
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < S) load_a(fn, wbase2, s + 1);
+            // B of the next step: next tap of this chunk, or tap 0 of the next chunk
+            int ntap = tap + 1, nchunk = chunk;
+            if (ntap == K2) {
+                ntap = 0;
+                nchunk++;
+            }
+            const bool more = s + 1 < S;
+            const uint32_t next = b_lane2 + (uint32_t)nchunk * a.y_chunk_bytes + (uint32_t)ntap * 16u;
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lds_older_half();
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(fc, H0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                load_b_half(H0, next, plane_b2);
+                wait_lds_older_half();
+            } else
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(fc, H1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) load_b_half(H1, next, plane_b2);
+            __builtin_amdgcn_sched_barrier(0);
+            tap = ntap;
+            chunk = nchunk;
+        };
+        for (int s = 0; s + 1 < S; s += 2) {
+            step(g0, g1, s);
+            step(g1, g0, s + 1);
+        }
+        if (S & 1) step(g0, g1, S - 1);
+    }
+
+    // =================================================================== epilogue: bias2 + x [+ xs] [/ n] -> raw
+    {
+        constexpr int flags = EPI;
+        float *rawb = a.out_raw + (int64_t)b * a.C * T;
+        const float wsc = a.wscale2, rdiv = a.div;
+        const float *biasp = a.bias2 ? a.bias2 : a.zeros;
+        const int b_on = a.bias2 ? 1 : 0;
+        const int row0 = wm * 32;
+        f32x4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
+        static_for<NW / 2>([&](auto R) {
+            constexpr int rr = decltype(R)::value;
+            f32x4 ad[2][4];
+            if constexpr ((flags & EPI_ACC) != 0) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int t = t0 + (wn * NW + rr * 2 + j) * 32 + l31;
+                    const int tl = t < T ? t : T - 1;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        ad[j][q] = *reinterpret_cast<const f32x4 *>(rawb + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int n = rr * 2 + j;
+                const int col = (wn * NW + n) * 32 + l31;
+                const int t = t0 + col;
+                if (col >= a.BNo || t >= T) continue;  // overlap columns belong to the next tile
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = __builtin_fmaf(acc[n][4 * q + e], wsc, bq[q][e]);
+                    v += pre[rr][j][q];
+                    if constexpr ((flags & EPI_ACC) != 0) v += ad[j][q];
+                    if constexpr ((flags & EPI_DIV) != 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = v[e] / rdiv;
+                    }
+                    *reinterpret_cast<f32x4 *>(rawb + ((int64_t)((row0 >> 3) + q) * T + t) * 8 + 4 * hi) = v;
+                }
+            }
+        });
+    }
+    if (a.peak) sx_publish_peak(a.peak, (int)blockIdx.x, pk);  // (uniform branch; every thread arrives)
+}
+
+template <int MW, int NW, int WM, int WN, int EPI>
+inline hipError_t launch_conv_sx_pair_k(const SxPairArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    auto kern = conv_sx_pair_kernel<MW, NW, WM, WN, EPI>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kSxMaxDynLds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    kern<<<grid, 256, lds, stream>>>(a);
+    return hipGetLastError();
+}
+
+// Can this pair of convs (both C -> C, same tile config cfg in {1: 64 rows, 2: 32 rows}, f16 planes) run fused?
+inline bool sx_pair_supported(int C, int cfg, int K1, int dil1, int K2, int dil2) {
+    if (dil2 != 1 || K1 < 3 || K2 < 3) return false;
+    if (!((C == 64 && cfg == 1) || (C == 32 && cfg == 2))) return false;  // one row tile holds every channel
+    const int LW1 = 256 + (K1 - 1) * dil1;
+    if (2 * LW1 > 768) return false;                                      // x staging: three cells per thread
+    if (256 - (K2 - 1) < 128) return false;
+    return true;
+}
+
+// flags: EPI_ACC (out += ...), EPI_DIV (then / div).  The residual (x) is always added.
+inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t stream) {
+    a.LW1 = 256 + (a.K1 - 1) * a.dil1;
+    a.x_bytes = (unsigned)(((size_t)4 * a.LW1 * 16 + 4095) / 4096 * 4096);
+    a.LW2 = 256 + 16;  // columns 256 .. 256 + K2 - 2 are only read for the discarded overlap outputs
+    a.y_chunk_bytes = (unsigned)(4 * a.LW2 * 16);
+    a.BNo = 256 - (a.K2 - 1);
+    a.NT = (a.T + a.BNo - 1) / a.BNo;
+    a.B = B;
+    a.nchunks = a.C / 16;
+    if (a.islope == 0.f) a.islope = 1.f;
+    if (a.mslope == 0.f) a.mslope = 1.f;
+    if (a.wscale1 == 0.f) a.wscale1 = 1.f;
+    if (a.wscale2 == 0.f) a.wscale2 = 1.f;
+    if ((long long)a.T * 64 + 64 >= (1ll << 32)) return hipErrorInvalidValue;
+    // Y overlays the two x stages
+    const size_t lds_x = 2 * (size_t)a.x_bytes, lds_y = (size_t)a.nchunks * a.y_chunk_bytes;
+    const size_t lds = lds_x > lds_y ? lds_x : lds_y;
+    if (lds > 80 * 1024) return hipErrorInvalidValue;
+    const long long nb = (long long)a.NT * B;
+    if (nb == 0) return hipSuccess;
+    const long long wgs = (nb + 7) / 8 * 8;
+    if (wgs >= (1ll << 31)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs, 1, 1);
+    const int epi = a.flags & (EPI_ACC | EPI_DIV);
+    if ((epi & EPI_DIV) && !(epi & EPI_ACC)) return hipErrorInvalidValue;
+#define SX_PAIR_CASES(MW, NW, WM, WN)                                                                        \
+    switch (epi) {                                                                                           \
+        case 0: return launch_conv_sx_pair_k<MW, NW, WM, WN, 0>(a, grid, lds, stream);                       \
+        case EPI_ACC: return launch_conv_sx_pair_k<MW, NW, WM, WN, EPI_ACC>(a, grid, lds, stream);           \
+        default: return launch_conv_sx_pair_k<MW, NW, WM, WN, EPI_ACC | EPI_DIV>(a, grid, lds, stream);      \
+    }
+    if (cfg == 1) {
+        SX_PAIR_CASES(1, 4, 2, 2)
+    }
+    SX_PAIR_CASES(1, 2, 1, 4)
+#undef SX_PAIR_CASES
+}
+
+}  // namespace vitsmi

@@ -17,6 +17,7 @@
 
 #include "../../include/vitsmi.h"
 #include "conv_sx_engine.hip.hpp"
+#include "conv_sx_pair.hip.hpp"
 #include "kernels.hip.hpp"
 #include "model.hpp"
 
@@ -349,6 +350,55 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     }
     conv_account(c, d, T);
     h->stats.sx_flops += 2.0 * d.macs_per_t * (double)T * c.B;
+    h->stats.sx_launches++;
+}
+
+// A whole ResBlock1 step, out = c2(lrelu(c1(lrelu(x)))) + x [+ out] [/ div], as ONE launch (conv_sx_pair.hip.hpp):
+// raw-format stages only (x, out: fp32 raw [B][C/8][T][8]).
+bool sx_pair_ok(const vits_handle *h, const ConvDesc &c1, const ConvDesc &c2) {
+    static const bool off = std::getenv("VITSMI_SX_NO_PAIR") != nullptr;  // A/B timing only
+    return !off && h->gen_nprod == 2 && c1.f16 && c2.f16 && c1.rawin && c2.rawin && c1.cfg == c2.cfg && c1.ups == 1 &&
+           c2.ups == 1 && c1.Cin == c1.Cout && c2.Cin == c2.Cout && c1.Cin == c2.Cin &&
+           sx_pair_supported(c1.Cin, c1.cfg, c1.K, c1.dil, c2.K, c2.dil);
+}
+
+void conv_sx_pair(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const float *x, int T, float *out, int flags, float div,
+                  float slope) {
+    SxPairArgs a{};
+    a.xr = x;
+    a.islope = slope;
+    a.mslope = slope;
+    a.T = T;
+    a.wp1 = reinterpret_cast<const u32x4 *>(c.P(c1.w_off));
+    a.wp2 = reinterpret_cast<const u32x4 *>(c.P(c2.w_off));
+    a.bias1 = c.P(c1.b_off);
+    a.bias2 = c.P(c2.b_off);
+    a.wscale1 = c1.wscale;
+    a.wscale2 = c2.wscale;
+    a.out_raw = out;
+    a.zeros = c.P(c.m.zeros_off);
+    a.C = c1.Cin;
+    a.K1 = c1.K;
+    a.dil1 = c1.dil;
+    a.pad1 = c1.padL;
+    a.K2 = c2.K;
+    a.pad2 = c2.padL;
+    a.flags = flags & (EPI_ACC | EPI_DIV);
+    a.div = div;
+    vits_handle *h = c.h;
+    a.peak = range_slots(h, true);
+    const bool ev = conv_event_begin(c);
+    c.note(launch_conv_sx_pair(a, c1.cfg, c.B, c.st));
+    if (ev) {
+        if (h->conv_event_sx.size() < h->conv_events.size()) h->conv_event_sx.resize(h->conv_events.size(), 0);
+        h->conv_event_sx[h->conv_events_used] = 1;
+        hipEventRecord(h->conv_events[h->conv_events_used++].second, c.st);
+    }
+    conv_account(c, c1, T);
+    conv_account(c, c2, T);
+    h->stats.conv_launches--;  // (two convs, one launch)
+    h->stats.total_launches--;
+    h->stats.sx_flops += 2.0 * (c1.macs_per_t + c2.macs_per_t) * (double)T * c.B;
     h->stats.sx_launches++;
 }
 
@@ -689,7 +739,10 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
                 }
                 const void *in = fr ? static_cast<const void *>(cur) : static_cast<const void *>(cura);
                 if (rbk.type1) {  // modules.py:301-314: x = c2(lrelu(c1(lrelu(x)))) + x
-                    if (fr) {
+                    if (fr && sx_pair_ok(h, rbk.c1[q], rbk.c2[q])) {
+                        // both convs in one launch: the intermediate stays in LDS, x is read once
+                        conv_sx_pair(c, rbk.c1[q], rbk.c2[q], cur, T, dst, fl, (float)nk, S);
+                    } else if (fr) {
                         conv_sx(c, rbk.c1[q], in, T, tmp_raw, nullptr, 0, nullptr, nullptr, 0, 1.f, 1.f, 1.f, S);
                         conv_sx(c, rbk.c2[q], tmp_raw, T, dst, nullptr, fl, cur, nullptr, 0, (float)nk, 1.f, 1.f, S);
                     } else {
@@ -1778,6 +1831,71 @@ int vits_test_conv_transpose1d_sx(int device_id, const float *x, int B, int Cin,
     set_sx_f16(false);
     if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
     return run_test_conv_sx(d, arena, x, B, T, 0, 0.f, out);
+}
+
+// out = c2(lrelu(c1(lrelu(x, slope)), slope)) + x through ONE fused launch (conv_sx_pair.hip.hpp; f16x3 arithmetic).
+// x, out: [B, C, T] host; w1, w2: [C, C, K]; c1 dilated by dil1, c2 dilation 1; flags bit0: also time it (ms_out).
+int vits_test_conv_pair_sx(int device_id, const float *x, int B, int C, int T, const float *w1, const float *b1,
+                           const float *w2, const float *b2, int K, int dil1, float slope, float *out, float *ms_out) {
+    if (int rc = test_dev(device_id)) return rc;
+    ConvDesc d1, d2;
+    std::vector<float> arena;
+    set_sx_f16(true);
+    std::string e = pack_test_conv(w1, b1, C, C, K, dil1, dil1 * (K - 1) / 2, 3, &d1, &arena);
+    if (e.empty()) e = pack_test_conv(w2, b2, C, C, K, 1, (K - 1) / 2, 3, &d2, &arena);
+    set_sx_f16(false);
+    if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
+    if (!d1.rawin || !d2.rawin || d1.cfg != d2.cfg || !sx_pair_supported(C, d1.cfg, d1.K, d1.dil, d2.K, d2.dil))
+        return fail(nullptr, VITS_E_ARG, "this conv pair cannot run fused (C %d, kernel %d, dilation %d)", C, K, dil1);
+    const size_t n = (size_t)B * C * T;
+    float *dA = nullptr, *dx = nullptr, *dxr = nullptr, *draw = nullptr, *dout = nullptr;
+    TCHECK(hipMalloc((void **)&dA, arena.size() * 4));
+    TCHECK(hipMalloc((void **)&dx, n * 4 + 16));
+    TCHECK(hipMalloc((void **)&dxr, n * 4 + 16));
+    TCHECK(hipMalloc((void **)&draw, n * 4 + 16));
+    TCHECK(hipMalloc((void **)&dout, n * 4 + 16));
+    TCHECK(hipMemcpy(dA, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemset(draw, 0, n * 4));
+    sx_block_kernel<<<dim3((T + 255) / 256, C / 8, B), 256>>>(dx, (int64_t)C * T, T, nullptr, dxr, C, T);
+    SxPairArgs a{};
+    a.xr = dxr;
+    a.islope = a.mslope = slope;
+    a.T = T;
+    a.wp1 = reinterpret_cast<const u32x4 *>(dA + d1.w_off);
+    a.wp2 = reinterpret_cast<const u32x4 *>(dA + d2.w_off);
+    a.bias1 = d1.b_off >= 0 ? dA + d1.b_off : nullptr;
+    a.bias2 = d2.b_off >= 0 ? dA + d2.b_off : nullptr;
+    a.wscale1 = d1.wscale;
+    a.wscale2 = d2.wscale;
+    a.out_raw = draw;
+    a.zeros = dA;
+    a.C = C;
+    a.K1 = d1.K; a.dil1 = d1.dil; a.pad1 = d1.padL;
+    a.K2 = d2.K; a.pad2 = d2.padL;
+    a.div = 1.f;
+    TCHECK(launch_conv_sx_pair(a, d1.cfg, B, nullptr));
+    TCHECK(hipDeviceSynchronize());
+    if (ms_out) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0, nullptr);
+        for (int i = 0; i < 10; i++) TCHECK(launch_conv_sx_pair(a, d1.cfg, B, nullptr));
+        hipEventRecord(e1, nullptr);
+        TCHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        *ms_out = ms / 10;
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+    }
+    sx_unblock_kernel<<<dim3((T + 255) / 256, C / 8, B), 256>>>(draw, nullptr, dout, C, T, 1);
+    TCHECK(hipGetLastError());
+    TCHECK(hipDeviceSynchronize());
+    TCHECK(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dx); hipFree(dxr); hipFree(draw); hipFree(dout);
+    return VITS_OK;
 }
 
 int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, int dil, int dbg, int iters,

@@ -587,6 +587,28 @@ def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=
     return out
 
 
+def test_conv_pair_sx(x, w1, b1, w2, b2, dil1=1, slope=0.1, device_id=0, timed=False):
+    """out = c2(lrelu(c1(lrelu(x)))) + x in ONE fused launch (ResBlock1 step on a raw-format stage; f16x3).
+    timed=True -> (out, ms per launch)."""
+    lib = _ffi.load()
+    x = np.ascontiguousarray(x, np.float32)
+    w1 = np.ascontiguousarray(w1, np.float32)
+    w2 = np.ascontiguousarray(w2, np.float32)
+    B, Cc, T = x.shape
+    K = w1.shape[2]
+    if w1.shape != (Cc, Cc, K) or w2.shape != (Cc, Cc, K):
+        raise ValueError("both convs are C -> C with the same kernel size")
+    b1 = None if b1 is None else np.ascontiguousarray(b1, np.float32)
+    b2 = None if b2 is None else np.ascontiguousarray(b2, np.float32)
+    out = np.empty_like(x)
+    ms = C.c_float(0.0)
+    rc = lib.vits_test_conv_pair_sx(device_id, _ffi.ptr(x), B, Cc, T, _ffi.ptr(w1), _ffi.ptr(b1), _ffi.ptr(w2),
+                                    _ffi.ptr(b2), K, dil1, float(slope), _ffi.ptr(out), C.byref(ms) if timed else None)
+    if rc != 0:
+        raise SessionError(_ffi.last_error(None))
+    return (out, float(ms.value)) if timed else out
+
+
 def bench_conv1d_sx(B, Cin, Cout, T, K, dil=1, dbg=0, iters=20, device_id=0):
     """Average launch time (ms) of one conv shape on the split-exact engine -> (ms, tile config)."""
     lib = _ffi.load()

@@ -253,6 +253,64 @@ def test_conv_sx_f16_mode_saturates_instead_of_overflowing():
     assert np.array_equal(got[0, 1:], np.clip(x[0, 1:], -65504, 65504))
 
 
+PAIR_CASES = [
+    # (B, C, T, K, dil1)        one fused launch = a ResBlock1 step on a raw-format stage
+    (2, 32, 700, 3, 1), (1, 32, 1000, 7, 3), (2, 32, 246, 11, 5), (1, 32, 247, 11, 1), (1, 32, 5, 7, 5),
+    (2, 64, 700, 3, 3), (1, 64, 513, 7, 5), (1, 64, 1000, 11, 5), (2, 64, 31, 11, 3), (1, 64, 256, 3, 1),
+]
+
+
+@pytest.mark.parametrize("B,C,T,K,dil", PAIR_CASES)
+def test_conv_pair_sx_equals_two_launches_and_oracle(B, C, T, K, dil):
+    """conv_sx_pair_kernel (c1 -> LDS -> c2 + x in one launch) against the two-launch form of the same f16x3
+    arithmetic - bit for bit: same operand planes, same products, same accumulation order, only the tile boundaries
+    move - and against the oracle's fp32 convolutions."""
+    from phoonnx_amd.session import test_conv1d_sx, test_conv_pair_sx
+    from vits_oracle import conv1d
+    rng = np.random.default_rng(C * 1000 + T + K + dil)
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    w1 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    w2 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K) * 3).astype(np.float32)
+    b1 = rng.standard_normal(C).astype(np.float32)
+    b2 = rng.standard_normal(C).astype(np.float32)
+    got = test_conv_pair_sx(x, w1, b1, w2, b2, dil1=dil, slope=0.1)
+    pad1, pad2 = dil * (K - 1) // 2, (K - 1) // 2
+    mid = test_conv1d_sx(x, w1, b1, dil=dil, pad_l=pad1, in_slope=0.1, precision="f16x3")
+    two = test_conv1d_sx(mid, w2, b2, dil=1, pad_l=pad2, in_slope=0.1, precision="f16x3") + x
+    assert np.array_equal(got, two), float(np.abs(got - two).max())
+    lr = lambda v: np.where(v > 0, v, v * np.float32(0.1)).astype(np.float32)
+    ref = conv1d(lr(conv1d(lr(x), w1, b1, dil=dil, pad_l=pad1, pad_r=pad1)), w2, b2, dil=1, pad_l=pad2, pad_r=pad2) + x
+    np.testing.assert_allclose(got, ref, atol=5e-5, rtol=1e-5)
+
+
+def test_conv_pair_sx_is_used_by_the_generator_and_can_be_switched_off(monkeypatch):
+    """A ResBlock1 voice with 64- and 32-channel raw-format stages: fused and unfused generators give the same
+    waveform bit for bit, and the fused one issues fewer launches."""
+    from phoonnx_amd import MiSession
+    path = os.path.join(GOLDEN, "sx_rb1.onnx")
+    g = np.load(os.path.join(GOLDEN, "sx_rb1.npz"))
+    args = [case_get(g, "b3_noise", k) for k in ("ids", "lens", "scales", "sid", "noise_dp", "noise_z")]
+    s = MiSession(path)
+    a = s.synthesize_batch(*args)
+    na = s.stats()["sx_launches"]
+    s.close()
+    monkeypatch.setenv("VITSMI_SX_NO_PAIR", "1")
+    import subprocess, sys  # (the switch is read once per process: ask a fresh one)
+    code = ("import sys, numpy as np; sys.path.insert(0, sys.argv[1]); from phoonnx_amd import MiSession; "
+            "g = np.load(sys.argv[3]); s = MiSession(sys.argv[2]); "
+            "r = s.synthesize_batch(*[g['b3_noise/' + k] if 'b3_noise/' + k in g.files else None for k in "
+            "('ids', 'lens', 'scales', 'sid', 'noise_dp', 'noise_z')]); "
+            "np.save(sys.argv[4], r['output']); print('LAUNCHES', s.stats()['sx_launches'])")
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "nopair_out.npy")
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, "-c", code, ROOT, path, os.path.join(GOLDEN, "sx_rb1.npz"), out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    nb = int(r.stdout.split("LAUNCHES")[1].split()[0])
+    assert na < nb, (na, nb)                     # 64- and 32-channel ResBlock1 steps: one launch instead of two
+    assert np.array_equal(np.load(out), a["output"])
+
+
 @pytest.mark.parametrize("B,Cin,Cout,T,K,u", [(2, 32, 32, 50, 16, 8), (2, 128, 64, 129, 4, 2)])
 def test_conv_transpose_sx_f16_mode_matches_oracle(B, Cin, Cout, T, K, u):
     from phoonnx_amd.session import test_conv_transpose1d
