@@ -48,8 +48,10 @@ struct SxPairArgs {
     unsigned *peak;           // f16 range guard slots (SxArgs::peak), may be nullptr
 };
 
+// (the 32-channel variant needs ~165 registers and <= 40 KiB of LDS: three workgroups per CU hide more of each
+// other's load / hand-over / store phases than two; the 64-channel one holds 64 accumulators + 64 residual registers)
 template <int MW, int NW, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_sx_pair_kernel(SxPairArgs a) {
+__global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPairArgs a) {
     constexpr int BN = NW * WN * 32, NH = NW / 2;
     static_assert(WM * WN == 4 && MW == 1 && BN == 256, "one block row per wave, 256 columns");
     constexpr int NPW = 2, STEPBYTES = WM * MW * NPW * 1024;
