@@ -38,6 +38,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sx_split.hip.hpp"
+
 namespace vitsmi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -53,6 +55,11 @@ enum : int {
     EPI_ACC = 32,       // out = out + value
     EPI_DIV = 64,       // out = value / div      (after EPI_ACC)
     EPI_COUPLING = 128,  // out = (out - value*mask) * mask   (modules.py:464, mean_only)
+    // WN res_skip conv with its update folded in (modules.py:203-209): rows [0, wn_split) are the residual half,
+    // out = (out + value * mask) [x = (x + res) * mask]; rows [wn_split, Cout) the skip half, out2 (+)= value * mask
+    // (the sum of masked terms equals the reference's masked sum).  wn_split = 0: skip rows only (the last WN layer).
+    EPI_WN = 256,
+    EPI_WN_FIRST = 512,  // ... first WN layer: the skip rows are stored, not accumulated
     DBG_NO_DMA = 1 << 16,  // ablation (tools/conv_bench.py): stop prefetching after the second chunk
     DBG_NO_EPI = 1 << 17   // ablation: skip the epilogue stores
 };
@@ -80,6 +87,13 @@ struct ConvArgs {
     int flags;
     float slope, div;
     float oslope, oslope2;  // leaky-relu slope applied to the value stored in out / out2 (1 = none)
+    int wn_split;           // EPI_WN: first skip row
+    // optional third output: the value stored in `out` (rows [0, pl_rows)) once more as the two fp16 operand planes a
+    // following split-operand conv reads (conv_sx_engine.hip.hpp: planes [3 slots][pl_rows/8][T][8], f16x3 format),
+    // so that no separate split launch is needed; pl_rows % 32 == 0, ups == 1
+    uint16_t *out_pl;
+    int pl_rows;
+    unsigned *peak;         // range-guard slots for those planes (SxArgs::peak), may be nullptr
 };
 
 template <int BYTES>
@@ -325,6 +339,10 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
         return;
     }
     float *ob2 = a.out2 ? a.out2 + (int64_t)b * a.out_bstride : nullptr;
+    const bool is_wn = (flags & EPI_WN) != 0;
+    uint16_t *plb = a.out_pl ? a.out_pl + (int64_t)b * 3 * a.pl_rows * T : nullptr;
+    const int64_t plane_elems = (int64_t)a.pl_rows * T;
+    float pk = 0.f;
     const float relu_floor = (flags & EPI_RELU) ? 0.f : -__builtin_inff();
     const float oslope = a.oslope, oslope2 = a.oslope2, div = a.div;
     // second operand added to the value: the residual tensor, or (EPI_ACC / EPI_COUPLING) the old output
@@ -334,9 +352,17 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
     for (int m = 0; m < MW; m++) {
         int orow_m[16];
         float brow_m[16];
+        // EPI_WN: this 32-row block is either residual rows (-> out, added to it) or skip rows (-> out2)
+        const bool skip_rows = is_wn && (mblk0 + m) * 32 >= a.wn_split;
+        float *obm = skip_rows ? ob2 : ob;
+        const float *addm = is_wn ? obm : addp;
+        const bool has_add_m = is_wn ? !(skip_rows && (flags & EPI_WN_FIRST)) : has_add;
+        const int co_shift = skip_rows ? a.wn_split : 0;
+        const bool planes_m = plb && !skip_rows && (mblk0 + m) * 32 < a.pl_rows;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             orow_m[r] = row_off(m, r);
+            if (is_wn && orow_m[r] >= 0) orow_m[r] -= co_shift * a.out_cstride;
             const int co = (mblk0 + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
             const int cc = co < a.Cout ? co : 0;
             brow_m[r] = biasp[cc * b_on] + bbp[cc * bb_on];
@@ -345,13 +371,13 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
         float ad[NB][16];
 #pragma unroll
         for (int n = 0; n < NW; n++) {
-            if (has_add && (n % NB) == 0) {
+            if (has_add_m && (n % NB) == 0) {
 #pragma unroll
                 for (int q = 0; q < NB; q++) {
                     const int tq = t0 + wn * (NW * 32) + (n + q) * 32 + l31;
                     const int ttq = tq * ups;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) ad[q][r] = (orow_m[r] >= 0 && tq < T) ? addp[orow_m[r] + ttq] : 0.f;
+                    for (int r = 0; r < 16; r++) ad[q][r] = (orow_m[r] >= 0 && tq < T) ? addm[orow_m[r] + ttq] : 0.f;
                 }
             }
             const int t = t0 + wn * (NW * 32) + n * 32 + l31;
@@ -360,8 +386,8 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
 #pragma unroll
                     for (int r = 0; r < 16; r++)
                         if (orow_m[r] >= 0) {
-                            ob[orow_m[r] + t] = 0.f;
-                            if (ob2) ob2[orow_m[r] + t] = 0.f;
+                            obm[orow_m[r] + t] = 0.f;
+                            if (ob2 && !is_wn) ob2[orow_m[r] + t] = 0.f;
                         }
                 }
                 continue;
@@ -378,7 +404,7 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
                     if (orow_m[r] >= 0) ob[orow_m[r] + tt] = (ad[n % NB][r] - v[r] * mk) * mk;
                 continue;
             }
-            if (has_add) {
+            if (has_add_m) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) v[r] = v[r] * mk_sel + ad[n % NB][r];
             } else {
@@ -398,14 +424,27 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
             }
 #pragma unroll
             for (int r = 0; r < 16; r++)
-                if (orow_m[r] >= 0) ob[orow_m[r] + tt] = lrelu_f(v[r], oslope);
-            if (ob2) {
+                if (orow_m[r] >= 0) obm[orow_m[r] + tt] = lrelu_f(v[r], oslope);
+            if (planes_m) {
+                // register quad q = 4 consecutive channels 8q + 4*hi .. +3 of channel group (block * 4 + q): half a cell
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    unsigned wa[2], wb[2];
+                    split2h_pair_pk(lrelu_f(v[4 * q], oslope), lrelu_f(v[4 * q + 1], oslope), wa[0], wa[1], pk);
+                    split2h_pair_pk(lrelu_f(v[4 * q + 2], oslope), lrelu_f(v[4 * q + 3], oslope), wb[0], wb[1], pk);
+                    const int64_t cell = ((int64_t)((mblk0 + m) * 4 + q) * T + t) * 8 + 4 * hi;
+                    *reinterpret_cast<u32x2 *>(plb + cell) = u32x2{wa[0], wb[0]};
+                    *reinterpret_cast<u32x2 *>(plb + plane_elems + cell) = u32x2{wa[1], wb[1]};
+                }
+            }
+            if (ob2 && !is_wn) {
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                     if (orow_m[r] >= 0) ob2[orow_m[r] + tt] = lrelu_f(v[r], oslope2);
             }
         }
     }
+    if (a.peak) sx_publish_peak(a.peak, (int)(blockIdx.x + blockIdx.y + blockIdx.z), pk);  // (uniform; every thread arrives)
 }
 
 // tile configs: index -> (BM, BN)
@@ -436,7 +475,7 @@ inline hipError_t launch_conv_k(const ConvArgs &a, dim3 grid, size_t lds, hipStr
     auto kern = conv_engine_kernel<MW, NW, WM, WN, VEC, ACT>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSxMaxDynLds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }

@@ -52,9 +52,6 @@ namespace vitsmi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 enum : int { SX_NO_RAW_STORE = 256 };  // out_raw is only the EPI_ACC operand, not a destination
 
@@ -91,8 +88,7 @@ struct SxArgs {
     unsigned *peak;
 };
 
-constexpr int kSxPeakSlots = 64;
-constexpr float kF16Max = 65504.f;
+
 
 template <int OFF>
 __device__ __forceinline__ u32x4 ds_read128(uint32_t addr) {
@@ -158,53 +154,6 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &w0, unsi
     w2 = cvt_pk_bf16(sx, sy);
 }
 
-// ---- f16 mode (NP = 2): an fp32 operand as TWO fp16 planes, round-to-nearest at each step:
-//     v ~ h0 + h1,   h0 = f16(v), h1 = f16(v - h0):   |v - h0 - h1| <= 2^-24 |v|  (11 + 11 bits and the sign of h1)
-// so a product needs only the three MFMAs h0g0 + h0g1 + h1g0 (the dropped h1g1 is <= 2^-24 |v||g|): the same
-// per-product error bound as one fp32 rounding, at half the matrix work of the six bf16 products.  fp16 has 5
-// exponent bits, so the planes are kept in range explicitly:
-//   weights      g = w * 2^k, k per tensor so that max |g| is in [2^14, 2^15); planes g0, g1 (packed two per block
-//                row) and g0' = g0 * 2^-11, made in registers; 2^-k is applied to the accumulators (SxArgs::wscale)
-//   activations  h0 = f16(x) (clamped to +-65504), h1' = f16((x - h0) * 2^11): the low plane is stored 2^11 up, which
-//                keeps it a normal number wherever h0 is one, and meets g0' instead of g0 in its product:
-//                x*g ~ h0*g0 + h0*g1 + h1'*g0'
-// Activations therefore carry ~2^-23 relative error down to |x| = 2^-14 and an absolute floor of 2^-36 below that.
-__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-}
-__device__ __forceinline__ void split2h_pair(float x, float y, unsigned &w0, unsigned &w1) {
-    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
-    y = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
-    w0 = cvt_pk_f16(x, y);
-    const f16x2 h = __builtin_bit_cast(f16x2, w0);
-    w1 = cvt_pk_f16((x - (float)h[0]) * 2048.f, (y - (float)h[1]) * 2048.f);
-}
-// ... the same, recording the largest magnitude seen (one v_max3_f32 per pair)
-__device__ __forceinline__ void split2h_pair_pk(float x, float y, unsigned &w0, unsigned &w1, float &pk) {
-    pk = __builtin_fmaxf(pk, __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y)));
-    split2h_pair(x, y, w0, w1);
-}
-// Publish a workgroup's peak (all 256 threads must call, uniformly): wave-wide max, the four wave maxima through LDS,
-// then ONE atomicMax on one of the launch's 64 slots - each slot on its own 128-byte line, and skipped when the slot
-// already holds as much (nearly always, after the first workgroups of a launch).  A first version with one atomic
-// per WAVE on 64 adjacent words made the 10 us split kernel take 200 us: atomics on one cache line serialise in the L2.
-constexpr int kSxPeakStride = 32;  // uints between slots: one 128-byte line each
-// (sx_publish_peak's four floats are static LDS: the dynamic part a kernel may ask for is the CU's 160 KiB less that)
-constexpr int kSxMaxDynLds = 160 * 1024 - 256;
-__device__ __forceinline__ void sx_publish_peak(unsigned *slots, int slot_idx, float pk) {
-    __shared__ float s_pk[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) pk = __builtin_fmaxf(pk, __shfl_xor(pk, o, 64));
-    if ((threadIdx.x & 63) == 0) s_pk[threadIdx.x >> 6] = pk;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        pk = __builtin_fmaxf(__builtin_fmaxf(s_pk[0], s_pk[1]), __builtin_fmaxf(s_pk[2], s_pk[3]));
-        unsigned *slot = slots + (slot_idx & (kSxPeakSlots - 1)) * kSxPeakStride;
-        const unsigned bits = __float_as_uint(pk);  // (non-negative floats order like their bit patterns; inf on top)
-        if (bits > __builtin_nontemporal_load(slot)) atomicMax(slot, bits);
-    }
-}
 __device__ __forceinline__ float f16_bits_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
 
 // Epilogue description bits beyond EPI_RES / EPI_ACC / EPI_DIV (conv_engine.hip.hpp).  The first group is

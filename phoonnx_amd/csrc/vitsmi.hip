@@ -260,10 +260,17 @@ bool conv_event_begin(Ctx &c) {
 }
 
 // Launch one conv through the engine; accounts algorithmic FLOPs/bytes per stage.
+struct ConvExtra {           // rarely used arguments of conv()
+    int wn_split = 0;        // EPI_WN: first skip row
+    uint16_t *out_pl = nullptr;  // fp16 operand planes of the rows [0, pl_rows) of `out` for a following sx conv
+    int pl_rows = 0;
+};
+
 void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, float *out, int64_t out_bstride,
           int flags, const int *len = nullptr, const float *res = nullptr, int64_t res_bstride = 0,
           const float *bias_b = nullptr, int bias_b_stride = 0, float slope = 0.1f, float div = 1.f,
-          float oslope = 1.f, float *out2 = nullptr, float oslope2 = 1.f, int x_cstride = 0, int out_cstride = 0) {
+          float oslope = 1.f, float *out2 = nullptr, float oslope2 = 1.f, int x_cstride = 0, int out_cstride = 0,
+          const ConvExtra *ex = nullptr) {
     ConvArgs a{};
     a.x = x;
     a.x_bstride = x_bstride;
@@ -295,6 +302,12 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
     a.x_cstride = x_cstride;
     a.out_cstride = out_cstride;
     vits_handle *h = c.h;
+    if (ex) {
+        a.wn_split = ex->wn_split;
+        a.out_pl = ex->out_pl;
+        a.pl_rows = ex->pl_rows;
+        a.peak = ex->out_pl ? range_slots(h, true) : nullptr;
+    }
     const bool ev = conv_event_begin(c);
     c.note(launch_conv(a, d.cfg, c.B, c.st));
     if (ev) hipEventRecord(h->conv_events[h->conv_events_used++].second, c.st);
@@ -1005,17 +1018,29 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
         }
         const float *x0 = z + (cd.swapped ? (int64_t)half * F : 0);
         float *x1 = z + (cd.swapped ? 0 : (int64_t)half * F);
+        // Launches per WN layer: [in-layer conv on the split engine] [tanh * sigmoid gate] [res_skip 1x1 conv].  The
+        // res_skip conv's epilogue applies the update (x = (x + res) * mask, skip += ...: EPI_WN) and, when the next
+        // in-layer runs on the split engine, also emits x as that conv's fp16 operand planes - as `pre` does for the
+        // first layer - so neither an update nor a split launch is left (they were 2 of the 5 launches of a layer).
+        const bool planes0 = cd.n_wn > 0 && cd.wn[0].in.sx && cd.wn[0].in.f16 && Hf % 32 == 0;
+        ConvExtra ex0;
+        ex0.out_pl = planes0 ? hx_pl : nullptr;
+        ex0.pl_rows = Hf;
         // h = pre(x0) * mask
-        conv(c, cd.pre, x0, sCF, F, hx, sHF, EPI_MASK, ylen);
+        conv(c, cd.pre, x0, sCF, F, hx, sHF, EPI_MASK, ylen, nullptr, 0, nullptr, 0, 0.1f, 1.f, 1.f, nullptr, 1.f, 0, 0, &ex0);
         for (int i = 0; i < cd.n_wn; i++) {
             const bool last = i == cd.n_wn - 1;
             // x_in = in_layer(h) + g_l ; acts = tanh * sigmoid ; rs = res_skip(acts)
             if (cd.wn[i].in.sx) {
-                // split-operand engine: hx -> planes, conv to the raw cell layout, gate reads that layout
-                sx_split_planes_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(hx, sHF, F, nullptr, hx_pl, Hf, F,
-                                                                                         cd.wn[i].in.f16 ? 1 : 0,
-                                                                                         range_slots(h, cd.wn[i].in.f16));
-                h->stats.total_launches++;
+                // split-operand engine: planes of hx (from the producing epilogue, or split here), conv to the raw cell
+                // layout, gate reads that layout
+                const bool have_planes = cd.wn[i].in.f16 && Hf % 32 == 0;
+                if (!have_planes) {
+                    sx_split_planes_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(hx, sHF, F, nullptr, hx_pl, Hf, F,
+                                                                                             cd.wn[i].in.f16 ? 1 : 0,
+                                                                                             range_slots(h, cd.wn[i].in.f16));
+                    h->stats.total_launches++;
+                }
                 conv_sx(c, cd.wn[i].in, hx_pl, F, a2, nullptr, 0, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr, gc_rows);
                 wn_gate_blocked_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(a2, acts, Hf, F);
             } else {
@@ -1023,9 +1048,15 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
                      gc ? gc + (int64_t)i * 2 * Hf : nullptr, gc_rows);
                 wn_gate_kernel<<<dim3((F + 255) / 256, Hf, B), 256, 0, st>>>(a2, acts, Hf, F);
             }
-            conv(c, cd.wn[i].rs, acts, sHF, F, rs, (int64_t)cd.wn[i].rs.Cout * F, 0);
-            wn_update_kernel<<<dim3((F + 255) / 256, Hf, B), 256, 0, st>>>(hx, skip, rs, ylen, Hf, F, i == 0, last);
-            h->stats.total_launches += 2;
+            h->stats.total_launches++;
+            // res_skip conv + update: rows [0, Hf) -> hx (residual half), rows [Hf, 2 Hf) -> skip; last layer: skip only
+            ConvExtra ex;
+            ex.wn_split = last ? 0 : Hf;
+            const bool next_planes = !last && cd.wn[i + 1].in.sx && cd.wn[i + 1].in.f16 && Hf % 32 == 0;
+            ex.out_pl = next_planes ? hx_pl : nullptr;
+            ex.pl_rows = Hf;
+            conv(c, cd.wn[i].rs, acts, sHF, F, hx, sHF, EPI_WN | EPI_MASK | (i == 0 ? EPI_WN_FIRST : 0), ylen, nullptr, 0,
+                 nullptr, 0, 0.1f, 1.f, 1.f, skip, 1.f, 0, 0, &ex);
         }
         // x1 = (x1 - post(skip)*mask) * mask
         conv(c, cd.post, skip, sHF, F, x1, sCF, EPI_COUPLING, ylen);
