@@ -721,7 +721,7 @@ def test_ttsvoice_loads_from_the_onnx_alone_and_rejects_inconsistent_json(tmp_pa
     chunks = list(voice.synthesize("hello world. again, hello?", syn))
     assert len(chunks) == 2 and all(len(c.audio_float_array) > 200 for c in chunks)   # (hop 32: short audio)
     # the same ids by hand through the session: identical audio
-    ids = voice.phonemes_to_ids(list("hello world."))
+    ids = voice.phonemes_to_ids(voice.phonemize("hello world. again, hello?")[0])
     raw = voice.phoneme_ids_to_audio(ids, syn)
     assert np.array_equal(chunks[0].audio_float_array, voice._postprocess(raw, syn))
     voice.session.close()
