@@ -258,11 +258,14 @@ int vits_test_conv_transpose1d_sx(int device_id, const float *x, int B, int Cin,
                                   const float *bias, int Cout, int K, int stride, float *out);
 int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, int dil, int dbg, int iters,
                          float *ms_out);
-/* One fused launch for a ResBlock1 step on a raw-format stage (csrc/conv_sx_pair.hip.hpp):
- * out = c2(leaky_relu(c1(leaky_relu(x, slope)), slope)) + x, c1 = Conv1d(C, C, K, dilation dil1), c2 = Conv1d(C, C, K),
- * both "same"-padded; C in {32, 64}; f16x3 arithmetic.  ms_out (nullable): average launch time over 10 launches. */
+/* Two dependent convs of a ResBlock in one fused launch on a raw-format stage (csrc/conv_sx_pair.hip.hpp), C in {32, 64},
+ * f16x3 arithmetic, c1 = Conv1d(C, C, K, dilation dil1), c2 = Conv1d(C, C, K, dilation dil2), both "same"-padded:
+ *   chain == 0 (ResBlock1 step):   out = c2(leaky_relu(c1(leaky_relu(x, slope)), slope)) + x
+ *   chain != 0 (two ResBlock2 steps): x1 = c1(leaky_relu(x, slope)) + x ; out = c2(leaky_relu(x1, slope)) + x1
+ * ms_out (nullable): average launch time over 10 launches. */
 int vits_test_conv_pair_sx(int device_id, const float *x, int B, int C, int T, const float *w1, const float *b1,
-                           const float *w2, const float *b2, int K, int dil1, float slope, float *out, float *ms_out);
+                           const float *w2, const float *b2, int K, int dil1, int dil2, int chain, float slope, float *out,
+                           float *ms_out);
 /* Relative-position multi-head self-attention core (attentions.py:225-272): q,k,v
  * [B,C,T] host, emb_rel_k/v [2w+1, dk], lens int64[B]; out [B,C,T]. */
 int vits_test_attention(int device_id, const float *qkv, int B, int C, int T, int n_heads, const float *rel_k,

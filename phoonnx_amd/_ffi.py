@@ -113,7 +113,7 @@ def load():
     lib.vits_test_conv_transpose1d_sx.argtypes = lib.vits_test_conv_transpose1d.argtypes
     lib.vits_bench_conv1d_sx.argtypes = [C.c_int] * 9 + [f32p]
     lib.vits_test_conv_pair_sx.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
-                                           C.c_float, vp, f32p]
+                                           C.c_int, C.c_int, C.c_float, vp, f32p]
     _LIB = lib
     return lib
 

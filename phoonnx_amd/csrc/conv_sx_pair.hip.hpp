@@ -1,5 +1,7 @@
-// conv_sx_pair.hip.hpp — one launch for a whole ResBlock1 step on the raw-format stages of the generator
-// (<= 64 channels):   out = c2(lrelu(c1(lrelu(x)))) + x        (phoonnx_train/vits/modules.py:301-314)
+// conv_sx_pair.hip.hpp — two dependent convs of a ResBlock in ONE launch, on the raw-format stages of the generator
+// (<= 64 channels):
+//   PAIR   a ResBlock1 step    out = c2(lrelu(c1(lrelu(x)))) + x                 (phoonnx_train/vits/modules.py:301-314)
+//   CHAIN  two ResBlock2 steps x1 = c1(lrelu(x)) + x ;  out = c2(lrelu(x1)) + x1  (modules.py:355-364)
 //
 // Why: these layers are HBM-bound (8-20 FLOP/B, 4-5 TB/s measured).  As two launches of conv_sx_kernel a step moves
 // 20 bytes per element: c1 reads x and writes the intermediate, c2 reads the intermediate AND x (the residual) and
@@ -18,9 +20,11 @@
 //   hand-over  accumulators * 2^-k1 + bias1 -> lrelu -> two fp16 planes -> LDS array Y[chunk][plane][half][col]
 //            (zero where the column lies outside the tensor: c2's zero padding); Y overlays the x stages, hence one
 //            barrier before and one after;
-//   phase 2  c2 over Y: weights global -> registers, B fragments from Y, no DMA and no barriers;
-//   epilogue bias2, residual (from registers), multi-receptive-field accumulate / divide, fp32 raw store of the
-//            256 - 2 P2 interior columns.
+//   phase 2  c2 over Y: weights global -> registers, B fragments from Y, no DMA and no barriers.  Y is stored P2 columns
+//            to the right, so that tap k of output column j reads Y[j + k * dil2]: phase 2 then produces column j in the
+//            lane that produced column j in phase 1 (its c1 accumulators are the CHAIN residual x1, no exchange);
+//   epilogue bias2, residual (x from registers; CHAIN: x1), multi-receptive-field accumulate / divide, fp32 raw store
+//            of the 256 - 2 P2 interior columns (P2 = c2's one-sided reach; columns nearer the tile edge saw garbage).
 #pragma once
 #include "conv_sx_engine.hip.hpp"
 
@@ -37,10 +41,10 @@ struct SxPairArgs {
     const float *zeros;
     int C, nchunks;           // channels (= Cin = Cout of both convs), C / 16
     int K1, dil1, pad1;       // c1
-    int K2, pad2;             // c2 (dilation 1)
+    int K2, dil2, pad2;       // c2
     int LW1;                  // x tile width in cells = 256 + (K1 - 1) * dil1
     unsigned x_bytes;         // one x stage (2 planes x 2 halves x LW1 cells, padded to 4 KiB)
-    int LW2;                  // Y row width in cells
+    int LW2;                  // Y row width in cells (256 + 2 * pad2, rounded up)
     unsigned y_chunk_bytes;   // bytes of one chunk of Y = 4 * LW2 * 16
     int BNo, NT, B;           // kept output columns per tile, tiles along time, utterances
     int flags;                // EPI_ACC | EPI_DIV (the residual is always added)
@@ -50,7 +54,7 @@ struct SxPairArgs {
 
 // (the 32-channel variant needs ~165 registers and <= 40 KiB of LDS: three workgroups per CU hide more of each
 // other's load / hand-over / store phases than two; the 64-channel one holds 64 accumulators + 64 residual registers)
-template <int MW, int NW, int WM, int WN, int EPI>
+template <int MW, int NW, int WM, int WN, int EPI, bool CHAIN>
 __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPairArgs a) {
     constexpr int BN = NW * WN * 32, NH = NW / 2;
     static_assert(WM * WN == 4 && MW == 1 && BN == 256, "one block row per wave, 256 columns");
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
     const std::integral_constant<int, 0> H0{};
     const std::integral_constant<int, 1> H1{};
 
-    // ---- residual operands of this wave (x itself, columns t0 ..): requested now, next to the x tile
+    // ---- residual operands of this wave (x itself, at the columns this lane produces: t1 + col): requested now, next
+    // to the x tile.  CHAIN turns them into x1 = c1(..) + x at the hand-over.
     f32x4 pre[NW / 2][2][4];
     {
         static_for<NW / 2>([&](auto R) {
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 const int row0 = wm * 32;
-                const int t = t0 + (wn * NW + rr * 2 + j) * 32 + l31;
-                const int tl = t < T ? t : T - 1;
+                const int t = t1 + (wn * NW + rr * 2 + j) * 32 + l31;
+                const int tl = t < 0 ? 0 : (t < T ? t : T - 1);  // (clamped columns are never kept)
 #pragma unroll
                 for (int q = 0; q < 4; q++)
                     pre[rr][j][q] = *reinterpret_cast<const f32x4 *>(xrb + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi);
@@ -293,7 +298,11 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const float v = __builtin_fmaf(acc[n][4 * q + e], wsc, bq[q][e]);
+                    float v = __builtin_fmaf(acc[n][4 * q + e], wsc, bq[q][e]);
+                    if constexpr (CHAIN) {  // x1 = c1(lrelu(x)) + x: c2's input and, kept in `pre`, its residual
+                        v += pre[n / 2][n % 2][q][e];
+                        pre[n / 2][n % 2][q][e] = v;
+                    }
                     o[e] = live ? fmaxf(v, v * msl) : 0.f;
                 }
                 unsigned wa[2], wb[2];
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
                 split2h_pair_pk(o[2], o[3], wb[0], wb[1], pk);
                 // channel group g = 4 * wm + q -> chunk g / 2, half g % 2; 4 channels = 8 bytes of the 16-byte cell
                 const int g = 4 * wm + q;
-                const uint32_t cell = lds0 + (uint32_t)(g >> 1) * YC + ((uint32_t)(g & 1) * LW2 + (uint32_t)col) * 16u + 8u * hi;
+                const uint32_t cell = lds0 + (uint32_t)(g >> 1) * YC + ((uint32_t)(g & 1) * LW2 + (uint32_t)(col + a.pad2)) * 16u + 8u * hi;
                 asm volatile("ds_write_b64 %0, %1" ::"v"(cell), "v"(u32x2{wa[0], wb[0]}) : "memory");
                 asm volatile("ds_write_b64 %0, %1" ::"v"(cell + 2u * LW2 * 16u), "v"(u32x2{wa[1], wb[1]}) : "memory");
             }
@@ -331,7 +340,7 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
                 nchunk++;
             }
             const bool more = s + 1 < S;
-            const uint32_t next = b_lane2 + (uint32_t)nchunk * a.y_chunk_bytes + (uint32_t)ntap * 16u;
+            const uint32_t next = b_lane2 + (uint32_t)nchunk * a.y_chunk_bytes + (uint32_t)(ntap * a.dil2) * 16u;
             __builtin_amdgcn_sched_barrier(0);
             wait_lds_older_half();
             __builtin_amdgcn_sched_barrier(0);
@@ -374,8 +383,8 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
             if constexpr ((flags & EPI_ACC) != 0) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
-                    const int t = t0 + (wn * NW + rr * 2 + j) * 32 + l31;
-                    const int tl = t < T ? t : T - 1;
+                    const int t = t1 + (wn * NW + rr * 2 + j) * 32 + l31;
+                    const int tl = t < 0 ? 0 : (t < T ? t : T - 1);
 #pragma unroll
                     for (int q = 0; q < 4; q++)
                         ad[j][q] = *reinterpret_cast<const f32x4 *>(rawb + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi);
@@ -385,8 +394,8 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
             for (int j = 0; j < 2; j++) {
                 const int n = rr * 2 + j;
                 const int col = (wn * NW + n) * 32 + l31;
-                const int t = t0 + col;
-                if (col >= a.BNo || t >= T) continue;  // overlap columns belong to the next tile
+                const int t = t1 + col;
+                if (col < a.pad2 || col >= a.pad2 + a.BNo || t >= T) continue;  // overlap columns belong to the neighbours
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     f32x4 v;
@@ -406,10 +415,10 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
     if (a.peak) sx_publish_peak(a.peak, (int)blockIdx.x, pk);  // (uniform branch; every thread arrives)
 }
 
-template <int MW, int NW, int WM, int WN, int EPI>
+template <int MW, int NW, int WM, int WN, int EPI, bool CHAIN>
 inline hipError_t launch_conv_sx_pair_k(const SxPairArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
-    auto kern = conv_sx_pair_kernel<MW, NW, WM, WN, EPI>;
+    auto kern = conv_sx_pair_kernel<MW, NW, WM, WN, EPI, CHAIN>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kSxMaxDynLds);
@@ -420,23 +429,30 @@ inline hipError_t launch_conv_sx_pair_k(const SxPairArgs &a, dim3 grid, size_t l
     return hipGetLastError();
 }
 
-// Can this pair of convs (both C -> C, same tile config cfg in {1: 64 rows, 2: 32 rows}, f16 planes) run fused?
+// Can these two convs (both C -> C, same tile config cfg in {1: 64 rows, 2: 32 rows}, f16 planes) run fused?
 inline bool sx_pair_supported(int C, int cfg, int K1, int dil1, int K2, int dil2) {
-    if (dil2 != 1 || K1 < 3 || K2 < 3) return false;
+    if (K1 < 3 || K2 < 3 || dil1 < 1 || dil2 < 1) return false;
     if (!((C == 64 && cfg == 1) || (C == 32 && cfg == 2))) return false;  // one row tile holds every channel
     const int LW1 = 256 + (K1 - 1) * dil1;
     if (2 * LW1 > 768) return false;                                      // x staging: three cells per thread
-    if (256 - (K2 - 1) < 128) return false;
-    return true;
+    const int halo2 = (K2 - 1) * dil2;
+    if (halo2 % 2 || 256 - halo2 < 160) return false;                     // (> 37 % of a tile recomputed: not worth it)
+    const size_t lds_y = (size_t)(C / 16) * 4 * (size_t)((256 + halo2 + 7) / 8 * 8) * 16;
+    const size_t lds_x = 2 * (((size_t)4 * LW1 * 16 + 4095) / 4096 * 4096);
+    return (lds_y > lds_x ? lds_y : lds_x) <= 80 * 1024;                  // two workgroups per CU
 }
 
-// flags: EPI_ACC (out += ...), EPI_DIV (then / div).  The residual (x) is always added.
-inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t stream) {
+// flags: EPI_ACC (out += ...), EPI_DIV (then / div).  chain = false: out = c2(lrelu(c1(lrelu(x)))) + x;
+// chain = true: x1 = c1(lrelu(x)) + x, out = c2(lrelu(x1)) + x1.
+inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t stream, bool chain = false) {
     a.LW1 = 256 + (a.K1 - 1) * a.dil1;
     a.x_bytes = (unsigned)(((size_t)4 * a.LW1 * 16 + 4095) / 4096 * 4096);
-    a.LW2 = 256 + 16;  // columns 256 .. 256 + K2 - 2 are only read for the discarded overlap outputs
+    if (a.dil2 < 1) a.dil2 = 1;
+    const int halo2 = (a.K2 - 1) * a.dil2;
+    if (a.pad2 * 2 != halo2) return hipErrorInvalidValue;  // "same" padding
+    a.LW2 = (256 + halo2 + 7) / 8 * 8;  // Y is stored pad2 columns to the right; the margins only feed discarded outputs
     a.y_chunk_bytes = (unsigned)(4 * a.LW2 * 16);
-    a.BNo = 256 - (a.K2 - 1);
+    a.BNo = 256 - halo2;
     a.NT = (a.T + a.BNo - 1) / a.BNo;
     a.B = B;
     a.nchunks = a.C / 16;
@@ -448,7 +464,7 @@ inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t 
     // Y overlays the two x stages
     const size_t lds_x = 2 * (size_t)a.x_bytes, lds_y = (size_t)a.nchunks * a.y_chunk_bytes;
     const size_t lds = lds_x > lds_y ? lds_x : lds_y;
-    if (lds > 80 * 1024) return hipErrorInvalidValue;
+    if (lds > 80 * 1024 || !sx_pair_supported(a.C, cfg, a.K1, a.dil1, a.K2, a.dil2)) return hipErrorInvalidValue;
     const long long nb = (long long)a.NT * B;
     if (nb == 0) return hipSuccess;
     const long long wgs = (nb + 7) / 8 * 8;
@@ -456,16 +472,22 @@ inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t 
     dim3 grid((unsigned)wgs, 1, 1);
     const int epi = a.flags & (EPI_ACC | EPI_DIV);
     if ((epi & EPI_DIV) && !(epi & EPI_ACC)) return hipErrorInvalidValue;
-#define SX_PAIR_CASES(MW, NW, WM, WN)                                                                        \
-    switch (epi) {                                                                                           \
-        case 0: return launch_conv_sx_pair_k<MW, NW, WM, WN, 0>(a, grid, lds, stream);                       \
-        case EPI_ACC: return launch_conv_sx_pair_k<MW, NW, WM, WN, EPI_ACC>(a, grid, lds, stream);           \
-        default: return launch_conv_sx_pair_k<MW, NW, WM, WN, EPI_ACC | EPI_DIV>(a, grid, lds, stream);      \
+#define SX_PAIR_CASES(MW, NW, WM, WN, CH)                                                                        \
+    switch (epi) {                                                                                               \
+        case 0: return launch_conv_sx_pair_k<MW, NW, WM, WN, 0, CH>(a, grid, lds, stream);                       \
+        case EPI_ACC: return launch_conv_sx_pair_k<MW, NW, WM, WN, EPI_ACC, CH>(a, grid, lds, stream);           \
+        default: return launch_conv_sx_pair_k<MW, NW, WM, WN, EPI_ACC | EPI_DIV, CH>(a, grid, lds, stream);      \
     }
     if (cfg == 1) {
-        SX_PAIR_CASES(1, 4, 2, 2)
+        if (chain) {
+            SX_PAIR_CASES(1, 4, 2, 2, true)
+        }
+        SX_PAIR_CASES(1, 4, 2, 2, false)
     }
-    SX_PAIR_CASES(1, 2, 1, 4)
+    if (chain) {
+        SX_PAIR_CASES(1, 2, 1, 4, true)
+    }
+    SX_PAIR_CASES(1, 2, 1, 4, false)
 #undef SX_PAIR_CASES
 }
 

@@ -366,17 +366,18 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     h->stats.sx_launches++;
 }
 
-// A whole ResBlock1 step, out = c2(lrelu(c1(lrelu(x)))) + x [+ out] [/ div], as ONE launch (conv_sx_pair.hip.hpp):
-// raw-format stages only (x, out: fp32 raw [B][C/8][T][8]).
+// Two dependent convs of a ResBlock as ONE launch (conv_sx_pair.hip.hpp), raw-format stages only (x, out: fp32 raw
+// [B][C/8][T][8]): a ResBlock1 step, out = c2(lrelu(c1(lrelu(x)))) + x, or (chain) two ResBlock2 steps,
+// x1 = c1(lrelu(x)) + x, out = c2(lrelu(x1)) + x1; then [+ out] [/ div].
 bool sx_pair_ok(const vits_handle *h, const ConvDesc &c1, const ConvDesc &c2) {
     static const bool off = std::getenv("VITSMI_SX_NO_PAIR") != nullptr;  // A/B timing only
     return !off && h->gen_nprod == 2 && c1.f16 && c2.f16 && c1.rawin && c2.rawin && c1.cfg == c2.cfg && c1.ups == 1 &&
-           c2.ups == 1 && c1.Cin == c1.Cout && c2.Cin == c2.Cout && c1.Cin == c2.Cin &&
+           c2.ups == 1 && c1.Cin == c1.Cout && c2.Cin == c2.Cout && c1.Cin == c2.Cin && c2.padL * 2 == (c2.K - 1) * c2.dil &&
            sx_pair_supported(c1.Cin, c1.cfg, c1.K, c1.dil, c2.K, c2.dil);
 }
 
 void conv_sx_pair(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const float *x, int T, float *out, int flags, float div,
-                  float slope) {
+                  float slope, bool chain = false) {
     SxPairArgs a{};
     a.xr = x;
     a.islope = slope;
@@ -395,13 +396,14 @@ void conv_sx_pair(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const float *x
     a.dil1 = c1.dil;
     a.pad1 = c1.padL;
     a.K2 = c2.K;
+    a.dil2 = c2.dil;
     a.pad2 = c2.padL;
     a.flags = flags & (EPI_ACC | EPI_DIV);
     a.div = div;
     vits_handle *h = c.h;
     a.peak = range_slots(h, true);
     const bool ev = conv_event_begin(c);
-    c.note(launch_conv_sx_pair(a, c1.cfg, c.B, c.st));
+    c.note(launch_conv_sx_pair(a, c1.cfg, c.B, c.st, chain));
     if (ev) {
         if (h->conv_event_sx.size() < h->conv_events.size()) h->conv_event_sx.resize(h->conv_events.size(), 0);
         h->conv_event_sx[h->conv_events_used] = 1;
@@ -762,6 +764,19 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
                         conv_sx(c, rbk.c1[q], in, T, nullptr, tmp_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
                         conv_sx(c, rbk.c2[q], tmp_pl, T, dst, dsta, fl, cur, nullptr, 0, (float)nk, 1.f, S);
                     }
+                } else if (fr && q + 1 < rbk.n && sx_pair_ok(h, rbk.c1[q], rbk.c1[q + 1])) {
+                    // modules.py:355-364, two steps in one launch: x1 = c(lrelu(x)) + x ; x = c'(lrelu(x1)) + x1
+                    q++;
+                    const bool last2 = q == rbk.n - 1;
+                    int fl2 = EPI_RES;
+                    float *dst2 = ra[q & 1];
+                    if (last2) {
+                        fl2 |= (j == 0 ? 0 : EPI_ACC) | (final_rb && nk > 1 ? EPI_DIV : 0);
+                        dst2 = xs_raw;
+                    }
+                    conv_sx_pair(c, rbk.c1[q - 1], rbk.c1[q], cur, T, dst2, fl2, (float)nk, S, /*chain=*/true);
+                    dst = dst2;
+                    dsta = nullptr;
                 } else  // modules.py:355-364: x = c(lrelu(x)) + x
                     conv_sx(c, rbk.c1[q], in, T, dst, dsta, fl, cur, nullptr, 0, (float)nk, 1.f, S, S);
                 cur = dst;
@@ -1867,13 +1882,14 @@ int vits_test_conv_transpose1d_sx(int device_id, const float *x, int B, int Cin,
 // out = c2(lrelu(c1(lrelu(x, slope)), slope)) + x through ONE fused launch (conv_sx_pair.hip.hpp; f16x3 arithmetic).
 // x, out: [B, C, T] host; w1, w2: [C, C, K]; c1 dilated by dil1, c2 dilation 1; flags bit0: also time it (ms_out).
 int vits_test_conv_pair_sx(int device_id, const float *x, int B, int C, int T, const float *w1, const float *b1,
-                           const float *w2, const float *b2, int K, int dil1, float slope, float *out, float *ms_out) {
+                           const float *w2, const float *b2, int K, int dil1, int dil2, int chain, float slope, float *out,
+                           float *ms_out) {
     if (int rc = test_dev(device_id)) return rc;
     ConvDesc d1, d2;
     std::vector<float> arena;
     set_sx_f16(true);
     std::string e = pack_test_conv(w1, b1, C, C, K, dil1, dil1 * (K - 1) / 2, 3, &d1, &arena);
-    if (e.empty()) e = pack_test_conv(w2, b2, C, C, K, 1, (K - 1) / 2, 3, &d2, &arena);
+    if (e.empty()) e = pack_test_conv(w2, b2, C, C, K, dil2, dil2 * (K - 1) / 2, 3, &d2, &arena);
     set_sx_f16(false);
     if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
     if (!d1.rawin || !d2.rawin || d1.cfg != d2.cfg || !sx_pair_supported(C, d1.cfg, d1.K, d1.dil, d2.K, d2.dil))
@@ -1903,16 +1919,16 @@ int vits_test_conv_pair_sx(int device_id, const float *x, int B, int C, int T, c
     a.zeros = dA;
     a.C = C;
     a.K1 = d1.K; a.dil1 = d1.dil; a.pad1 = d1.padL;
-    a.K2 = d2.K; a.pad2 = d2.padL;
+    a.K2 = d2.K; a.dil2 = d2.dil; a.pad2 = d2.padL;
     a.div = 1.f;
-    TCHECK(launch_conv_sx_pair(a, d1.cfg, B, nullptr));
+    TCHECK(launch_conv_sx_pair(a, d1.cfg, B, nullptr, chain != 0));
     TCHECK(hipDeviceSynchronize());
     if (ms_out) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
         hipEventCreate(&e1);
         hipEventRecord(e0, nullptr);
-        for (int i = 0; i < 10; i++) TCHECK(launch_conv_sx_pair(a, d1.cfg, B, nullptr));
+        for (int i = 0; i < 10; i++) TCHECK(launch_conv_sx_pair(a, d1.cfg, B, nullptr, chain != 0));
         hipEventRecord(e1, nullptr);
         TCHECK(hipEventSynchronize(e1));
         float ms = 0.f;

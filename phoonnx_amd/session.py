@@ -587,9 +587,10 @@ def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=
     return out
 
 
-def test_conv_pair_sx(x, w1, b1, w2, b2, dil1=1, slope=0.1, device_id=0, timed=False):
-    """out = c2(lrelu(c1(lrelu(x)))) + x in ONE fused launch (ResBlock1 step on a raw-format stage; f16x3).
-    timed=True -> (out, ms per launch)."""
+def test_conv_pair_sx(x, w1, b1, w2, b2, dil1=1, dil2=1, chain=False, slope=0.1, device_id=0, timed=False):
+    """Two dependent convs in ONE fused launch (raw-format stage of the generator; f16x3):
+    chain=False (ResBlock1 step): out = c2(lrelu(c1(lrelu(x)))) + x
+    chain=True (two ResBlock2 steps): x1 = c1(lrelu(x)) + x; out = c2(lrelu(x1)) + x1.    timed=True -> (out, ms)."""
     lib = _ffi.load()
     x = np.ascontiguousarray(x, np.float32)
     w1 = np.ascontiguousarray(w1, np.float32)
@@ -603,7 +604,8 @@ def test_conv_pair_sx(x, w1, b1, w2, b2, dil1=1, slope=0.1, device_id=0, timed=F
     out = np.empty_like(x)
     ms = C.c_float(0.0)
     rc = lib.vits_test_conv_pair_sx(device_id, _ffi.ptr(x), B, Cc, T, _ffi.ptr(w1), _ffi.ptr(b1), _ffi.ptr(w2),
-                                    _ffi.ptr(b2), K, dil1, float(slope), _ffi.ptr(out), C.byref(ms) if timed else None)
+                                    _ffi.ptr(b2), K, dil1, dil2, 1 if chain else 0, float(slope), _ffi.ptr(out),
+                                    C.byref(ms) if timed else None)
     if rc != 0:
         raise SessionError(_ffi.last_error(None))
     return (out, float(ms.value)) if timed else out

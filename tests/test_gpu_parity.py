@@ -273,13 +273,47 @@ def test_conv_pair_sx_equals_two_launches_and_oracle(B, C, T, K, dil):
     w2 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K) * 3).astype(np.float32)
     b1 = rng.standard_normal(C).astype(np.float32)
     b2 = rng.standard_normal(C).astype(np.float32)
-    got = test_conv_pair_sx(x, w1, b1, w2, b2, dil1=dil, slope=0.1)
+    got = test_conv_pair_sx(x, w1, b1, w2, b2, dil1=dil, dil2=1, slope=0.1)
     pad1, pad2 = dil * (K - 1) // 2, (K - 1) // 2
     mid = test_conv1d_sx(x, w1, b1, dil=dil, pad_l=pad1, in_slope=0.1, precision="f16x3")
     two = test_conv1d_sx(mid, w2, b2, dil=1, pad_l=pad2, in_slope=0.1, precision="f16x3") + x
     assert np.array_equal(got, two), float(np.abs(got - two).max())
     lr = lambda v: np.where(v > 0, v, v * np.float32(0.1)).astype(np.float32)
     ref = conv1d(lr(conv1d(lr(x), w1, b1, dil=dil, pad_l=pad1, pad_r=pad1)), w2, b2, dil=1, pad_l=pad2, pad_r=pad2) + x
+    np.testing.assert_allclose(got, ref, atol=5e-5, rtol=1e-5)
+
+
+CHAIN_CASES = [
+    # (B, C, T, K, dil1, dil2): two ResBlock2 steps per launch (medium preset: k (3,5,7), d ((1,2),(2,6),(3,12)))
+    (2, 32, 700, 3, 1, 2), (1, 32, 1000, 5, 2, 6), (2, 32, 300, 7, 3, 12), (1, 32, 9, 5, 2, 6),
+    (2, 64, 700, 3, 1, 2), (1, 64, 513, 5, 2, 6), (1, 64, 31, 3, 1, 2),
+]
+
+
+@pytest.mark.parametrize("B,C,T,K,d1,d2", CHAIN_CASES)
+def test_conv_chain_sx_equals_two_launches_and_oracle(B, C, T, K, d1, d2):
+    """CHAIN mode of conv_sx_pair_kernel: x1 = c1(lrelu(x)) + x; out = c2(lrelu(x1)) + x1 in one launch, against the
+    two-launch form bit for bit and against the oracle."""
+    from phoonnx_amd.session import test_conv1d_sx, test_conv_pair_sx
+    from vits_oracle import conv1d
+    rng = np.random.default_rng(C * 999 + T + K + d1)
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    w1 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    w2 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K) * 2).astype(np.float32)
+    b1 = rng.standard_normal(C).astype(np.float32)
+    b2 = rng.standard_normal(C).astype(np.float32)
+    try:
+        got = test_conv_pair_sx(x, w1, b1, w2, b2, dil1=d1, dil2=d2, chain=True, slope=0.1)
+    except Exception as e:  # the widest second conv at 64 channels does not fit two workgroups per CU: not fused
+        assert C == 64 and (K - 1) * d2 > 48, e
+        return
+    p1, p2 = d1 * (K - 1) // 2, d2 * (K - 1) // 2
+    x1 = test_conv1d_sx(x, w1, b1, dil=d1, pad_l=p1, in_slope=0.1, residual=True, precision="f16x3")
+    two = test_conv1d_sx(x1, w2, b2, dil=d2, pad_l=p2, in_slope=0.1, residual=True, precision="f16x3")
+    assert np.array_equal(got, two), float(np.abs(got - two).max())
+    lr = lambda v: np.where(v > 0, v, v * np.float32(0.1)).astype(np.float32)
+    r1 = conv1d(lr(x), w1, b1, dil=d1, pad_l=p1, pad_r=p1) + x
+    ref = conv1d(lr(r1), w2, b2, dil=d2, pad_l=p2, pad_r=p2) + r1
     np.testing.assert_allclose(got, ref, atol=5e-5, rtol=1e-5)
 
 
