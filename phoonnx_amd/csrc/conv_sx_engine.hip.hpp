@@ -170,9 +170,16 @@ enum : int {
     // registers.  Requested in the epilogue it is a second HBM read of the tensor (measured: 1.40 GB read per launch
     // against a 0.71 GB tensor; the tile's lines are gone from the 4 MB L2 by then), requested here the two reads of a
     // line merge in the L2.
-    SX_RES_EARLY = 1 << 14
+    SX_RES_EARLY = 1 << 14,
+    // WN in-layer with the gate folded in (modules.py:193-199, commons.py:99-106): the rows were packed so that every
+    // 64-row tile holds 32 tanh channels (rows 0-31: channels 32 m ..) and their 32 sigmoid partners (rows 32-63:
+    // channels H + 32 m ..).  The sigmoid waves hand their values to the tanh waves through LDS; the output is
+    // acts = tanh(a) * sigmoid(b) as a PLANAR fp32 tensor [H][T] (what the res_skip conv on the f32 engine reads).
+    // out_raw = acts, raw_bstride = H * T, Cr = 2 H; bias_b indexes ORIGINAL rows.  64-row tiles only.
+    SX_GATE = 1 << 15
 };
-constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB | SX_RES_EARLY;
+constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB | SX_RES_EARLY |
+                           SX_GATE;
 
 // One 256-thread workgroup = 4 waves arranged WM x WN, each owning MW x NW 32x32 accumulator blocks.
 // RAWIN: the input is the fp32 raw tensor itself; each x tile is loaded into registers, leaky-ReLU'd (islope) and
@@ -590,6 +597,66 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
         if (sdbg == 12345.678f && a.out_raw) a.out_raw[tid] = sdbg;
         return;
     }
+    if constexpr (EPI >= 0 && (EPI & SX_GATE) != 0) {
+        static_assert(EPI < 0 || !(EPI & SX_GATE) || (WM == 2 && MW == 1), "gate: a tanh wave and a sigmoid wave per column group");
+        const int H = a.Cr >> 1;                      // gate channels
+        const int ch0 = mt * 32;                      // first tanh channel of this tile (sigmoid partner: H + ch0)
+        const int orow0 = wm == 0 ? ch0 : H + ch0;    // ORIGINAL first row of this wave's block (bias_b index)
+        const int vrow0 = mt * BM + wm * 32;          // virtual (packed) first row (bias index)
+        const float wsc = a.wscale;
+        const float *biasp = a.bias ? a.bias : a.zeros;
+        const int b_on = a.bias ? 1 : 0;
+        const float *bbp = a.bias_b ? a.bias_b + (int64_t)b * a.bias_b_stride : a.zeros;
+        const int bb_on = a.bias_b ? 1 : 0;
+        f32x4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (vrow0 + 8 * q + 4 * hi) * b_on) +
+                    *reinterpret_cast<const f32x4 *>(bbp + (orow0 + 8 * q + 4 * hi) * bb_on);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave has left the main loop: the x stages become the exchange buffer
+        __builtin_amdgcn_sched_barrier(0);
+        // exchange slot of (column group wn, block column n, quad q): 64 lanes x 16 bytes
+        const uint32_t exch = lds0 + (uint32_t)wn * (NW * 4 * 1024) + (uint32_t)lane * 16u;
+        if (wm == 1) {
+#pragma unroll
+            for (int n = 0; n < NW; n++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f32x4 sg;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float v = F16 ? __builtin_fmaf(acc[0][n][4 * q + e], wsc, bq[q][e]) : acc[0][n][4 * q + e] + bq[q][e];
+                        sg[e] = 1.0f / (1.0f + expf(-v));
+                    }
+                    ds_write128(exch + (uint32_t)(n * 4 + q) * 1024u, __builtin_bit_cast(u32x4, sg));
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (wm == 0) {
+            float *actb = a.out_raw + (int64_t)b * a.raw_bstride;
+#pragma unroll
+            for (int n = 0; n < NW; n++) {
+                const int t = t0 + (wn * NW + n) * 32 + l31;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    u32x4 raw;
+                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(exch + (uint32_t)(n * 4 + q) * 1024u) : "memory");
+                    const f32x4 sg = __builtin_bit_cast(f32x4, raw);
+                    if (t < T) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float v = F16 ? __builtin_fmaf(acc[0][n][4 * q + e], wsc, bq[q][e]) : acc[0][n][4 * q + e] + bq[q][e];
+                            actb[(int64_t)(ch0 + 8 * q + 4 * hi + e) * T + t] = tanhf(v) * sg[e];
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     const int u = a.ups, Cr = a.Cr, Tout = T * u, CGo = Cr >> 3;
     float *rawb = a.out_raw + (int64_t)b * a.raw_bstride;     // (only dereferenced when the flags say so)
     uint16_t *plb = a.out_pl + (int64_t)b * a.pl_bstride;
@@ -740,6 +807,7 @@ constexpr int kSxEpiInner = EPI_RES | SX_HAS_RAW | SX_HAS_PL | SX_PL_ACT;       
 constexpr int kSxEpiFirst = EPI_RES | SX_HAS_RAW;                                    // xs  = block output
 constexpr int kSxEpiAccum = EPI_RES | EPI_ACC | SX_HAS_RAW;                          // xs += block output
 constexpr int kSxEpiRaw = SX_HAS_RAW;                                                // raw only (raw-format stages)
+constexpr int kSxEpiGate = SX_GATE | SX_HAS_RAW;                                     // WN in-layer + gate -> planar acts
 
 template <int MW, int NW, int WM, int WN, int NP = 6>
 inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
@@ -751,8 +819,13 @@ inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t
         case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst, false, false, NP>(a, grid, lds, stream);
         case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum, false, false, NP>(a, grid, lds, stream);
         case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw, false, false, NP>(a, grid, lds, stream);  // flow WN convs
-        default: return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, NP>(a, grid, lds, stream);
+        default: break;
     }
+    if constexpr (WM == 2 && MW == 1) {  // 64-row tiles: the gated WN in-layer (per-utterance bias or not)
+        if ((epi & ~SX_HAS_BIASB) == kSxEpiGate) return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiGate, false, false, NP>(a, grid, lds, stream);
+    }
+    if (epi & SX_GATE) return hipErrorInvalidValue;  // (no generic form of the gate epilogue)
+    return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, NP>(a, grid, lds, stream);
 }
 
 // raw-input kernels (tensors of <= 64 channels): outputs are raw only
@@ -819,6 +892,12 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     if (a.out_raw && !(a.flags & SX_NO_RAW_STORE)) epi |= SX_HAS_RAW | (a.oslope != 1.f ? SX_RAW_ACT : 0);
     if (a.out_pl) epi |= SX_HAS_PL | (a.oslope2 != 1.f ? SX_PL_ACT : 0);
     if (a.bias_b) epi |= SX_HAS_BIASB;
+    if (a.flags & SX_GATE) {
+        if (rawin || cfg != 1 || (nprod != 2 && nprod != 6) || a.ups != 1 || !a.out_raw || a.out_pl || (a.Cr & 63) ||
+            lds < (size_t)2 * 4 * 4 * 1024)
+            return hipErrorInvalidValue;
+        epi |= SX_GATE;
+    }
     // (SX_RES_EARLY has compile-time instantiations only: where none matches, the residual is read in the epilogue)
     // (bf16x6 on the 64-row tile has no registers left for it: 256 VGPRs and a spill)
     const bool early_ok = rawin && (nprod == 2 || (nprod == 6 && cfg == 2)) && (a.flags & EPI_RES) && !(a.flags & (DBG_NO_DMA | DBG_NO_EPI)) &&

@@ -436,14 +436,24 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     return d;
 }
 
-ConvDesc pack_named_sx(Packer &P, const Resolver &R, const std::string &name, int dil, int padL) {
+// out_perm (optional): packed row r holds the module's output channel out_perm[r]
+ConvDesc pack_named_sx(Packer &P, const Resolver &R, const std::string &name, int dil, int padL,
+                       const std::vector<int> *out_perm = nullptr) {
     const TRef &w = R.need(name + ".weight", 3);
     int Cout = int(w.dims[0]), Cin = int(w.dims[1]), K = int(w.dims[2]);
     if (R.geti(name + ".group", 1) != 1) throw std::runtime_error(name + ": grouped conv not expected here");
     const TRef *b = R.bias_of(name + ".bias", Cout);
+    if (out_perm && int(out_perm->size()) != Cout) throw std::runtime_error(name + ": bad row permutation");
     const float *wp = w.p;
-    auto wf = [&](int co, int ci, int tap) { return wp[(int64_t(co) * Cin + ci) * K + tap]; };
-    return pack_conv_sx(P, Cin, Cout, K, dil, padL, wf, b ? b->p : nullptr);
+    auto wf = [&](int co, int ci, int tap) { return wp[(int64_t(out_perm ? (*out_perm)[co] : co) * Cin + ci) * K + tap]; };
+    std::vector<float> bperm;
+    const float *bp = b ? b->p : nullptr;
+    if (b && out_perm) {
+        bperm.resize(Cout);
+        for (int c = 0; c < Cout; c++) bperm[c] = b->p[(*out_perm)[c]];
+        bp = bperm.data();
+    }
+    return pack_conv_sx(P, Cin, Cout, K, dil, padL, wf, bp);
 }
 
 // geometry of ConvTranspose1d [Cin, Cout, K] (stride u, padding p) as a dense conv over taps o_min..o_max
@@ -849,7 +859,21 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
                         // frame-domain tensors are short (F ~ 3 T): 64-row tiles give the grid twice the workgroups
                         // (288 -> 576 at batch 32), measured 3.04 -> 2.87 ms for the flow
                         t_sx_min_cfg = 1;
-                        cd.wn[i].in = pack_named_sx(P, R, in, dil, same_pad(k, dil));
+                        // Gate folded into this conv's epilogue (SX_GATE): rows permuted so that every 64-row tile holds
+                        // 32 tanh channels and their 32 sigmoid partners (row r of tile m: channel 32 m + r for r < 32,
+                        // H + 32 m + r - 32 above).  VITSMI_FLOW_NO_GATE keeps the separate gate kernel (A/B timing).
+                        static const bool no_gate = std::getenv("VITSMI_FLOW_NO_GATE") != nullptr;
+                        std::vector<int> perm;
+                        const bool gate = !no_gate && co == 2 * flow_H && flow_H % 32 == 0 && sx_pick_cfg(co) == 1;
+                        if (gate) {
+                            perm.resize(co);
+                            for (int r = 0; r < co; r++) {
+                                const int m = r / 64, rr = r % 64;
+                                perm[r] = rr < 32 ? 32 * m + rr : flow_H + 32 * m + rr - 32;
+                            }
+                        }
+                        cd.wn[i].in = pack_named_sx(P, R, in, dil, same_pad(k, dil), gate ? &perm : nullptr);
+                        cd.wn[i].in.gate = gate;
                         t_sx_min_cfg = 0;
                         t_sx_f16 = false;
                     } else

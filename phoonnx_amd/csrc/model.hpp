@@ -36,6 +36,9 @@ struct ConvDesc {
     // wscale = 2^-k is applied to the accumulators (conv_sx_engine.hip.hpp, f16 mode)
     bool f16 = false;
     float wscale = 1.f;
+    // sx only (flow WN in-layers): rows packed as [32 tanh | 32 sigmoid] per 64-row tile, the conv's epilogue applies
+    // the gate and writes planar acts (conv_sx_engine.hip.hpp SX_GATE)
+    bool gate = false;
     double macs_per_t = 0;   // algorithmic MACs per input time step (reference definition)
     bool valid() const { return w_off >= 0; }
 };

@@ -334,7 +334,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.bias_b = bias_b;
     a.bias_b_stride = bias_b_stride;
     a.out_raw = out_raw;
-    a.raw_bstride = (int64_t)Cr * Tout;
+    a.raw_bstride = (flags & SX_GATE) ? (int64_t)(Cr / 2) * Tout : (int64_t)Cr * Tout;  // (gate: planar acts [H][T])
     a.out_pl = out_pl;
     a.pl_bstride = (int64_t)3 * Cr * Tout;
     a.res = res;
@@ -1056,8 +1056,14 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
                                                                                              range_slots(h, cd.wn[i].in.f16));
                     h->stats.total_launches++;
                 }
-                conv_sx(c, cd.wn[i].in, hx_pl, F, a2, nullptr, 0, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr, gc_rows);
-                wn_gate_blocked_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(a2, acts, Hf, F);
+                if (cd.wn[i].in.gate) {  // tanh * sigmoid in the conv's epilogue: acts directly
+                    conv_sx(c, cd.wn[i].in, hx_pl, F, acts, nullptr, SX_GATE, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr,
+                            gc_rows);
+                    h->stats.total_launches--;  // (no gate launch: undo the increment below)
+                } else {
+                    conv_sx(c, cd.wn[i].in, hx_pl, F, a2, nullptr, 0, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr, gc_rows);
+                    wn_gate_blocked_kernel<<<dim3((F + 255) / 256, Hf / 8, B), 256, 0, st>>>(a2, acts, Hf, F);
+                }
             } else {
                 conv(c, cd.wn[i].in, hx, sHF, F, a2, 2 * sHF, 0, nullptr, nullptr, 0,
                      gc ? gc + (int64_t)i * 2 * Hf : nullptr, gc_rows);
