@@ -192,6 +192,175 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
     }
 }
 
+// ---- a6 fused: one whole DDSConv layer per launch (modules.py:117-129):
+//     y = GELU(LN1(dwconv_k3,dil(x * mask)));  y = GELU(LN2(conv1x1(y)));  out = (x + y) [* mask]
+// As three launches (depthwise + LN, 1x1 conv on the conv engine, LN + accumulate) a layer costs ~85 us at batch 32 x 256
+// tokens, nearly all of it launch / drain latency on 256 small workgroups; here one workgroup takes 32 time steps
+// through all three stages: the depthwise + LN1 result goes to LDS as the B operand of the 1x1 conv, which runs on
+// v_mfma_f32_32x32x2_f32 with the packed conv-engine weights read straight from L2 (each lane's float4 = four k-steps
+// of its row), and LN2 reduces the accumulators over channels through LDS.  C % 32 == 0, C <= 256, K = 3.
+// `in` and `out` must be different buffers (neighbouring workgroups read `in` in their halo).
+struct DdsLayerArgs {
+    const float *in;
+    float *out;
+    const int *len;
+    const float *dw_w, *dw_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const float *pw;       // packed 1x1 weights (pack_conv layout), pw_bias [C]
+    const float *pw_bias;
+    int C, T, dil, mask_out;
+    int CK, nchunks, MB;   // packing geometry of pw: chunk depth, chunks, 32-row blocks per m-tile
+};
+
+__global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
+    typedef float f32x16_ __attribute__((ext_vector_type(16)));
+    __shared__ float y1[256 * 32];   // [ci][tl]: B operand of the 1x1 conv
+    __shared__ float red[8][32];
+    __shared__ float stat[2][32];
+    const int tid = threadIdx.x, tl = tid & 31, cg = tid >> 5;
+    const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+    const int t0 = blockIdx.x * 32, t = t0 + tl, b = blockIdx.y;
+    const int C = a.C, T = a.T;
+    const int L = a.len ? a.len[b] : T;
+    const bool tv = t < T;
+    const float *p = a.in + (int64_t)b * C * T;
+    float *o = a.out + (int64_t)b * C * T;
+    // ---- stage 1: depthwise conv (k = 3) of x * mask, LayerNorm over channels, GELU -> y1 (thread: channels cg + 8 i)
+    constexpr int CPT = 32;
+    {
+        float v[CPT];
+        const int pad = a.dil;  // (3 * dil - dil) / 2
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = cg + 8 * i;
+            float x = 0.f;
+            if (c < C && tv) {
+                x = a.dw_b[c];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int tt = t + k * a.dil - pad;
+                    const float xv = (tt >= 0 && tt < T && tt < L) ? p[(int64_t)c * T + tt] : 0.f;
+                    x += a.dw_w[c * 3 + k] * xv;
+                }
+            }
+            v[i] = x;
+            s += x;
+        }
+        red[cg][tl] = s;
+        __syncthreads();
+        float mean = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; g++) mean += red[g][tl];
+        mean /= (float)C;
+        __syncthreads();
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const float d = (cg + 8 * i < C) ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+        red[cg][tl] = q;
+        __syncthreads();
+        float var = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; g++) var += red[g][tl];
+        var /= (float)C;
+        const float rs = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = cg + 8 * i;
+            if (c < C) y1[c * 32 + tl] = tv ? gelu_erf((v[i] - mean) * rs * a.ln1_g[c] + a.ln1_b[c]) : 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- stage 2: 1x1 conv on the matrix cores.  Block rows (32 output channels each) are dealt to the waves round-robin.
+    const int nblk = C >> 5;
+    const int spc = a.CK >> 3;           // float4 groups per (block, chunk)
+    const int half = a.CK >> 1;          // k-steps (channel pairs) per chunk
+    constexpr int MAXB = 2;              // blocks per wave: C <= 256 -> 8 blocks over 4 waves
+    f32x16_ acc[MAXB];
+#pragma unroll
+    for (int j = 0; j < MAXB; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXB; j++) {
+        const int mb = wave + 4 * j;
+        if (mb < nblk) {  // (uniform per wave)
+            for (int ch = 0; ch < a.nchunks; ch++) {
+                const float4 *wg = reinterpret_cast<const float4 *>(a.pw) +
+                                   ((int64_t)((mb / a.MB) * a.nchunks + ch) * a.MB + (mb % a.MB)) * spc * 64 + lane;
+                for (int g = 0; g < spc; g++) {
+                    const float4 w4 = wg[(int64_t)g * 64];
+                    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int ci = ch * a.CK + 2 * (4 * g + k) + hi;  // this lane's k index of the step
+                        const float bv = ci < C ? y1[ci * 32 + (lane & 31)] : 0.f;
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[k], bv, acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    (void)half;
+    // ---- stage 3: + bias, LayerNorm over channels (column = lane & 31, rows spread over registers, `hi`, blocks, waves),
+    // GELU, residual, mask.  C/D layout: row = (r & 3) + 8 * (r >> 2) + 4 * hi, col = lane & 31.
+    const int col = lane & 31;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXB; j++) {
+        const int mb = wave + 4 * j;
+        if (mb < nblk) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                acc[j][r] += a.pw_bias[mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+                s += acc[j][r];
+            }
+        }
+    }
+    s += __shfl_xor(s, 32, 64);
+    __syncthreads();  // (red is free again)
+    if (hi == 0) red[wave][col] = s;
+    __syncthreads();
+    if (tid < 32) stat[0][tid] = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) / (float)C;
+    __syncthreads();
+    const float mean = stat[0][col];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXB; j++) {
+        const int mb = wave + 4 * j;
+        if (mb < nblk) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float d = acc[j][r] - mean;
+                q += d * d;
+            }
+        }
+    }
+    q += __shfl_xor(q, 32, 64);
+    if (hi == 0) red[4 + wave][col] = q;
+    __syncthreads();
+    if (tid < 32) stat[1][tid] = 1.0f / sqrtf((red[4][tid] + red[5][tid] + red[6][tid] + red[7][tid]) / (float)C + 1e-5f);
+    __syncthreads();
+    const float rs = stat[1][col];
+    const int tc = t0 + col;
+    if (tc >= T) return;
+    const float mk = (!a.mask_out || tc < L) ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXB; j++) {
+        const int mb = wave + 4 * j;
+        if (mb < nblk) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int c = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float y = gelu_erf((acc[j][r] - mean) * rs * a.ln2_g[c] + a.ln2_b[c]);
+                o[(int64_t)c * T + tc] = (p[(int64_t)c * T + tc] + y) * mk;
+            }
+        }
+    }
+}
+
 // ---- a7: ConvFlow pre (1 -> C) + conditioning add: h = w*z[ch] + b + cond (modules.py:498-499,119)
 // grid (T / 256, C, B): one element per thread (a per-thread loop over the channels is a chain of C dependent
 // load -> store round trips on a handful of waves)

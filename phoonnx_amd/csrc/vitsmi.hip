@@ -455,6 +455,51 @@ void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const 
 
 // DDSConv (modules.py:117-129) in place on h [B,C,T]; y,y2 are scratch of the same size.
 void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const int *len, int C, int T) {
+    static const bool unfused = std::getenv("VITSMI_DDS_UNFUSED") != nullptr;  // A/B timing only
+    if (!unfused && C <= 256 && C % 32 == 0 && d.K == 3 && d.n_layers > 0) {
+        // one launch per layer (dds_layer_kernel), ping-ponging between the three buffers so that the result of the
+        // last layer lands in hbuf: each layer must write a buffer other than the one it reads
+        float *bufs[3] = {hbuf, y, y2};
+        int cur = 0;
+        for (int l = 0; l < d.n_layers; l++) {
+            const auto &L = d.l[l];
+            const int left = d.n_layers - 1 - l;          // layers after this one
+            int nxt = left == 0 ? 0 : (cur == 1 ? 2 : 1); // last layer writes hbuf ...
+            if (nxt == cur) {                             // ... unless it would read it too (n_layers == 1): detour
+                nxt = 1;
+            }
+            DdsLayerArgs a{};
+            a.in = bufs[cur];
+            a.out = bufs[nxt];
+            a.len = len;
+            a.dw_w = c.P(L.dw_w);
+            a.dw_b = c.P(L.dw_b);
+            a.ln1_g = c.P(L.ln1_g);
+            a.ln1_b = c.P(L.ln1_b);
+            a.ln2_g = c.P(L.ln2_g);
+            a.ln2_b = c.P(L.ln2_b);
+            a.pw = c.P(L.pw.w_off);
+            a.pw_bias = L.pw.b_off >= 0 ? c.P(L.pw.b_off) : c.P(c.m.zeros_off);
+            a.C = C;
+            a.T = T;
+            a.dil = L.dil;
+            a.mask_out = l == d.n_layers - 1;
+            a.CK = L.pw.CK;
+            a.nchunks = L.pw.nchunks;
+            a.MB = (L.pw.cfg == 2 ? 128 : ((L.pw.cfg == 1 || L.pw.cfg == 3) ? 64 : 32)) / 32;
+            dds_layer_kernel<<<dim3((T + 31) / 32, c.B), 256, 0, c.st>>>(a);
+            c.note(hipGetLastError());
+            c.h->stats.total_launches++;
+            {   // the 1x1 conv's algorithmic work, as conv() would account it
+                const double fl = 2.0 * L.pw.macs_per_t * (double)T * c.B;
+                c.h->stats.conv_flops += fl;
+                (c.h->cur_stage == 1 ? c.h->stats.dp_flops : c.h->stats.enc_flops) += fl;
+            }
+            cur = nxt;
+        }
+        if (cur != 0) c.note(hipMemcpyAsync(hbuf, bufs[cur], (size_t)c.B * C * T * 4, hipMemcpyDeviceToDevice, c.st));
+        return;
+    }
     for (int l = 0; l < d.n_layers; l++) {
         const auto &L = d.l[l];
         if (C <= 256 && d.K == 3)
