@@ -224,6 +224,23 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
     const bool tv = t < T;
     const float *p = a.in + (int64_t)b * C * T;
     float *o = a.out + (int64_t)b * C * T;
+    // packed 1x1 weights: float4 group gi of block mb = k-steps 4 gi .. 4 gi + 3 (two input channels each) of its 32 rows
+    const int nblk = C >> 5;
+    const int spc = a.CK >> 3;           // float4 groups per (block, chunk)
+    const int ngroups = C >> 3;          // groups per block
+    constexpr int MAXB = 2;              // blocks per wave: C <= 256 -> 8 blocks over 4 waves
+    constexpr int MAXG = 32;
+    float4 wa[MAXG];
+    auto load_w = [&](int mb) {
+#pragma unroll
+        for (int gi = 0; gi < MAXG; gi++) {
+            if (gi < ngroups) {
+                const int ch = gi / spc, g = gi - ch * spc;
+                wa[gi] = reinterpret_cast<const float4 *>(a.pw)[(((int64_t)((mb / a.MB) * a.nchunks + ch) * a.MB + (mb % a.MB)) * spc + g) * 64 + lane];
+            }
+        }
+    };
+    if (wave < nblk) load_w(wave);
     // ---- stage 1: depthwise conv (k = 3) of x * mask, LayerNorm over channels, GELU -> y1 (thread: channels cg + 8 i)
     constexpr int CPT = 32;
     {
@@ -274,10 +291,9 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
     }
     __syncthreads();
     // ---- stage 2: 1x1 conv on the matrix cores.  Block rows (32 output channels each) are dealt to the waves round-robin.
-    const int nblk = C >> 5;
-    const int spc = a.CK >> 3;           // float4 groups per (block, chunk)
-    const int half = a.CK >> 1;          // k-steps (channel pairs) per chunk
-    constexpr int MAXB = 2;              // blocks per wave: C <= 256 -> 8 blocks over 4 waves
+    // (the weights of this wave's first block were requested before stage 1 and arrived under it; all loads of a block are
+    // issued together: fetched one group at a time in front of its four MFMAs, 48 dependent L2 round trips made this
+    // kernel as slow as the three launches it replaces)
     f32x16_ acc[MAXB];
 #pragma unroll
     for (int j = 0; j < MAXB; j++)
@@ -287,12 +303,12 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
     for (int j = 0; j < MAXB; j++) {
         const int mb = wave + 4 * j;
         if (mb < nblk) {  // (uniform per wave)
-            for (int ch = 0; ch < a.nchunks; ch++) {
-                const float4 *wg = reinterpret_cast<const float4 *>(a.pw) +
-                                   ((int64_t)((mb / a.MB) * a.nchunks + ch) * a.MB + (mb % a.MB)) * spc * 64 + lane;
-                for (int g = 0; g < spc; g++) {
-                    const float4 w4 = wg[(int64_t)g * 64];
-                    const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+            if (j > 0) load_w(mb);
+#pragma unroll
+            for (int gi = 0; gi < MAXG; gi++) {
+                if (gi < ngroups) {
+                    const float wv[4] = {wa[gi].x, wa[gi].y, wa[gi].z, wa[gi].w};
+                    const int ch = gi / spc, g = gi - ch * spc;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const int ci = ch * a.CK + 2 * (4 * g + k) + hi;  // this lane's k index of the step
@@ -303,7 +319,6 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
             }
         }
     }
-    (void)half;
     // ---- stage 3: + bias, LayerNorm over channels (column = lane & 31, rows spread over registers, `hi`, blocks, waves),
     // GELU, residual, mask.  C/D layout: row = (r & 3) + 8 * (r >> 2) + 4 * hi, col = lane & 31.
     const int col = lane & 31;
