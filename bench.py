@@ -193,6 +193,14 @@ def main():
     ap.add_argument("--total-batch", type=int, default=0,
                     help="strong scaling: this many utterances in total, split evenly over the GPUs (BASELINE config 5: 256)")
     ap.add_argument("--tokens", type=int, default=256)
+    ap.add_argument("--speakers", type=int, default=1,
+                    help="> 1: a multi-speaker voice (speaker-embedding path, gin 512) with sid uniform in [0, speakers) "
+                         "(BASELINE config 4: --preset medium --speakers 4 --batch 64 --mixed-lengths --gen-precision bf16)")
+    ap.add_argument("--mixed-lengths", action="store_true",
+                    help="utterance lengths uniform in [tokens/4, tokens] (seed 1235), zero-padded, instead of all = tokens")
+    ap.add_argument("--also-cooldown", type=float, default=3.0,
+                    help="seconds of idle before the secondary `also` (medium) measurement: it follows ~20 s of the "
+                         "power-limited headline workload in the same process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -246,15 +254,15 @@ def main():
 
     cache = os.environ.get("VITSMI_BENCH_CACHE", "/tmp/vitsmi_bench")
 
-    def voice_path(preset):
-        p = os.path.join(cache, f"synth_{preset}.onnx")
+    def voice_path(preset, speakers=1):
+        p = os.path.join(cache, f"synth_{preset}{'' if speakers <= 1 else f'_spk{speakers}'}.onnx")
         if rank == 0 and not os.path.exists(p):
             os.makedirs(cache, exist_ok=True)
-            write_voice(p + ".tmp", preset, seed=1234)
+            write_voice(p + ".tmp", preset, seed=1234, **({"n_speakers": speakers} if speakers > 1 else {}))
             os.replace(p + ".tmp", p)
         return p
 
-    voice = voice_path(a.preset)
+    voice = voice_path(a.preset, a.speakers)
     if dist:
         dist.barrier()
 
@@ -291,7 +299,18 @@ def main():
         g = torch.Generator(device="cpu").manual_seed(seed)
         ids = torch.randint(0, 256, (Bn, T), generator=g, dtype=torch.int64)
         lens = torch.full((Bn,), T, dtype=torch.int64)
+        if a.mixed_lengths:  # ragged lengths, zero-padded ids, padding mask in play
+            g2 = torch.Generator(device="cpu").manual_seed(1235 + seed)
+            lens = torch.randint(max(1, T // 4), T + 1, (Bn,), generator=g2, dtype=torch.int64)
+            lens[0] = T
+            ids = ids * (torch.arange(T)[None, :] < lens[:, None])
         return ids, lens
+
+    def make_sid(seed, first, Bn=B):
+        if int(first.hparam("n_speakers")) <= 1:
+            return None
+        g = torch.Generator(device="cpu").manual_seed(77 + seed)
+        return torch.randint(0, int(first.hparam("n_speakers")), (Bn,), generator=g, dtype=torch.int64)
 
     def measure(first, preset, steps, warmup, parts, lockstep, seed):
         """K timed passes of the whole path on `parts` handles sharing `first`'s arena -> (dt, samples, pipe)."""
@@ -299,17 +318,20 @@ def main():
         pipe.set_seed(1234 + rank * 16)
         scales = np.array([0.667, LENGTH_SCALE[preset], 0.8], np.float32)
         ids_h, lens_h = make_inputs(seed)
+        sid_h = make_sid(seed, first)
         ids, lens = ids_h.cuda(), lens_h.cuda()
+        sid = None if sid_h is None else sid_h.cuda()
+        sid_ptr = None if sid is None else sid.data_ptr()
         torch.cuda.synchronize()
 
         def run_steps(k):
             if lockstep or len(pipe.parts) == 1:
                 n = 0
                 for _ in range(k):
-                    pipe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+                    pipe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales, sid_ptr)
                     n += int(pipe.last_y_lengths(B).sum()) * hop
                 return n
-            return int(pipe.run_device_steps(ids.data_ptr(), lens.data_ptr(), B, T, scales, k).sum()) * hop
+            return int(pipe.run_device_steps(ids.data_ptr(), lens.data_ptr(), B, T, scales, k, sid_ptr).sum()) * hop
 
         if warmup > 0:
             run_steps(warmup)
@@ -326,19 +348,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        return dt, samples, pipe, (ids, lens, ids_h, lens_h, scales)
+        return dt, samples, pipe, (ids, lens, ids_h, lens_h, scales, sid, sid_h)
 
     def roofline_of(s, preset, inputs, n_t):
         """Per-kernel timing with HIP events on the engine's own stream (vits_set_timing), one handle, whole batch."""
-        ids, lens, _, _, scales = inputs
+        ids, lens, _, _, scales, sid, _ = inputs
+        sid_ptr = None if sid is None else sid.data_ptr()
         s.set_timing(True)
         fl = ms = by = 0.0
         launches = 0
         agg = {}
-        s.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)  # (untimed: creates the handle's HIP events)
+        s.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales, sid_ptr)  # (untimed: creates the handle's HIP events)
         s.stats()
         for _ in range(n_t):
-            s.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+            s.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales, sid_ptr)
             st = s.stats()
             fl += st["conv_flops"]
             by += st["conv_bytes"]
@@ -399,7 +422,8 @@ def main():
         roofline, stage, f16_range = roofline_of(sess, a.preset, inputs, max(3, min(a.steps, 5)))
 
     extras = world == 1 and not a.no_extras
-    ids, lens, ids_h, lens_h, scales = inputs
+    ids, lens, ids_h, lens_h, scales, sid, sid_h = inputs
+    sid_ptr = None if sid is None else sid.data_ptr()
 
     # per-step wall times (lock-step: every step joined), median / p10 / p90
     step_pct = None
@@ -407,7 +431,7 @@ def main():
         per = []
         for _ in range(max(a.steps, 10)):
             t0 = time.perf_counter()
-            pipe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales)
+            pipe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales, sid_ptr)
             pipe.sync()
             per.append((time.perf_counter() - t0) * 1e3)
         step_pct = dict(pctl(per), unit="ms", note="lock-step passes, each one synchronised (no overlap between passes)")
@@ -416,11 +440,12 @@ def main():
     host_io = None
     if extras:
         ids_n, lens_n = ids_h.numpy(), lens_h.numpy()
-        pipe.synthesize_batch(ids_n, lens_n, scales)
+        sid_n = None if sid_h is None else sid_h.numpy()
+        pipe.synthesize_batch(ids_n, lens_n, scales, sid_n)
         per, n_s = [], 0
         for _ in range(max(3, a.steps // 2)):
             t0 = time.perf_counter()
-            r = pipe.synthesize_batch(ids_n, lens_n, scales)
+            r = pipe.synthesize_batch(ids_n, lens_n, scales, sid_n)
             per.append(time.perf_counter() - t0)
             n_s += int(r["y_lengths"].sum()) * hop
         host_io = {"value": n_s / sum(per), "unit": "samples/s", "ms_per_step": 1e3 * sum(per) / len(per),
@@ -444,21 +469,25 @@ def main():
 
     # "headline = high; always also report medium"
     also = None
-    if extras and a.preset != "medium":
+    if extras and a.preset != "medium" and a.speakers <= 1:
         try:
+            time.sleep(max(0.0, a.also_cooldown))
             mfirst = MiSession(voice_path("medium"), device_id=local_rank)
             km = max(5, a.steps)
             dtm, nm, mp_, minputs = measure(mfirst, "medium", km, max(2, a.warmup), a.parts, a.lockstep, 1234 + rank)
             mroof, mstage, mrange = (None, None, None) if a.no_roofline else roofline_of(mfirst, "medium", minputs, 3)
             also = {"preset": "medium", "value": nm / dtm, "unit": "samples/s", "steps": km, "ms_per_step": dtm / km * 1e3,
                     "frames_per_id": nm / km / hop_of(mfirst) / (B * T), "roofline": mroof, "stages": mstage,
-                    "f16_range": mrange}
+                    "f16_range": mrange,
+                    "note": f"measured in the same process after the headline, roofline, host_io and exact-arithmetic runs "
+                            f"of the power-limited headline voice and {a.also_cooldown:.0f} s of idle; a run of its own "
+                            f"(`bench.py --preset medium`) reads higher"}
             mp_.close()
         except Exception as e:  # noqa: BLE001
             also = {"preset": "medium", "value": None, "note": f"failed: {type(e).__name__}: {e}"}
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:  # (N = 1 only: the other ranks would sit in the final barrier)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.speakers <= 1:  # (N = 1 only: the other ranks would sit in the final barrier)
         try:
             cpu = cpu_baseline(voice, a.preset, T, scales, 1234, hop)
         except Exception as e:  # noqa: BLE001 - the baseline is a report, never the product
@@ -474,14 +503,16 @@ def main():
             "vs_baseline": None, "dtype": DTYPE.get(gen_nprod, "f32") if sess.hparam("gen_sx") else "f32",
             "data": "synthetic", "gen_precision": a.gen_precision,
             "rtf": dt_max / (samples_all / world / 22050.0) if samples_all else None,
-            "config": {"workload": f"VITS full pipeline (encoder+duration+flow+HiFi-GAN), preset={a.preset}, "
-                                   f"batch={B}/GPU x {T} phoneme ids, scales=[0.667,{scales[1]:.2f},0.8], "
-                                   f"device Philox noise, seeded synthetic weights",
+            "config": {"workload": f"VITS full pipeline (encoder+duration+flow+HiFi-GAN), preset={a.preset}"
+                                   f"{'' if a.speakers <= 1 else f', {a.speakers} speakers (sid per utterance)'}, "
+                                   f"batch={B}/GPU x {T} phoneme ids"
+                                   f"{' (lengths uniform in [T/4, T], zero-padded)' if a.mixed_lengths else ''}, "
+                                   f"scales=[0.667,{scales[1]:.2f},0.8], device Philox noise, seeded synthetic weights",
                        "preset": a.preset, "batch_per_gpu": B, "global_batch": B * world, "tokens": T, "hop": hop,
                        "pipeline_parts": len(pipe.parts),
                        "pipeline_host": "lockstep" if (a.lockstep or len(pipe.parts) == 1) else "one free-running host thread per part",
                        "samples_per_step": samples_all / a.steps,
-                       "frames_per_id": samples_all / a.steps / hop / (B * world * T),
+                       "frames_per_id": samples_all / a.steps / hop / (float(lens_h.sum()) * world),
                        "weights": weights, "commit": git_head()},
             "roofline": roofline, "cpu_baseline": cpu, "step_ms": step_pct, "host_io": host_io,
             "exact_arithmetic": exact, "also": also, "stages": stage, "f16_range": f16_range,

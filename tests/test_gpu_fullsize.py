@@ -448,3 +448,27 @@ print("SHARDED_OK")
     r = subprocess.run([sys.executable, "-c", code, ROOT, os.path.join(GOLDEN, "sx_rb2_ms.onnx")], capture_output=True,
                        text=True, timeout=600, env=env)
     assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_spline_with_16_bins_matches_oracle(tmp_path):
+    """the spline-parameter buffer was sized for the reference's 10 bins (29 rows); a voice with 16 bins (47
+    rows) used to run past it into the flow state.  The buffer now follows the model; durations stay exact."""
+    from phoonnx_amd import MiSession
+    from phoonnx_amd.synth import write_voice
+    from vits_oracle import VitsOracle
+    path = str(tmp_path / "bins16.onnx")
+    write_voice(path, "small", seed=21, n_bins=16)
+    s, o = MiSession(path), VitsOracle(path)
+    rng = np.random.default_rng(16)
+    B, T = 3, 50
+    ids = rng.integers(0, 256, (B, T)).astype(np.int64)
+    lens = np.array([T, 37, 5], np.int64)
+    sc = np.array([0.5, 1.3, 0.9], np.float32)
+    ndp = rng.standard_normal((B, 2, T)).astype(np.float32)
+    nz = rng.standard_normal((B, 64, T * 8)).astype(np.float32)
+    ref = o.infer(ids, lens, sc, None, ndp, nz)
+    got = s.synthesize_batch(ids, lens, sc, None, ndp, nz, taps=("logw", "w_ceil"))
+    np.testing.assert_allclose(got["logw"], ref["logw"], atol=2e-4, rtol=0)
+    assert np.array_equal(got["w_ceil"], ref["w_ceil"]) and np.array_equal(got["y_lengths"], ref["y_lengths"])
+    np.testing.assert_allclose(got["output"], ref["output"], atol=1e-3, rtol=0)
+    s.close()
