@@ -198,9 +198,6 @@ def main():
                          "(BASELINE config 4: --preset medium --speakers 4 --batch 64 --mixed-lengths --gen-precision bf16)")
     ap.add_argument("--mixed-lengths", action="store_true",
                     help="utterance lengths uniform in [tokens/4, tokens] (seed 1235), zero-padded, instead of all = tokens")
-    ap.add_argument("--also-cooldown", type=float, default=3.0,
-                    help="seconds of idle before the secondary `also` (medium) measurement: it follows ~20 s of the "
-                         "power-limited headline workload in the same process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -467,11 +464,17 @@ def main():
         except Exception as e:  # noqa: BLE001
             exact = {"gen_precision": "bf16x6", "value": None, "note": f"failed: {e}"}
 
+    # The headline voice's handles are done: free their ~60 GB of workspace before another voice is measured (with them
+    # open, the second voice's freshly allocated workspace measured 25-30 % slower on its HBM-bound kernels - 404 vs 523 M
+    # samples/s, tools/exp_order.py - and recovered the moment they were closed)
+    n_parts = len(pipe.parts)
+    gen_sx = bool(sess.hparam("gen_sx"))
+    pipe.close()
+
     # "headline = high; always also report medium"
     also = None
     if extras and a.preset != "medium" and a.speakers <= 1:
         try:
-            time.sleep(max(0.0, a.also_cooldown))
             mfirst = MiSession(voice_path("medium"), device_id=local_rank)
             km = max(5, a.steps)
             dtm, nm, mp_, minputs = measure(mfirst, "medium", km, max(2, a.warmup), a.parts, a.lockstep, 1234 + rank)
@@ -479,9 +482,7 @@ def main():
             also = {"preset": "medium", "value": nm / dtm, "unit": "samples/s", "steps": km, "ms_per_step": dtm / km * 1e3,
                     "frames_per_id": nm / km / hop_of(mfirst) / (B * T), "roofline": mroof, "stages": mstage,
                     "f16_range": mrange,
-                    "note": f"measured in the same process after the headline, roofline, host_io and exact-arithmetic runs "
-                            f"of the power-limited headline voice and {a.also_cooldown:.0f} s of idle; a run of its own "
-                            f"(`bench.py --preset medium`) reads higher"}
+                    "note": "measured in the same process after the headline voice's handles were closed"}
             mp_.close()
         except Exception as e:  # noqa: BLE001
             also = {"preset": "medium", "value": None, "note": f"failed: {type(e).__name__}: {e}"}
@@ -500,7 +501,7 @@ def main():
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt_max / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if a.total_batch else "weak",
-            "vs_baseline": None, "dtype": DTYPE.get(gen_nprod, "f32") if sess.hparam("gen_sx") else "f32",
+            "vs_baseline": None, "dtype": DTYPE.get(gen_nprod, "f32") if gen_sx else "f32",
             "data": "synthetic", "gen_precision": a.gen_precision,
             "rtf": dt_max / (samples_all / world / 22050.0) if samples_all else None,
             "config": {"workload": f"VITS full pipeline (encoder+duration+flow+HiFi-GAN), preset={a.preset}"
@@ -509,8 +510,8 @@ def main():
                                    f"{' (lengths uniform in [T/4, T], zero-padded)' if a.mixed_lengths else ''}, "
                                    f"scales=[0.667,{scales[1]:.2f},0.8], device Philox noise, seeded synthetic weights",
                        "preset": a.preset, "batch_per_gpu": B, "global_batch": B * world, "tokens": T, "hop": hop,
-                       "pipeline_parts": len(pipe.parts),
-                       "pipeline_host": "lockstep" if (a.lockstep or len(pipe.parts) == 1) else "one free-running host thread per part",
+                       "pipeline_parts": n_parts,
+                       "pipeline_host": "lockstep" if (a.lockstep or n_parts == 1) else "one free-running host thread per part",
                        "samples_per_step": samples_all / a.steps,
                        "frames_per_id": samples_all / a.steps / hop / (float(lens_h.sum()) * world),
                        "weights": weights, "commit": git_head()},
@@ -519,7 +520,6 @@ def main():
         }
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = value / world / cpu["value"]
-    pipe.close()
     if dist:
         dist.barrier()
         dist.destroy_process_group()
