@@ -15,8 +15,10 @@
 // fused launch with the two-launch form bit for bit and with the oracle.
 //
 // Structure (one workgroup = 4 waves, all C output channels, 256 columns):
-//   phase 1  c1 over columns [t0 - P2, t0 - P2 + 256): the main loop of conv_sx_kernel's RAWIN f16 instantiation
-//            (x tile global -> registers -> lrelu -> split -> LDS per 16-channel chunk, weights global -> registers);
+//   prologue the whole x tile (all channels, 256 + halo columns) global -> registers -> lrelu -> fp16 split -> LDS, one
+//            HBM round trip;
+//   phase 1  c1 over columns [t0 - P2, t0 - P2 + 256) from that tile: weights global -> registers one step ahead, B
+//            fragments from LDS, no DMA and no barriers;
 //   hand-over  accumulators * 2^-k1 + bias1 -> lrelu -> two fp16 planes -> LDS array Y[chunk][plane][half][col]
 //            (zero where the column lies outside the tensor: c2's zero padding); Y overlays the x stages, hence one
 //            barrier before and one after;
@@ -43,7 +45,7 @@ struct SxPairArgs {
     int K1, dil1, pad1;       // c1
     int K2, dil2, pad2;       // c2
     int LW1;                  // x tile width in cells = 256 + (K1 - 1) * dil1
-    unsigned x_bytes;         // one x stage (2 planes x 2 halves x LW1 cells, padded to 4 KiB)
+    unsigned x_bytes;         // one chunk's x stage (2 planes x 2 halves x LW1 cells)
     int LW2;                  // Y row width in cells (256 + 2 * pad2, rounded up)
     unsigned y_chunk_bytes;   // bytes of one chunk of Y = 4 * LW2 * 16
     int BNo, NT, B;           // kept output columns per tile, tiles along time, utterances
@@ -59,6 +61,7 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
     constexpr int BN = NW * WN * 32, NH = NW / 2;
     static_assert(WM * WN == 4 && MW == 1 && BN == 256, "one block row per wave, 256 columns");
     constexpr int NPW = 2, STEPBYTES = WM * MW * NPW * 1024;
+    constexpr int MAXCH = WM * 2;  // 16-channel chunks: C = 32 * WM
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_sx[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -69,79 +72,81 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
     if (tile_nb >= a.NT * a.B) return;
     const int b = tile_nb / a.NT, t0 = (tile_nb - b * a.NT) * a.BNo;  // first kept output column
     const int t1 = t0 - a.pad2;                                        // first column phase 1 computes
-    const int T = a.T, LW = a.LW1, K1 = a.K1, K2 = a.K2;
+    const int T = a.T, LW = a.LW1;
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_sx;
     const uint32_t XB = a.x_bytes;
     const char *wbase1 = reinterpret_cast<const char *>(a.wp1) + wm * (MW * NPW * 1024);
     const char *wbase2 = reinterpret_cast<const char *>(a.wp2) + wm * (MW * NPW * 1024);
+    const float *xrb = a.xr + (int64_t)b * a.C * T;
     float pk = 0.f;
 
-    // ---- x tile through registers (as conv_sx_kernel<RAWIN>): a thread owns cells i = it*256 + tid of [2][LW]
+    struct ASet {
+        u32x4 fa[2];
+    };
+    const uint32_t voff0 = (uint32_t)lane * 16u;
+    auto load_a = [&](ASet &f, const char *wb, int step) {
+        const char *sb = wb + (int64_t)step * STEPBYTES;
+        f.fa[0] = global_read128<0>(voff0, sb);
+        f.fa[1] = global_read128<1024>(voff0, sb);
+    };
+
+    // ---- prologue: the WHOLE x tile (every 16-channel chunk) is requested at once, converted (leaky-ReLU, fp16 split)
+    // and written to its LDS stage: one HBM round trip per tile.  (A first version fetched chunk c + 1 during chunk c,
+    // like conv_sx_kernel: with K = 3 a chunk is three steps of matrix work, an HBM round trip is ten, and - vector
+    // loads return in order - every weight load behind an x load waits for it: ~2.5 us of stall per chunk, 25 of the
+    // 31 us a 64-channel k = 3 tile took.)  A thread owns cells i = it*256 + tid of a chunk's [2 halves][LW] cells.
     constexpr int NXC = 3;
-    u32x4 xst[NXC][2];
-    const float *xrb = a.xr + (int64_t)b * a.C * T;
-    const int nxc = (2 * LW + 255) >> 8;
-    auto xcell = [&](int it, int &kh, int &col) {
-        const int i = it * 256 + tid;
-        kh = (i >= LW ? 1 : 0) + (i >= 2 * LW ? 1 : 0);
-        col = i - kh * LW;
-    };
-    uint32_t xroff[NXC];
-    bool xrok[NXC];
+    {
+        u32x4 xst[MAXCH][NXC][2];
+        const int nxc = (2 * LW + 255) >> 8;
+        uint32_t xroff[NXC];
+        bool xrok[NXC];
+        int xkh[NXC], xcol[NXC];
 #pragma unroll
-    for (int it = 0; it < NXC; it++) {
-        int kh, col;
-        xcell(it, kh, col);
-        const int t = t1 - a.pad1 + col;
-        xrok[it] = it < nxc && kh < 2 && t >= 0 && t < T;
-        xroff[it] = xrok[it] ? (uint32_t)(((int64_t)kh * T + t) * 32) : 0u;
-    }
-    auto xload = [&](int chunk) {
-        const float *cbase = xrb + (int64_t)(2 * chunk) * T * 8;
-        static_for<NXC>([&](auto I) {
-            constexpr int it = decltype(I)::value;
-            if (it < nxc) {
-                xst[it][0] = global_read128<0>(xroff[it], cbase);
-                xst[it][1] = global_read128<16>(xroff[it], cbase);
-            }
+        for (int it = 0; it < NXC; it++) {
+            const int i = it * 256 + tid;
+            const int kh = (i >= LW ? 1 : 0) + (i >= 2 * LW ? 1 : 0);
+            const int col = i - kh * LW;
+            const int t = t1 - a.pad1 + col;
+            xkh[it] = kh;
+            xcol[it] = col;
+            xrok[it] = it < nxc && kh < 2 && t >= 0 && t < T;
+            xroff[it] = xrok[it] ? (uint32_t)(((int64_t)kh * T + t) * 32) : 0u;
+        }
+        static_for<MAXCH>([&](auto CH) {
+            constexpr int ch = decltype(CH)::value;
+            const float *cbase = xrb + (int64_t)(2 * ch) * T * 8;
+            static_for<NXC>([&](auto I) {
+                constexpr int it = decltype(I)::value;
+                if (it < nxc) {
+                    xst[ch][it][0] = global_read128<0>(xroff[it], cbase);
+                    xst[ch][it][1] = global_read128<16>(xroff[it], cbase);
+                }
+            });
         });
-    };
-    auto xstore = [&](uint32_t xoff) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const float isl = a.islope;
-        static_for<NXC>([&](auto I) {
-            constexpr int it = decltype(I)::value;
-            if (it < nxc) {
-                int kh, col;
-                xcell(it, kh, col);
-                if (kh < 2) {
+        static_for<MAXCH>([&](auto CH) {
+            constexpr int ch = decltype(CH)::value;
+            static_for<NXC>([&](auto I) {
+                constexpr int it = decltype(I)::value;
+                if (it < nxc && xkh[it] < 2) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        const float x = xrok[it] ? __uint_as_float(xst[it][e >> 2][e & 3]) : 0.f;
+                        const float x = xrok[it] ? __uint_as_float(xst[ch][it][e >> 2][e & 3]) : 0.f;
                         v[e] = fmaxf(x, x * isl);
                     }
                     unsigned p0[4], p1[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) split2h_pair_pk(v[2 * e], v[2 * e + 1], p0[e], p1[e], pk);
-                    const uint32_t ad = lds0 + xoff + (uint32_t)(kh * LW + col) * 16u;
+                    const uint32_t ad = lds0 + (uint32_t)ch * XB + (uint32_t)(xkh[it] * LW + xcol[it]) * 16u;
                     ds_write128(ad, u32x4{p0[0], p0[1], p0[2], p0[3]});
                     ds_write128(ad + (uint32_t)(2 * LW) * 16u, u32x4{p1[0], p1[1], p1[2], p1[3]});
                 }
-            }
+            });
         });
-    };
-    const int nxv = 2 * nxc;
-    auto wait_vm = [&](int n) {
-        switch (n) {
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        }
-    };
+    }
 
     f32x16 acc[NW];
     auto zero_acc = [&]() {
@@ -151,17 +156,7 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
             for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
     };
     zero_acc();
-
-    struct ASet {
-        u32x4 fa[2];
-    };
     u32x4 fb[NW][2];
-    const uint32_t voff0 = (uint32_t)lane * 16u;
-    auto load_a = [&](ASet &f, const char *wb, int step) {
-        const char *sb = wb + (int64_t)step * STEPBYTES;
-        f.fa[0] = global_read128<0>(voff0, sb);
-        f.fa[1] = global_read128<1024>(voff0, sb);
-    };
     // B fragments of one half (block columns [h*NH, (h+1)*NH)) from the rows at byte address `rows` (plane 0,
     // half-group `hi` selected by the lane), plane stride `pstride`
     auto load_b_half = [&](auto H, uint32_t rows, uint32_t pstride) {
@@ -193,89 +188,79 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
     const std::integral_constant<int, 0> H0{};
     const std::integral_constant<int, 1> H1{};
 
-    // ---- residual operands of this wave (x itself, at the columns this lane produces: t1 + col): requested now, next
-    // to the x tile.  CHAIN turns them into x1 = c1(..) + x at the hand-over.
-    f32x4 pre[NW / 2][2][4];
-    {
-        static_for<NW / 2>([&](auto R) {
-            constexpr int rr = decltype(R)::value;
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int row0 = wm * 32;
-                const int t = t1 + (wn * NW + rr * 2 + j) * 32 + l31;
-                const int tl = t < 0 ? 0 : (t < T ? t : T - 1);  // (clamped columns are never kept)
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    pre[rr][j][q] = *reinterpret_cast<const f32x4 *>(xrb + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi);
-            }
-        });
-    }
-
-    // =================================================================== phase 1: c1 over columns [t1, t1 + 256)
-    const int nchunks = a.nchunks;
-    const uint32_t b_lane1 = lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u;
-    const uint32_t plane_b1 = (uint32_t)(2 * LW) * 16u;
-    ASet f0, f1;
-    xload(0);
-    load_a(f0, wbase1, 0);
-    wait_vm(2);  // in-order return: the residual and x loads have landed, A(0) may still be in flight
-    xstore(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
+    // One conv over an operand that is completely resident in LDS (chunk c at `rows0 + c * chunk_bytes`, tap k `k * dil`
+    // cells to the right): weights one step ahead in two register sets, B fragments half a step ahead, no barriers.
+    // The first weights (step 0) must have been requested into `fa`.
+    auto run_conv = [&](ASet &fa, ASet &fbset, const char *wb, int K, int dil, uint32_t rows0, uint32_t chunk_bytes,
+                        uint32_t pstride) {
+        const int S = a.nchunks * K;
         int chunk = 0, tap = 0;
-        const int S = nchunks * K1;
+        load_b_half(H0, rows0, pstride);
+        load_b_half(H1, rows0, pstride);
         auto step = [&](ASet &fc, ASet &fn, int s) {
-            const bool more_x = chunk + 1 < nchunks;
-            const uint32_t rows = b_lane1 + (uint32_t)(chunk & 1) * XB;
-            if (tap == 0) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                load_b_half(H0, rows, plane_b1);
-                load_b_half(H1, rows, plane_b1);
-            } else {
-                if (tap == 1 && more_x) wait_vm(nxv);
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A(s)
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < S) load_a(fn, wb, s + 1);
+            int ntap = tap + 1, nchunk = chunk;
+            if (ntap == K) {
+                ntap = 0;
+                nchunk++;
             }
+            const bool more = s + 1 < S;
+            const uint32_t next = rows0 + (uint32_t)nchunk * chunk_bytes + (uint32_t)(ntap * dil) * 16u;
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < S) load_a(fn, wbase1, s + 1);
-            if (tap == 0 && more_x) xload(chunk + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            const bool more_taps = tap + 1 < K1;
-            const uint32_t next = rows + (uint32_t)((tap + 1) * a.dil1) * 16u;
             wait_lds_older_half();
             __builtin_amdgcn_sched_barrier(0);
             mma_half(fc, H0);
             __builtin_amdgcn_sched_barrier(0);
-            if (more_taps) {
-                load_b_half(H0, next, plane_b1);
+            if (more) {
+                load_b_half(H0, next, pstride);
                 wait_lds_older_half();
             } else
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             mma_half(fc, H1);
             __builtin_amdgcn_sched_barrier(0);
-            if (tap == 2 && more_x) xstore(((chunk + 1) & 1) * XB);
+            if (more) load_b_half(H1, next, pstride);
             __builtin_amdgcn_sched_barrier(0);
-            if (more_taps) load_b_half(H1, next, plane_b1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (++tap == K1) {
-                tap = 0;
-                chunk++;
-            }
+            tap = ntap;
+            chunk = nchunk;
         };
         for (int s = 0; s + 1 < S; s += 2) {
-            step(f0, f1, s);
-            step(f1, f0, s + 1);
+            step(fa, fbset, s);
+            step(fbset, fa, s + 1);
         }
-        if (S & 1) step(f0, f1, S - 1);
-    }
+        if (S & 1) step(fa, fbset, S - 1);
+    };
+
+    // =================================================================== phase 1: c1 over columns [t1, t1 + 256)
+    ASet f0, f1;
+    load_a(f0, wbase1, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // the x tile is complete
+    __builtin_amdgcn_sched_barrier(0);
+    run_conv(f0, f1, wbase1, a.K1, a.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u, XB,
+             (uint32_t)(2 * LW) * 16u);
+
+    // ---- residual operands of this wave (x itself, at the columns this lane produces: t1 + col); the tile's lines were
+    // fetched a phase ago and are served by the L2.  CHAIN turns them into x1 = c1(..) + x at the hand-over.
+    f32x4 pre[NW / 2][2][4];
+    static_for<NW / 2>([&](auto R) {
+        constexpr int rr = decltype(R)::value;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int row0 = wm * 32;
+            const int t = t1 + (wn * NW + rr * 2 + j) * 32 + l31;
+            const int tl = t < 0 ? 0 : (t < T ? t : T - 1);  // (clamped columns are never kept)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                pre[rr][j][q] = *reinterpret_cast<const f32x4 *>(xrb + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi);
+        }
+    });
 
     // =================================================================== hand-over: c1's output -> Y (fp16 planes in LDS)
-    // first weights of c2 travel meanwhile (S1 odd: the last step left its weights in f0, so f1 is free either way)
     ASet g0, g1;
-    load_a(g0, wbase2, 0);
+    load_a(g0, wbase2, 0);  // first weights of c2 travel meanwhile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave has finished reading the x stages Y is about to overwrite
     __builtin_amdgcn_sched_barrier(0);
@@ -321,50 +306,9 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
     __builtin_amdgcn_s_barrier();  // Y is complete
     __builtin_amdgcn_sched_barrier(0);
 
-    // =================================================================== phase 2: c2 over Y (no DMA, no barriers)
-    {
-        const uint32_t b_lane2 = lds0 + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31) * 16u;
-        const uint32_t plane_b2 = (uint32_t)(2 * a.LW2) * 16u;
-        int chunk = 0, tap = 0;
-        const int S = nchunks * K2;
-        load_b_half(H0, b_lane2, plane_b2);
-        load_b_half(H1, b_lane2, plane_b2);
-        auto step = [&](ASet &fc, ASet &fn, int s) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A(s)
-            __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < S) load_a(fn, wbase2, s + 1);
-            // B of the next step: next tap of this chunk, or tap 0 of the next chunk
-            int ntap = tap + 1, nchunk = chunk;
-            if (ntap == K2) {
-                ntap = 0;
-                nchunk++;
-            }
-            const bool more = s + 1 < S;
-            const uint32_t next = b_lane2 + (uint32_t)nchunk * a.y_chunk_bytes + (uint32_t)(ntap * a.dil2) * 16u;
-            __builtin_amdgcn_sched_barrier(0);
-            wait_lds_older_half();
-            __builtin_amdgcn_sched_barrier(0);
-            mma_half(fc, H0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                load_b_half(H0, next, plane_b2);
-                wait_lds_older_half();
-            } else
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            mma_half(fc, H1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) load_b_half(H1, next, plane_b2);
-            __builtin_amdgcn_sched_barrier(0);
-            tap = ntap;
-            chunk = nchunk;
-        };
-        for (int s = 0; s + 1 < S; s += 2) {
-            step(g0, g1, s);
-            step(g1, g0, s + 1);
-        }
-        if (S & 1) step(g0, g1, S - 1);
-    }
+    // =================================================================== phase 2: c2 over Y
+    run_conv(g0, g1, wbase2, a.K2, a.dil2, lds0 + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31) * 16u, a.y_chunk_bytes,
+             (uint32_t)(2 * a.LW2) * 16u);
 
     // =================================================================== epilogue: bias2 + x [+ xs] [/ n] -> raw
     {
@@ -438,15 +382,15 @@ inline bool sx_pair_supported(int C, int cfg, int K1, int dil1, int K2, int dil2
     const int halo2 = (K2 - 1) * dil2;
     if (halo2 % 2 || 256 - halo2 < 160) return false;                     // (> 37 % of a tile recomputed: not worth it)
     const size_t lds_y = (size_t)(C / 16) * 4 * (size_t)((256 + halo2 + 7) / 8 * 8) * 16;
-    const size_t lds_x = 2 * (((size_t)4 * LW1 * 16 + 4095) / 4096 * 4096);
-    return (lds_y > lds_x ? lds_y : lds_x) <= 80 * 1024;                  // two workgroups per CU
+    const size_t lds_x = (size_t)(C / 16) * 4 * LW1 * 16;                 // the whole x tile is resident
+    return (lds_y > lds_x ? lds_y : lds_x) <= 80 * 1024 - 256;            // two workgroups per CU
 }
 
 // flags: EPI_ACC (out += ...), EPI_DIV (then / div).  chain = false: out = c2(lrelu(c1(lrelu(x)))) + x;
 // chain = true: x1 = c1(lrelu(x)) + x, out = c2(lrelu(x1)) + x1.
 inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t stream, bool chain = false) {
     a.LW1 = 256 + (a.K1 - 1) * a.dil1;
-    a.x_bytes = (unsigned)(((size_t)4 * a.LW1 * 16 + 4095) / 4096 * 4096);
+    a.x_bytes = (unsigned)((size_t)4 * a.LW1 * 16);  // one 16-channel chunk: 2 planes x 2 halves x LW1 cells
     if (a.dil2 < 1) a.dil2 = 1;
     const int halo2 = (a.K2 - 1) * a.dil2;
     if (a.pad2 * 2 != halo2) return hipErrorInvalidValue;  // "same" padding
@@ -461,10 +405,10 @@ inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t 
     if (a.wscale1 == 0.f) a.wscale1 = 1.f;
     if (a.wscale2 == 0.f) a.wscale2 = 1.f;
     if ((long long)a.T * 64 + 64 >= (1ll << 32)) return hipErrorInvalidValue;
-    // Y overlays the two x stages
-    const size_t lds_x = 2 * (size_t)a.x_bytes, lds_y = (size_t)a.nchunks * a.y_chunk_bytes;
+    // Y overlays the x stages (every chunk has its own)
+    const size_t lds_x = (size_t)a.nchunks * a.x_bytes, lds_y = (size_t)a.nchunks * a.y_chunk_bytes;
     const size_t lds = lds_x > lds_y ? lds_x : lds_y;
-    if (lds > 80 * 1024 || !sx_pair_supported(a.C, cfg, a.K1, a.dil1, a.K2, a.dil2)) return hipErrorInvalidValue;
+    if (lds > 80 * 1024 - 256 || !sx_pair_supported(a.C, cfg, a.K1, a.dil1, a.K2, a.dil2)) return hipErrorInvalidValue;
     const long long nb = (long long)a.NT * B;
     if (nb == 0) return hipSuccess;
     const long long wgs = (nb + 7) / 8 * 8;
