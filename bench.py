@@ -58,7 +58,13 @@ def pmc_traffic(preset, kernel_prefix):
     (profiles/*_<preset>_b32_pmc.json, written by tools/profile_gpu.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate
     passes, per MI355X_MICROARCH.md).  Launch-weighted mean over the family's instantiations; None if absent."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{preset}_b32_pmc.json")), key=os.path.getmtime)
+    # newest = highest (round, version) in the name rNN_vM_...: a fresh checkout gives every file the same mtime
+    import re
+
+    def ver(f):
+        m = re.match(r"r(\d+)(?:_v(\d+))?_", os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2) or 0)) if m else (0, 0)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{preset}_b32_pmc.json")), key=ver)
     if not files:
         return None
     try:

@@ -616,41 +616,48 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave has left the main loop: the x stages become the exchange buffer
         __builtin_amdgcn_sched_barrier(0);
-        // exchange slot of (column group wn, block column n, quad q): 64 lanes x 16 bytes
+        // Exchange slot of (column group wn, block column n, quad q): 64 lanes x 16 bytes.  The work is split by block
+        // column so that both waves of a pair apply transcendentals to all their values and store half of the result:
+        // columns [0, NW/2): the sigmoid wave sends sigmoid(b), the tanh wave multiplies and stores;
+        // columns [NW/2, NW): the tanh wave sends tanh(a), the sigmoid wave multiplies and stores.
         const uint32_t exch = lds0 + (uint32_t)wn * (NW * 4 * 1024) + (uint32_t)lane * 16u;
-        if (wm == 1) {
+        f32x4 mine[NW][4];
 #pragma unroll
-            for (int n = 0; n < NW; n++)
+        for (int n = 0; n < NW; n++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    f32x4 sg;
+            for (int q = 0; q < 4; q++) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float v = F16 ? __builtin_fmaf(acc[0][n][4 * q + e], wsc, bq[q][e]) : acc[0][n][4 * q + e] + bq[q][e];
-                        sg[e] = 1.0f / (1.0f + expf(-v));
-                    }
-                    ds_write128(exch + (uint32_t)(n * 4 + q) * 1024u, __builtin_bit_cast(u32x4, sg));
+                for (int e = 0; e < 4; e++) {
+                    const float v = F16 ? __builtin_fmaf(acc[0][n][4 * q + e], wsc, bq[q][e]) : acc[0][n][4 * q + e] + bq[q][e];
+                    mine[n][q][e] = wm == 0 ? tanhf(v) : 1.0f / (1.0f + expf(-v));
                 }
-        }
+                const bool send = (wm == 1) == (n < NW / 2);  // (uniform per wave)
+                if (send) ds_write128(exch + (uint32_t)(n * 4 + q) * 1024u, __builtin_bit_cast(u32x4, mine[n][q]));
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (wm == 0) {
+        {
             float *actb = a.out_raw + (int64_t)b * a.raw_bstride;
+            const int n_lo = wm == 0 ? 0 : NW / 2;
+            u32x4 got[NW / 2][4];
 #pragma unroll
-            for (int n = 0; n < NW; n++) {
-                const int t = t0 + (wn * NW + n) * 32 + l31;
+            for (int k = 0; k < NW / 2; k++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(got[k][q]) : "v"(exch + (uint32_t)((n_lo + k) * 4 + q) * 1024u) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < NW / 2; k++) {
+                // (compile-time register index for both halves: select after the multiply)
+                const int t = t0 + (wn * NW + n_lo + k) * 32 + l31;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    u32x4 raw;
-                    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(exch + (uint32_t)(n * 4 + q) * 1024u) : "memory");
-                    const f32x4 sg = __builtin_bit_cast(f32x4, raw);
+                    const f32x4 other = __builtin_bit_cast(f32x4, got[k][q]);
+                    const f32x4 own = wm == 0 ? mine[k][q] : mine[NW / 2 + k][q];
                     if (t < T) {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const float v = F16 ? __builtin_fmaf(acc[0][n][4 * q + e], wsc, bq[q][e]) : acc[0][n][4 * q + e] + bq[q][e];
-                            actb[(int64_t)(ch0 + 8 * q + 4 * hi + e) * T + t] = tanhf(v) * sg[e];
-                        }
+                        for (int e = 0; e < 4; e++) actb[(int64_t)(ch0 + 8 * q + 4 * hi + e) * T + t] = own[e] * other[e];
                     }
                 }
             }
