@@ -53,6 +53,10 @@ EXPORTS = [
 ]
 
 
+G2P_EXPORTS = ["g2p_open", "g2p_close", "g2p_last_error", "g2p_hparam", "g2p_num_outputs", "g2p_output_name", "g2p_bucket",
+               "g2p_run", "g2p_generate"]
+
+
 def lib_path():
     return os.path.join(_HERE, "libvitsmi.so")
 
@@ -114,6 +118,18 @@ def load():
     lib.vits_bench_conv1d_sx.argtypes = [C.c_int] * 9 + [f32p]
     lib.vits_test_conv_pair_sx.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_float, vp, f32p]
+    lib.g2p_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.g2p_close.argtypes = [vp]
+    lib.g2p_close.restype = None
+    lib.g2p_last_error.argtypes = [vp]
+    lib.g2p_last_error.restype = C.c_char_p
+    lib.g2p_hparam.argtypes = [vp, C.c_char_p, i64p]
+    lib.g2p_num_outputs.argtypes = [vp]
+    lib.g2p_output_name.argtypes = [vp, C.c_int]
+    lib.g2p_output_name.restype = C.c_char_p
+    lib.g2p_bucket.argtypes = [vp, C.c_int, C.c_int]
+    lib.g2p_run.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp]
+    lib.g2p_generate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, C.POINTER(C.c_int)]
     _LIB = lib
     return lib
 

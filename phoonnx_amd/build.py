@@ -7,8 +7,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvitsmi.so")
-SOURCES = ["vitsmi.hip", "model.cpp", "onnx_reader.cpp"]
-HEADERS = ["kernels.hip.hpp", "conv_engine.hip.hpp", "conv_sx_engine.hip.hpp", "model.hpp", "onnx_reader.hpp", "../../include/vitsmi.h"]
+SOURCES = ["vitsmi.hip", "g2p.hip", "model.cpp", "onnx_reader.cpp"]
+HEADERS = ["kernels.hip.hpp", "conv_engine.hip.hpp", "conv_sx_engine.hip.hpp", "conv_sx_pair.hip.hpp", "sx_split.hip.hpp", "model.hpp",
+           "g2p_model.hpp", "onnx_reader.hpp", "../../include/vitsmi.h", "../../include/g2pmi.h"]
 
 
 def hipcc():

@@ -60,6 +60,7 @@ enum : int {
     // (the sum of masked terms equals the reference's masked sum).  wn_split = 0: skip rows only (the last WN layer).
     EPI_WN = 256,
     EPI_WN_FIRST = 512,  // ... first WN layer: the skip rows are stored, not accumulated
+    EPI_NO_PADFILL = 1 << 18,  // do not zero the columns between T and the row pitch (the output is a window into wider rows)
     DBG_NO_DMA = 1 << 16,  // ablation (tools/conv_bench.py): stop prefetching after the second chunk
     DBG_NO_EPI = 1 << 17   // ablation: skip the epilogue stores
 };
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
             }
             const int t = t0 + wn * (NW * 32) + n * 32 + l31;
             if (t >= T) {
-                if (ups == 1 && t < a.out_cstride) {  // row padding up to the pitch: zeros (see x_cstride)
+                if (ups == 1 && t < a.out_cstride && !(flags & EPI_NO_PADFILL)) {  // row padding up to the pitch: zeros (see x_cstride)
 #pragma unroll
                     for (int r = 0; r < 16; r++)
                         if (orow_m[r] >= 0) {

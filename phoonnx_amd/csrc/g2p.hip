@@ -1,0 +1,535 @@
+// g2p.hip — ByT5 G2P engine: host pipeline + the C ABI of include/g2pmi.h.
+//
+// T5ForConditionalGeneration as phoonnx/phonemizers/mul.py runs it (batch 1): encoder over the input bytes, decoder over
+// the generated prefix, lm_head.  Activations are [channels][time] fp32 (the layout of the f32 conv engine, whose 1x1
+// convolution IS the Linear layer: every projection runs on v_mfma_f32_32x32x2_f32 through conv_engine_kernel); RMS norm,
+// attention with the bucketed relative-position bias, the gated activation, embedding and argmax are small kernels below.
+// g2p_generate keeps the decoder's self-attention keys / values and the cross-attention keys / values of the encoder
+// output in a cache, so a generated token costs one decoder step instead of a whole-graph run.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/g2pmi.h"
+#include "../../include/vitsmi.h"
+#include "conv_engine.hip.hpp"
+#include "g2p_model.hpp"
+
+using namespace vitsmi;
+
+namespace {
+thread_local std::string g_g2p_open_error;
+
+// x[c][t] = table[ids[t]][c]
+__global__ void g2p_embed_kernel(const int64_t *ids, const float *table, float *x, int C, int T, int pitch, int vocab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (c >= C) return;
+    int64_t id = ids[t];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // (range-checked on the host for host inputs; generated ids are in range)
+    x[(int64_t)c * pitch + t] = table[id * C + c];
+}
+
+// T5LayerNorm (modeling_t5.py): y = x * rsqrt(mean(x^2) + eps) * g, over channels, one workgroup per time step
+__global__ __launch_bounds__(256) void g2p_rmsnorm_kernel(const float *x, const float *g, float *y, int C, int T, int xpitch,
+                                                          int ypitch, float eps) {
+    __shared__ float red[256];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    float s = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        const float v = x[(int64_t)c * xpitch + t];
+        s += v * v;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float rs = 1.0f / sqrtf(red[0] / (float)C + eps);
+    for (int c = tid; c < C; c += 256) y[(int64_t)c * ypitch + t] = x[(int64_t)c * xpitch + t] * rs * g[c];
+}
+
+// Attention of one (query position, head): scores_j = q . k_j + bias[bucket(j - (i + q_off))][head] (no 1/sqrt(d) in T5),
+// causal: keys j <= i + q_off only; softmax; out = sum_j p_j v_j.  q [inner][Tq] (pitch qp), k / v [inner][Tk] (pitch kp).
+// bucket_lut: bucket of (j - i) at index (j - i) + lut_zero, or nullptr (cross attention: no position bias).
+__global__ __launch_bounds__(256) void g2p_attention_kernel(const float *q, int qp, const float *k, const float *v, int kp,
+                                                            const float *bias, const int *bucket_lut, int lut_zero,
+                                                            float *out, int op, int heads, int dk, int Tq, int Tk,
+                                                            int q_off, int causal) {
+    extern __shared__ float sc[];  // [Tk] scores, then [dk] reduction scratch
+    __shared__ float red[256];
+    const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int ipos = i + q_off;
+    const int lim = causal ? (ipos + 1 < Tk ? ipos + 1 : Tk) : Tk;
+    const float *qh = q + (int64_t)h * dk * qp + i;
+    float mx = -__builtin_inff();
+    for (int j = tid; j < lim; j += 256) {
+        float s = 0.f;
+        for (int d = 0; d < dk; d++) s += qh[(int64_t)d * qp] * k[((int64_t)h * dk + d) * kp + j];
+        if (bucket_lut) s += bias[bucket_lut[j - ipos + lut_zero] * heads + h];
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = tid; j < lim; j += 256) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float inv = 1.0f / red[0];
+    // out[d] = sum_j p_j v[d][j]: 256 threads = (256 / dkp) key groups x dkp channels
+    int dkp = 1;
+    while (dkp < dk) dkp <<= 1;
+    const int groups = 256 / dkp, d = tid % dkp, gidx = tid / dkp;
+    float acc = 0.f;
+    if (d < dk)
+        for (int j = gidx; j < lim; j += groups) acc += sc[j] * v[((int64_t)h * dk + d) * kp + j];
+    __syncthreads();
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < dkp && tid < dk) {
+        float a = 0.f;
+        for (int g2 = 0; g2 < groups; g2++) a += red[g2 * dkp + tid];
+        out[((int64_t)h * dk + tid) * op + i] = a * inv;
+    }
+}
+
+// T5DenseGatedActDense: h = act(a) * b;  T5DenseActDense: h = act(a)     act: 0 gelu_new, 1 relu, 2 gelu (erf)
+__global__ void g2p_act_kernel(const float *a, const float *b, float *out, int64_t n, int act) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i];
+    float y;
+    if (act == 1) y = fmaxf(x, 0.f);
+    else if (act == 2) y = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    else y = 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+    out[i] = b ? y * b[i] : y;
+}
+
+__global__ void g2p_scale_kernel(float *x, int64_t n, float s) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= s;
+}
+
+// argmax over the vocabulary of column t of logits [V][pitch] (first maximum, as np.argmax) -> ids[slot] (int64)
+__global__ __launch_bounds__(256) void g2p_argmax_kernel(const float *logits, int V, int pitch, int t, int64_t *ids, int slot) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const int tid = threadIdx.x;
+    float best = -__builtin_inff();
+    int idx = 0x7fffffff;
+    for (int c = tid; c < V; c += 256) {
+        const float v = logits[(int64_t)c * pitch + t];
+        if (v > best || (v == best && c < idx)) {
+            best = v;
+            idx = c;
+        }
+    }
+    bv[tid] = best;
+    bi[tid] = idx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o && (bv[tid + o] > bv[tid] || (bv[tid + o] == bv[tid] && bi[tid + o] < bi[tid]))) {
+            bv[tid] = bv[tid + o];
+            bi[tid] = bi[tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) ids[slot] = bi[0];
+}
+
+// logits [V][T] (channels-first) -> [T][V] (what the graph returns)
+__global__ void g2p_transpose_kernel(const float *in, float *out, int V, int T) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (c < V) out[(int64_t)t * V + c] = in[(int64_t)c * T + t];
+}
+
+}  // namespace
+
+struct g2p_handle {
+    G2PModel model;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    float *arena_dev = nullptr;
+    int *d_bucket_enc = nullptr, *d_bucket_dec = nullptr;
+    char *ws = nullptr;
+    size_t ws_cap = 0;
+    std::mutex mu;
+    std::string err;
+};
+
+namespace {
+
+int gfail(g2p_handle *h, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_g2p_open_error = buf;
+    return code;
+}
+
+struct Run {
+    g2p_handle *h;
+    hipStream_t st;
+    const float *A;
+    hipError_t err = hipSuccess;
+    char *ws;
+    size_t used = 0;
+    const float *P(int64_t off) const { return A + off; }
+    void note(hipError_t e) {
+        if (err == hipSuccess && e != hipSuccess) err = e;
+    }
+    template <class Tp>
+    Tp *take(size_t n) {
+        size_t off = (used + 255) & ~size_t(255);
+        used = off + n * sizeof(Tp);
+        return reinterpret_cast<Tp *>(ws + off);
+    }
+};
+
+// y[Cout][T] (pitch yp) = W x (x [Cin][T], pitch xp) [+ res]
+void linear(Run &r, const ConvDesc &d, const float *x, int xp, int T, float *y, int yp, const float *res = nullptr) {
+    ConvArgs a{};
+    a.x = x;
+    a.x_bstride = 0;
+    a.x_cstride = xp;
+    a.T = T;
+    a.wp = r.P(d.w_off);
+    a.out = y;
+    a.out_bstride = 0;
+    a.out_cstride = yp;
+    a.res = res;
+    a.res_bstride = 0;
+    a.zeros = r.P(r.h->model.zeros_off);
+    a.Cin = d.Cin;
+    a.Cout = d.Cout;
+    a.K = 1;
+    a.dil = 1;
+    a.padL = 0;
+    a.CK = d.CK;
+    a.nchunks = d.nchunks;
+    a.ups = 1;
+    a.flags = (res ? EPI_RES : 0) | (yp != T ? EPI_NO_PADFILL : 0);  // (a cache column is a window into wider rows)
+    a.slope = 1.f;
+    a.div = 1.f;
+    a.oslope = 1.f;
+    a.oslope2 = 1.f;
+    r.note(launch_conv(a, d.cfg, 1, r.st));
+}
+
+void rmsnorm(Run &r, const float *x, int xp, int64_t g, float *y, int yp, int T) {
+    const G2PModel &m = r.h->model;
+    g2p_rmsnorm_kernel<<<T, 256, 0, r.st>>>(x, r.P(g), y, m.d_model, T, xp, yp, m.eps);
+}
+
+void attention(Run &r, const float *q, int qp, const float *k, const float *v, int kp, int64_t bias, const int *lut, float *out,
+               int op, int Tq, int Tk, int q_off, bool causal) {
+    const G2PModel &m = r.h->model;
+    g2p_attention_kernel<<<dim3(Tq, m.heads), 256, (size_t)Tk * sizeof(float), r.st>>>(
+        q, qp, k, v, kp, bias >= 0 ? r.P(bias) : nullptr, lut, G2PModel::kMaxPos - 1, out, op, m.heads, m.d_kv, Tq, Tk, q_off,
+        causal ? 1 : 0);
+}
+
+void ffn(Run &r, const T5FfnDesc &f, const float *hn, float *x, int T, float *a, float *b) {
+    const G2PModel &m = r.h->model;
+    linear(r, f.wi0, hn, T, T, a, T);
+    if (f.gated) linear(r, f.wi1, hn, T, T, b, T);
+    const int64_t n = (int64_t)m.d_ff * T;
+    g2p_act_kernel<<<(unsigned)((n + 255) / 256), 256, 0, r.st>>>(a, f.gated ? b : nullptr, a, n, m.act);
+    linear(r, f.wo, a, T, T, x, T, x);  // x += wo(h)
+}
+
+int ws_reserve(g2p_handle *h, size_t bytes) {
+    if (bytes <= h->ws_cap) return 0;
+    if (h->ws) {
+        hipStreamSynchronize(h->stream);
+        hipFree(h->ws);
+        h->ws = nullptr;
+        h->ws_cap = 0;
+    }
+    const size_t want = bytes + bytes / 4 + (1 << 20);
+    if (hipMalloc((void **)&h->ws, want) != hipSuccess) return gfail(h, VITS_E_NOMEM, "hipMalloc(%zu) failed", want);
+    h->ws_cap = want;
+    return 0;
+}
+
+// encoder over ids [S] (device) -> enc_out [d_model][S]
+void run_encoder(Run &r, const int64_t *d_ids, int S, float *x, float *hn, float *q, float *k, float *v, float *att, float *fa,
+                 float *fb) {
+    g2p_handle *h = r.h;
+    const G2PModel &m = h->model;
+    g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, S), 256, 0, r.st>>>(d_ids, r.P(m.shared), x, m.d_model, S, S, m.vocab);
+    for (const auto &b : m.enc) {
+        rmsnorm(r, x, S, b.ln_self, hn, S, S);
+        linear(r, b.self.q, hn, S, S, q, S);
+        linear(r, b.self.k, hn, S, S, k, S);
+        linear(r, b.self.v, hn, S, S, v, S);
+        attention(r, q, S, k, v, S, m.enc_bias, h->d_bucket_enc, att, S, S, S, 0, false);
+        linear(r, b.self.o, att, S, S, x, S, x);
+        rmsnorm(r, x, S, b.ln_ffn, hn, S, S);
+        ffn(r, b.ffn, hn, x, S, fa, fb);
+    }
+    rmsnorm(r, x, S, m.enc_final_ln, x, S, S);
+}
+
+int check_dev(g2p_handle *h) {
+    if (!h) return VITS_E_ARG;
+    if (h->device < 0) return gfail(h, VITS_E_DEVICE, "handle was opened host-only");
+    if (hipSetDevice(h->device) != hipSuccess) return gfail(h, VITS_E_DEVICE, "hipSetDevice(%d) failed", h->device);
+    return 0;
+}
+
+int check_ids(g2p_handle *h, const int64_t *ids, int n, const char *what) {
+    for (int i = 0; i < n; i++)
+        if (ids[i] < 0 || ids[i] >= h->model.vocab)
+            return gfail(h, VITS_E_ARG, "%s[%d]=%lld is out of range [0,%d)", what, i, (long long)ids[i], h->model.vocab);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int g2p_open(const char *path, int device, g2p_handle **out) {
+    if (!out || !path) return gfail(nullptr, VITS_E_ARG, "null argument");
+    *out = nullptr;
+    OnnxModel om;
+    std::string e = om.load(path);
+    if (!e.empty()) return gfail(nullptr, e.rfind("cannot open", 0) == 0 ? VITS_E_IO : VITS_E_FORMAT, "%s", e.c_str());
+    g2p_handle *h = new g2p_handle();
+    e = h->model.build(om);
+    if (!e.empty()) {
+        delete h;
+        return gfail(nullptr, VITS_E_FORMAT, "%s: %s", path, e.c_str());
+    }
+    if (device >= 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || device >= n) {
+            delete h;
+            return gfail(nullptr, VITS_E_DEVICE, "no usable HIP device %d", device);
+        }
+        h->device = device;
+        const size_t bytes = h->model.arena.size() * 4, lut = h->model.bucket_enc.size() * sizeof(int);
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipMalloc((void **)&h->arena_dev, bytes) != hipSuccess ||
+            hipMemcpy(h->arena_dev, h->model.arena.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMalloc((void **)&h->d_bucket_enc, lut) != hipSuccess || hipMalloc((void **)&h->d_bucket_dec, lut) != hipSuccess ||
+            hipMemcpy(h->d_bucket_enc, h->model.bucket_enc.data(), lut, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_bucket_dec, h->model.bucket_dec.data(), lut, hipMemcpyHostToDevice) != hipSuccess) {
+            g2p_close(h);
+            return gfail(nullptr, VITS_E_NOMEM, "cannot place the G2P model on device %d", device);
+        }
+        std::vector<float>().swap(h->model.arena);  // the host copy is not needed again
+    }
+    *out = h;
+    return VITS_OK;
+}
+
+void g2p_close(g2p_handle *h) {
+    if (!h) return;
+    if (h->device >= 0) {
+        hipSetDevice(h->device);
+        if (h->stream) hipStreamSynchronize(h->stream);
+        if (h->arena_dev) hipFree(h->arena_dev);
+        if (h->d_bucket_enc) hipFree(h->d_bucket_enc);
+        if (h->d_bucket_dec) hipFree(h->d_bucket_dec);
+        if (h->ws) hipFree(h->ws);
+        if (h->stream) hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+const char *g2p_last_error(g2p_handle *h) { return h ? h->err.c_str() : g_g2p_open_error.c_str(); }
+
+int g2p_hparam(g2p_handle *h, const char *key, int64_t *out) {
+    if (!h || !key || !out) return VITS_E_ARG;
+    const G2PModel &m = h->model;
+    const std::string k = key;
+    if (k == "vocab") *out = m.vocab;
+    else if (k == "d_model") *out = m.d_model;
+    else if (k == "heads") *out = m.heads;
+    else if (k == "d_kv") *out = m.d_kv;
+    else if (k == "d_ff") *out = m.d_ff;
+    else if (k == "n_enc") *out = (int64_t)m.enc.size();
+    else if (k == "n_dec") *out = (int64_t)m.dec.size();
+    else if (k == "num_buckets") *out = m.num_buckets;
+    else if (k == "max_distance") *out = m.max_distance;
+    else if (k == "gated") *out = m.enc[0].ffn.gated ? 1 : 0;
+    else if (k == "act") *out = m.act;
+    else if (k == "scale_out") *out = m.scale_out ? 1 : 0;
+    else if (k == "max_positions") *out = G2PModel::kMaxPos;
+    else return gfail(h, VITS_E_ARG, "unknown hparam %s", key);
+    return VITS_OK;
+}
+
+int g2p_num_outputs(g2p_handle *h) { return h ? (int)(h->model.output_names.empty() ? 1 : h->model.output_names.size()) : 0; }
+const char *g2p_output_name(g2p_handle *h, int i) {
+    if (!h || i < 0) return nullptr;
+    if (h->model.output_names.empty()) return i == 0 ? "logits" : nullptr;
+    return i < (int)h->model.output_names.size() ? h->model.output_names[i].c_str() : nullptr;
+}
+
+int g2p_bucket(g2p_handle *h, int decoder, int rel) {
+    if (!h || rel <= -G2PModel::kMaxPos || rel >= G2PModel::kMaxPos) return VITS_E_ARG;
+    return (decoder ? h->model.bucket_dec : h->model.bucket_enc)[rel + G2PModel::kMaxPos - 1];
+}
+
+int g2p_run(g2p_handle *h, const int64_t *input_ids, int S, const int64_t *mask, const int64_t *dec_ids, int T, float *logits) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const G2PModel &m = h->model;
+    if (!input_ids || !dec_ids || !logits || S <= 0 || T <= 0) return gfail(h, VITS_E_ARG, "bad g2p_run arguments");
+    if (S >= G2PModel::kMaxPos || T >= G2PModel::kMaxPos) return gfail(h, VITS_E_ARG, "sequence longer than %d", G2PModel::kMaxPos - 1);
+    if (int rc = check_ids(h, input_ids, S, "input_ids")) return rc;
+    if (int rc = check_ids(h, dec_ids, T, "decoder_input_ids")) return rc;
+    for (int i = 0; mask && i < S; i++)
+        if (mask[i] != 1) return gfail(h, VITS_E_ARG, "attention_mask with zeros is not supported (mul.py:187 passes all ones)");
+    const int L = S > T ? S : T;
+    const size_t per = (size_t)(m.d_model > m.inner ? m.d_model : m.inner) * L * 4 + 512;
+    const size_t need = 8 * per + 2 * ((size_t)m.d_ff * L * 4 + 512) + (size_t)m.vocab * T * 8 + (size_t)(S + T) * 8 + 4096 +
+                        2 * ((size_t)m.inner * S * 4 + 512);
+    if (int rc = ws_reserve(h, need)) return rc;
+    Run r{h, h->stream, h->arena_dev};
+    r.ws = h->ws;
+    int64_t *d_in = r.take<int64_t>(S), *d_dec = r.take<int64_t>(T);
+    const size_t nA = (size_t)(m.d_model > m.inner ? m.d_model : m.inner) * L;
+    float *xe = r.take<float>(nA), *xd = r.take<float>(nA), *hn = r.take<float>(nA), *q = r.take<float>(nA);
+    float *k = r.take<float>(nA), *v = r.take<float>(nA), *att = r.take<float>(nA);
+    float *fa = r.take<float>((size_t)m.d_ff * L), *fb = r.take<float>((size_t)m.d_ff * L);
+    float *kc = r.take<float>((size_t)m.inner * S), *vc = r.take<float>((size_t)m.inner * S);
+    float *lg = r.take<float>((size_t)m.vocab * T), *lgt = r.take<float>((size_t)m.vocab * T);
+    hipStream_t st = h->stream;
+    r.note(hipMemcpyAsync(d_in, input_ids, (size_t)S * 8, hipMemcpyHostToDevice, st));
+    r.note(hipMemcpyAsync(d_dec, dec_ids, (size_t)T * 8, hipMemcpyHostToDevice, st));
+    run_encoder(r, d_in, S, xe, hn, q, k, v, att, fa, fb);
+    // decoder over the whole prefix (teacher forced, causal)
+    g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, T), 256, 0, st>>>(d_dec, r.P(m.shared), xd, m.d_model, T, T, m.vocab);
+    for (const auto &b : m.dec) {
+        rmsnorm(r, xd, T, b.ln_self, hn, T, T);
+        linear(r, b.self.q, hn, T, T, q, T);
+        linear(r, b.self.k, hn, T, T, k, T);
+        linear(r, b.self.v, hn, T, T, v, T);
+        attention(r, q, T, k, v, T, m.dec_bias, h->d_bucket_dec, att, T, T, T, 0, true);
+        linear(r, b.self.o, att, T, T, xd, T, xd);
+        rmsnorm(r, xd, T, b.ln_cross, hn, T, T);
+        linear(r, b.cross.q, hn, T, T, q, T);
+        linear(r, b.cross.k, xe, S, S, kc, S);
+        linear(r, b.cross.v, xe, S, S, vc, S);
+        attention(r, q, T, kc, vc, S, -1, nullptr, att, T, T, S, 0, false);
+        linear(r, b.cross.o, att, T, T, xd, T, xd);
+        rmsnorm(r, xd, T, b.ln_ffn, hn, T, T);
+        ffn(r, b.ffn, hn, xd, T, fa, fb);
+    }
+    rmsnorm(r, xd, T, m.dec_final_ln, xd, T, T);
+    if (m.scale_out) {
+        const int64_t n = (int64_t)m.d_model * T;
+        g2p_scale_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(xd, n, 1.0f / std::sqrt((float)m.d_model));
+    }
+    linear(r, m.lm_head, xd, T, T, lg, T);
+    g2p_transpose_kernel<<<dim3((m.vocab + 255) / 256, T), 256, 0, st>>>(lg, lgt, m.vocab, T);
+    r.note(hipGetLastError());
+    r.note(hipMemcpyAsync(logits, lgt, (size_t)m.vocab * T * 4, hipMemcpyDeviceToHost, st));
+    r.note(hipStreamSynchronize(st));
+    if (r.err != hipSuccess) return gfail(h, VITS_E_DEVICE, "g2p_run failed: %s", hipGetErrorString(r.err));
+    return VITS_OK;
+}
+
+int g2p_generate(g2p_handle *h, const int64_t *input_ids, int S, int max_length, int64_t start_id, int64_t eos_id,
+                 int64_t *out_ids, int *n_out) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const G2PModel &m = h->model;
+    if (!input_ids || !out_ids || !n_out || S <= 0 || max_length <= 0) return gfail(h, VITS_E_ARG, "bad g2p_generate arguments");
+    if (S >= G2PModel::kMaxPos || max_length >= G2PModel::kMaxPos)
+        return gfail(h, VITS_E_ARG, "sequence longer than %d", G2PModel::kMaxPos - 1);
+    if (int rc = check_ids(h, input_ids, S, "input_ids")) return rc;
+    if (start_id < 0 || start_id >= m.vocab) return gfail(h, VITS_E_ARG, "start id out of range");
+    const int TM = max_length + 1;  // decoder positions: the start token + every generated one
+    const size_t nA = (size_t)(m.d_model > m.inner ? m.d_model : m.inner) * S;
+    const int nd = (int)m.dec.size();
+    const size_t need = 8 * (nA * 4 + 512) + 2 * ((size_t)m.d_ff * S * 4 + 512) + (size_t)nd * 2 * ((size_t)m.inner * TM * 4 + 512) +
+                        (size_t)nd * 2 * ((size_t)m.inner * S * 4 + 512) + (size_t)(S + TM) * 8 + (size_t)m.vocab * 4 + (1 << 16) +
+                        8 * ((size_t)m.d_ff * 4 + (size_t)m.d_model * 4 + 1024);
+    if (int rc = ws_reserve(h, need)) return rc;
+    Run r{h, h->stream, h->arena_dev};
+    r.ws = h->ws;
+    hipStream_t st = h->stream;
+    int64_t *d_in = r.take<int64_t>(S), *d_gen = r.take<int64_t>(TM);
+    float *xe = r.take<float>(nA), *hn = r.take<float>(nA), *q = r.take<float>(nA), *k = r.take<float>(nA);
+    float *v = r.take<float>(nA), *att = r.take<float>(nA);
+    float *fa = r.take<float>((size_t)m.d_ff * S), *fb = r.take<float>((size_t)m.d_ff * S);
+    std::vector<float *> ks(nd), vs(nd), kc(nd), vc(nd);
+    for (int l = 0; l < nd; l++) {
+        ks[l] = r.take<float>((size_t)m.inner * TM);  // self-attention cache [inner][TM]
+        vs[l] = r.take<float>((size_t)m.inner * TM);
+        kc[l] = r.take<float>((size_t)m.inner * S);   // cross-attention keys / values of the encoder output
+        vc[l] = r.take<float>((size_t)m.inner * S);
+    }
+    float *x1 = r.take<float>(m.d_model), *h1 = r.take<float>(m.d_model), *q1 = r.take<float>(m.inner);
+    float *a1 = r.take<float>(m.inner), *f1 = r.take<float>(m.d_ff), *f2 = r.take<float>(m.d_ff), *lg = r.take<float>(m.vocab);
+    r.note(hipMemcpyAsync(d_in, input_ids, (size_t)S * 8, hipMemcpyHostToDevice, st));
+    r.note(hipMemcpyAsync(d_gen, &start_id, 8, hipMemcpyHostToDevice, st));
+    run_encoder(r, d_in, S, xe, hn, q, k, v, att, fa, fb);
+    for (int l = 0; l < nd; l++) {
+        linear(r, m.dec[l].cross.k, xe, S, S, kc[l], S);
+        linear(r, m.dec[l].cross.v, xe, S, S, vc[l], S);
+    }
+    int n = 0;
+    for (int t = 0; t < max_length; t++) {
+        // one decoder step for position t (input: d_gen[t]); keys / values of position t join the cache
+        g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, 1), 256, 0, st>>>(d_gen + t, r.P(m.shared), x1, m.d_model, 1, 1, m.vocab);
+        for (int l = 0; l < nd; l++) {
+            const auto &b = m.dec[l];
+            rmsnorm(r, x1, 1, b.ln_self, h1, 1, 1);
+            linear(r, b.self.q, h1, 1, 1, q1, 1);
+            linear(r, b.self.k, h1, 1, 1, ks[l] + t, TM);
+            linear(r, b.self.v, h1, 1, 1, vs[l] + t, TM);
+            attention(r, q1, 1, ks[l], vs[l], TM, m.dec_bias, h->d_bucket_dec, a1, 1, 1, t + 1, t, true);
+            linear(r, b.self.o, a1, 1, 1, x1, 1, x1);
+            rmsnorm(r, x1, 1, b.ln_cross, h1, 1, 1);
+            linear(r, b.cross.q, h1, 1, 1, q1, 1);
+            attention(r, q1, 1, kc[l], vc[l], S, -1, nullptr, a1, 1, 1, S, 0, false);
+            linear(r, b.cross.o, a1, 1, 1, x1, 1, x1);
+            rmsnorm(r, x1, 1, b.ln_ffn, h1, 1, 1);
+            ffn(r, b.ffn, h1, x1, 1, f1, f2);
+        }
+        rmsnorm(r, x1, 1, m.dec_final_ln, h1, 1, 1);
+        if (m.scale_out) g2p_scale_kernel<<<(m.d_model + 255) / 256, 256, 0, st>>>(h1, m.d_model, 1.0f / std::sqrt((float)m.d_model));
+        linear(r, m.lm_head, h1, 1, 1, lg, 1);
+        g2p_argmax_kernel<<<1, 256, 0, st>>>(lg, m.vocab, 1, 0, d_gen, t + 1);
+        r.note(hipGetLastError());
+        int64_t tok = 0;
+        r.note(hipMemcpyAsync(&tok, d_gen + t + 1, 8, hipMemcpyDeviceToHost, st));
+        r.note(hipStreamSynchronize(st));  // (the loop's one data-dependent decision: stop at EOS)
+        if (r.err != hipSuccess) return gfail(h, VITS_E_DEVICE, "g2p_generate failed: %s", hipGetErrorString(r.err));
+        out_ids[n++] = tok;
+        if (tok == eos_id) break;
+    }
+    *n_out = n;
+    return VITS_OK;
+}
+
+}  // extern "C"

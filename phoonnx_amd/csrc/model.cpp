@@ -6,6 +6,7 @@
 // initializers.  Node names carry the module path
 // ("/flow/flows.6/enc/in_layers.0/Conv"), which is what we key on.
 #include "model.hpp"
+#include "g2p_model.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -1057,6 +1058,243 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
             if (gin) input_names.push_back("sid");
         }
         arena_floats = P.size;
+    } catch (const std::exception &e) {
+        return e.what();
+    }
+    return "";
+}
+
+
+// ====================================================================================== ByT5 G2P
+// Parameters are found by following nodes, as for VITS: every Linear is a MatMul whose second input is an anonymous
+// transposed initializer [in, out]; node names carry the module path (".../encoder/block.3/layer.0/SelfAttention/q/MatMul",
+// with whatever prefix the exporting wrapper added).
+
+namespace {
+
+struct T5Refs {
+    std::map<std::string, TRef> t;  // "encoder.3.0.SelfAttention.q" -> [in, out]; "...layer_norm" -> [d]; "shared"; "lm_head"
+};
+
+// module path components after the last "encoder/" or "decoder/" component of a node name
+bool t5_parse(const std::string &name, std::string &stack, std::vector<std::string> &rest) {
+    std::vector<std::string> parts;
+    std::string cur;
+    for (char c : name) {
+        if (c == '/') {
+            if (!cur.empty()) parts.push_back(cur);
+            cur.clear();
+        } else
+            cur.push_back(c);
+    }
+    if (!cur.empty()) parts.push_back(cur);
+    int at = -1;
+    for (int i = 0; i < int(parts.size()); i++)
+        if (parts[i] == "encoder" || parts[i] == "decoder") at = i;
+    if (at < 0) return false;
+    stack = parts[at];
+    rest.assign(parts.begin() + at + 1, parts.end());
+    return true;
+}
+
+int t5_index(const std::string &s, const char *prefix) {  // "block.12" -> 12
+    const size_t n = std::strlen(prefix);
+    if (s.compare(0, n, prefix) != 0 || s.size() == n) return -1;
+    int v = 0;
+    for (size_t i = n; i < s.size(); i++) {
+        if (s[i] < '0' || s[i] > '9') return -1;
+        v = v * 10 + (s[i] - '0');
+        if (v > 4096) return -1;
+    }
+    return v;
+}
+
+}  // namespace
+
+std::string G2PModel::build(const OnnxModel &om) {
+    try {
+        T5Refs R;
+        auto init = [&](const std::string &n) -> const OnnxTensor * {
+            auto it = om.init.find(n);
+            return it == om.init.end() ? nullptr : &it->second;
+        };
+        auto put = [&](const std::string &key, const OnnxTensor *ot, size_t rank) {
+            if (!ot || !ot->data() || ot->dims.size() != rank || R.t.count(key)) return;
+            for (auto d : ot->dims)
+                if (d <= 0) return;
+            const float *p = ot->data();
+            const int64_t n = ot->numel();
+            for (int64_t i = 0; i < n; i++)
+                if (!std::isfinite(p[i])) throw std::runtime_error("non-finite value in parameter " + key);
+            TRef r;
+            r.p = p;
+            r.dims = ot->dims;
+            R.t[key] = r;
+        };
+        std::map<std::string, const OnnxNode *> producer;
+        const OnnxNode *lm_node = nullptr;
+        bool saw_tanh = false, saw_erf = false, saw_relu = false;
+        for (const auto &n : om.nodes) {
+            for (const auto &o : n.outputs) producer[o] = &n;
+            if (n.name.empty()) continue;
+            if (n.name.find("DenseReluDense") != std::string::npos) {
+                saw_tanh = saw_tanh || n.op == "Tanh";
+                saw_erf = saw_erf || n.op == "Erf";
+                saw_relu = saw_relu || n.op == "Relu";
+            }
+            if (n.op == "MatMul" && n.inputs.size() > 1 && n.name.size() >= 14 &&
+                n.name.compare(n.name.size() - 14, 14, "lm_head/MatMul") == 0) {
+                put("lm_head", init(n.inputs[1]), 2);
+                lm_node = &n;
+                continue;
+            }
+            std::string stack;
+            std::vector<std::string> rest;
+            if (!t5_parse(n.name, stack, rest)) continue;
+            if (n.op == "Gather" && rest.size() == 2 && rest[0] == "embed_tokens" && !n.inputs.empty()) {
+                put("shared", init(n.inputs[0]), 2);
+                continue;
+            }
+            if (n.op == "Mul" && rest.size() == 2 && rest[0] == "final_layer_norm") {
+                for (const auto &i : n.inputs) put(stack + ".final_layer_norm", init(i), 1);
+                continue;
+            }
+            if (rest.size() < 3) continue;
+            const int blk = t5_index(rest[0], "block."), lay = t5_index(rest[1], "layer.");
+            if (blk < 0 || lay < 0) continue;
+            const std::string base = stack + "." + std::to_string(blk) + "." + std::to_string(lay);
+            if (n.op == "Mul" && rest.size() == 4 && rest[2] == "layer_norm") {
+                for (const auto &i : n.inputs) put(base + ".layer_norm", init(i), 1);
+            } else if (n.op == "MatMul" && rest.size() == 5 && n.inputs.size() > 1) {
+                put(base + "." + rest[2] + "." + rest[3], init(n.inputs[1]), 2);  // SelfAttention.q, DenseReluDense.wi_0 ...
+            } else if (n.op == "Gather" && rest.size() == 5 && rest[3] == "relative_attention_bias" && !n.inputs.empty()) {
+                put(base + "." + rest[2] + ".relative_attention_bias", init(n.inputs[0]), 2);
+            }
+        }
+        auto need = [&](const std::string &k, size_t rank) -> const TRef & {
+            auto it = R.t.find(k);
+            if (it == R.t.end()) throw std::runtime_error("T5 parameter not found in graph: " + k);
+            if (it->second.dims.size() != rank) throw std::runtime_error(k + ": unexpected rank");
+            return it->second;
+        };
+        input_names = om.inputs;
+        output_names = om.outputs;
+        for (const auto &n : input_names)
+            if (n != "input_ids" && n != "attention_mask" && n != "decoder_input_ids")
+                throw std::runtime_error("unsupported graph input '" + n + "' (expected the T5 seq2seq signature)");
+        const TRef &emb = need("shared", 2);
+        vocab = int(emb.dims[0]);
+        d_model = int(emb.dims[1]);
+        const TRef &rb = need("encoder.0.0.SelfAttention.relative_attention_bias", 2);
+        num_buckets = int(rb.dims[0]);
+        heads = int(rb.dims[1]);
+        const TRef &q0 = need("encoder.0.0.SelfAttention.q", 2);
+        if (q0.dims[0] != d_model || heads <= 0 || q0.dims[1] % heads) throw std::runtime_error("unexpected attention shape");
+        inner = int(q0.dims[1]);
+        d_kv = inner / heads;
+        if (d_kv > 256 || num_buckets < 2 || num_buckets % 2) throw std::runtime_error("unsupported T5 attention geometry");
+        act = saw_tanh ? 0 : (saw_erf ? 2 : (saw_relu ? 1 : 0));
+        if (lm_node) {  // a Mul between the decoder's final layer norm and lm_head = the tied-embedding output scale
+            auto it = producer.find(lm_node->inputs[0]);
+            scale_out = it != producer.end() && it->second->op == "Mul" &&
+                        it->second->name.find("final_layer_norm") == std::string::npos;
+        }
+        arena.clear();
+        Packer P(arena, false);
+        zeros_off = P.alloc(1024);
+        t_hint = 2;
+        t_sx_f16 = false;
+        auto linear = [&](const std::string &key, int in, int out) {
+            const TRef &w = need(key, 2);
+            if (w.dims[0] != in || w.dims[1] != out)
+                throw std::runtime_error(key + ": expected [" + std::to_string(in) + ", " + std::to_string(out) + "]");
+            const float *wp = w.p;
+            const int64_t ld = w.dims[1];
+            auto wf = [&](int co, int ci, int) { return wp[int64_t(ci) * ld + co]; };  // MatMul initializers are [in, out]
+            return pack_conv(P, in, out, 1, 1, 0, wf, nullptr);
+        };
+        auto vec = [&](const std::string &key) {
+            const TRef &g = need(key, 1);
+            if (g.dims[0] != d_model) throw std::runtime_error(key + ": expected d_model values");
+            return P.put(g);
+        };
+        shared = P.put(emb);
+        enc_bias = P.put(rb);
+        const TRef &rbd = need("decoder.0.0.SelfAttention.relative_attention_bias", 2);
+        if (rbd.dims[0] != num_buckets || rbd.dims[1] != heads) throw std::runtime_error("decoder bias table differs from the encoder's");
+        dec_bias = P.put(rbd);
+        auto attn = [&](const std::string &pfx) {
+            T5AttnDesc a;
+            a.q = linear(pfx + ".q", d_model, inner);
+            a.k = linear(pfx + ".k", d_model, inner);
+            a.v = linear(pfx + ".v", d_model, inner);
+            a.o = linear(pfx + ".o", inner, d_model);
+            return a;
+        };
+        auto ffn = [&](const std::string &pfx) {
+            T5FfnDesc f;
+            f.gated = R.t.count(pfx + ".wi_0") != 0;
+            const TRef &w0 = need(pfx + (f.gated ? ".wi_0" : ".wi"), 2);
+            const int ff = int(w0.dims[1]);
+            if (d_ff && ff != d_ff) throw std::runtime_error("feed-forward widths differ between blocks");
+            d_ff = ff;
+            f.wi0 = linear(pfx + (f.gated ? ".wi_0" : ".wi"), d_model, ff);
+            if (f.gated) f.wi1 = linear(pfx + ".wi_1", d_model, ff);
+            f.wo = linear(pfx + ".wo", ff, d_model);
+            return f;
+        };
+        for (int b = 0;; b++) {
+            const std::string e = "encoder." + std::to_string(b);
+            if (!R.t.count(e + ".0.SelfAttention.q")) break;
+            T5BlockDesc d;
+            d.ln_self = vec(e + ".0.layer_norm");
+            d.self = attn(e + ".0.SelfAttention");
+            d.ln_ffn = vec(e + ".1.layer_norm");
+            d.ffn = ffn(e + ".1.DenseReluDense");
+            enc.push_back(d);
+        }
+        for (int b = 0;; b++) {
+            const std::string e = "decoder." + std::to_string(b);
+            if (!R.t.count(e + ".0.SelfAttention.q")) break;
+            T5BlockDesc d;
+            d.ln_self = vec(e + ".0.layer_norm");
+            d.self = attn(e + ".0.SelfAttention");
+            d.ln_cross = vec(e + ".1.layer_norm");
+            d.cross = attn(e + ".1.EncDecAttention");
+            d.ln_ffn = vec(e + ".2.layer_norm");
+            d.ffn = ffn(e + ".2.DenseReluDense");
+            dec.push_back(d);
+        }
+        if (enc.empty() || dec.empty()) throw std::runtime_error("no T5 encoder / decoder blocks found");
+        enc_final_ln = vec("encoder.final_layer_norm");
+        dec_final_ln = vec("decoder.final_layer_norm");
+        lm_head = linear("lm_head", d_model, vocab);
+        arena_floats = P.size;
+        // relative-position buckets (integers: the float32 arithmetic of the published function, step by step)
+        bucket_enc.assign(2 * kMaxPos - 1, 0);
+        bucket_dec.assign(2 * kMaxPos - 1, 0);
+        for (int d = -(kMaxPos - 1); d < kMaxPos; d++) {
+            for (int bidir = 0; bidir < 2; bidir++) {
+                int nb = num_buckets, ret = 0, n;
+                if (bidir) {
+                    nb /= 2;
+                    ret = d > 0 ? nb : 0;
+                    n = d < 0 ? -d : d;
+                } else
+                    n = d < 0 ? -d : 0;
+                const int max_exact = nb / 2;
+                int bucket;
+                if (n < max_exact) bucket = n;
+                else {
+                    const float ratio = float(n) / float(max_exact);
+                    const float denom = float(std::log(double(max_distance) / double(max_exact)));  // python float -> f32 scalar
+                    const float v = std::log(ratio) / denom * float(nb - max_exact);
+                    bucket = max_exact + int(v);
+                    if (bucket > nb - 1) bucket = nb - 1;
+                }
+                (bidir ? bucket_enc : bucket_dec)[d + kMaxPos - 1] = ret + bucket;
+            }
+        }
     } catch (const std::exception &e) {
         return e.what();
     }

@@ -1,0 +1,161 @@
+"""ByT5 G2P on the MI355X: the session object that stands where `onnxruntime.InferenceSession` stands in
+`phoonnx/phonemizers/mul.py:106`, and a mirror of `ByT5Phonemizer` around it.
+
+    MiG2PSession(path)                       mul.py:106
+    session.get_outputs() -> [.name]         mul.py:183
+    session.run(names, feed) -> [logits]     mul.py:199-211   (float32 [1, T, vocab])
+plus `generate(input_ids)`: the whole greedy loop of mul.py:192-230 in one engine call with a key/value cache (the
+reference re-runs the entire graph, encoder included, for every generated token).
+
+No CPU fallback: without libvitsmi.so and an MI355X this raises.
+"""
+import ctypes as C
+import json
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .session import NodeArg, SessionError
+
+BYT5_LANGS = ['ca-ES', 'cy-GB', 'da-DK', 'de-DE', 'en-GB', 'en-US', 'es-ES', 'et-EE', 'eu-ES', 'fa-IR', 'fr-FR',
+              'ga-IE', 'hr-HR', 'hu-HU', 'id-ID', 'is-IS', 'it-IT', 'ja-JP', 'ko-KR', 'nb-NO', 'nl-NL', 'pl-PL',
+              'pt-BR', 'pt-PT', 'qu-PE', 'ro-RO', 'sr-RS', 'sv-SE', 'tr-TR', 'yue-CN', 'zh-CN']  # mul.py:31-33
+
+
+def encode_text(text: str, lang: str) -> np.ndarray:
+    """`ByT5Phonemizer._encode_text` (mul.py:152-170): "<lang>: text" as UTF-8 bytes, shifted by the 3 special ids."""
+    data = f"<{lang}>: {text}".encode("utf-8")
+    return np.array([[b + 3 for b in data]], dtype=np.int64)
+
+
+def decode_phones(preds: Sequence[int], added_tokens: Dict[str, object]) -> str:
+    """`ByT5Phonemizer._decode_phones` (mul.py:135-150): ids minus 3 are bytes; special / added tokens are dropped."""
+    data = b"".join(bytes([t - 3]) for t in preds if str(t) not in added_tokens)
+    return data.decode("utf-8", errors="ignore")
+
+
+class MiG2PSession:
+    def __init__(self, path, sess_options=None, providers=None, device_id: int = 0, host_only: bool = False, **kwargs):
+        self._lib = _ffi.load()
+        self._h = C.c_void_p()
+        self.path = str(path)
+        rc = self._lib.g2p_open(self.path.encode(), -1 if host_only else device_id, C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise SessionError(f"g2p_open({self.path!r}) failed [{rc}]: {self._lib.g2p_last_error(None).decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.g2p_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self):
+        return self._lib.g2p_last_error(self._h).decode("utf-8", "replace")
+
+    def hparam(self, key) -> int:
+        v = C.c_int64()
+        if self._lib.g2p_hparam(self._h, key.encode(), C.byref(v)) != 0:
+            raise SessionError(self._err())
+        return v.value
+
+    def bucket(self, rel: int, decoder: bool = False) -> int:
+        return self._lib.g2p_bucket(self._h, 1 if decoder else 0, int(rel))
+
+    # ------------------------------------------------------------------ onnxruntime surface
+    def get_inputs(self) -> List[NodeArg]:
+        return [NodeArg(n, "tensor(int64)", ["batch", "sequence"]) for n in ("input_ids", "attention_mask", "decoder_input_ids")]
+
+    def get_outputs(self) -> List[NodeArg]:
+        n = self._lib.g2p_num_outputs(self._h)
+        return [NodeArg(self._lib.g2p_output_name(self._h, i).decode(), "tensor(float)", ["batch", "target", "vocab"])
+                for i in range(n)]
+
+    def run(self, output_names: Optional[Sequence[str]], input_feed: Dict[str, np.ndarray], run_options=None):
+        names = [o.name for o in self.get_outputs()]
+        if output_names is not None and any(n not in names for n in output_names):
+            raise SessionError(f"unknown output names {output_names!r}")
+        for k in input_feed:
+            if k not in ("input_ids", "attention_mask", "decoder_input_ids"):
+                raise SessionError(f"Invalid input name: {k}")
+        for k in ("input_ids", "decoder_input_ids"):
+            if k not in input_feed:
+                raise SessionError(f"Required input {k} is missing")
+        ids = np.ascontiguousarray(input_feed["input_ids"])
+        dec = np.ascontiguousarray(input_feed["decoder_input_ids"])
+        mask = input_feed.get("attention_mask")
+        if ids.dtype != np.int64 or dec.dtype != np.int64 or ids.ndim != 2 or dec.ndim != 2 or ids.shape[0] != 1 or dec.shape[0] != 1:
+            raise SessionError("input_ids / decoder_input_ids must be int64 of shape [1, length] (batch 1, as mul.py feeds them)")
+        if mask is not None:
+            mask = np.ascontiguousarray(mask)
+            if mask.dtype != np.int64 or mask.shape != ids.shape:
+                raise SessionError("attention_mask must be int64 with the shape of input_ids")
+        T, V = dec.shape[1], self.hparam("vocab")
+        out = np.empty((1, T, V), np.float32)
+        rc = self._lib.g2p_run(self._h, _ffi.ptr(ids), ids.shape[1], _ffi.ptr(mask), _ffi.ptr(dec), T, _ffi.ptr(out))
+        if rc != 0:
+            raise SessionError(f"g2p_run failed [{rc}]: {self._err()}")
+        return [out]
+
+    # ------------------------------------------------------------------ extension: the whole greedy loop on the device
+    def generate(self, input_ids, max_length: int = 512, start_id: int = 0, eos_id: int = 1) -> List[int]:
+        ids = np.ascontiguousarray(np.asarray(input_ids, np.int64).reshape(-1))
+        out = np.zeros(max_length, np.int64)
+        n = C.c_int(0)
+        rc = self._lib.g2p_generate(self._h, _ffi.ptr(ids), ids.shape[0], int(max_length), int(start_id), int(eos_id),
+                                    _ffi.ptr(out), C.byref(n))
+        if rc != 0:
+            raise SessionError(f"g2p_generate failed [{rc}]: {self._err()}")
+        return out[:n.value].tolist()
+
+
+class ByT5Phonemizer:
+    """Mirror of `phoonnx.phonemizers.mul.ByT5Phonemizer` over `MiG2PSession` (no downloads: the model and tokenizer
+    config are files the caller supplies).  `phonemize_string(text, lang)` as mul.py:232-233."""
+
+    def __init__(self, model: str, tokenizer_config: Optional[str] = None, device_id: int = 0, device_loop: bool = True):
+        self.session = MiG2PSession(model, device_id=device_id)
+        self.tokens: Dict[str, object] = {"0": "<pad>", "1": "</s>", "2": "<unk>"}
+        if tokenizer_config:
+            with open(tokenizer_config, "r") as f:
+                self.tokens = json.load(f).get("added_tokens_decoder", {})
+        self.device_loop = device_loop
+
+    @staticmethod
+    def get_lang(target_lang: str) -> str:
+        if target_lang in BYT5_LANGS:
+            return target_lang
+        base = target_lang.split("-")[0].lower()
+        for l in BYT5_LANGS:  # (the reference resolves through langcodes: closest supported tag)
+            if l.split("-")[0].lower() == base:
+                return l
+        raise ValueError(f"unsupported language {target_lang}")
+
+    def _infer(self, text: str, lang: str, max_length: int = 512) -> str:
+        if not text.strip():
+            return ""
+        ids = encode_text(text, self.get_lang(lang))
+        if self.device_loop:
+            return decode_phones(self.session.generate(ids[0], max_length), self.tokens)
+        # the reference's loop, call for call (mul.py:192-230)
+        names = [o.name for o in self.session.get_outputs()]
+        mask = np.ones_like(ids)
+        dec = np.array([[0]], np.int64)
+        gen: List[int] = []
+        for _ in range(max_length):
+            logits = self.session.run(names, {"input_ids": ids, "attention_mask": mask, "decoder_input_ids": dec})[0]
+            nxt = int(np.argmax(logits[0, -1, :]))
+            gen.append(nxt)
+            if nxt == 1:
+                break
+            dec = np.concatenate((dec, np.array([[nxt]], np.int64)), axis=1)
+        return decode_phones(gen, self.tokens)
+
+    def phonemize_string(self, text: str, lang: str) -> str:
+        return self._infer(text, lang)
