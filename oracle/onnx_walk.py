@@ -200,6 +200,11 @@ class OnnxModel:
         for n in self.nodes:
             if n.op == "Constant" and "value" in n.attrs and n.attrs["value"] is not None:
                 self.const[n.outputs[0]] = n.attrs["value"]
+        # Identity nodes: the exporter de-duplicates initializers with identical bytes (e.g. every layer-norm weight of a
+        # freshly initialised model) and re-introduces the other names as Identity(kept name)
+        for n in self.nodes:
+            if n.op == "Identity" and n.inputs and n.outputs and n.inputs[0] in self.init and n.outputs[0] not in self.init:
+                self.init[n.outputs[0]] = self.init[n.inputs[0]]
         self.inputs = [i for i in self.inputs if i not in self.init]
 
     def tensor(self, name):

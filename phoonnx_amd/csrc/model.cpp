@@ -100,10 +100,7 @@ void split_path(const std::string &node_name, std::string &mod, std::string &lea
 }
 
 void resolve(const OnnxModel &om, Resolver &R) {
-    auto init = [&](const std::string &n) -> const OnnxTensor * {
-        auto it = om.init.find(n);
-        return it == om.init.end() ? nullptr : &it->second;
-    };
+    auto init = [&](const std::string &n) -> const OnnxTensor * { return om.find_init(n); };
     std::map<std::string, int> pad_seen;
     for (const auto &n : om.nodes) {
         if (n.name.empty()) continue;
@@ -1114,10 +1111,7 @@ int t5_index(const std::string &s, const char *prefix) {  // "block.12" -> 12
 std::string G2PModel::build(const OnnxModel &om) {
     try {
         T5Refs R;
-        auto init = [&](const std::string &n) -> const OnnxTensor * {
-            auto it = om.init.find(n);
-            return it == om.init.end() ? nullptr : &it->second;
-        };
+        auto init = [&](const std::string &n) -> const OnnxTensor * { return om.find_init(n); };
         auto put = [&](const std::string &key, const OnnxTensor *ot, size_t rank) {
             if (!ot || !ot->data() || ot->dims.size() != rank || R.t.count(key)) return;
             for (auto d : ot->dims)

@@ -212,6 +212,9 @@ std::string OnnxModel::load(const std::string &path) {
         }
         for (auto &n : all_inputs)
             if (!init.count(n)) inputs.push_back(n);
+        for (const auto &n : nodes)
+            if (n.op == "Identity" && !n.inputs.empty() && !n.outputs.empty() && !init.count(n.outputs[0]))
+                alias[n.outputs[0]] = n.inputs[0];
     } catch (const std::exception &e) {
         return std::string("malformed onnx file: ") + e.what();
     }

@@ -49,6 +49,23 @@ struct OnnxModel {
     std::vector<uint8_t> buf;  // whole file
     std::vector<OnnxNode> nodes;
     std::map<std::string, OnnxTensor> init;
+    // Identity(initializer) outputs: the exporter de-duplicates initializers with identical bytes and re-introduces the
+    // other names this way (alias -> kept name)
+    std::map<std::string, std::string> alias;
+    // initializer by name, following aliases; nullptr if absent
+    const OnnxTensor *find_init(const std::string &name) const {
+        auto it = init.find(name);
+        if (it != init.end()) return &it->second;
+        std::string cur = name;
+        for (int hop = 0; hop < 8; hop++) {
+            auto a = alias.find(cur);
+            if (a == alias.end()) return nullptr;
+            cur = a->second;
+            it = init.find(cur);
+            if (it != init.end()) return &it->second;
+        }
+        return nullptr;
+    }
     std::vector<std::string> inputs;  // graph inputs that are not initializers
     std::vector<std::string> outputs;
     std::map<std::string, std::string> meta;
