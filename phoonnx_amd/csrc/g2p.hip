@@ -126,6 +126,28 @@ __global__ void g2p_act_kernel(const float *a, const float *b, float *out, int64
     out[i] = b ? y * b[i] : y;
 }
 
+// Matrix-vector product for the one-column decoder step: W row-major [out][in] streams once (float4 per lane when the
+// row length allows), x comes from L2, one wave per output row, four rows per workgroup.
+__global__ __launch_bounds__(256) void g2p_gemv_kernel(const float *W, const float *x, float *y, int ys, const float *res,
+                                                       int in, int out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= out) return;
+    const float *w = W + (int64_t)row * in;
+    float s = 0.f;
+    if ((in & 3) == 0) {
+        const float4 *w4 = reinterpret_cast<const float4 *>(w);
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (int i = lane; i < (in >> 2); i += 64) {
+            const float4 a = w4[i], b = x4[i];
+            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+    } else
+        for (int i = lane; i < in; i += 64) s += w[i] * x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) y[(int64_t)row * ys] = res ? s + res[row] : s;
+}
+
 __global__ void g2p_scale_kernel(float *x, int64_t n, float s) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] *= s;
@@ -211,7 +233,8 @@ struct Run {
 };
 
 // y[Cout][T] (pitch yp) = W x (x [Cin][T], pitch xp) [+ res]
-void linear(Run &r, const ConvDesc &d, const float *x, int xp, int T, float *y, int yp, const float *res = nullptr) {
+void linear(Run &r, const T5Linear &L, const float *x, int xp, int T, float *y, int yp, const float *res = nullptr) {
+    const ConvDesc &d = L.conv;
     ConvArgs a{};
     a.x = x;
     a.x_bstride = 0;
@@ -240,6 +263,11 @@ void linear(Run &r, const ConvDesc &d, const float *x, int xp, int T, float *y, 
     r.note(launch_conv(a, d.cfg, 1, r.st));
 }
 
+// one column: y[co * ys] = sum_ci W[co][ci] x[ci] (+ res[co]) from the row-major copy; a wave per output row
+void gemv(Run &r, const T5Linear &L, const float *x, float *y, int ys, const float *res = nullptr) {
+    g2p_gemv_kernel<<<(L.out + 3) / 4, 256, 0, r.st>>>(r.P(L.rowmajor), x, y, ys, res, L.in, L.out);
+}
+
 void rmsnorm(Run &r, const float *x, int xp, int64_t g, float *y, int yp, int T) {
     const G2PModel &m = r.h->model;
     g2p_rmsnorm_kernel<<<T, 256, 0, r.st>>>(x, r.P(g), y, m.d_model, T, xp, yp, m.eps);
@@ -260,6 +288,14 @@ void ffn(Run &r, const T5FfnDesc &f, const float *hn, float *x, int T, float *a,
     const int64_t n = (int64_t)m.d_ff * T;
     g2p_act_kernel<<<(unsigned)((n + 255) / 256), 256, 0, r.st>>>(a, f.gated ? b : nullptr, a, n, m.act);
     linear(r, f.wo, a, T, T, x, T, x);  // x += wo(h)
+}
+
+void ffn1(Run &r, const T5FfnDesc &f, const float *hn, float *x, float *a, float *b) {  // one column
+    const G2PModel &m = r.h->model;
+    gemv(r, f.wi0, hn, a, 1);
+    if (f.gated) gemv(r, f.wi1, hn, b, 1);
+    g2p_act_kernel<<<(m.d_ff + 255) / 256, 256, 0, r.st>>>(a, f.gated ? b : nullptr, a, m.d_ff, m.act);
+    gemv(r, f.wo, a, x, 1, x);
 }
 
 int ws_reserve(g2p_handle *h, size_t bytes) {
@@ -504,21 +540,21 @@ int g2p_generate(g2p_handle *h, const int64_t *input_ids, int S, int max_length,
         for (int l = 0; l < nd; l++) {
             const auto &b = m.dec[l];
             rmsnorm(r, x1, 1, b.ln_self, h1, 1, 1);
-            linear(r, b.self.q, h1, 1, 1, q1, 1);
-            linear(r, b.self.k, h1, 1, 1, ks[l] + t, TM);
-            linear(r, b.self.v, h1, 1, 1, vs[l] + t, TM);
+            gemv(r, b.self.q, h1, q1, 1);
+            gemv(r, b.self.k, h1, ks[l] + t, TM);  // this position's keys / values join the cache
+            gemv(r, b.self.v, h1, vs[l] + t, TM);
             attention(r, q1, 1, ks[l], vs[l], TM, m.dec_bias, h->d_bucket_dec, a1, 1, 1, t + 1, t, true);
-            linear(r, b.self.o, a1, 1, 1, x1, 1, x1);
+            gemv(r, b.self.o, a1, x1, 1, x1);
             rmsnorm(r, x1, 1, b.ln_cross, h1, 1, 1);
-            linear(r, b.cross.q, h1, 1, 1, q1, 1);
+            gemv(r, b.cross.q, h1, q1, 1);
             attention(r, q1, 1, kc[l], vc[l], S, -1, nullptr, a1, 1, 1, S, 0, false);
-            linear(r, b.cross.o, a1, 1, 1, x1, 1, x1);
+            gemv(r, b.cross.o, a1, x1, 1, x1);
             rmsnorm(r, x1, 1, b.ln_ffn, h1, 1, 1);
-            ffn(r, b.ffn, h1, x1, 1, f1, f2);
+            ffn1(r, b.ffn, h1, x1, f1, f2);
         }
         rmsnorm(r, x1, 1, m.dec_final_ln, h1, 1, 1);
         if (m.scale_out) g2p_scale_kernel<<<(m.d_model + 255) / 256, 256, 0, st>>>(h1, m.d_model, 1.0f / std::sqrt((float)m.d_model));
-        linear(r, m.lm_head, h1, 1, 1, lg, 1);
+        gemv(r, m.lm_head, h1, lg, 1);
         g2p_argmax_kernel<<<1, 256, 0, st>>>(lg, m.vocab, 1, 0, d_gen, t + 1);
         r.note(hipGetLastError());
         int64_t tok = 0;

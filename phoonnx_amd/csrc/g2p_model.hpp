@@ -9,13 +9,21 @@
 
 namespace vitsmi {
 
+// A Linear layer without bias: packed for the f32 conv engine (a 1x1 conv over [C][T] activations) and - decoder layers,
+// which the greedy loop applies to ONE column per step - once more row-major [out][in] for the matrix-vector kernel.
+struct T5Linear {
+    ConvDesc conv;
+    int64_t rowmajor = -1;  // arena offset of W[out][in], or -1
+    int in = 0, out = 0;
+};
+
 struct T5AttnDesc {
-    ConvDesc q, k, v, o;  // Linear layers without bias, as 1x1 convs on the f32 conv engine ([C][T] activations)
+    T5Linear q, k, v, o;
 };
 
 struct T5FfnDesc {
     bool gated = true;    // T5DenseGatedActDense (wi_0, wi_1) vs T5DenseActDense (wi)
-    ConvDesc wi0, wi1, wo;
+    T5Linear wi0, wi1, wo;
 };
 
 struct T5BlockDesc {
@@ -33,7 +41,7 @@ struct G2PModel {
     int64_t enc_bias = -1, dec_bias = -1;  // relative_attention_bias [num_buckets][heads] of block 0 of each stack
     int64_t enc_final_ln = -1, dec_final_ln = -1;
     std::vector<T5BlockDesc> enc, dec;
-    ConvDesc lm_head;                    // d_model -> vocab
+    T5Linear lm_head;                    // d_model -> vocab
     std::vector<float> arena;
     int64_t arena_floats = 0;
     int64_t zeros_off = 0;
