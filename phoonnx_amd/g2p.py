@@ -159,3 +159,31 @@ class ByT5Phonemizer:
 
     def phonemize_string(self, text: str, lang: str) -> str:
         return self._infer(text, lang)
+
+
+CHARSIU_LANGS = ['ady', 'afr', 'sqi', 'amh', 'ara', 'arg', 'arm-e', 'arm-w', 'aze', 'bak', 'eus', 'bel', 'ben', 'bos',
+                 'bul', 'bur', 'cat', 'yue', 'zho-t', 'zho-s', 'min', 'cze', 'dan', 'dut', 'eng-uk', 'eng-us', 'epo',
+                 'est', 'fin', 'fra', 'fra-qu', 'gla', 'geo', 'ger', 'gre', 'grc', 'grn', 'guj', 'hin', 'hun', 'ido',
+                 'ind', 'ina', 'ita', 'jam', 'jpn', 'kaz', 'khm', 'kor', 'kur', 'lat-clas', 'lat-eccl', 'lit', 'ltz',
+                 'mac', 'mlt', 'tts', 'nob', 'ori', 'pap', 'fas', 'pol', 'por-po', 'por-bz', 'ron', 'rus', 'san',
+                 'srp', 'hbs-latn', 'hbs-cyrl', 'snd', 'slo', 'slv', 'spa', 'spa-latin', 'spa-me', 'swa', 'swe', 'tgl',
+                 'tam', 'tat', 'tha', 'tur', 'tuk', 'ukr', 'vie-n', 'vie-c', 'vie-s', 'wel-nw', 'wel-sw', 'ice', 'ang',
+                 'gle', 'enm', 'syc', 'glg', 'sme', 'egy']  # mul.py:248-256
+
+
+class CharsiuPhonemizer(ByT5Phonemizer):
+    """Mirror of `phoonnx.phonemizers.mul.CharsiuPhonemizer` (mul.py:239-286): the same engine, Charsiu's language tags,
+    and - these models cannot handle whitespace - one G2P call per word."""
+
+    @staticmethod
+    def get_lang(target_lang: str) -> str:
+        if target_lang in CHARSIU_LANGS:
+            return target_lang
+        base = target_lang.split("-")[0].lower()
+        for l in CHARSIU_LANGS:
+            if l.split("-")[0] == base:
+                return l
+        raise ValueError(f"unsupported language {target_lang}")
+
+    def phonemize_string(self, text: str, lang: str) -> str:
+        return " ".join(self._infer(w, lang) for w in text.split())

@@ -91,3 +91,16 @@ def test_byt5_phonemizer_mirror(tmp_path):
     assert p.phonemize_string("   ", "en-US") == ""
     assert p.get_lang("pt") == "pt-BR" or p.get_lang("pt").startswith("pt")
     p.session.close()
+
+
+def test_charsiu_phonemizer_goes_word_by_word(tmp_path):
+    from phoonnx_amd.g2p import ByT5Phonemizer, CharsiuPhonemizer
+    path = os.path.join(GOLDEN, "byt5_tiny.onnx")
+    c = CharsiuPhonemizer(path)
+    words = "one two".split()
+    c_out = c._infer
+    got = c.phonemize_string("one  two", "eng-us")
+    assert got == " ".join(c_out(w, "eng-us") for w in words)       # mul.py:284-286
+    with pytest.raises(ValueError):
+        c.get_lang("xx-YY")
+    c.session.close()
