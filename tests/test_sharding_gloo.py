@@ -112,3 +112,20 @@ def test_arena_checksum_detects_corruption():
     b = a.clone()
     b[12345] ^= 0x40
     assert arena_checksum(b) != c0 and arena_checksum(a.clone()) == c0
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus N` used to measure one GPU whatever N was.  Without a GPU the ranks cannot run,
+    but the launcher can: --gpus 2 started by hand must spawn two torch.distributed ranks (each of which then refuses to
+    run without an MI355X) and exit non-zero; under a launcher whose WORLD_SIZE disagrees with --gpus it must refuse."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-1500:]      # both ranks got as far as the device check
+    assert '"metric"' not in r.stdout
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       timeout=120, env=env2)
+    assert r.returncode != 0 and "--gpus 4 but the launcher started 1 rank" in (r.stderr + r.stdout)
