@@ -189,18 +189,22 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
     const std::integral_constant<int, 1> H1{};
 
     // One conv over an operand that is completely resident in LDS (chunk c at `rows0 + c * chunk_bytes`, tap k `k * dil`
-    // cells to the right): weights one step ahead in two register sets, B fragments half a step ahead, no barriers.
-    // The first weights (step 0) must have been requested into `fa`.
-    auto run_conv = [&](ASet &fa, ASet &fbset, const char *wb, int K, int dil, uint32_t rows0, uint32_t chunk_bytes,
+    // cells to the right): weights TWO steps ahead in three register sets (a step of a one-block-row wave is 6-12 MFMAs,
+    // 190-380 cycles: less than an L2 round trip), B fragments half a step ahead, no barriers.  The first weights
+    // (step 0) must have been requested into `fa`.
+    auto run_conv = [&](ASet &fa, ASet &fbset, ASet &fcset, const char *wb, int K, int dil, uint32_t rows0, uint32_t chunk_bytes,
                         uint32_t pstride) {
         const int S = a.nchunks * K;
         int chunk = 0, tap = 0;
+        if (S > 1) load_a(fbset, wb, 1);
         load_b_half(H0, rows0, pstride);
         load_b_half(H1, rows0, pstride);
-        auto step = [&](ASet &fc, ASet &fn, int s) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // A(s)
+        auto step = [&](ASet &fc, ASet &fload, int s) {
+            // A(s) has landed when at most the loads of A(s + 1) are still in flight (vector loads return in order)
+            if (s + 1 < S) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < S) load_a(fn, wb, s + 1);
+            if (s + 2 < S) load_a(fload, wb, s + 2);
             int ntap = tap + 1, nchunk = chunk;
             if (ntap == K) {
                 ntap = 0;
@@ -226,25 +230,31 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
             tap = ntap;
             chunk = nchunk;
         };
-        for (int s = 0; s + 1 < S; s += 2) {
-            step(fa, fbset, s);
+        // (no exit from the middle of the unrolled triple: a mid-loop break makes hipcc copy the accumulators)
+        int s = 0;
+        for (; s + 2 < S; s += 3) {
+            step(fa, fcset, s);
             step(fbset, fa, s + 1);
+            step(fcset, fbset, s + 2);
         }
-        if (S & 1) step(fa, fbset, S - 1);
+        if (s < S) step(fa, fcset, s);
+        if (s + 1 < S) step(fbset, fa, s + 1);
     };
 
     // =================================================================== phase 1: c1 over columns [t1, t1 + 256)
-    ASet f0, f1;
+    ASet f0, f1, f2;
     load_a(f0, wbase1, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // the x tile is complete
     __builtin_amdgcn_sched_barrier(0);
-    run_conv(f0, f1, wbase1, a.K1, a.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u, XB,
+    run_conv(f0, f1, f2, wbase1, a.K1, a.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u, XB,
              (uint32_t)(2 * LW) * 16u);
 
     // ---- residual operands of this wave (x itself, at the columns this lane produces: t1 + col); the tile's lines were
-    // fetched a phase ago and are served by the L2.  CHAIN turns them into x1 = c1(..) + x at the hand-over.
+    // fetched a phase or two ago and are served by the L2.  CHAIN needs them now (x1 = c1(..) + x at the hand-over); PAIR
+    // only in the epilogue and requests them there, so that they do not occupy registers during phase 2.
     f32x4 pre[NW / 2][2][4];
+    auto load_pre = [&]() {
     static_for<NW / 2>([&](auto R) {
         constexpr int rr = decltype(R)::value;
 #pragma unroll
@@ -257,9 +267,11 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
                 pre[rr][j][q] = *reinterpret_cast<const f32x4 *>(xrb + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi);
         }
     });
+    };
+    if constexpr (CHAIN) load_pre();
 
     // =================================================================== hand-over: c1's output -> Y (fp16 planes in LDS)
-    ASet g0, g1;
+    ASet g0, g1, g2;
     load_a(g0, wbase2, 0);  // first weights of c2 travel meanwhile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave has finished reading the x stages Y is about to overwrite
@@ -307,8 +319,9 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
     __builtin_amdgcn_sched_barrier(0);
 
     // =================================================================== phase 2: c2 over Y
-    run_conv(g0, g1, wbase2, a.K2, a.dil2, lds0 + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31) * 16u, a.y_chunk_bytes,
+    run_conv(g0, g1, g2, wbase2, a.K2, a.dil2, lds0 + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31) * 16u, a.y_chunk_bytes,
              (uint32_t)(2 * a.LW2) * 16u);
+    if constexpr (!CHAIN) load_pre();
 
     // =================================================================== epilogue: bias2 + x [+ xs] [/ n] -> raw
     {
