@@ -9,9 +9,10 @@ W=$(mktemp -d)
 N=${1:-300}
 cat > "$W/drv.cpp" <<'EOF'
 #include "model.hpp"
+#include "g2p_model.hpp"
 #include <cstdio>
 int main(int argc, char **argv) {
-    int bad = 0, ok = 0;
+    int bad = 0, ok = 0, g2p_ok = 0;
     for (int i = 1; i < argc; i++) {
         vitsmi::OnnxModel om;
         std::string e = om.load(argv[i]);
@@ -19,8 +20,12 @@ int main(int argc, char **argv) {
         vitsmi::Model m;
         e = m.build(om);
         if (e.empty()) ok++; else bad++;
+        vitsmi::Model lay;
+        lay.build(om, true);      // the layout-only path (vits_open_with_arena)
+        vitsmi::G2PModel g;       // ... and the T5 reader on the same bytes
+        if (g.build(om).empty()) g2p_ok++;
     }
-    printf("loaded %d rejected %d\n", ok, bad);
+    printf("loaded %d rejected %d (as T5: %d)\n", ok, bad, g2p_ok);
     return 0;
 }
 EOF
@@ -33,8 +38,17 @@ CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}   # (g++ 11 lacks -ftrivial-auto-var-
 python3 - "$R" "$W" "$N" <<'EOF'
 import random, sys
 root, w, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
-src = open(f"{root}/tests/golden/tiny_rb2_ms.onnx", "rb").read()
 rng = random.Random(12)
+t5 = open(f"{root}/tests/golden/byt5_tiny.onnx", "rb").read()
+for i in range(n // 2):   # damaged copies of the T5 fixture
+    b = bytearray(t5)
+    if i % 3 == 0:
+        b = b[:rng.randrange(len(b))]
+    else:
+        for _ in range(rng.randrange(1, 12)):
+            b[rng.randrange(len(b))] = rng.randrange(256)
+    open(f"{w}/t{i}.onnx", "wb").write(bytes(b))
+src = open(f"{root}/tests/golden/tiny_rb2_ms.onnx", "rb").read()
 for i in range(n):
     b = bytearray(src)
     if i % 3 == 0:
@@ -61,5 +75,5 @@ for blob in (bytes([0x3a, 4, 0x2a, 2, 0x40, 1]), bytes([0x3a, 4, 0x2a, 2, 0x48, 
     open(f"{w}/dk{k}.onnx", "wb").write(blob); k += 1
 print("targeted cases", k)
 EOF
-"$W/drv" "$R"/tests/golden/*.onnx "$W"/d*.onnx
+"$W/drv" "$R"/tests/golden/*.onnx "$W"/d*.onnx "$W"/t*.onnx
 rm -rf "$W"
