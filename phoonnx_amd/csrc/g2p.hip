@@ -126,26 +126,79 @@ __global__ void g2p_act_kernel(const float *a, const float *b, float *out, int64
     out[i] = b ? y * b[i] : y;
 }
 
-// Matrix-vector product for the one-column decoder step: W row-major [out][in] streams once (float4 per lane when the
-// row length allows), x comes from L2, one wave per output row, four rows per workgroup.
-__global__ __launch_bounds__(256) void g2p_gemv_kernel(const float *W, const float *x, float *y, int ys, const float *res,
-                                                       int in, int out) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= out) return;
-    const float *w = W + (int64_t)row * in;
-    float s = 0.f;
-    if ((in & 3) == 0) {
-        const float4 *w4 = reinterpret_cast<const float4 *>(w);
-        const float4 *x4 = reinterpret_cast<const float4 *>(x);
-        for (int i = lane; i < (in >> 2); i += 64) {
-            const float4 a = w4[i], b = x4[i];
-            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+// The decoder step's matrix-vector products, up to three per launch (q | k | v of one attention share their input):
+//   y_j[row * ys_j] = post * rs * sum_i W_j[row][i] g[i] x[i]  (+ res_j[row])        rs = rsqrt(mean(x^2) + eps) if g
+// i.e. the T5 RMS norm in front of the projection is folded in (every wave streams x anyway, so the sum of squares is
+// free), and with `gate` the two input projections of T5DenseGatedActDense are one job: y = act(W x') * (W2 x').
+// One wave per output row, four rows per workgroup; weights stream once, float4 per lane.
+struct G2PStepJob {
+    const float *W, *W2;
+    float *y;
+    const float *res;
+    int ys, out, blocks;  // blocks = ceil(out / 4)
+};
+struct G2PStepArgs {
+    G2PStepJob job[3];
+    const float *x, *g;
+    int njobs, in, act;
+    float eps, post;
+};
+
+__device__ __forceinline__ float g2p_activation(float x, int act) {
+    if (act == 1) return fmaxf(x, 0.f);
+    if (act == 2) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+
+__global__ __launch_bounds__(256) void g2p_step_kernel(G2PStepArgs a) {
+    int blk = blockIdx.x, j = 0;
+    while (j + 1 < a.njobs && blk >= a.job[j].blocks) blk -= a.job[j++].blocks;
+    const G2PStepJob &J = a.job[j];
+    const int lane = threadIdx.x & 63, row = blk * 4 + (threadIdx.x >> 6);
+    if (row >= J.out) return;
+    const float4 *w4 = reinterpret_cast<const float4 *>(J.W + (int64_t)row * a.in);
+    const float4 *v4 = J.W2 ? reinterpret_cast<const float4 *>(J.W2 + (int64_t)row * a.in) : nullptr;
+    const float4 *x4 = reinterpret_cast<const float4 *>(a.x);
+    const float4 *g4 = reinterpret_cast<const float4 *>(a.g);
+    float s = 0.f, s2 = 0.f, ss = 0.f;
+    if (a.in & 3) {  // rows not 16-byte aligned: one float per lane
+        const float *w = J.W + (int64_t)row * a.in, *v = J.W2 ? J.W2 + (int64_t)row * a.in : nullptr;
+        for (int i = lane; i < a.in; i += 64) {
+            float x = a.x[i];
+            if (a.g) {
+                ss += x * x;
+                x *= a.g[i];
+            }
+            s += w[i] * x;
+            if (v) s2 += v[i] * x;
         }
     } else
-        for (int i = lane; i < in; i += 64) s += w[i] * x[i];
+    for (int i = lane; i < (a.in >> 2); i += 64) {
+        float4 x = x4[i];
+        const float4 w = w4[i];
+        if (g4) {
+            ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+            const float4 g = g4[i];
+            x.x *= g.x, x.y *= g.y, x.z *= g.z, x.w *= g.w;
+        }
+        s += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+        if (v4) {
+            const float4 v = v4[i];
+            s2 += v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+        }
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) y[(int64_t)row * ys] = res ? s + res[row] : s;
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+        ss += __shfl_xor(ss, o, 64);
+    }
+    if (lane) return;
+    const float rs = (g4 ? 1.0f / sqrtf(ss / (float)a.in + a.eps) : 1.0f) * a.post;
+    float y = s * rs;
+    if (v4) y = g2p_activation(y, a.act) * (s2 * rs);
+    else if (a.act >= 0) y = g2p_activation(y, a.act);
+    J.y[(int64_t)row * J.ys] = J.res ? y + J.res[row] : y;
 }
 
 __global__ void g2p_scale_kernel(float *x, int64_t n, float s) {
@@ -154,7 +207,8 @@ __global__ void g2p_scale_kernel(float *x, int64_t n, float s) {
 }
 
 // argmax over the vocabulary of column t of logits [V][pitch] (first maximum, as np.argmax) -> ids[slot] (int64)
-__global__ __launch_bounds__(256) void g2p_argmax_kernel(const float *logits, int V, int pitch, int t, int64_t *ids, int slot) {
+__global__ __launch_bounds__(256) void g2p_argmax_kernel(const float *logits, int V, int pitch, int t, int64_t *ids, int slot,
+                                                         int64_t *host_copy) {
     __shared__ float bv[256];
     __shared__ int bi[256];
     const int tid = threadIdx.x;
@@ -177,7 +231,10 @@ __global__ __launch_bounds__(256) void g2p_argmax_kernel(const float *logits, in
         }
         __syncthreads();
     }
-    if (tid == 0) ids[slot] = bi[0];
+    if (tid == 0) {
+        ids[slot] = bi[0];
+        if (host_copy) host_copy[slot] = bi[0];  // (pinned, mapped: visible to the host once the step's event has fired)
+    }
 }
 
 // logits [V][T] (channels-first) -> [T][V] (what the graph returns)
@@ -196,6 +253,8 @@ struct g2p_handle {
     int *d_bucket_enc = nullptr, *d_bucket_dec = nullptr;
     char *ws = nullptr;
     size_t ws_cap = 0;
+    int64_t *tok_host = nullptr, *tok_dev = nullptr;  // generated ids, pinned + mapped: the step's argmax writes them
+    hipEvent_t step_done[2] = {nullptr, nullptr};
     std::mutex mu;
     std::string err;
 };
@@ -263,9 +322,34 @@ void linear(Run &r, const T5Linear &L, const float *x, int xp, int T, float *y, 
     r.note(launch_conv(a, d.cfg, 1, r.st));
 }
 
-// one column: y[co * ys] = sum_ci W[co][ci] x[ci] (+ res[co]) from the row-major copy; a wave per output row
-void gemv(Run &r, const T5Linear &L, const float *x, float *y, int ys, const float *res = nullptr) {
-    g2p_gemv_kernel<<<(L.out + 3) / 4, 256, 0, r.st>>>(r.P(L.rowmajor), x, y, ys, res, L.in, L.out);
+// One launch of the decoder step (see g2p_step_kernel): `g` = RMS-norm weight folded in front (or -1).
+struct StepJob {
+    const T5Linear *L, *gate;
+    float *y;
+    int ys;
+    const float *res;
+};
+void step(Run &r, std::initializer_list<StepJob> jobs, const float *x, int64_t g, int act = -1, float post = 1.f) {
+    G2PStepArgs a{};
+    int nb = 0;
+    for (const StepJob &j : jobs) {
+        G2PStepJob &d = a.job[a.njobs++];
+        d.W = r.P(j.L->rowmajor);
+        d.W2 = j.gate ? r.P(j.gate->rowmajor) : nullptr;
+        d.y = j.y;
+        d.ys = j.ys;
+        d.res = j.res;
+        d.out = j.L->out;
+        d.blocks = (j.L->out + 3) / 4;
+        nb += d.blocks;
+        a.in = j.L->in;
+    }
+    a.x = x;
+    a.g = g >= 0 ? r.P(g) : nullptr;
+    a.act = act;
+    a.eps = r.h->model.eps;
+    a.post = post;
+    g2p_step_kernel<<<nb, 256, 0, r.st>>>(a);
 }
 
 void rmsnorm(Run &r, const float *x, int xp, int64_t g, float *y, int yp, int T) {
@@ -288,14 +372,6 @@ void ffn(Run &r, const T5FfnDesc &f, const float *hn, float *x, int T, float *a,
     const int64_t n = (int64_t)m.d_ff * T;
     g2p_act_kernel<<<(unsigned)((n + 255) / 256), 256, 0, r.st>>>(a, f.gated ? b : nullptr, a, n, m.act);
     linear(r, f.wo, a, T, T, x, T, x);  // x += wo(h)
-}
-
-void ffn1(Run &r, const T5FfnDesc &f, const float *hn, float *x, float *a, float *b) {  // one column
-    const G2PModel &m = r.h->model;
-    gemv(r, f.wi0, hn, a, 1);
-    if (f.gated) gemv(r, f.wi1, hn, b, 1);
-    g2p_act_kernel<<<(m.d_ff + 255) / 256, 256, 0, r.st>>>(a, f.gated ? b : nullptr, a, m.d_ff, m.act);
-    gemv(r, f.wo, a, x, 1, x);
 }
 
 int ws_reserve(g2p_handle *h, size_t bytes) {
@@ -374,7 +450,11 @@ int g2p_open(const char *path, int device, g2p_handle **out) {
             hipMemcpy(h->arena_dev, h->model.arena.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
             hipMalloc((void **)&h->d_bucket_enc, lut) != hipSuccess || hipMalloc((void **)&h->d_bucket_dec, lut) != hipSuccess ||
             hipMemcpy(h->d_bucket_enc, h->model.bucket_enc.data(), lut, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(h->d_bucket_dec, h->model.bucket_dec.data(), lut, hipMemcpyHostToDevice) != hipSuccess) {
+            hipMemcpy(h->d_bucket_dec, h->model.bucket_dec.data(), lut, hipMemcpyHostToDevice) != hipSuccess ||
+            hipHostMalloc((void **)&h->tok_host, G2PModel::kMaxPos * sizeof(int64_t), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&h->tok_dev, h->tok_host, 0) != hipSuccess ||
+            hipEventCreateWithFlags(&h->step_done[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->step_done[1], hipEventDisableTiming) != hipSuccess) {
             g2p_close(h);
             return gfail(nullptr, VITS_E_NOMEM, "cannot place the G2P model on device %d", device);
         }
@@ -393,6 +473,9 @@ void g2p_close(g2p_handle *h) {
         if (h->d_bucket_enc) hipFree(h->d_bucket_enc);
         if (h->d_bucket_dec) hipFree(h->d_bucket_dec);
         if (h->ws) hipFree(h->ws);
+        if (h->tok_host) hipHostFree(h->tok_host);
+        for (hipEvent_t e : h->step_done)
+            if (e) hipEventDestroy(e);
         if (h->stream) hipStreamDestroy(h->stream);
     }
     delete h;
@@ -524,8 +607,8 @@ int g2p_generate(g2p_handle *h, const int64_t *input_ids, int S, int max_length,
         kc[l] = r.take<float>((size_t)m.inner * S);   // cross-attention keys / values of the encoder output
         vc[l] = r.take<float>((size_t)m.inner * S);
     }
-    float *x1 = r.take<float>(m.d_model), *h1 = r.take<float>(m.d_model), *q1 = r.take<float>(m.inner);
-    float *a1 = r.take<float>(m.inner), *f1 = r.take<float>(m.d_ff), *f2 = r.take<float>(m.d_ff), *lg = r.take<float>(m.vocab);
+    float *x1 = r.take<float>(m.d_model), *q1 = r.take<float>(m.inner);
+    float *a1 = r.take<float>(m.inner), *f1 = r.take<float>(m.d_ff), *lg = r.take<float>(m.vocab);
     r.note(hipMemcpyAsync(d_in, input_ids, (size_t)S * 8, hipMemcpyHostToDevice, st));
     r.note(hipMemcpyAsync(d_gen, &start_id, 8, hipMemcpyHostToDevice, st));
     run_encoder(r, d_in, S, xe, hn, q, k, v, att, fa, fb);
@@ -533,34 +616,42 @@ int g2p_generate(g2p_handle *h, const int64_t *input_ids, int S, int max_length,
         linear(r, m.dec[l].cross.k, xe, S, S, kc[l], S);
         linear(r, m.dec[l].cross.v, xe, S, S, vc[l], S);
     }
-    int n = 0;
-    for (int t = 0; t < max_length; t++) {
-        // one decoder step for position t (input: d_gen[t]); keys / values of position t join the cache
+    // One decoder step for position t (input: d_gen[t]; the argmax lands in d_gen[t + 1] and in the pinned copy); keys /
+    // values of position t join the cache.  8 launches per layer: norm + q|k|v, attention, o (+x), norm + q, cross
+    // attention, o (+x), norm + gated input projections, wo (+x).
+    const float post = m.scale_out ? 1.0f / std::sqrt((float)m.d_model) : 1.0f;
+    auto enqueue_step = [&](int t) {
         g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, 1), 256, 0, st>>>(d_gen + t, r.P(m.shared), x1, m.d_model, 1, 1, m.vocab);
         for (int l = 0; l < nd; l++) {
             const auto &b = m.dec[l];
-            rmsnorm(r, x1, 1, b.ln_self, h1, 1, 1);
-            gemv(r, b.self.q, h1, q1, 1);
-            gemv(r, b.self.k, h1, ks[l] + t, TM);  // this position's keys / values join the cache
-            gemv(r, b.self.v, h1, vs[l] + t, TM);
+            step(r, {{&b.self.q, nullptr, q1, 1, nullptr}, {&b.self.k, nullptr, ks[l] + t, TM, nullptr},
+                     {&b.self.v, nullptr, vs[l] + t, TM, nullptr}}, x1, b.ln_self);
             attention(r, q1, 1, ks[l], vs[l], TM, m.dec_bias, h->d_bucket_dec, a1, 1, 1, t + 1, t, true);
-            gemv(r, b.self.o, a1, x1, 1, x1);
-            rmsnorm(r, x1, 1, b.ln_cross, h1, 1, 1);
-            gemv(r, b.cross.q, h1, q1, 1);
+            step(r, {{&b.self.o, nullptr, x1, 1, x1}}, a1, -1);
+            step(r, {{&b.cross.q, nullptr, q1, 1, nullptr}}, x1, b.ln_cross);
             attention(r, q1, 1, kc[l], vc[l], S, -1, nullptr, a1, 1, 1, S, 0, false);
-            gemv(r, b.cross.o, a1, x1, 1, x1);
-            rmsnorm(r, x1, 1, b.ln_ffn, h1, 1, 1);
-            ffn1(r, b.ffn, h1, x1, f1, f2);
+            step(r, {{&b.cross.o, nullptr, x1, 1, x1}}, a1, -1);
+            step(r, {{&b.ffn.wi0, b.ffn.gated ? &b.ffn.wi1 : nullptr, f1, 1, nullptr}}, x1, b.ln_ffn, m.act);
+            step(r, {{&b.ffn.wo, nullptr, x1, 1, x1}}, f1, -1);
         }
-        rmsnorm(r, x1, 1, m.dec_final_ln, h1, 1, 1);
-        if (m.scale_out) g2p_scale_kernel<<<(m.d_model + 255) / 256, 256, 0, st>>>(h1, m.d_model, 1.0f / std::sqrt((float)m.d_model));
-        gemv(r, m.lm_head, h1, lg, 1);
-        g2p_argmax_kernel<<<1, 256, 0, st>>>(lg, m.vocab, 1, 0, d_gen, t + 1);
+        step(r, {{&m.lm_head, nullptr, lg, 1, nullptr}}, x1, m.dec_final_ln, -1, post);
+        g2p_argmax_kernel<<<1, 256, 0, st>>>(lg, m.vocab, 1, 0, d_gen, t + 1, h->tok_dev);
         r.note(hipGetLastError());
-        int64_t tok = 0;
-        r.note(hipMemcpyAsync(&tok, d_gen + t + 1, 8, hipMemcpyDeviceToHost, st));
-        r.note(hipStreamSynchronize(st));  // (the loop's one data-dependent decision: stop at EOS)
-        if (r.err != hipSuccess) return gfail(h, VITS_E_DEVICE, "g2p_generate failed: %s", hipGetErrorString(r.err));
+        r.note(hipEventRecord(h->step_done[t & 1], st));
+    };
+    // The loop's one data-dependent decision (stop at EOS) needs the token on the host; step t + 1 is queued before
+    // the host waits for step t, so the device never idles on that round trip.  The step queued behind the EOS step is
+    // wasted work on private buffers (everything later on this stream is ordered behind it).
+    int n = 0;
+    enqueue_step(0);
+    for (int t = 0; t < max_length; t++) {
+        if (t + 1 < max_length) enqueue_step(t + 1);
+        r.note(hipEventSynchronize(h->step_done[t & 1]));
+        if (r.err != hipSuccess) {
+            hipStreamSynchronize(st);
+            return gfail(h, VITS_E_DEVICE, "g2p_generate failed: %s", hipGetErrorString(r.err));
+        }
+        const int64_t tok = h->tok_host[t + 1];
         out_ids[n++] = tok;
         if (tok == eos_id) break;
     }

@@ -96,7 +96,12 @@ def test_byt5_phonemizer_mirror(tmp_path):
 def test_charsiu_phonemizer_goes_word_by_word(tmp_path):
     from phoonnx_amd.g2p import ByT5Phonemizer, CharsiuPhonemizer
     path = os.path.join(GOLDEN, "byt5_tiny.onnx")
-    c = CharsiuPhonemizer(path)
+    F = json.load(open(os.path.join(GOLDEN, "byt5_frontend.json"), encoding="utf-8"))
+    cfg = tmp_path / "tokenizer_config.json"    # (a random-weight model emits special ids: they must be known as such)
+    added = dict(F["tokenizer_config"]["added_tokens_decoder"])
+    added.update({str(i): {"content": f"<extra_id_{i - 259}>"} for i in range(259, 384)})   # ByT5's 125 sentinel ids
+    cfg.write_text(json.dumps({"added_tokens_decoder": added}))
+    c = CharsiuPhonemizer(path, str(cfg))
     words = "one two".split()
     c_out = c._infer
     got = c.phonemize_string("one  two", "eng-us")
