@@ -56,9 +56,16 @@ struct SxPairArgs {
 
 // (the 32-channel variant needs ~165 registers and <= 40 KiB of LDS: three workgroups per CU hide more of each
 // other's load / hand-over / store phases than two; the 64-channel one holds 64 accumulators + 64 residual registers)
+#ifndef SX_PAIR_EARLY32
+#define SX_PAIR_EARLY32 1
+#endif
 template <int MW, int NW, int WM, int WN, int EPI, bool CHAIN>
-__global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPairArgs a) {
+__global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY32) ? 3 : 2) void conv_sx_pair_kernel(SxPairArgs a) {
     constexpr int BN = NW * WN * 32, NH = NW / 2;
+    // 32-channel variant: the residual and (EPI_ACC) the running sum are requested in the prologue, right behind the
+    // x tile, and wait in registers: one HBM round trip per tile instead of three.
+    constexpr bool EARLY = NW == 2 && SX_PAIR_EARLY32;
+    constexpr bool ACC = (EPI & EPI_ACC) != 0;
     static_assert(WM * WN == 4 && MW == 1 && BN == 256, "one block row per wave, 256 columns");
     constexpr int NPW = 2, STEPBYTES = WM * MW * NPW * 1024;
     constexpr int MAXCH = WM * 2;  // 16-channel chunks: C = 32 * WM
@@ -89,6 +96,28 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
         f.fa[0] = global_read128<0>(voff0, sb);
         f.fa[1] = global_read128<1024>(voff0, sb);
     };
+
+    // Residual operands of this wave (x itself at the columns this lane produces: t1 + col) and, with EPI_ACC, the
+    // running sum of the resblocks at the same places, in the accumulator layout.
+    f32x4 pre[NW / 2][2][4], ad[EARLY && ACC ? NW / 2 : 1][2][4];
+    auto load_res = [&](const float *base, f32x4 (*dst)[2][4]) {
+        static_for<NW / 2>([&](auto R) {
+            constexpr int rr = decltype(R)::value;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int row0 = wm * 32;
+                const int t = t1 + (wn * NW + rr * 2 + j) * 32 + l31;
+                const int tl = t < 0 ? 0 : (t < T ? t : T - 1);  // (clamped columns are never kept)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float *p = base + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi;
+                    if constexpr (EARLY) dst[rr][j][q] = __builtin_bit_cast(f32x4, global_read128_v<0>(p));
+                    else dst[rr][j][q] = *reinterpret_cast<const f32x4 *>(p);
+                }
+            }
+        });
+    };
+    auto load_pre = [&]() { load_res(xrb, pre); };
 
     // ---- prologue: the WHOLE x tile (every 16-channel chunk) is requested at once, converted (leaky-ReLU, fp16 split)
     // and written to its LDS stage: one HBM round trip per tile.  (A first version fetched chunk c + 1 during chunk c,
@@ -124,7 +153,15 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
                 }
             });
         });
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (EARLY) {  // (vector loads return in order: the x tile has landed when only these are in flight)
+            load_pre();
+            if constexpr (ACC) {
+                load_res(a.out_raw + (int64_t)b * a.C * T, ad);
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            } else
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const float isl = a.islope;
         static_for<MAXCH>([&](auto CH) {
             constexpr int ch = decltype(CH)::value;
@@ -250,25 +287,10 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
     run_conv(f0, f1, f2, wbase1, a.K1, a.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u, XB,
              (uint32_t)(2 * LW) * 16u);
 
-    // ---- residual operands of this wave (x itself, at the columns this lane produces: t1 + col); the tile's lines were
-    // fetched a phase or two ago and are served by the L2.  CHAIN needs them now (x1 = c1(..) + x at the hand-over); PAIR
-    // only in the epilogue and requests them there, so that they do not occupy registers during phase 2.
-    f32x4 pre[NW / 2][2][4];
-    auto load_pre = [&]() {
-    static_for<NW / 2>([&](auto R) {
-        constexpr int rr = decltype(R)::value;
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int row0 = wm * 32;
-            const int t = t1 + (wn * NW + rr * 2 + j) * 32 + l31;
-            const int tl = t < 0 ? 0 : (t < T ? t : T - 1);  // (clamped columns are never kept)
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                pre[rr][j][q] = *reinterpret_cast<const f32x4 *>(xrb + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi);
-        }
-    });
-    };
-    if constexpr (CHAIN) load_pre();
+    // ---- the residual (64-channel variant): the tile's lines were fetched a phase or two ago; CHAIN needs them now
+    // (x1 = c1(..) + x at the hand-over), PAIR only in the epilogue and requests them there, so that they do not occupy
+    // registers during phase 2.
+    if constexpr (CHAIN && !EARLY) load_pre();
 
     // =================================================================== hand-over: c1's output -> Y (fp16 planes in LDS)
     ASet g0, g1, g2;
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
     // =================================================================== phase 2: c2 over Y
     run_conv(g0, g1, g2, wbase2, a.K2, a.dil2, lds0 + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31) * 16u, a.y_chunk_bytes,
              (uint32_t)(2 * a.LW2) * 16u);
-    if constexpr (!CHAIN) load_pre();
+    if constexpr (!CHAIN && !EARLY) load_pre();
 
     // =================================================================== epilogue: bias2 + x [+ xs] [/ n] -> raw
     {
@@ -336,15 +358,15 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
         for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
         static_for<NW / 2>([&](auto R) {
             constexpr int rr = decltype(R)::value;
-            f32x4 ad[2][4];
-            if constexpr ((flags & EPI_ACC) != 0) {
+            f32x4 adl[2][4];
+            if constexpr ((flags & EPI_ACC) != 0 && !EARLY) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const int t = t1 + (wn * NW + rr * 2 + j) * 32 + l31;
                     const int tl = t < 0 ? 0 : (t < T ? t : T - 1);
 #pragma unroll
                     for (int q = 0; q < 4; q++)
-                        ad[j][q] = *reinterpret_cast<const f32x4 *>(rawb + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi);
+                        adl[j][q] = *reinterpret_cast<const f32x4 *>(rawb + ((int64_t)((row0 >> 3) + q) * T + tl) * 8 + 4 * hi);
                 }
             }
 #pragma unroll
@@ -359,7 +381,10 @@ __global__ __launch_bounds__(256, NW == 2 ? 3 : 2) void conv_sx_pair_kernel(SxPa
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = __builtin_fmaf(acc[n][4 * q + e], wsc, bq[q][e]);
                     v += pre[rr][j][q];
-                    if constexpr ((flags & EPI_ACC) != 0) v += ad[j][q];
+                    if constexpr ((flags & EPI_ACC) != 0) {
+                        if constexpr (EARLY) v += ad[rr][j][q];
+                        else v += adl[j][q];
+                    }
                     if constexpr ((flags & EPI_DIV) != 0) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = v[e] / rdiv;

@@ -71,6 +71,16 @@ def main():
     t0 = time.perf_counter()
     dev = s.generate(ids[0], max_length=n_tok, eos_id=-1)
     gen_s = time.perf_counter() - t0
+    # encoder + cross keys / values + one decoder step, and the marginal cost of a token (two lengths' difference)
+    s.generate(ids[0], max_length=1, eos_id=-1)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        s.generate(ids[0], max_length=1, eos_id=-1)
+    first_s = (time.perf_counter() - t0) / 5
+    t0 = time.perf_counter()
+    for _ in range(3):
+        s.generate(ids[0], max_length=4 * n_tok, eos_id=-1)
+    long_s = (time.perf_counter() - t0) / 3
     dec = np.array([[0]], np.int64)
     t0 = time.perf_counter()
     for i in range(n_tok):
@@ -83,6 +93,8 @@ def main():
         "input_bytes": int(ids.shape[1]), "tokens": n_tok,
         "logits_max_abs_err_vs_transformers": err, "logits_scale": float(np.abs(ref_logits).max()),
         "generated_ids_equal": dev == gen[1:],
+        "ms_first_token (encoder + cross keys/values + one step)": first_s * 1e3,
+        "ms_per_further_token": (long_s - first_s) / (4 * n_tok - 1) * 1e3,
         "ms_per_token": {"g2p_generate (device loop, KV cache)": gen_s / n_tok * 1e3,
                          "session.run per token (the reference's call pattern, on the GPU)": run_s / n_tok * 1e3,
                          f"transformers on the host CPU, whole graph per token ({torch.get_num_threads()} threads)": cpu_s / n_tok * 1e3}}))
