@@ -18,7 +18,6 @@
 
 #include "../../include/g2pmi.h"
 #include "../../include/vitsmi.h"
-#include "conv_engine.hip.hpp"
 #include "g2p_model.hpp"
 
 using namespace vitsmi;
@@ -58,20 +57,34 @@ __global__ __launch_bounds__(256) void g2p_rmsnorm_kernel(const float *x, const 
 // Attention of one (query position, head): scores_j = q . k_j + bias[bucket(j - (i + q_off))][head] (no 1/sqrt(d) in T5),
 // causal: keys j <= i + q_off only; softmax; out = sum_j p_j v_j.  q [inner][Tq] (pitch qp), k / v [inner][Tk] (pitch kp).
 // bucket_lut: bucket of (j - i) at index (j - i) + lut_zero, or nullptr (cross attention: no position bias).
-__global__ __launch_bounds__(256) void g2p_attention_kernel(const float *q, int qp, const float *k, const float *v, int kp,
-                                                            const float *bias, const int *bucket_lut, int lut_zero,
-                                                            float *out, int op, int heads, int dk, int Tq, int Tk,
+// Keys / values are channel-major (time contiguous): lanes run along time, and every loop over channels issues its
+// loads eight at a time (one dependent load per channel made a decoder step's eight attention calls 30 us each).
+__global__ __launch_bounds__(256) void g2p_attention_kernel(const float *__restrict__ q, int qp, const float *__restrict__ k,
+                                                            const float *__restrict__ v, int kp, const float *__restrict__ bias,
+                                                            const int *__restrict__ bucket_lut, int lut_zero,
+                                                            float *__restrict__ out, int op, int heads, int dk, int Tq, int Tk,
                                                             int q_off, int causal) {
-    extern __shared__ float sc[];  // [Tk] scores, then [dk] reduction scratch
+    extern __shared__ float sc[];  // [Tk] scores, then [dk] the query
     __shared__ float red[256];
-    const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ipos = i + q_off;
     const int lim = causal ? (ipos + 1 < Tk ? ipos + 1 : Tk) : Tk;
-    const float *qh = q + (int64_t)h * dk * qp + i;
+    float *qs = sc + Tk;
+    for (int d = tid; d < dk; d += 256) qs[d] = q[((int64_t)h * dk + d) * qp + i];
+    __syncthreads();
+    const float *kh = k + (int64_t)h * dk * kp, *vh = v + (int64_t)h * dk * kp;
     float mx = -__builtin_inff();
     for (int j = tid; j < lim; j += 256) {
         float s = 0.f;
-        for (int d = 0; d < dk; d++) s += qh[(int64_t)d * qp] * k[((int64_t)h * dk + d) * kp + j];
+        int d = 0;
+        for (; d + 8 <= dk; d += 8) {
+            float kv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) kv[e] = kh[(int64_t)(d + e) * kp + j];
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += qs[d + e] * kv[e];
+        }
+        for (; d < dk; d++) s += qs[d] * kh[(int64_t)d * kp + j];
         if (bucket_lut) s += bias[bucket_lut[j - ipos + lut_zero] * heads + h];
         sc[j] = s;
         mx = fmaxf(mx, s);
@@ -97,20 +110,25 @@ __global__ __launch_bounds__(256) void g2p_attention_kernel(const float *q, int 
         __syncthreads();
     }
     const float inv = 1.0f / red[0];
-    // out[d] = sum_j p_j v[d][j]: 256 threads = (256 / dkp) key groups x dkp channels
-    int dkp = 1;
-    while (dkp < dk) dkp <<= 1;
-    const int groups = 256 / dkp, d = tid % dkp, gidx = tid / dkp;
-    float acc = 0.f;
-    if (d < dk)
-        for (int j = gidx; j < lim; j += groups) acc += sc[j] * v[((int64_t)h * dk + d) * kp + j];
-    __syncthreads();
-    red[tid] = acc;
-    __syncthreads();
-    if (tid < dkp && tid < dk) {
-        float a = 0.f;
-        for (int g2 = 0; g2 < groups; g2++) a += red[g2 * dkp + tid];
-        out[((int64_t)h * dk + tid) * op + i] = a * inv;
+    // out[d] = sum_j p_j v[d][j]: a wave per group of eight channels, lanes along the keys, wave reduction
+    for (int d0 = wave * 8; d0 < dk; d0 += 32) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = 0.f;
+        for (int j = lane; j < lim; j += 64) {
+            const float pj = sc[j];
+            float vv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) vv[e] = d0 + e < dk ? vh[(int64_t)(d0 + e) * kp + j] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += pj * vv[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+            if (lane == 0 && d0 + e < dk) out[((int64_t)h * dk + d0 + e) * op + i] = acc[e] * inv;
+        }
     }
 }
 
@@ -124,6 +142,98 @@ __global__ void g2p_act_kernel(const float *a, const float *b, float *out, int64
     else if (act == 2) y = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
     else y = 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
     out[i] = b ? y * b[i] : y;
+}
+
+// Linear layers over a short sequence (the encoder over the input bytes, teacher-forced decoder prefixes, the cross
+// keys / values): Y_j[out_j][T] = W_j[out_j][in] X[in][T] (+ res), up to three W per launch.  T is tens to a few
+// hundred columns, so a launch is bound by streaming W once and - per wave - by the depth of the reduction, not by
+// matrix throughput: a workgroup owns 16 output rows x up to 128 columns and splits the reduction over its 8 waves
+// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains), partial tiles are summed through LDS in a fixed order.
+// A operand: lane (m = l % 16, kq = l / 16) holds W[row0 + m][k0 + 4 kq .. + 3] (one 16-byte load per 16 k); the j-th
+// MFMA of a step contracts k = k0 + 4 kq + j.  B operand: x[k0 + 4 kq + j][t0 + 16 n + l % 16].
+struct G2PLinJob {
+    const float *W;
+    float *y;
+    const float *res;
+    int out, tiles;  // tiles = ceil(out / 16)
+};
+struct G2PLinArgs {
+    G2PLinJob job[3];
+    const float *x;
+    int njobs, in, T, xp, yp;
+};
+typedef float g2p_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void g2p_linear_kernel(G2PLinArgs a) {
+    extern __shared__ float part[];  // [8 waves][8 blocks][4][64]
+    int blk = blockIdx.x, jb = 0;
+    while (jb + 1 < a.njobs && blk >= a.job[jb].tiles) blk -= a.job[jb++].tiles;
+    const G2PLinJob &J = a.job[jb];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int row0 = blk * 16, t0 = blockIdx.y * 128;
+    const int ncol = a.T - t0 < 128 ? a.T - t0 : 128, nb = (ncol + 15) >> 4;
+    const int steps = (a.in + 15) >> 4;                        // 16 k per step
+    const int s0 = steps * wave / 8, s1 = steps * (wave + 1) / 8;
+    const bool row_ok = row0 + m < J.out;
+    const float *wrow = J.W + (int64_t)(row0 + m < J.out ? row0 + m : 0) * a.in;
+    const bool vec_ok = (a.in & 3) == 0;
+    g2p_f32x4 acc[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) acc[n] = g2p_f32x4{0.f, 0.f, 0.f, 0.f};
+    struct Frag {
+        float av[4];
+        float bv[4][8];
+    };
+    auto load = [&](Frag &f, int s) {
+        const int k = s * 16 + 4 * kq;
+        if (vec_ok && k + 4 <= a.in && row_ok) {
+            const float4 w = *reinterpret_cast<const float4 *>(wrow + k);
+            f.av[0] = w.x, f.av[1] = w.y, f.av[2] = w.z, f.av[3] = w.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) f.av[j] = row_ok && k + j < a.in ? wrow[k + j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float *xr = a.x + (int64_t)(k + j < a.in ? k + j : 0) * a.xp + t0 + m;
+            const bool k_ok = k + j < a.in;
+#pragma unroll
+            for (int n = 0; n < 8; n++) f.bv[j][n] = n < nb && k_ok && 16 * n + m < ncol ? xr[16 * n] : 0.f;
+        }
+    };
+    auto mma = [&](const Frag &f) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int n = 0; n < 8; n++)
+                if (n < nb) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[j], f.bv[j][n], acc[n], 0, 0, 0);
+    };
+    Frag f0, f1;
+    if (s0 < s1) load(f0, s0);
+    for (int s = s0; s < s1; s += 2) {
+        if (s + 1 < s1) load(f1, s + 1);
+        mma(f0);
+        if (s + 2 < s1) load(f0, s + 2);
+        if (s + 1 < s1) mma(f1);
+    }
+#pragma unroll
+    for (int n = 0; n < 8; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[((wave * 8 + n) * 4 + r) * 64 + lane] = acc[n][r];
+    __syncthreads();
+    // element e = (n * 4 + r) * 64 + l: row = row0 + 4 (l / 16) + r, column = t0 + 16 n + l % 16
+    for (int e = tid; e < nb * 256; e += 512) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) v += part[w * 2048 + e];
+        const int l = e & 63, r = (e >> 6) & 3, n = e >> 8;
+        const int row = row0 + 4 * (l >> 4) + r, col = 16 * n + (l & 15);
+        if (row < J.out && col < ncol) {
+            const int64_t o = (int64_t)row * a.yp + t0 + col;
+            J.y[o] = J.res ? v + J.res[o] : v;
+        }
+    }
 }
 
 // The decoder step's matrix-vector products, up to three per launch (q | k | v of one attention share their input):
@@ -291,35 +401,39 @@ struct Run {
     }
 };
 
-// y[Cout][T] (pitch yp) = W x (x [Cin][T], pitch xp) [+ res]
-void linear(Run &r, const T5Linear &L, const float *x, int xp, int T, float *y, int yp, const float *res = nullptr) {
-    const ConvDesc &d = L.conv;
-    ConvArgs a{};
+// y_j[out_j][T] (pitch yp) = W_j x (x [in][T], pitch xp) [+ res_j], up to three W over the same x per launch
+struct LinJob {
+    const T5Linear *L;
+    float *y;
+    const float *res;
+};
+void linear(Run &r, std::initializer_list<LinJob> jobs, const float *x, int xp, int T, int yp) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        r.note(hipFuncSetAttribute(reinterpret_cast<const void *>(g2p_linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   64 * 1024));
+        attr_set = true;
+    }
+    G2PLinArgs a{};
+    int tiles = 0;
+    for (const LinJob &j : jobs) {
+        G2PLinJob &d = a.job[a.njobs++];
+        d.W = r.P(j.L->rowmajor);
+        d.y = j.y;
+        d.res = j.res;
+        d.out = j.L->out;
+        d.tiles = (j.L->out + 15) / 16;
+        tiles += d.tiles;
+        a.in = j.L->in;
+    }
     a.x = x;
-    a.x_bstride = 0;
-    a.x_cstride = xp;
     a.T = T;
-    a.wp = r.P(d.w_off);
-    a.out = y;
-    a.out_bstride = 0;
-    a.out_cstride = yp;
-    a.res = res;
-    a.res_bstride = 0;
-    a.zeros = r.P(r.h->model.zeros_off);
-    a.Cin = d.Cin;
-    a.Cout = d.Cout;
-    a.K = 1;
-    a.dil = 1;
-    a.padL = 0;
-    a.CK = d.CK;
-    a.nchunks = d.nchunks;
-    a.ups = 1;
-    a.flags = (res ? EPI_RES : 0) | (yp != T ? EPI_NO_PADFILL : 0);  // (a cache column is a window into wider rows)
-    a.slope = 1.f;
-    a.div = 1.f;
-    a.oslope = 1.f;
-    a.oslope2 = 1.f;
-    r.note(launch_conv(a, d.cfg, 1, r.st));
+    a.xp = xp;
+    a.yp = yp;
+    g2p_linear_kernel<<<dim3(tiles, (T + 127) / 128), 512, 64 * 1024, r.st>>>(a);
+}
+void linear(Run &r, const T5Linear &L, const float *x, int xp, int T, float *y, int yp, const float *res = nullptr) {
+    linear(r, {{&L, y, res}}, x, xp, T, yp);
 }
 
 // One launch of the decoder step (see g2p_step_kernel): `g` = RMS-norm weight folded in front (or -1).
@@ -360,15 +474,15 @@ void rmsnorm(Run &r, const float *x, int xp, int64_t g, float *y, int yp, int T)
 void attention(Run &r, const float *q, int qp, const float *k, const float *v, int kp, int64_t bias, const int *lut, float *out,
                int op, int Tq, int Tk, int q_off, bool causal) {
     const G2PModel &m = r.h->model;
-    g2p_attention_kernel<<<dim3(Tq, m.heads), 256, (size_t)Tk * sizeof(float), r.st>>>(
+    g2p_attention_kernel<<<dim3(Tq, m.heads), 256, (size_t)(Tk + m.d_kv) * sizeof(float), r.st>>>(
         q, qp, k, v, kp, bias >= 0 ? r.P(bias) : nullptr, lut, G2PModel::kMaxPos - 1, out, op, m.heads, m.d_kv, Tq, Tk, q_off,
         causal ? 1 : 0);
 }
 
 void ffn(Run &r, const T5FfnDesc &f, const float *hn, float *x, int T, float *a, float *b) {
     const G2PModel &m = r.h->model;
-    linear(r, f.wi0, hn, T, T, a, T);
-    if (f.gated) linear(r, f.wi1, hn, T, T, b, T);
+    if (f.gated) linear(r, {{&f.wi0, a, nullptr}, {&f.wi1, b, nullptr}}, hn, T, T, T);
+    else linear(r, f.wi0, hn, T, T, a, T);
     const int64_t n = (int64_t)m.d_ff * T;
     g2p_act_kernel<<<(unsigned)((n + 255) / 256), 256, 0, r.st>>>(a, f.gated ? b : nullptr, a, n, m.act);
     linear(r, f.wo, a, T, T, x, T, x);  // x += wo(h)
@@ -396,9 +510,7 @@ void run_encoder(Run &r, const int64_t *d_ids, int S, float *x, float *hn, float
     g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, S), 256, 0, r.st>>>(d_ids, r.P(m.shared), x, m.d_model, S, S, m.vocab);
     for (const auto &b : m.enc) {
         rmsnorm(r, x, S, b.ln_self, hn, S, S);
-        linear(r, b.self.q, hn, S, S, q, S);
-        linear(r, b.self.k, hn, S, S, k, S);
-        linear(r, b.self.v, hn, S, S, v, S);
+        linear(r, {{&b.self.q, q, nullptr}, {&b.self.k, k, nullptr}, {&b.self.v, v, nullptr}}, hn, S, S, S);
         attention(r, q, S, k, v, S, m.enc_bias, h->d_bucket_enc, att, S, S, S, 0, false);
         linear(r, b.self.o, att, S, S, x, S, x);
         rmsnorm(r, x, S, b.ln_ffn, hn, S, S);
@@ -548,15 +660,12 @@ int g2p_run(g2p_handle *h, const int64_t *input_ids, int S, const int64_t *mask,
     g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, T), 256, 0, st>>>(d_dec, r.P(m.shared), xd, m.d_model, T, T, m.vocab);
     for (const auto &b : m.dec) {
         rmsnorm(r, xd, T, b.ln_self, hn, T, T);
-        linear(r, b.self.q, hn, T, T, q, T);
-        linear(r, b.self.k, hn, T, T, k, T);
-        linear(r, b.self.v, hn, T, T, v, T);
+        linear(r, {{&b.self.q, q, nullptr}, {&b.self.k, k, nullptr}, {&b.self.v, v, nullptr}}, hn, T, T, T);
         attention(r, q, T, k, v, T, m.dec_bias, h->d_bucket_dec, att, T, T, T, 0, true);
         linear(r, b.self.o, att, T, T, xd, T, xd);
         rmsnorm(r, xd, T, b.ln_cross, hn, T, T);
         linear(r, b.cross.q, hn, T, T, q, T);
-        linear(r, b.cross.k, xe, S, S, kc, S);
-        linear(r, b.cross.v, xe, S, S, vc, S);
+        linear(r, {{&b.cross.k, kc, nullptr}, {&b.cross.v, vc, nullptr}}, xe, S, S, S);
         attention(r, q, T, kc, vc, S, -1, nullptr, att, T, T, S, 0, false);
         linear(r, b.cross.o, att, T, T, xd, T, xd);
         rmsnorm(r, xd, T, b.ln_ffn, hn, T, T);
@@ -613,8 +722,7 @@ int g2p_generate(g2p_handle *h, const int64_t *input_ids, int S, int max_length,
     r.note(hipMemcpyAsync(d_gen, &start_id, 8, hipMemcpyHostToDevice, st));
     run_encoder(r, d_in, S, xe, hn, q, k, v, att, fa, fb);
     for (int l = 0; l < nd; l++) {
-        linear(r, m.dec[l].cross.k, xe, S, S, kc[l], S);
-        linear(r, m.dec[l].cross.v, xe, S, S, vc[l], S);
+        linear(r, {{&m.dec[l].cross.k, kc[l], nullptr}, {&m.dec[l].cross.v, vc[l], nullptr}}, xe, S, S, S);
     }
     // One decoder step for position t (input: d_gen[t]; the argmax lands in d_gen[t + 1] and in the pinned copy); keys /
     // values of position t join the cache.  8 launches per layer: norm + q|k|v, attention, o (+x), norm + q, cross

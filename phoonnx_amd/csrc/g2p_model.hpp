@@ -9,11 +9,10 @@
 
 namespace vitsmi {
 
-// A Linear layer without bias: packed for the f32 conv engine (a 1x1 conv over [C][T] activations) and - decoder layers,
-// which the greedy loop applies to ONE column per step - once more row-major [out][in] for the matrix-vector kernel.
+// A Linear layer without bias, row-major W[out][in]: what both the short-sequence kernel (encoder, prefixes) and the
+// matrix-vector kernel of the greedy loop's one-column steps stream.
 struct T5Linear {
-    ConvDesc conv;
-    int64_t rowmajor = -1;  // arena offset of W[out][in], or -1
+    int64_t rowmajor = -1;  // arena offset of W[out][in]
     int in = 0, out = 0;
 };
 

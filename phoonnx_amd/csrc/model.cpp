@@ -1196,26 +1196,20 @@ std::string G2PModel::build(const OnnxModel &om) {
         arena.clear();
         Packer P(arena, false);
         zeros_off = P.alloc(1024);
-        t_hint = 2;
-        t_sx_f16 = false;
-        bool want_rowmajor = false;  // (set while the decoder's layers are packed)
         auto linear = [&](const std::string &key, int in, int out) {
             const TRef &w = need(key, 2);
             if (w.dims[0] != in || w.dims[1] != out)
                 throw std::runtime_error(key + ": expected [" + std::to_string(in) + ", " + std::to_string(out) + "]");
             const float *wp = w.p;
             const int64_t ld = w.dims[1];
-            auto wf = [&](int co, int ci, int) { return wp[int64_t(ci) * ld + co]; };  // MatMul initializers are [in, out]
             T5Linear L;
             L.in = in;
             L.out = out;
-            L.conv = pack_conv(P, in, out, 1, 1, 0, wf, nullptr);
-            if (want_rowmajor) {
-                L.rowmajor = P.alloc(int64_t(in) * out);
-                float *dst = P.arena.data() + L.rowmajor;
-                for (int ci = 0; ci < in; ci++)
-                    for (int co = 0; co < out; co++) dst[int64_t(co) * in + ci] = wp[int64_t(ci) * ld + co];
-            }
+            L.rowmajor = P.alloc(int64_t(in) * out);
+            float *dst = P.arena.data() + L.rowmajor;
+            for (int ci0 = 0; ci0 < in; ci0 += 64)  // (blocked transpose: MatMul initializers are [in, out])
+                for (int co = 0; co < out; co++)
+                    for (int ci = ci0; ci < in && ci < ci0 + 64; ci++) dst[int64_t(co) * in + ci] = wp[int64_t(ci) * ld + co];
             return L;
         };
         auto vec = [&](const std::string &key) {
@@ -1258,7 +1252,6 @@ std::string G2PModel::build(const OnnxModel &om) {
             d.ffn = ffn(e + ".1.DenseReluDense");
             enc.push_back(d);
         }
-        want_rowmajor = true;
         for (int b = 0;; b++) {
             const std::string e = "decoder." + std::to_string(b);
             if (!R.t.count(e + ".0.SelfAttention.q")) break;
