@@ -48,6 +48,12 @@
 
 #include "conv_engine.hip.hpp"
 
+#ifndef SX_CFG0_WIDE
+#define SX_CFG0_WIDE 0  // 128 x 256 tile as four 32-row waves x 256 columns (half the weight bytes per workgroup)
+#endif
+#ifndef SX_NOA
+#define SX_NOA 0  // ablation: weights are not re-fetched after the first steps (wrong results, timing only)
+#endif
 namespace vitsmi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
             stamp(1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < S && !(dbg_nodma && s > 0)) load_a(fn, s + 1);
+        if (s + 1 < S && !(dbg_nodma && s > 0) && !(SX_NOA && s > 0)) load_a(fn, s + 1);
         if (tap == 0 && more_x) {
             if constexpr (RAWIN) xload(chunk + 1);
             else issue_x(chunk + 1, ((chunk + 1) & 1) * XB);
@@ -921,7 +927,11 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
                             : launch_conv_sx_rawin<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
         if (a.prof && cfg == 0) return launch_conv_sx_k<2, 4, 2, 2, -1, true, false, 2>(a, grid, lds, stream);
         switch (cfg) {
+#if SX_CFG0_WIDE
+            case 0: return launch_conv_sx_epi<1, 8, 4, 1, 2>(a, epi, grid, lds, stream);
+#else
             case 0: return launch_conv_sx_epi<2, 4, 2, 2, 2>(a, epi, grid, lds, stream);
+#endif
             case 1: return launch_conv_sx_epi<1, 4, 2, 2, 2>(a, epi, grid, lds, stream);
             default: return launch_conv_sx_epi<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
         }

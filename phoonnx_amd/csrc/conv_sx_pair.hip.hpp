@@ -56,6 +56,12 @@ struct SxPairArgs {
 
 // (the 32-channel variant needs ~165 registers and <= 40 KiB of LDS: three workgroups per CU hide more of each
 // other's load / hand-over / store phases than two; the 64-channel one holds 64 accumulators + 64 residual registers)
+#ifndef SX_PAIR_DEPTH32
+#define SX_PAIR_DEPTH32 2
+#endif
+#ifndef SX_PAIR_DEPTH64
+#define SX_PAIR_DEPTH64 2
+#endif
 #ifndef SX_PAIR_EARLY32
 #define SX_PAIR_EARLY32 1
 #endif
@@ -65,6 +71,8 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY32) ? 3 : 2) void co
     // 32-channel variant: the residual and (EPI_ACC) the running sum are requested in the prologue, right behind the
     // x tile, and wait in registers: one HBM round trip per tile instead of three.
     constexpr bool EARLY = NW == 2 && SX_PAIR_EARLY32;
+    constexpr int DEPTH = NW == 2 ? SX_PAIR_DEPTH32 : SX_PAIR_DEPTH64;  // weight look-ahead in steps (run_conv)
+    static_assert(DEPTH >= 2 && DEPTH <= 6, "wait_a covers up to five younger sets");
     constexpr bool ACC = (EPI & EPI_ACC) != 0;
     static_assert(WM * WN == 4 && MW == 1 && BN == 256, "one block row per wave, 256 columns");
     constexpr int NPW = 2, STEPBYTES = WM * MW * NPW * 1024;
@@ -226,22 +234,35 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY32) ? 3 : 2) void co
     const std::integral_constant<int, 1> H1{};
 
     // One conv over an operand that is completely resident in LDS (chunk c at `rows0 + c * chunk_bytes`, tap k `k * dil`
-    // cells to the right): weights TWO steps ahead in three register sets (a step of a one-block-row wave is 6-12 MFMAs,
-    // 190-380 cycles: less than an L2 round trip), B fragments half a step ahead, no barriers.  The first weights
-    // (step 0) must have been requested into `fa`.
-    auto run_conv = [&](ASet &fa, ASet &fbset, ASet &fcset, const char *wb, int K, int dil, uint32_t rows0, uint32_t chunk_bytes,
+    // cells to the right): weights DEPTH steps ahead in DEPTH + 1 register sets (a step of a one-block-row wave is 6-12
+    // MFMAs, 190-380 cycles; an L2 round trip under load is several of those), B fragments half a step ahead, no
+    // barriers.  The first weights (step 0) must have been requested into fs[0].
+    auto wait_a = [&](int younger) {  // A(s) has landed when only the `younger` later sets are in flight (loads return in order)
+        switch (younger) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        }
+    };
+    auto run_conv = [&](ASet(&fs)[DEPTH + 1], const char *wb, int K, int dil, uint32_t rows0, uint32_t chunk_bytes,
                         uint32_t pstride) {
+        constexpr int NS = DEPTH + 1;
         const int S = a.nchunks * K;
         int chunk = 0, tap = 0;
-        if (S > 1) load_a(fbset, wb, 1);
+        static_for<DEPTH - 1>([&](auto I) {
+            constexpr int i = decltype(I)::value + 1;
+            if (i < S) load_a(fs[i], wb, i);
+        });
         load_b_half(H0, rows0, pstride);
         load_b_half(H1, rows0, pstride);
         auto step = [&](ASet &fc, ASet &fload, int s) {
-            // A(s) has landed when at most the loads of A(s + 1) are still in flight (vector loads return in order)
-            if (s + 1 < S) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int left = S - 1 - s;
+            wait_a(left < DEPTH - 1 ? left : DEPTH - 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 2 < S) load_a(fload, wb, s + 2);
+            if (s + DEPTH < S && !SX_NOA) load_a(fload, wb, s + DEPTH);
             int ntap = tap + 1, nchunk = chunk;
             if (ntap == K) {
                 ntap = 0;
@@ -267,24 +288,26 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY32) ? 3 : 2) void co
             tap = ntap;
             chunk = nchunk;
         };
-        // (no exit from the middle of the unrolled triple: a mid-loop break makes hipcc copy the accumulators)
+        // (no exit from the middle of the unrolled group: a mid-loop break makes hipcc copy the accumulators)
         int s = 0;
-        for (; s + 2 < S; s += 3) {
-            step(fa, fcset, s);
-            step(fbset, fa, s + 1);
-            step(fcset, fbset, s + 2);
-        }
-        if (s < S) step(fa, fcset, s);
-        if (s + 1 < S) step(fbset, fa, s + 1);
+        for (; s + NS <= S; s += NS)
+            static_for<NS>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                step(fs[i], fs[(i + DEPTH) % NS], s + i);
+            });
+        static_for<NS - 1>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            if (s + i < S) step(fs[i], fs[(i + DEPTH) % NS], s + i);
+        });
     };
 
     // =================================================================== phase 1: c1 over columns [t1, t1 + 256)
-    ASet f0, f1, f2;
-    load_a(f0, wbase1, 0);
+    ASet f1s[DEPTH + 1];
+    load_a(f1s[0], wbase1, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // the x tile is complete
     __builtin_amdgcn_sched_barrier(0);
-    run_conv(f0, f1, f2, wbase1, a.K1, a.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u, XB,
+    run_conv(f1s, wbase1, a.K1, a.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u, XB,
              (uint32_t)(2 * LW) * 16u);
 
     // ---- the residual (64-channel variant): the tile's lines were fetched a phase or two ago; CHAIN needs them now
@@ -293,8 +316,8 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY32) ? 3 : 2) void co
     if constexpr (CHAIN && !EARLY) load_pre();
 
     // =================================================================== hand-over: c1's output -> Y (fp16 planes in LDS)
-    ASet g0, g1, g2;
-    load_a(g0, wbase2, 0);  // first weights of c2 travel meanwhile
+    ASet f2s[DEPTH + 1];
+    load_a(f2s[0], wbase2, 0);  // first weights of c2 travel meanwhile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave has finished reading the x stages Y is about to overwrite
     __builtin_amdgcn_sched_barrier(0);
@@ -341,7 +364,7 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY32) ? 3 : 2) void co
     __builtin_amdgcn_sched_barrier(0);
 
     // =================================================================== phase 2: c2 over Y
-    run_conv(g0, g1, g2, wbase2, a.K2, a.dil2, lds0 + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31) * 16u, a.y_chunk_bytes,
+    run_conv(f2s, wbase2, a.K2, a.dil2, lds0 + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31) * 16u, a.y_chunk_bytes,
              (uint32_t)(2 * a.LW2) * 16u);
     if constexpr (!CHAIN && !EARLY) load_pre();
 

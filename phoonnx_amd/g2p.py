@@ -16,6 +16,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import _ffi
+from .phonemizers import SimplePhonemizer
 from .session import NodeArg, SessionError
 
 BYT5_LANGS = ['ca-ES', 'cy-GB', 'da-DK', 'de-DE', 'en-GB', 'en-US', 'es-ES', 'et-EE', 'eu-ES', 'fa-IR', 'fr-FR',
@@ -115,9 +116,10 @@ class MiG2PSession:
         return out[:n.value].tolist()
 
 
-class ByT5Phonemizer:
+class ByT5Phonemizer(SimplePhonemizer):
     """Mirror of `phoonnx.phonemizers.mul.ByT5Phonemizer` over `MiG2PSession` (no downloads: the model and tokenizer
-    config are files the caller supplies).  `phonemize_string(text, lang)` as mul.py:232-233."""
+    config are files the caller supplies).  `phonemize_string(text, lang)` as mul.py:232-233; `phonemize(text, lang)`
+    (chunking, one entry per chunk) from the base class, as in the reference."""
 
     def __init__(self, model: str, tokenizer_config: Optional[str] = None, device_id: int = 0, device_loop: bool = True):
         self.session = MiG2PSession(model, device_id=device_id)

@@ -10,6 +10,7 @@ Provided here: the three "no G2P" phonemizers of `phoonnx/phonemizers/base.py:17
 reference's number/date text normalisation (`phoonnx/util.py`, also out of scope).  For every
 other phoneme type the reference package's phonemizer is used if it is importable.
 """
+import os
 import re
 import string
 import unicodedata
@@ -34,15 +35,16 @@ class SimplePhonemizer:
         return text  # Hebrew/Arabic diacritisers are separate neural models in the reference (out of scope)
 
     def phonemize(self, text: str, lang: str) -> List[List[str]]:
+        """base.py:62-86: every chunk (a sentence, or a piece of one between `, ` `:` `;` `...` `|`) is phonemized on its
+        own and closes an entry of its own (the reference marks each chunk end-of-sentence, base.py:70), the delimiters
+        themselves are dropped."""
         sentences: List[List[str]] = []
         for sentence in (s.strip() for s in _SENTENCE_END.split(text or "")):
             if not sentence:
                 continue
-            phones: List[str] = []
             for chunk in _CHUNK_DELIMS.split(sentence)[::2]:
                 cleaned = _PUNCT.sub("", chunk).strip()
-                phones.extend(_LANG_FLAG.sub("", self.phonemize_string(cleaned, lang)))
-            sentences.append(phones)
+                sentences.append(list(_LANG_FLAG.sub("", self.phonemize_string(cleaned, lang))))
         return sentences
 
 
@@ -77,6 +79,13 @@ def get_phonemizer(phoneme_type: PhonemeType, alphabet: Optional[Alphabet] = Non
         return GraphemePhonemizer()
     if phoneme_type == PhonemeType.UNICODE:
         return UnicodeCodepointPhonemizer()
+    if phoneme_type in (PhonemeType.BYT5, PhonemeType.CHARSIU) and model and os.path.isfile(model):
+        # the neural G2P runs on this engine too; `model` is a local .onnx (nothing is downloaded), its
+        # tokenizer_config.json is looked for next to it (mul.py:60-63 keeps one per data directory)
+        from .g2p import ByT5Phonemizer, CharsiuPhonemizer
+        tok = os.path.join(os.path.dirname(os.path.abspath(model)), "tokenizer_config.json")
+        cls = ByT5Phonemizer if phoneme_type == PhonemeType.BYT5 else CharsiuPhonemizer
+        return cls(model, tok if os.path.isfile(tok) else None)
     try:  # defer to the reference package when it is installed next to us
         from phoonnx.config import PhonemeType as RefType, get_phonemizer as ref_get
         return ref_get(RefType(phoneme_type.value), alphabet.value if alphabet else "ipa", model)

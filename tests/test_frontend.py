@@ -169,7 +169,8 @@ def test_audio_chunk_int16():
 def test_builtin_phonemizers_and_missing_id_map():
     from phoonnx_amd.config import PhonemeType
     from phoonnx_amd.phonemizers import get_phonemizer
-    assert get_phonemizer(PhonemeType.RAW).phonemize("ab, c. de!", "en") == [list("abc"), list("de")]
+    # base.py:70 marks EVERY chunk end-of-sentence (`results += [(phoneme_str, punct, True)]`): one entry per chunk
+    assert get_phonemizer(PhonemeType.RAW).phonemize("ab, c. de!", "en") == [list("ab"), list("c"), list("de")]
     # like the reference, punctuation is stripped from a chunk before its phonemize_string (base.py:64)
     assert get_phonemizer(PhonemeType.GRAPHEMES).phonemize("Hello  World.", "en") == [list("hello world")]
     assert get_phonemizer(PhonemeType.UNICODE).phonemize("é", "pt") == [["e", "́"]]

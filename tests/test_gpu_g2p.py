@@ -109,3 +109,45 @@ def test_charsiu_phonemizer_goes_word_by_word(tmp_path):
     with pytest.raises(ValueError):
         c.get_lang("xx-YY")
     c.session.close()
+
+
+def test_ttsvoice_with_the_byt5_phonemizer_end_to_end(tmp_path):
+    """f4 behind the boundary: a voice whose JSON says phoneme_type "byt5" + a local phonemizer_model gets its phonemes
+    from the G2P engine (config.py:405-406 -> mul.py), then its audio from the VITS engine: text -> wav, both on the GPU."""
+    import shutil
+    from phoonnx_amd.config import SynthesisConfig
+    from phoonnx_amd.g2p import ByT5Phonemizer
+    from phoonnx_amd.voice import TTSVoice
+    F = json.load(open(os.path.join(GOLDEN, "byt5_frontend.json"), encoding="utf-8"))
+    g2p_dir = tmp_path / "g2p"
+    g2p_dir.mkdir()
+    shutil.copy(os.path.join(GOLDEN, "byt5_tiny.onnx"), g2p_dir / "model.onnx")
+    added = dict(F["tokenizer_config"]["added_tokens_decoder"])
+    added.update({str(i): {"content": f"<extra_id_{i - 259}>"} for i in range(259, 384)})
+    (g2p_dir / "tokenizer_config.json").write_text(json.dumps({"added_tokens_decoder": added}))
+    model = tmp_path / "voice.onnx"
+    shutil.copy(os.path.join(GOLDEN, "tiny_rb1.onnx"), model)
+    # (a random-weight G2P emits arbitrary bytes: map every printable latin-1 character, the rest is skipped with a
+    # warning as in the reference, phoneme_ids.py)
+    id_map = {"_": 0, "^": 1, "$": 2, " ": 3}
+    for c in range(33, 256):
+        if chr(c) not in id_map and len(id_map) < 60:
+            id_map[chr(c)] = len(id_map)
+    (tmp_path / "voice.onnx.json").write_text(json.dumps({
+        "phoneme_type": "byt5", "phonemizer_model": str(g2p_dir / "model.onnx"), "lang_code": "en-US", "alphabet": "ipa",
+        "audio": {"sample_rate": 22050}, "phoneme_id_map": id_map, "pad": "_", "blank": "_", "bos": "^", "eos": "$",
+        "inference": {"noise_scale": 0.0, "length_scale": 1.5, "noise_w": 0.0}}))
+    voice = TTSVoice.load(str(model))
+    assert isinstance(voice.phonemizer, ByT5Phonemizer) or voice.phonemizer is None
+    voice.dedupe_sentences = True
+    text = "hello world. again, hello"
+    sentences = voice.phonemize(text)
+    assert isinstance(voice.phonemizer, ByT5Phonemizer)
+    assert 1 <= len(sentences) <= 3 and sentences[0]   # (an empty last entry is dropped, voice.py:208-209)
+    # the phonemes are what the G2P engine's greedy loop says for each chunk, character by character
+    assert sentences[0] == list(voice.phonemizer.phonemize_string("hello world", "en-US"))
+    chunks = list(voice.synthesize(text, SynthesisConfig(noise_scale=0.0, noise_w_scale=0.0)))
+    assert len(chunks) == sum(1 for p in sentences if p) and all(c.sample_rate == 22050 for c in chunks)
+    assert all(np.isfinite(c.audio_float_array).all() and len(c.audio_float_array) > 0 for c in chunks)
+    voice.phonemizer.session.close()
+    voice.session.close()
