@@ -12,7 +12,7 @@
  * decoder_input_ids; output logits); weights are read from the same .onnx file.
  *
  * Conventions as in vitsmi.h: plain pointers and sizes; int functions return 0 or a negative VITS_E_* code
- * (vitsmi.h), message from g2p_last_error().  Batch size 1, as the reference calls it.
+ * (vitsmi.h), message from g2p_last_error().  g2p_run: batch size 1, as the reference calls it.
  */
 #ifndef G2PMI_H
 #define G2PMI_H
@@ -52,6 +52,15 @@ int g2p_run(g2p_handle *h, const int64_t *input_ids, int S, const int64_t *atten
  * max_length tokens.  out_ids receives at most max_length ids; *n_out their count. */
 int g2p_generate(g2p_handle *h, const int64_t *input_ids, int S, int max_length, int64_t start_id, int64_t eos_id,
                  int64_t *out_ids, int *n_out);
+
+/* The same loop for B independent inputs side by side (extension: the reference phonemizes chunk after chunk,
+ * base.py:66-70): input_ids holds the B sequences back to back, lens[b] their lengths.  One encoder pass over the padded
+ * batch (padding is masked out of every attention), then every decoder step streams the weights once for all B
+ * sequences; a sequence that has produced eos_id stops collecting tokens while the others finish.  Each sequence's ids
+ * are exactly what g2p_generate returns for it alone.  out_ids: [B][max_length]; n_out: [B].  B <= G2P_MAX_BATCH. */
+#define G2P_MAX_BATCH 64
+int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens, int B, int max_length, int64_t start_id,
+                       int64_t eos_id, int64_t *out_ids, int *n_out);
 
 #ifdef __cplusplus
 }

@@ -26,10 +26,11 @@ namespace {
 thread_local std::string g_g2p_open_error;
 
 // x[c][t] = table[ids[t]][c]
-__global__ void g2p_embed_kernel(const int64_t *ids, const float *table, float *x, int C, int T, int pitch, int vocab) {
+__global__ void g2p_embed_kernel(const int64_t *ids, int id_stride, const float *table, float *x, int C, int T, int pitch,
+                                 int vocab) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
     if (c >= C) return;
-    int64_t id = ids[t];
+    int64_t id = ids[(int64_t)t * id_stride];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // (range-checked on the host for host inputs; generated ids are in range)
     x[(int64_t)c * pitch + t] = table[id * C + c];
 }
@@ -54,25 +55,31 @@ __global__ __launch_bounds__(256) void g2p_rmsnorm_kernel(const float *x, const 
     for (int c = tid; c < C; c += 256) y[(int64_t)c * ypitch + t] = x[(int64_t)c * xpitch + t] * rs * g[c];
 }
 
-// Attention of one (query position, head): scores_j = q . k_j + bias[bucket(j - (i + q_off))][head] (no 1/sqrt(d) in T5),
-// causal: keys j <= i + q_off only; softmax; out = sum_j p_j v_j.  q [inner][Tq] (pitch qp), k / v [inner][Tk] (pitch kp).
-// bucket_lut: bucket of (j - i) at index (j - i) + lut_zero, or nullptr (cross attention: no position bias).
+// Attention of one (query column, head): scores_j = q . k_j + bias[bucket(j - (i + q_off))][head] (no 1/sqrt(d) in T5),
+// causal: keys j <= i + q_off only; softmax; out = sum_j p_j v_j.
+// Columns are grouped in sequences of `seg` queries: column c is query i = c % seg of sequence b = c / seg, whose keys /
+// values start kv_bs floats into k / v (channel stride kp, time contiguous) and number lens[b] (or Tk if lens is null).
+// q / out element (channel ch, column c) sits at ch * q_cs + c * q_ts: [C][T] activations have (T, 1), the decoder step's
+// [NB][C] vectors (1, C).  bucket_lut: bucket of (j - i) at index (j - i) + lut_zero, or nullptr (cross attention).
 // Keys / values are channel-major (time contiguous): lanes run along time, and every loop over channels issues its
 // loads eight at a time (one dependent load per channel made a decoder step's eight attention calls 30 us each).
-__global__ __launch_bounds__(256) void g2p_attention_kernel(const float *__restrict__ q, int qp, const float *__restrict__ k,
-                                                            const float *__restrict__ v, int kp, const float *__restrict__ bias,
+__global__ __launch_bounds__(256) void g2p_attention_kernel(const float *__restrict__ q, int q_cs, int q_ts,
+                                                            const float *__restrict__ k, const float *__restrict__ v, int kp,
+                                                            int64_t kv_bs, const float *__restrict__ bias,
                                                             const int *__restrict__ bucket_lut, int lut_zero,
-                                                            float *__restrict__ out, int op, int heads, int dk, int Tq, int Tk,
-                                                            int q_off, int causal) {
+                                                            float *__restrict__ out, int heads, int dk, int seg,
+                                                            const int *__restrict__ lens, int Tk, int q_off, int causal) {
     extern __shared__ float sc[];  // [Tk] scores, then [dk] the query
     __shared__ float red[256];
-    const int i = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = c / seg, i = c - b * seg;
     const int ipos = i + q_off;
-    const int lim = causal ? (ipos + 1 < Tk ? ipos + 1 : Tk) : Tk;
+    const int nk = lens ? lens[b] : Tk;
+    const int lim = causal ? (ipos + 1 < nk ? ipos + 1 : nk) : nk;
     float *qs = sc + Tk;
-    for (int d = tid; d < dk; d += 256) qs[d] = q[((int64_t)h * dk + d) * qp + i];
+    for (int d = tid; d < dk; d += 256) qs[d] = q[((int64_t)h * dk + d) * q_cs + (int64_t)c * q_ts];
     __syncthreads();
-    const float *kh = k + (int64_t)h * dk * kp, *vh = v + (int64_t)h * dk * kp;
+    const float *kh = k + (int64_t)b * kv_bs + (int64_t)h * dk * kp, *vh = v + (int64_t)b * kv_bs + (int64_t)h * dk * kp;
     float mx = -__builtin_inff();
     for (int j = tid; j < lim; j += 256) {
         float s = 0.f;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256) void g2p_attention_kernel(const float *__restr
         for (int e = 0; e < 8; e++) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) acc[e] += __shfl_xor(acc[e], o, 64);
-            if (lane == 0 && d0 + e < dk) out[((int64_t)h * dk + d0 + e) * op + i] = acc[e] * inv;
+            if (lane == 0 && d0 + e < dk) out[((int64_t)h * dk + d0 + e) * q_cs + (int64_t)c * q_ts] = acc[e] * inv;
         }
     }
 }
@@ -155,12 +162,14 @@ struct G2PLinJob {
     const float *W;
     float *y;
     const float *res;
-    int out, tiles;  // tiles = ceil(out / 16)
+    int out, tiles;      // tiles = ceil(out / 16)
+    int64_t y_rs, y_cs;  // output (and residual) element (row, column) at row * y_rs + column * y_cs
 };
 struct G2PLinArgs {
     G2PLinJob job[3];
     const float *x;
-    int njobs, in, T, xp, yp;
+    int njobs, in, T, xp;
+    int cb;              // 16-column blocks per workgroup (1 .. 8): narrower tiles = more workgroups on a short grid
 };
 typedef float g2p_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -171,8 +180,8 @@ __global__ __launch_bounds__(512) void g2p_linear_kernel(G2PLinArgs a) {
     const G2PLinJob &J = a.job[jb];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
-    const int row0 = blk * 16, t0 = blockIdx.y * 128;
-    const int ncol = a.T - t0 < 128 ? a.T - t0 : 128, nb = (ncol + 15) >> 4;
+    const int row0 = blk * 16, t0 = blockIdx.y * (16 * a.cb);
+    const int ncol = a.T - t0 < 16 * a.cb ? a.T - t0 : 16 * a.cb, nb = (ncol + 15) >> 4;
     const int steps = (a.in + 15) >> 4;                        // 16 k per step
     const int s0 = steps * wave / 8, s1 = steps * (wave + 1) / 8;
     const bool row_ok = row0 + m < J.out;
@@ -181,41 +190,52 @@ __global__ __launch_bounds__(512) void g2p_linear_kernel(G2PLinArgs a) {
     g2p_f32x4 acc[8];
 #pragma unroll
     for (int n = 0; n < 8; n++) acc[n] = g2p_f32x4{0.f, 0.f, 0.f, 0.f};
-    struct Frag {
-        float av[4];
-        float bv[4][8];
-    };
-    auto load = [&](Frag &f, int s) {
+    // The weights are the stream that comes from HBM (each byte once per launch): a wave requests its whole share - up to
+    // 16 steps, 64 registers - before anything else, so that it pays that latency once.  The activations (L2) follow in
+    // groups of four steps.
+    auto load_w = [&](float (&av)[4], int s) {
         const int k = s * 16 + 4 * kq;
         if (vec_ok && k + 4 <= a.in && row_ok) {
             const float4 w = *reinterpret_cast<const float4 *>(wrow + k);
-            f.av[0] = w.x, f.av[1] = w.y, f.av[2] = w.z, f.av[3] = w.w;
+            av[0] = w.x, av[1] = w.y, av[2] = w.z, av[3] = w.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) f.av[j] = row_ok && k + j < a.in ? wrow[k + j] : 0.f;
+            for (int j = 0; j < 4; j++) av[j] = row_ok && k + j < a.in ? wrow[k + j] : 0.f;
         }
+    };
+    auto load_x = [&](float (&bv)[4][8], int s) {
+        const int k = s * 16 + 4 * kq;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float *xr = a.x + (int64_t)(k + j < a.in ? k + j : 0) * a.xp + t0 + m;
             const bool k_ok = k + j < a.in;
 #pragma unroll
-            for (int n = 0; n < 8; n++) f.bv[j][n] = n < nb && k_ok && 16 * n + m < ncol ? xr[16 * n] : 0.f;
+            for (int n = 0; n < 8; n++) bv[j][n] = n < nb && k_ok && 16 * n + m < ncol ? xr[16 * n] : 0.f;
         }
     };
-    auto mma = [&](const Frag &f) {
+    auto mma = [&](const float (&av)[4], const float (&bv)[4][8]) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int n = 0; n < 8; n++)
-                if (n < nb) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.av[j], f.bv[j][n], acc[n], 0, 0, 0);
+                if (n < nb) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j][n], acc[n], 0, 0, 0);
     };
-    Frag f0, f1;
-    if (s0 < s1) load(f0, s0);
-    for (int s = s0; s < s1; s += 2) {
-        if (s + 1 < s1) load(f1, s + 1);
-        mma(f0);
-        if (s + 2 < s1) load(f0, s + 2);
-        if (s + 1 < s1) mma(f1);
+    for (int g0 = s0; g0 < s1; g0 += 16) {
+        float av[16][4];
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            if (g0 + u < s1) load_w(av[u], g0 + u);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            if (g0 + 4 * q4 >= s1) break;
+            float bv[4][4][8];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (g0 + 4 * q4 + u < s1) load_x(bv[u], g0 + 4 * q4 + u);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (g0 + 4 * q4 + u < s1) mma(av[4 * q4 + u], bv[u]);
+        }
     }
 #pragma unroll
     for (int n = 0; n < 8; n++)
@@ -230,22 +250,24 @@ __global__ __launch_bounds__(512) void g2p_linear_kernel(G2PLinArgs a) {
         const int l = e & 63, r = (e >> 6) & 3, n = e >> 8;
         const int row = row0 + 4 * (l >> 4) + r, col = 16 * n + (l & 15);
         if (row < J.out && col < ncol) {
-            const int64_t o = (int64_t)row * a.yp + t0 + col;
+            const int64_t o = (int64_t)row * J.y_rs + (int64_t)(t0 + col) * J.y_cs;
             J.y[o] = J.res ? v + J.res[o] : v;
         }
     }
 }
 
-// The decoder step's matrix-vector products, up to three per launch (q | k | v of one attention share their input):
-//   y_j[row * ys_j] = post * rs * sum_i W_j[row][i] g[i] x[i]  (+ res_j[row])        rs = rsqrt(mean(x^2) + eps) if g
-// i.e. the T5 RMS norm in front of the projection is folded in (every wave streams x anyway, so the sum of squares is
-// free), and with `gate` the two input projections of T5DenseGatedActDense are one job: y = act(W x') * (W2 x').
-// One wave per output row, four rows per workgroup; weights stream once, float4 per lane.
+// The decoder step's matrix-vector products for NB sequences decoded side by side, up to three W per launch (q | k | v of
+// one attention share their input):
+//   y_j[b * yb_j + row * ys_j] = post * rs_b * sum_i W_j[row][i] g[i] x[b][i]  (+ res_j[same place])
+//   rs_b = rsqrt(mean(x[b]^2) + eps) if g: the T5 RMS norm in front of the projection is folded in (every wave streams
+// x anyway, so the sum of squares is free); with `W2` the two input projections of T5DenseGatedActDense are one job:
+// y = act(W x') * (W2 x').  One wave per output row, four rows per workgroup; the weights stream ONCE for all NB
+// sequences (float4 per lane), the NB input vectors [NB][in] come from L2.
 struct G2PStepJob {
     const float *W, *W2;
     float *y;
     const float *res;
-    int ys, out, blocks;  // blocks = ceil(out / 4)
+    int ys, yb, out, blocks;  // row stride, sequence stride; blocks = ceil(out / 4)
 };
 struct G2PStepArgs {
     G2PStepJob job[3];
@@ -260,6 +282,7 @@ __device__ __forceinline__ float g2p_activation(float x, int act) {
     return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }
 
+template <int NB>
 __global__ __launch_bounds__(256) void g2p_step_kernel(G2PStepArgs a) {
     int blk = blockIdx.x, j = 0;
     while (j + 1 < a.njobs && blk >= a.job[j].blocks) blk -= a.job[j++].blocks;
@@ -270,45 +293,68 @@ __global__ __launch_bounds__(256) void g2p_step_kernel(G2PStepArgs a) {
     const float4 *v4 = J.W2 ? reinterpret_cast<const float4 *>(J.W2 + (int64_t)row * a.in) : nullptr;
     const float4 *x4 = reinterpret_cast<const float4 *>(a.x);
     const float4 *g4 = reinterpret_cast<const float4 *>(a.g);
-    float s = 0.f, s2 = 0.f, ss = 0.f;
+    float s[NB], s2[NB], ss[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) s[b] = s2[b] = ss[b] = 0.f;
     if (a.in & 3) {  // rows not 16-byte aligned: one float per lane
         const float *w = J.W + (int64_t)row * a.in, *v = J.W2 ? J.W2 + (int64_t)row * a.in : nullptr;
         for (int i = lane; i < a.in; i += 64) {
-            float x = a.x[i];
-            if (a.g) {
-                ss += x * x;
-                x *= a.g[i];
+            const float wi = w[i], vi = v ? v[i] : 0.f, gi = a.g ? a.g[i] : 1.f;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                float x = a.x[(int64_t)b * a.in + i];
+                ss[b] += x * x;
+                x *= gi;
+                s[b] += wi * x;
+                s2[b] += vi * x;
             }
-            s += w[i] * x;
-            if (v) s2 += v[i] * x;
         }
-    } else
-    for (int i = lane; i < (a.in >> 2); i += 64) {
-        float4 x = x4[i];
-        const float4 w = w4[i];
-        if (g4) {
-            ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
-            const float4 g = g4[i];
-            x.x *= g.x, x.y *= g.y, x.z *= g.z, x.w *= g.w;
-        }
-        s += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
-        if (v4) {
-            const float4 v = v4[i];
-            s2 += v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+    } else {
+        const int n4 = a.in >> 2;
+        for (int i = lane; i < n4; i += 64) {
+            const float4 w = w4[i];
+            float4 v = float4{0.f, 0.f, 0.f, 0.f}, g = float4{1.f, 1.f, 1.f, 1.f};
+            if (v4) v = v4[i];
+            if (g4) g = g4[i];
+            float4 x[NB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) x[b] = x4[(int64_t)b * n4 + i];
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                ss[b] += x[b].x * x[b].x + x[b].y * x[b].y + x[b].z * x[b].z + x[b].w * x[b].w;
+                x[b].x *= g.x, x[b].y *= g.y, x[b].z *= g.z, x[b].w *= g.w;
+                s[b] += w.x * x[b].x + w.y * x[b].y + w.z * x[b].z + w.w * x[b].w;
+                s2[b] += v.x * x[b].x + v.y * x[b].y + v.z * x[b].z + v.w * x[b].w;
+            }
         }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        s += __shfl_xor(s, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-        ss += __shfl_xor(ss, o, 64);
-    }
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s[b] += __shfl_xor(s[b], o, 64);
+            s2[b] += __shfl_xor(s2[b], o, 64);
+            ss[b] += __shfl_xor(ss[b], o, 64);
+        }
     if (lane) return;
-    const float rs = (g4 ? 1.0f / sqrtf(ss / (float)a.in + a.eps) : 1.0f) * a.post;
-    float y = s * rs;
-    if (v4) y = g2p_activation(y, a.act) * (s2 * rs);
-    else if (a.act >= 0) y = g2p_activation(y, a.act);
-    J.y[(int64_t)row * J.ys] = J.res ? y + J.res[row] : y;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const float rs = (g4 ? 1.0f / sqrtf(ss[b] / (float)a.in + a.eps) : 1.0f) * a.post;
+        float y = s[b] * rs;
+        if (v4) y = g2p_activation(y, a.act) * (s2[b] * rs);
+        else if (a.act >= 0) y = g2p_activation(y, a.act);
+        const int64_t o = (int64_t)b * J.yb + (int64_t)row * J.ys;
+        J.y[o] = J.res ? y + J.res[o] : y;
+    }
+}
+
+// x[b][c] = table[ids[b * id_stride]][c]: the embeddings of the tokens the NB sequences decode next
+__global__ void g2p_embed_rows_kernel(const int64_t *ids, int id_stride, const float *table, float *x, int C, int vocab) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    int64_t id = ids[(int64_t)b * id_stride];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    x[(int64_t)b * C + c] = table[id * C + c];
 }
 
 __global__ void g2p_scale_kernel(float *x, int64_t n, float s) {
@@ -316,12 +362,15 @@ __global__ void g2p_scale_kernel(float *x, int64_t n, float s) {
     if (i < n) x[i] *= s;
 }
 
-// argmax over the vocabulary of column t of logits [V][pitch] (first maximum, as np.argmax) -> ids[slot] (int64)
-__global__ __launch_bounds__(256) void g2p_argmax_kernel(const float *logits, int V, int pitch, int t, int64_t *ids, int slot,
-                                                         int64_t *host_copy) {
+// argmax over the vocabulary (first maximum, as np.argmax), one workgroup per sequence b = blockIdx.x:
+// logits element v of sequence b at b * lb + v * pitch + t  ->  ids[b * ib + slot] (int64) and, if given, the same
+// place of the pinned host copy
+__global__ __launch_bounds__(256) void g2p_argmax_kernel(const float *logits, int V, int pitch, int t, int64_t lb, int64_t *ids,
+                                                         int64_t ib, int slot, int64_t *host_copy) {
     __shared__ float bv[256];
     __shared__ int bi[256];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    logits += (int64_t)b * lb;
     float best = -__builtin_inff();
     int idx = 0x7fffffff;
     for (int c = tid; c < V; c += 256) {
@@ -342,8 +391,8 @@ __global__ __launch_bounds__(256) void g2p_argmax_kernel(const float *logits, in
         __syncthreads();
     }
     if (tid == 0) {
-        ids[slot] = bi[0];
-        if (host_copy) host_copy[slot] = bi[0];  // (pinned, mapped: visible to the host once the step's event has fired)
+        ids[(int64_t)b * ib + slot] = bi[0];
+        if (host_copy) host_copy[(int64_t)b * ib + slot] = bi[0];  // (pinned, mapped: visible once the step's event has fired)
     }
 }
 
@@ -406,8 +455,9 @@ struct LinJob {
     const T5Linear *L;
     float *y;
     const float *res;
+    int64_t y_rs = 0, y_cs = 1;  // (0: the call's default row stride)
 };
-void linear(Run &r, std::initializer_list<LinJob> jobs, const float *x, int xp, int T, int yp) {
+void linear(Run &r, std::initializer_list<LinJob> jobs, const float *x, int xp, int T, int64_t y_rs) {
     static bool attr_set = false;
     if (!attr_set) {
         r.note(hipFuncSetAttribute(reinterpret_cast<const void *>(g2p_linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -423,39 +473,45 @@ void linear(Run &r, std::initializer_list<LinJob> jobs, const float *x, int xp, 
         d.res = j.res;
         d.out = j.L->out;
         d.tiles = (j.L->out + 15) / 16;
+        d.y_rs = j.y_rs ? j.y_rs : y_rs;
+        d.y_cs = j.y_cs;
         tiles += d.tiles;
         a.in = j.L->in;
     }
     a.x = x;
     a.T = T;
     a.xp = xp;
-    a.yp = yp;
-    g2p_linear_kernel<<<dim3(tiles, (T + 127) / 128), 512, 64 * 1024, r.st>>>(a);
+    // column tile: 128 wide.  (Narrower tiles on short grids - 32 columns at T = 80 - were measured slower: a
+    // workgroup's time is the latency of its weight rows, not its matrix work.)
+    a.cb = 8;
+    g2p_linear_kernel<<<dim3(tiles, (T + 16 * a.cb - 1) / (16 * a.cb)), 512, 64 * 1024, r.st>>>(a);
 }
 void linear(Run &r, const T5Linear &L, const float *x, int xp, int T, float *y, int yp, const float *res = nullptr) {
     linear(r, {{&L, y, res}}, x, xp, T, yp);
 }
 
-// One launch of the decoder step (see g2p_step_kernel): `g` = RMS-norm weight folded in front (or -1).
+// One launch of the decoder step for nb sequences (see g2p_step_kernel): `g` = RMS-norm weight folded in front (or -1).
+// y / res element (sequence b, row) at b * yb + row * ys.
 struct StepJob {
     const T5Linear *L, *gate;
     float *y;
-    int ys;
+    int ys, yb;
     const float *res;
 };
-void step(Run &r, std::initializer_list<StepJob> jobs, const float *x, int64_t g, int act = -1, float post = 1.f) {
+void step(Run &r, int nb, std::initializer_list<StepJob> jobs, const float *x, int64_t g, int act = -1, float post = 1.f) {
     G2PStepArgs a{};
-    int nb = 0;
+    int blocks = 0;
     for (const StepJob &j : jobs) {
         G2PStepJob &d = a.job[a.njobs++];
         d.W = r.P(j.L->rowmajor);
         d.W2 = j.gate ? r.P(j.gate->rowmajor) : nullptr;
         d.y = j.y;
         d.ys = j.ys;
+        d.yb = j.yb;
         d.res = j.res;
         d.out = j.L->out;
         d.blocks = (j.L->out + 3) / 4;
-        nb += d.blocks;
+        blocks += d.blocks;
         a.in = j.L->in;
     }
     a.x = x;
@@ -463,7 +519,12 @@ void step(Run &r, std::initializer_list<StepJob> jobs, const float *x, int64_t g
     a.act = act;
     a.eps = r.h->model.eps;
     a.post = post;
-    g2p_step_kernel<<<nb, 256, 0, r.st>>>(a);
+    switch (nb) {
+        case 1: g2p_step_kernel<1><<<blocks, 256, 0, r.st>>>(a); break;
+        case 2: g2p_step_kernel<2><<<blocks, 256, 0, r.st>>>(a); break;
+        case 4: g2p_step_kernel<4><<<blocks, 256, 0, r.st>>>(a); break;
+        default: g2p_step_kernel<4><<<blocks, 256, 0, r.st>>>(a); break;
+    }
 }
 
 void rmsnorm(Run &r, const float *x, int xp, int64_t g, float *y, int yp, int T) {
@@ -471,12 +532,13 @@ void rmsnorm(Run &r, const float *x, int xp, int64_t g, float *y, int yp, int T)
     g2p_rmsnorm_kernel<<<T, 256, 0, r.st>>>(x, r.P(g), y, m.d_model, T, xp, yp, m.eps);
 }
 
-void attention(Run &r, const float *q, int qp, const float *k, const float *v, int kp, int64_t bias, const int *lut, float *out,
-               int op, int Tq, int Tk, int q_off, bool causal) {
+// attention over `cols` query columns in sequences of `seg` (see g2p_attention_kernel for the strides)
+void attention(Run &r, const float *q, int q_cs, int q_ts, const float *k, const float *v, int kp, int64_t kv_bs, int64_t bias,
+               const int *lut, float *out, int cols, int seg, const int *lens, int Tk, int q_off, bool causal) {
     const G2PModel &m = r.h->model;
-    g2p_attention_kernel<<<dim3(Tq, m.heads), 256, (size_t)(Tk + m.d_kv) * sizeof(float), r.st>>>(
-        q, qp, k, v, kp, bias >= 0 ? r.P(bias) : nullptr, lut, G2PModel::kMaxPos - 1, out, op, m.heads, m.d_kv, Tq, Tk, q_off,
-        causal ? 1 : 0);
+    g2p_attention_kernel<<<dim3(cols, m.heads), 256, (size_t)(Tk + m.d_kv) * sizeof(float), r.st>>>(
+        q, q_cs, q_ts, k, v, kp, kv_bs, bias >= 0 ? r.P(bias) : nullptr, lut, G2PModel::kMaxPos - 1, out, m.heads, m.d_kv, seg,
+        lens, Tk, q_off, causal ? 1 : 0);
 }
 
 void ffn(Run &r, const T5FfnDesc &f, const float *hn, float *x, int T, float *a, float *b) {
@@ -502,21 +564,23 @@ int ws_reserve(g2p_handle *h, size_t bytes) {
     return 0;
 }
 
-// encoder over ids [S] (device) -> enc_out [d_model][S]
-void run_encoder(Run &r, const int64_t *d_ids, int S, float *x, float *hn, float *q, float *k, float *v, float *att, float *fa,
-                 float *fb) {
+// encoder over nseq sequences of S ids each (device, zero-padded; true lengths in d_lens, or nullptr = all S)
+// -> enc_out [d_model][nseq * S]; a padded column attends like the others and is never attended to
+void run_encoder(Run &r, const int64_t *d_ids, int S, int nseq, const int *d_lens, float *x, float *hn, float *q, float *k,
+                 float *v, float *att, float *fa, float *fb) {
     g2p_handle *h = r.h;
     const G2PModel &m = h->model;
-    g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, S), 256, 0, r.st>>>(d_ids, r.P(m.shared), x, m.d_model, S, S, m.vocab);
+    const int T = S * nseq;
+    g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, T), 256, 0, r.st>>>(d_ids, 1, r.P(m.shared), x, m.d_model, T, T, m.vocab);
     for (const auto &b : m.enc) {
-        rmsnorm(r, x, S, b.ln_self, hn, S, S);
-        linear(r, {{&b.self.q, q, nullptr}, {&b.self.k, k, nullptr}, {&b.self.v, v, nullptr}}, hn, S, S, S);
-        attention(r, q, S, k, v, S, m.enc_bias, h->d_bucket_enc, att, S, S, S, 0, false);
-        linear(r, b.self.o, att, S, S, x, S, x);
-        rmsnorm(r, x, S, b.ln_ffn, hn, S, S);
-        ffn(r, b.ffn, hn, x, S, fa, fb);
+        rmsnorm(r, x, T, b.ln_self, hn, T, T);
+        linear(r, {{&b.self.q, q, nullptr}, {&b.self.k, k, nullptr}, {&b.self.v, v, nullptr}}, hn, T, T, T);
+        attention(r, q, T, 1, k, v, T, S, m.enc_bias, h->d_bucket_enc, att, T, S, d_lens, S, 0, false);
+        linear(r, b.self.o, att, T, T, x, T, x);
+        rmsnorm(r, x, T, b.ln_ffn, hn, T, T);
+        ffn(r, b.ffn, hn, x, T, fa, fb);
     }
-    rmsnorm(r, x, S, m.enc_final_ln, x, S, S);
+    rmsnorm(r, x, T, m.enc_final_ln, x, T, T);
 }
 
 int check_dev(g2p_handle *h) {
@@ -563,7 +627,7 @@ int g2p_open(const char *path, int device, g2p_handle **out) {
             hipMalloc((void **)&h->d_bucket_enc, lut) != hipSuccess || hipMalloc((void **)&h->d_bucket_dec, lut) != hipSuccess ||
             hipMemcpy(h->d_bucket_enc, h->model.bucket_enc.data(), lut, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(h->d_bucket_dec, h->model.bucket_dec.data(), lut, hipMemcpyHostToDevice) != hipSuccess ||
-            hipHostMalloc((void **)&h->tok_host, G2PModel::kMaxPos * sizeof(int64_t), hipHostMallocMapped) != hipSuccess ||
+            hipHostMalloc((void **)&h->tok_host, (size_t)G2P_MAX_BATCH * G2PModel::kMaxPos * sizeof(int64_t), hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void **)&h->tok_dev, h->tok_host, 0) != hipSuccess ||
             hipEventCreateWithFlags(&h->step_done[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->step_done[1], hipEventDisableTiming) != hipSuccess) {
@@ -655,18 +719,18 @@ int g2p_run(g2p_handle *h, const int64_t *input_ids, int S, const int64_t *mask,
     hipStream_t st = h->stream;
     r.note(hipMemcpyAsync(d_in, input_ids, (size_t)S * 8, hipMemcpyHostToDevice, st));
     r.note(hipMemcpyAsync(d_dec, dec_ids, (size_t)T * 8, hipMemcpyHostToDevice, st));
-    run_encoder(r, d_in, S, xe, hn, q, k, v, att, fa, fb);
+    run_encoder(r, d_in, S, 1, nullptr, xe, hn, q, k, v, att, fa, fb);
     // decoder over the whole prefix (teacher forced, causal)
-    g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, T), 256, 0, st>>>(d_dec, r.P(m.shared), xd, m.d_model, T, T, m.vocab);
+    g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, T), 256, 0, st>>>(d_dec, 1, r.P(m.shared), xd, m.d_model, T, T, m.vocab);
     for (const auto &b : m.dec) {
         rmsnorm(r, xd, T, b.ln_self, hn, T, T);
         linear(r, {{&b.self.q, q, nullptr}, {&b.self.k, k, nullptr}, {&b.self.v, v, nullptr}}, hn, T, T, T);
-        attention(r, q, T, k, v, T, m.dec_bias, h->d_bucket_dec, att, T, T, T, 0, true);
+        attention(r, q, T, 1, k, v, T, 0, m.dec_bias, h->d_bucket_dec, att, T, T, nullptr, T, 0, true);
         linear(r, b.self.o, att, T, T, xd, T, xd);
         rmsnorm(r, xd, T, b.ln_cross, hn, T, T);
         linear(r, b.cross.q, hn, T, T, q, T);
         linear(r, {{&b.cross.k, kc, nullptr}, {&b.cross.v, vc, nullptr}}, xe, S, S, S);
-        attention(r, q, T, kc, vc, S, -1, nullptr, att, T, T, S, 0, false);
+        attention(r, q, T, 1, kc, vc, S, 0, -1, nullptr, att, T, T, nullptr, S, 0, false);
         linear(r, b.cross.o, att, T, T, xd, T, xd);
         rmsnorm(r, xd, T, b.ln_ffn, hn, T, T);
         ffn(r, b.ffn, hn, xd, T, fa, fb);
@@ -685,86 +749,155 @@ int g2p_run(g2p_handle *h, const int64_t *input_ids, int S, const int64_t *mask,
     return VITS_OK;
 }
 
-int g2p_generate(g2p_handle *h, const int64_t *input_ids, int S, int max_length, int64_t start_id, int64_t eos_id,
-                 int64_t *out_ids, int *n_out) {
+int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens, int B, int max_length, int64_t start_id,
+                       int64_t eos_id, int64_t *out_ids, int *n_out) {
     if (int rc = check_dev(h)) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
     const G2PModel &m = h->model;
-    if (!input_ids || !out_ids || !n_out || S <= 0 || max_length <= 0) return gfail(h, VITS_E_ARG, "bad g2p_generate arguments");
-    if (S >= G2PModel::kMaxPos || max_length >= G2PModel::kMaxPos)
-        return gfail(h, VITS_E_ARG, "sequence longer than %d", G2PModel::kMaxPos - 1);
-    if (int rc = check_ids(h, input_ids, S, "input_ids")) return rc;
+    if (!input_ids || !lens || !out_ids || !n_out || B <= 0 || max_length <= 0) return gfail(h, VITS_E_ARG, "bad g2p_generate arguments");
+    if (B > G2P_MAX_BATCH) return gfail(h, VITS_E_ARG, "at most %d sequences per call", G2P_MAX_BATCH);
+    if (max_length >= G2PModel::kMaxPos) return gfail(h, VITS_E_ARG, "sequence longer than %d", G2PModel::kMaxPos - 1);
     if (start_id < 0 || start_id >= m.vocab) return gfail(h, VITS_E_ARG, "start id out of range");
+    int S = 0, total = 0;
+    for (int b = 0; b < B; b++) {
+        if (lens[b] <= 0 || lens[b] >= G2PModel::kMaxPos) return gfail(h, VITS_E_ARG, "input %d: length %d not in [1, %d)", b, lens[b], G2PModel::kMaxPos);
+        S = lens[b] > S ? lens[b] : S;
+        total += lens[b];
+    }
+    if (int rc = check_ids(h, input_ids, total, "input_ids")) return rc;
+    // NB sequences run side by side (B rounded up to a size the step kernel is instantiated for; the spare ones decode
+    // a one-token input and are ignored)
+    int NB = 1;
+    while (NB < B && NB < 4) NB *= 2;
+    if (B > 4) NB = (B + 7) / 8 * 8;
+    // Up to 4 sequences: the fused matrix-vector step (norm and gate folded in, 8 launches per layer).  More: the
+    // sequences become the columns of [C][NB] activations and the step runs on the short-sequence kernels the encoder
+    // uses (12 launches per layer, but one MFMA column per sequence instead of NB dot products per weight).
+    const bool wide = NB > 4;
     const int TM = max_length + 1;  // decoder positions: the start token + every generated one
-    const size_t nA = (size_t)(m.d_model > m.inner ? m.d_model : m.inner) * S;
+    const int T = S * NB;
+    const size_t nA = (size_t)(m.d_model > m.inner ? m.d_model : m.inner) * T;
     const int nd = (int)m.dec.size();
-    const size_t need = 8 * (nA * 4 + 512) + 2 * ((size_t)m.d_ff * S * 4 + 512) + (size_t)nd * 2 * ((size_t)m.inner * TM * 4 + 512) +
-                        (size_t)nd * 2 * ((size_t)m.inner * S * 4 + 512) + (size_t)(S + TM) * 8 + (size_t)m.vocab * 4 + (1 << 16) +
-                        8 * ((size_t)m.d_ff * 4 + (size_t)m.d_model * 4 + 1024);
+    const size_t need = 8 * (nA * 4 + 512) + 2 * ((size_t)m.d_ff * T * 4 + 512) +
+                        (size_t)nd * 2 * ((size_t)NB * m.inner * TM * 4 + 512) + (size_t)nd * 2 * ((size_t)m.inner * T * 4 + 512) +
+                        (size_t)(T + (size_t)NB * TM) * 8 + (size_t)NB * (m.vocab + 2 * m.d_model + 2 * m.inner + 2 * m.d_ff + 64) * 4 +
+                        (1 << 16);
     if (int rc = ws_reserve(h, need)) return rc;
     Run r{h, h->stream, h->arena_dev};
     r.ws = h->ws;
     hipStream_t st = h->stream;
-    int64_t *d_in = r.take<int64_t>(S), *d_gen = r.take<int64_t>(TM);
+    int64_t *d_in = r.take<int64_t>(T), *d_gen = r.take<int64_t>((size_t)NB * TM);
+    int *d_lens = r.take<int>(NB);
     float *xe = r.take<float>(nA), *hn = r.take<float>(nA), *q = r.take<float>(nA), *k = r.take<float>(nA);
     float *v = r.take<float>(nA), *att = r.take<float>(nA);
-    float *fa = r.take<float>((size_t)m.d_ff * S), *fb = r.take<float>((size_t)m.d_ff * S);
+    float *fa = r.take<float>((size_t)m.d_ff * T), *fb = r.take<float>((size_t)m.d_ff * T);
     std::vector<float *> ks(nd), vs(nd), kc(nd), vc(nd);
     for (int l = 0; l < nd; l++) {
-        ks[l] = r.take<float>((size_t)m.inner * TM);  // self-attention cache [inner][TM]
-        vs[l] = r.take<float>((size_t)m.inner * TM);
-        kc[l] = r.take<float>((size_t)m.inner * S);   // cross-attention keys / values of the encoder output
-        vc[l] = r.take<float>((size_t)m.inner * S);
+        ks[l] = r.take<float>((size_t)NB * m.inner * TM);  // self-attention cache [NB][inner][TM]
+        vs[l] = r.take<float>((size_t)NB * m.inner * TM);
+        kc[l] = r.take<float>((size_t)m.inner * T);        // cross-attention keys / values of the encoder output [inner][NB * S]
+        vc[l] = r.take<float>((size_t)m.inner * T);
     }
-    float *x1 = r.take<float>(m.d_model), *q1 = r.take<float>(m.inner);
-    float *a1 = r.take<float>(m.inner), *f1 = r.take<float>(m.d_ff), *lg = r.take<float>(m.vocab);
-    r.note(hipMemcpyAsync(d_in, input_ids, (size_t)S * 8, hipMemcpyHostToDevice, st));
-    r.note(hipMemcpyAsync(d_gen, &start_id, 8, hipMemcpyHostToDevice, st));
-    run_encoder(r, d_in, S, xe, hn, q, k, v, att, fa, fb);
-    for (int l = 0; l < nd; l++) {
-        linear(r, {{&m.dec[l].cross.k, kc[l], nullptr}, {&m.dec[l].cross.v, vc[l], nullptr}}, xe, S, S, S);
+    float *x1 = r.take<float>((size_t)NB * m.d_model), *q1 = r.take<float>((size_t)NB * m.inner);
+    float *a1 = r.take<float>((size_t)NB * m.inner), *f1 = r.take<float>((size_t)NB * m.d_ff), *lg = r.take<float>((size_t)NB * m.vocab);
+    float *h1 = r.take<float>((size_t)NB * m.d_model), *f2 = r.take<float>((size_t)NB * m.d_ff);  // (wide step only)
+    {   // padded ids [NB][S], lengths, start tokens: one staging buffer each (pageable -> the copies are staged at once)
+        std::vector<int64_t> ids((size_t)T, 0), gen((size_t)NB * TM, 0);
+        std::vector<int> ln(NB, 1);
+        for (int b = 0, o = 0; b < B; o += lens[b], b++) {
+            std::memcpy(ids.data() + (size_t)b * S, input_ids + o, (size_t)lens[b] * 8);
+            ln[b] = lens[b];
+        }
+        for (int b = 0; b < NB; b++) gen[(size_t)b * TM] = start_id;
+        r.note(hipMemcpyAsync(d_in, ids.data(), (size_t)T * 8, hipMemcpyHostToDevice, st));
+        r.note(hipMemcpyAsync(d_gen, gen.data(), (size_t)NB * TM * 8, hipMemcpyHostToDevice, st));
+        r.note(hipMemcpyAsync(d_lens, ln.data(), (size_t)NB * 4, hipMemcpyHostToDevice, st));
+        r.note(hipStreamSynchronize(st));  // (the staging vectors go out of scope)
     }
-    // One decoder step for position t (input: d_gen[t]; the argmax lands in d_gen[t + 1] and in the pinned copy); keys /
-    // values of position t join the cache.  8 launches per layer: norm + q|k|v, attention, o (+x), norm + q, cross
-    // attention, o (+x), norm + gated input projections, wo (+x).
+    run_encoder(r, d_in, S, NB, d_lens, xe, hn, q, k, v, att, fa, fb);
+    for (int l = 0; l < nd; l++)
+        linear(r, {{&m.dec[l].cross.k, kc[l], nullptr}, {&m.dec[l].cross.v, vc[l], nullptr}}, xe, T, T, T);
+    // One decoder step for position t of every sequence (inputs d_gen[b][t]; the argmax lands in d_gen[b][t + 1] and in
+    // the pinned copy); keys / values of position t join the caches.  8 launches per layer: norm + q|k|v, attention,
+    // o (+x), norm + q, cross attention, o (+x), norm + gated input projections, wo (+x).
     const float post = m.scale_out ? 1.0f / std::sqrt((float)m.d_model) : 1.0f;
-    auto enqueue_step = [&](int t) {
-        g2p_embed_kernel<<<dim3((m.d_model + 255) / 256, 1), 256, 0, st>>>(d_gen + t, r.P(m.shared), x1, m.d_model, 1, 1, m.vocab);
+    const int D = m.d_model, I = m.inner;
+    const int64_t cache_bs = (int64_t)I * TM;
+    auto enqueue_wide = [&](int t) {  // activations [C][NB]: column b = sequence b at position t
+        g2p_embed_kernel<<<dim3((D + 255) / 256, NB), 256, 0, st>>>(d_gen + t, TM, r.P(m.shared), x1, D, NB, NB, m.vocab);
         for (int l = 0; l < nd; l++) {
             const auto &b = m.dec[l];
-            step(r, {{&b.self.q, nullptr, q1, 1, nullptr}, {&b.self.k, nullptr, ks[l] + t, TM, nullptr},
-                     {&b.self.v, nullptr, vs[l] + t, TM, nullptr}}, x1, b.ln_self);
-            attention(r, q1, 1, ks[l], vs[l], TM, m.dec_bias, h->d_bucket_dec, a1, 1, 1, t + 1, t, true);
-            step(r, {{&b.self.o, nullptr, x1, 1, x1}}, a1, -1);
-            step(r, {{&b.cross.q, nullptr, q1, 1, nullptr}}, x1, b.ln_cross);
-            attention(r, q1, 1, kc[l], vc[l], S, -1, nullptr, a1, 1, 1, S, 0, false);
-            step(r, {{&b.cross.o, nullptr, x1, 1, x1}}, a1, -1);
-            step(r, {{&b.ffn.wi0, b.ffn.gated ? &b.ffn.wi1 : nullptr, f1, 1, nullptr}}, x1, b.ln_ffn, m.act);
-            step(r, {{&b.ffn.wo, nullptr, x1, 1, x1}}, f1, -1);
+            rmsnorm(r, x1, NB, b.ln_self, h1, NB, NB);
+            linear(r, {{&b.self.q, q1, nullptr}, {&b.self.k, ks[l] + t, nullptr, TM, cache_bs},
+                       {&b.self.v, vs[l] + t, nullptr, TM, cache_bs}}, h1, NB, NB, NB);
+            attention(r, q1, NB, 1, ks[l], vs[l], TM, cache_bs, m.dec_bias, h->d_bucket_dec, a1, NB, 1, nullptr, t + 1, t, true);
+            linear(r, b.self.o, a1, NB, NB, x1, NB, x1);
+            rmsnorm(r, x1, NB, b.ln_cross, h1, NB, NB);
+            linear(r, b.cross.q, h1, NB, NB, q1, NB);
+            attention(r, q1, NB, 1, kc[l], vc[l], T, S, -1, nullptr, a1, NB, 1, d_lens, S, 0, false);
+            linear(r, b.cross.o, a1, NB, NB, x1, NB, x1);
+            rmsnorm(r, x1, NB, b.ln_ffn, h1, NB, NB);
+            ffn(r, b.ffn, h1, x1, NB, f1, f2);
         }
-        step(r, {{&m.lm_head, nullptr, lg, 1, nullptr}}, x1, m.dec_final_ln, -1, post);
-        g2p_argmax_kernel<<<1, 256, 0, st>>>(lg, m.vocab, 1, 0, d_gen, t + 1, h->tok_dev);
+        rmsnorm(r, x1, NB, m.dec_final_ln, h1, NB, NB);
+        if (m.scale_out) g2p_scale_kernel<<<(unsigned)(((size_t)D * NB + 255) / 256), 256, 0, st>>>(h1, (int64_t)D * NB, post);
+        linear(r, m.lm_head, h1, NB, NB, lg, NB);
+        g2p_argmax_kernel<<<NB, 256, 0, st>>>(lg, m.vocab, NB, 0, 1, d_gen, TM, t + 1, h->tok_dev);
         r.note(hipGetLastError());
         r.note(hipEventRecord(h->step_done[t & 1], st));
     };
-    // The loop's one data-dependent decision (stop at EOS) needs the token on the host; step t + 1 is queued before
-    // the host waits for step t, so the device never idles on that round trip.  The step queued behind the EOS step is
-    // wasted work on private buffers (everything later on this stream is ordered behind it).
-    int n = 0;
+    auto enqueue_step = [&](int t) {
+        if (wide) return enqueue_wide(t);
+        g2p_embed_rows_kernel<<<dim3((D + 255) / 256, NB), 256, 0, st>>>(d_gen + t, TM, r.P(m.shared), x1, D, m.vocab);
+        for (int l = 0; l < nd; l++) {
+            const auto &b = m.dec[l];
+            step(r, NB, {{&b.self.q, nullptr, q1, 1, I, nullptr}, {&b.self.k, nullptr, ks[l] + t, TM, (int)cache_bs, nullptr},
+                         {&b.self.v, nullptr, vs[l] + t, TM, (int)cache_bs, nullptr}}, x1, b.ln_self);
+            attention(r, q1, 1, I, ks[l], vs[l], TM, cache_bs, m.dec_bias, h->d_bucket_dec, a1, NB, 1, nullptr, t + 1, t, true);
+            step(r, NB, {{&b.self.o, nullptr, x1, 1, D, x1}}, a1, -1);
+            step(r, NB, {{&b.cross.q, nullptr, q1, 1, I, nullptr}}, x1, b.ln_cross);
+            attention(r, q1, 1, I, kc[l], vc[l], T, S, -1, nullptr, a1, NB, 1, d_lens, S, 0, false);
+            step(r, NB, {{&b.cross.o, nullptr, x1, 1, D, x1}}, a1, -1);
+            step(r, NB, {{&b.ffn.wi0, b.ffn.gated ? &b.ffn.wi1 : nullptr, f1, 1, m.d_ff, nullptr}}, x1, b.ln_ffn, m.act);
+            step(r, NB, {{&b.ffn.wo, nullptr, x1, 1, D, x1}}, f1, -1);
+        }
+        step(r, NB, {{&m.lm_head, nullptr, lg, 1, m.vocab, nullptr}}, x1, m.dec_final_ln, -1, post);
+        g2p_argmax_kernel<<<NB, 256, 0, st>>>(lg, m.vocab, 1, 0, m.vocab, d_gen, TM, t + 1, h->tok_dev);
+        r.note(hipGetLastError());
+        r.note(hipEventRecord(h->step_done[t & 1], st));
+    };
+    // The loop's one data-dependent decision (stop when every sequence has produced EOS) needs the tokens on the host;
+    // step t + 1 is queued before the host waits for step t, so the device never idles on that round trip.  The step
+    // queued behind the last one is wasted work on private buffers (everything later on this stream is ordered behind
+    // it); a sequence that has finished keeps decoding until the others have, its tokens are dropped.
+    std::vector<char> done(B, 0);
+    int open_seqs = B;
+    for (int b = 0; b < B; b++) n_out[b] = 0;
     enqueue_step(0);
-    for (int t = 0; t < max_length; t++) {
+    for (int t = 0; t < max_length && open_seqs > 0; t++) {
         if (t + 1 < max_length) enqueue_step(t + 1);
         r.note(hipEventSynchronize(h->step_done[t & 1]));
         if (r.err != hipSuccess) {
             hipStreamSynchronize(st);
             return gfail(h, VITS_E_DEVICE, "g2p_generate failed: %s", hipGetErrorString(r.err));
         }
-        const int64_t tok = h->tok_host[t + 1];
-        out_ids[n++] = tok;
-        if (tok == eos_id) break;
+        for (int b = 0; b < B; b++) {
+            if (done[b]) continue;
+            const int64_t tok = h->tok_host[(size_t)b * TM + t + 1];
+            out_ids[(size_t)b * max_length + n_out[b]++] = tok;
+            if (tok == eos_id) {
+                done[b] = 1;
+                open_seqs--;
+            }
+        }
     }
-    *n_out = n;
     return VITS_OK;
+}
+
+int g2p_generate(g2p_handle *h, const int64_t *input_ids, int S, int max_length, int64_t start_id, int64_t eos_id,
+                 int64_t *out_ids, int *n_out) {
+    if (!n_out) return gfail(h, VITS_E_ARG, "bad g2p_generate arguments");
+    return g2p_generate_batch(h, input_ids, &S, 1, max_length, start_id, eos_id, out_ids, n_out);
 }
 
 }  // extern "C"

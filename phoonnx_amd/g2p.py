@@ -116,6 +116,30 @@ class MiG2PSession:
         return out[:n.value].tolist()
 
 
+    MAX_BATCH = 64  # G2P_MAX_BATCH (include/g2pmi.h)
+
+    def generate_batch(self, inputs: Sequence[Sequence[int]], max_length: int = 512, start_id: int = 0,
+                       eos_id: int = 1) -> List[List[int]]:
+        """`generate` for several inputs side by side (g2p_generate_batch): same ids as one call each.  Inputs are
+        grouped by length, at most MAX_BATCH per engine call; results come back in the order given."""
+        seqs = [np.ascontiguousarray(np.asarray(x, np.int64).reshape(-1)) for x in inputs]
+        order = sorted(range(len(seqs)), key=lambda i: len(seqs[i]))
+        res: List[List[int]] = [[] for _ in seqs]
+        for g in range(0, len(order), self.MAX_BATCH):
+            idx = order[g:g + self.MAX_BATCH]
+            flat = np.ascontiguousarray(np.concatenate([seqs[i] for i in idx]))
+            lens = np.array([len(seqs[i]) for i in idx], np.int32)
+            out = np.zeros((len(idx), max_length), np.int64)
+            n = np.zeros(len(idx), np.int32)
+            rc = self._lib.g2p_generate_batch(self._h, _ffi.ptr(flat), _ffi.ptr(lens), len(idx), int(max_length), int(start_id),
+                                              int(eos_id), _ffi.ptr(out), _ffi.ptr(n))
+            if rc != 0:
+                raise SessionError(f"g2p_generate_batch failed [{rc}]: {self._err()}")
+            for j, i in enumerate(idx):
+                res[i] = out[j, :n[j]].tolist()
+        return res
+
+
 class ByT5Phonemizer(SimplePhonemizer):
     """Mirror of `phoonnx.phonemizers.mul.ByT5Phonemizer` over `MiG2PSession` (no downloads: the model and tokenizer
     config are files the caller supplies).  `phonemize_string(text, lang)` as mul.py:232-233; `phonemize(text, lang)`
@@ -162,6 +186,18 @@ class ByT5Phonemizer(SimplePhonemizer):
     def phonemize_string(self, text: str, lang: str) -> str:
         return self._infer(text, lang)
 
+    def phonemize_strings(self, chunks: List[str], lang: str, max_length: int = 512) -> List[str]:
+        """Every chunk of a text in one batched greedy loop (the reference runs them one after the other, base.py:66-70;
+        the ids of each chunk are the same either way)."""
+        if not self.device_loop or len(chunks) < 2:
+            return [self.phonemize_string(c, lang) for c in chunks]
+        todo = [i for i, c in enumerate(chunks) if c.strip()]
+        gen = self.session.generate_batch([encode_text(chunks[i], self.get_lang(lang))[0] for i in todo], max_length)
+        out = [""] * len(chunks)
+        for i, ids in zip(todo, gen):
+            out[i] = decode_phones(ids, self.tokens)
+        return out
+
 
 CHARSIU_LANGS = ['ady', 'afr', 'sqi', 'amh', 'ara', 'arg', 'arm-e', 'arm-w', 'aze', 'bak', 'eus', 'bel', 'ben', 'bos',
                  'bul', 'bur', 'cat', 'yue', 'zho-t', 'zho-s', 'min', 'cze', 'dan', 'dut', 'eng-uk', 'eng-us', 'epo',
@@ -189,3 +225,15 @@ class CharsiuPhonemizer(ByT5Phonemizer):
 
     def phonemize_string(self, text: str, lang: str) -> str:
         return " ".join(self._infer(w, lang) for w in text.split())
+
+    def phonemize_strings(self, chunks: List[str], lang: str, max_length: int = 512) -> List[str]:
+        """All words of all chunks in one batched loop, re-joined per chunk (mul.py:284-286 word by word)."""
+        if not self.device_loop:
+            return [self.phonemize_string(c, lang) for c in chunks]
+        words = [c.split() for c in chunks]
+        flat = [w for ws in words for w in ws]
+        if not flat:
+            return ["" for _ in chunks]
+        gen = self.session.generate_batch([encode_text(w, self.get_lang(lang))[0] for w in flat], max_length)
+        it = iter(decode_phones(ids, self.tokens) for ids in gen)
+        return [" ".join(next(it) for _ in ws) for ws in words]

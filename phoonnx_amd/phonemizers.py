@@ -38,14 +38,16 @@ class SimplePhonemizer:
         """base.py:62-86: every chunk (a sentence, or a piece of one between `, ` `:` `;` `...` `|`) is phonemized on its
         own and closes an entry of its own (the reference marks each chunk end-of-sentence, base.py:70), the delimiters
         themselves are dropped."""
-        sentences: List[List[str]] = []
+        chunks: List[str] = []
         for sentence in (s.strip() for s in _SENTENCE_END.split(text or "")):
             if not sentence:
                 continue
-            for chunk in _CHUNK_DELIMS.split(sentence)[::2]:
-                cleaned = _PUNCT.sub("", chunk).strip()
-                sentences.append(list(_LANG_FLAG.sub("", self.phonemize_string(cleaned, lang))))
-        return sentences
+            chunks.extend(_PUNCT.sub("", chunk).strip() for chunk in _CHUNK_DELIMS.split(sentence)[::2])
+        return [list(_LANG_FLAG.sub("", p)) for p in self.phonemize_strings(chunks, lang)]
+
+    def phonemize_strings(self, chunks: List[str], lang: str) -> List[str]:
+        """All chunks of a text; a phonemizer that can run them side by side overrides this (g2p.ByT5Phonemizer)."""
+        return [self.phonemize_string(c, lang) for c in chunks]
 
 
 class RawPhonemes(SimplePhonemizer):

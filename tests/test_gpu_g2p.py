@@ -140,14 +140,52 @@ def test_ttsvoice_with_the_byt5_phonemizer_end_to_end(tmp_path):
     voice = TTSVoice.load(str(model))
     assert isinstance(voice.phonemizer, ByT5Phonemizer) or voice.phonemizer is None
     voice.dedupe_sentences = True
-    text = "hello world. again, hello"
+    # (what a random-weight model says is arbitrary: for "testing the engine" this one repeats the byte "9" until
+    # max_length, for "again" only special ids, i.e. no phonemes - oracle/t5_oracle.py greedy says the same)
+    text = "testing the engine. again, testing the engine"
     sentences = voice.phonemize(text)
     assert isinstance(voice.phonemizer, ByT5Phonemizer)
-    assert 1 <= len(sentences) <= 3 and sentences[0]   # (an empty last entry is dropped, voice.py:208-209)
+    assert len(sentences) == 3 and sentences[1] == [] and set(sentences[0]) == {"9"} and sentences[2] == sentences[0]
     # the phonemes are what the G2P engine's greedy loop says for each chunk, character by character
-    assert sentences[0] == list(voice.phonemizer.phonemize_string("hello world", "en-US"))
+    assert sentences[0] == list(voice.phonemizer.phonemize_string("testing the engine", "en-US"))
     chunks = list(voice.synthesize(text, SynthesisConfig(noise_scale=0.0, noise_w_scale=0.0)))
-    assert len(chunks) == sum(1 for p in sentences if p) and all(c.sample_rate == 22050 for c in chunks)
+    assert len(chunks) == 2 and all(c.sample_rate == 22050 for c in chunks)     # (an entry without phonemes is skipped)
+    assert np.array_equal(chunks[0].audio_float_array, chunks[1].audio_float_array)
     assert all(np.isfinite(c.audio_float_array).all() and len(c.audio_float_array) > 0 for c in chunks)
     voice.phonemizer.session.close()
     voice.session.close()
+
+
+def test_generate_batch_equals_one_call_each(sess):
+    """g2p_generate_batch: padded batch, masked attention, shared weight stream - each sequence's ids are exactly those of
+    a call of its own (the arithmetic per sequence is the same, only the neighbours differ)."""
+    rng = np.random.default_rng(11)
+    for B in (1, 2, 3, 5, 8, 11):
+        inputs = [rng.integers(3, 259, int(n)).astype(np.int64) for n in rng.integers(4, 60, B)]
+        singles = [sess.generate(x, max_length=24) for x in inputs]
+        assert sess.generate_batch(inputs, max_length=24) == singles, B
+    # more inputs than one engine call takes; eos handling: with eos_id = the first token every sequence stops at once
+    inputs = [rng.integers(3, 259, int(n)).astype(np.int64) for n in rng.integers(4, 40, 19)]
+    assert sess.generate_batch(inputs, max_length=12) == [sess.generate(x, max_length=12) for x in inputs]
+    first = sess.generate(inputs[0], max_length=4)[0]
+    assert sess.generate_batch(inputs[:3], max_length=8, eos_id=first)[0] == [first]
+    from phoonnx_amd.session import SessionError
+    with pytest.raises(SessionError):
+        sess.generate_batch([np.array([5000], np.int64)], max_length=4)
+
+
+def test_phonemize_batches_the_chunks(tmp_path):
+    from phoonnx_amd.g2p import ByT5Phonemizer, CharsiuPhonemizer
+    F = json.load(open(os.path.join(GOLDEN, "byt5_frontend.json"), encoding="utf-8"))
+    added = dict(F["tokenizer_config"]["added_tokens_decoder"])
+    added.update({str(i): {"content": f"<extra_id_{i - 259}>"} for i in range(259, 384)})
+    cfg = tmp_path / "tokenizer_config.json"
+    cfg.write_text(json.dumps({"added_tokens_decoder": added}))
+    path = os.path.join(GOLDEN, "byt5_tiny.onnx")
+    text = "one two, three. four; five six seven"
+    for cls, lang in ((ByT5Phonemizer, "en-US"), (CharsiuPhonemizer, "eng-us")):
+        p = cls(path, str(cfg))
+        batched = p.phonemize(text, lang)
+        p.device_loop = False          # the reference's call-by-call loop, chunk after chunk
+        assert p.phonemize(text, lang) == batched and len(batched) == 4
+        p.session.close()

@@ -81,6 +81,20 @@ def main():
     for _ in range(3):
         s.generate(ids[0], max_length=4 * n_tok, eos_id=-1)
     long_s = (time.perf_counter() - t0) / 3
+    # batched loop: 8 and 16 inputs side by side (same length here), tokens per second over all of them
+    batch = {}
+    for nb in (4, 8, 16, 64):
+        many = [np.roll(ids[0], i) for i in range(nb)]
+        s.generate_batch(many, max_length=8, eos_id=-1)
+        t0 = time.perf_counter()
+        s.generate_batch(many, max_length=n_tok, eos_id=-1)
+        dt = time.perf_counter() - t0
+        s.generate_batch(many, max_length=1, eos_id=-1)
+        t0 = time.perf_counter()
+        s.generate_batch(many, max_length=1, eos_id=-1)
+        d1 = time.perf_counter() - t0
+        batch[f"batch {nb}"] = {"ms_first_step (encoder)": d1 * 1e3, "ms_per_further_step": (dt - d1) / (n_tok - 1) * 1e3,
+                                "tokens_per_s": nb * n_tok / dt}
     dec = np.array([[0]], np.int64)
     t0 = time.perf_counter()
     for i in range(n_tok):
@@ -95,6 +109,7 @@ def main():
         "generated_ids_equal": dev == gen[1:],
         "ms_first_token (encoder + cross keys/values + one step)": first_s * 1e3,
         "ms_per_further_token": (long_s - first_s) / (4 * n_tok - 1) * 1e3,
+        "generate_batch": batch,
         "ms_per_token": {"g2p_generate (device loop, KV cache)": gen_s / n_tok * 1e3,
                          "session.run per token (the reference's call pattern, on the GPU)": run_s / n_tok * 1e3,
                          f"transformers on the host CPU, whole graph per token ({torch.get_num_threads()} threads)": cpu_s / n_tok * 1e3}}))
