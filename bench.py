@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA (v_mfma_f32_32x32x2_f32) = fp32 vector peak
 # split-operand engine: dense 16-bit MFMA peak (256 CUs x 4096 FLOP/clk x 2.4 GHz = 2516.6 TFLOP/s) / plane products
 MFMA16_PEAK_TFLOPS = 2516.6
+HBM_PEAK_BPS = 8.0e12      # HBM3E peak (MI355X_MICROARCH.md)
 # scales[1]: ~3 frames per phoneme id with the synthetic weight sets (1.5 gave 2.4)
 LENGTH_SCALE = {"high": 1.95, "medium": 1.95, "small": 1.95}
 DTYPE = {2: "f32 (f16x3 split: fp32 operands as two fp16 planes, three MFMA products, fp32 accumulate)",
@@ -371,14 +372,15 @@ def main():
             ms += st["conv_ms"]
             launches += st["conv_launches"]
             for k in ("enc_ms", "dp_ms", "flow_ms", "dec_ms", "total_ms", "dec_flops", "dec_bytes", "flow_flops",
-                      "sx_flops", "sx_ms", "sx_launches", "total_launches"):
+                      "sx_flops", "sx_bytes", "sx_ms", "sx_launches", "total_launches"):
                 agg[k] = agg.get(k, 0.0) + st[k]
             rng_stats = {"f16_peak_max": st["f16_peak_max"], "f16_peak_min": st["f16_peak_min"],
                          "f16_launches_tracked": st["f16_tracked"], "f16_saturated": st["f16_saturated"]}
         s.set_timing(False)
         nprod = int(s.hparam("gen_nprod"))
+        kby = by
         if agg.get("sx_launches", 0) > 0:
-            kfl, kms, kn = agg["sx_flops"], agg["sx_ms"], int(agg["sx_launches"])
+            kfl, kms, kn, kby = agg["sx_flops"], agg["sx_ms"], int(agg["sx_launches"]), agg["sx_bytes"]
             kname = ("conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 2 fp16 planes, 3 x v_mfma_f32_32x32x16_f16 per product)"
                      if nprod == 2 else
                      "conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 3 bf16 planes, v_mfma_f32_32x32x16_bf16 plane products)")
@@ -389,7 +391,19 @@ def main():
             peak = FP32_PEAK_TFLOPS
         ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         tr = pmc_traffic(preset, kname.split(" ")[0]) if (B, T) == (32, 256) else None
-        roof = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        # Which roof bounds this kernel family on this voice: t_min = max(FLOPs / matrix peak, layer-granular bytes /
+        # 8 TB/s).  The LJSpeech-size voice is matrix-bound (152 FLOP/B), phoonnx's default voice is
+        # HBM-bound under the split arithmetic (60 FLOP/B against a ridge of 838.9 / 8 = 105).
+        t_mfma, t_hbm = kfl / (peak * 1e12), kby / HBM_PEAK_BPS
+        hbm_ach = kby / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        if t_hbm > t_mfma:
+            roof = {"bound": "hbm", "kernel": kname, "achieved": hbm_ach, "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+                    "frac": hbm_ach / (HBM_PEAK_BPS / 1e9)}
+        else:
+            roof = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak}
+        roof.update({
+                "mfma_frac": ach / peak, "hbm_frac": hbm_ach / (HBM_PEAK_BPS / 1e9),
+                "algorithmic_gbytes_per_launch": kby / max(kn, 1) / 1e9,
                 "traffic": (tr or {}).get("bytes_per_launch"),
                 "traffic_source": (tr or {}).get("source"), "traffic_commit": (tr or {}).get("commit"),
                 "launches_per_step": kn // n_t, "avg_launch_ms": kms / max(kn, 1),
@@ -401,7 +415,7 @@ def main():
                 "algorithmic_gbytes_per_step": by / n_t / 1e9,
                 "hbm_frac_of_8TBs": (by / (ms * 1e-3)) / 8.0e12 if ms > 0 else 0.0,
                 "note": "one handle, whole batch, HIP events around every conv launch (serialises the stream): the step "
-                        "this describes is stages.total_ms, not ms_per_step of the pipelined headline run"}
+                        "this describes is stages.total_ms, not ms_per_step of the pipelined headline run"})
         stage = {k: v / n_t for k, v in agg.items()}
         if stage.get("dec_ms", 0) > 0:
             stage["dec_tflops"] = stage["dec_flops"] / (stage["dec_ms"] * 1e-3) / 1e12

@@ -218,6 +218,7 @@ typedef struct {
      * ~2^-12 would lose relative precision: planes resolve 2^-36 absolute); f16_tracked: launches recorded. */
     float f16_peak_max, f16_peak_min;
     int f16_tracked, f16_saturated;
+    double sx_bytes;        /* layer-granular bytes of the split-engine launches (as conv_bytes) */
 } vits_stats;
 
 /* Enable per-stage HIP-event timing (adds event records on the handle's stream). */

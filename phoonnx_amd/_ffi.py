@@ -27,7 +27,7 @@ class VitsStats(C.Structure):
                 ("enc_ms", C.c_float), ("dp_ms", C.c_float), ("total_ms", C.c_float), ("conv_launches", C.c_int),
                 ("total_launches", C.c_int), ("sx_flops", C.c_double), ("sx_ms", C.c_float), ("sx_launches", C.c_int),
                 ("f16_peak_max", C.c_float), ("f16_peak_min", C.c_float), ("f16_tracked", C.c_int),
-                ("f16_saturated", C.c_int)]
+                ("f16_saturated", C.c_int), ("sx_bytes", C.c_double)]
 
 
 class VitsOpenOptions(C.Structure):

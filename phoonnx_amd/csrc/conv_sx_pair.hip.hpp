@@ -62,18 +62,23 @@ struct SxPairArgs {
 #ifndef SX_PAIR_DEPTH64
 #define SX_PAIR_DEPTH64 2
 #endif
+#ifndef SX_PAIR_EARLY_ACC
+#define SX_PAIR_EARLY_ACC 0
+#endif
 #ifndef SX_PAIR_EARLY32
 #define SX_PAIR_EARLY32 1
 #endif
 template <int MW, int NW, int WM, int WN, int EPI, bool CHAIN>
-__global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY32) ? 3 : 2) void conv_sx_pair_kernel(SxPairArgs a) {
+__global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC) ? 3 : 2) void conv_sx_pair_kernel(SxPairArgs a) {
     constexpr int BN = NW * WN * 32, NH = NW / 2;
-    // 32-channel variant: the residual and (EPI_ACC) the running sum are requested in the prologue, right behind the
-    // x tile, and wait in registers: one HBM round trip per tile instead of three.
+    // 32-channel variant: the residual is requested in the prologue, right behind the x tile, and waits in registers
+    // (its lines are in flight at that moment; after phase 1 they have left the L2: PMC showed the re-read going to
+    // the fabric).  The running sum (EPI_ACC) is NOT: with it the variant needs 188 registers, loses the third
+    // workgroup per CU and runs 12-16 % slower (profiles r02_v5 -> r02_v6).
     constexpr bool EARLY = NW == 2 && SX_PAIR_EARLY32;
     constexpr int DEPTH = NW == 2 ? SX_PAIR_DEPTH32 : SX_PAIR_DEPTH64;  // weight look-ahead in steps (run_conv)
     static_assert(DEPTH >= 2 && DEPTH <= 6, "wait_a covers up to five younger sets");
-    constexpr bool ACC = (EPI & EPI_ACC) != 0;
+    constexpr bool ACC = (EPI & EPI_ACC) != 0 && SX_PAIR_EARLY_ACC;
     static_assert(WM * WN == 4 && MW == 1 && BN == 256, "one block row per wave, 256 columns");
     constexpr int NPW = 2, STEPBYTES = WM * MW * NPW * 1024;
     constexpr int MAXCH = WM * 2;  // 16-channel chunks: C = 32 * WM
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY32) ? 3 : 2) void co
         static_for<NW / 2>([&](auto R) {
             constexpr int rr = decltype(R)::value;
             f32x4 adl[2][4];
-            if constexpr ((flags & EPI_ACC) != 0 && !EARLY) {
+            if constexpr ((flags & EPI_ACC) != 0 && !(EARLY && ACC)) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const int t = t1 + (wn * NW + rr * 2 + j) * 32 + l31;
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY32) ? 3 : 2) void co
                     for (int e = 0; e < 4; e++) v[e] = __builtin_fmaf(acc[n][4 * q + e], wsc, bq[q][e]);
                     v += pre[rr][j][q];
                     if constexpr ((flags & EPI_ACC) != 0) {
-                        if constexpr (EARLY) v += ad[rr][j][q];
+                        if constexpr (EARLY && ACC) v += ad[rr][j][q];
                         else v += adl[j][q];
                     }
                     if constexpr ((flags & EPI_DIV) != 0) {

@@ -363,6 +363,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     }
     conv_account(c, d, T);
     h->stats.sx_flops += 2.0 * d.macs_per_t * (double)T * c.B;
+    h->stats.sx_bytes += 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T);
     h->stats.sx_launches++;
 }
 
@@ -414,6 +415,7 @@ void conv_sx_pair(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const float *x
     h->stats.conv_launches--;  // (two convs, one launch)
     h->stats.total_launches--;
     h->stats.sx_flops += 2.0 * (c1.macs_per_t + c2.macs_per_t) * (double)T * c.B;
+    h->stats.sx_bytes += 4.0 * c.B * ((double)(c1.Cin + c1.Cout) * T + (double)(c2.Cin + c2.Cout) * T);
     h->stats.sx_launches++;
 }
 
