@@ -68,6 +68,8 @@ struct SxArgs {
     float islope;         // ... with leaky_relu(islope) applied on the way in (1 = none)
     int T;                // input length
     const u32x4 *wp;      // packed weights
+    int wshift;           // log2(packed tile height / this kernel's tile height): a 64- or 32-row kernel can run on weights
+                          // packed for 128-row tiles (short grids: launch_conv_sx's pack_cfg)
     const float *bias;    // [virtual rows] or nullptr
     const float *bias_b;  // per-utterance bias [B][bias_b_stride] over real channels, or nullptr
     int bias_b_stride;
@@ -224,10 +226,11 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     const uint32_t XB = a.x_bytes;
     const u32x4 *xb = a.xp + (int64_t)b * a.x_bstride;
     const int64_t pstride = (int64_t)CG * T;  // cells per plane
-    constexpr int STEPBYTES = MB * NPW * 1024;  // packed weights of one step (one tap of one 16-channel chunk)
+    // packed weights of one step (one tap of one 16-channel chunk): the tile height they were packed for
+    const int STEPBYTES = (MB << a.wshift) * NPW * 1024;
     // this wave's A rows of step 0 (uniform address: lives in SGPRs)
-    const char *wbase = reinterpret_cast<const char *>(a.wp) + (int64_t)mt * a.nchunks * K * STEPBYTES +
-                        wm * (MW * NPW * 1024);
+    const char *wbase = reinterpret_cast<const char *>(a.wp) + (int64_t)(mt >> a.wshift) * a.nchunks * K * STEPBYTES +
+                        (mt & ((1 << a.wshift) - 1)) * (MB * NPW * 1024) + wm * (MW * NPW * 1024);
     const int nit = a.x_bytes >> 12;           // DMA rounds of 256 cells per x tile (the stage is padded to 4 KiB)
     float pk = 0.f;                            // f16 mode: largest |value| this thread split into fp16 planes
 
@@ -876,8 +879,17 @@ inline hipError_t launch_conv_sx_np(const SxArgs &a, int nprod, dim3 grid, size_
 
 // rawin: the input is a.xr (fp32 raw) instead of a.xp (planes); only the 64- and 32-row tiles have the
 // registers for it (cfg 1 / 2).  nprod: 6 (exact, default), 3 or 1 (declared reduced-precision modes).
-inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin = false, int nprod = 6) {
+// pack_cfg: the tile config the weights were packed for, if not `cfg` (a taller one: 128-row packing read by the 64-
+// or 32-row kernel - same products in the same order, a shorter reduction per workgroup and 2-4x the workgroups).
+inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin = false, int nprod = 6,
+                                 int pack_cfg = -1) {
     const int BM = sx_tile_m(cfg), BN = sx_tile_n(cfg);
+    a.wshift = 0;
+    if (pack_cfg >= 0 && pack_cfg != cfg) {
+        const int PM = sx_tile_m(pack_cfg);
+        if (PM < BM || PM % BM || rawin) return hipErrorInvalidValue;
+        while ((BM << a.wshift) < PM) a.wshift++;
+    }
     a.LW = BN + (a.K - 1) * a.dil;
     a.magic = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
     // an x stage is padded to whole DMA rounds (256 cells = 4 KiB), so that every wave issues the same count

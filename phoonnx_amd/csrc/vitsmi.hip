@@ -355,7 +355,16 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     vits_handle *h = c.h;
     a.peak = range_slots(h, d.f16 && (d.rawin || out_pl));  // launches that split values into fp16 planes
     const bool ev = conv_event_begin(c);
-    c.note(launch_conv_sx(a, d.cfg, c.B, c.st, d.rawin, d.f16 ? 2 : (h->cur_stage == 3 ? h->gen_nprod : 6)));
+    // Short grids (a single utterance, a streaming chunk): the 128-row packing is read by the 64- or 32-row kernel -
+    // 2-4x the workgroups, each with half / a quarter of the reduction work per step.  Same arithmetic.
+    static const bool tall_only = std::getenv("VITSMI_SX_NO_SHORT_TILES") != nullptr;  // A/B timing only
+    int run_cfg = d.cfg;
+    if (d.cfg == 0 && !d.rawin && !tall_only) {
+        const long long wgs0 = (long long)((T + 255) / 256) * c.B * (d.Cout / 128);
+        if (wgs0 <= 128) run_cfg = 2;
+        else if (wgs0 <= 256) run_cfg = 1;
+    }
+    c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, d.f16 ? 2 : (h->cur_stage == 3 ? h->gen_nprod : 6), d.cfg));
     if (ev) {
         if (h->conv_event_sx.size() < h->conv_events.size()) h->conv_event_sx.resize(h->conv_events.size(), 0);
         h->conv_event_sx[h->conv_events_used] = 1;

@@ -189,3 +189,31 @@ def test_phonemize_batches_the_chunks(tmp_path):
         p.device_loop = False          # the reference's call-by-call loop, chunk after chunk
         assert p.phonemize(text, lang) == batched and len(batched) == 4
         p.session.close()
+
+
+def test_generate_batch_argument_checks_and_limits(sess):
+    """g2p_generate_batch refuses what it cannot do (no clamping, no partial results), and works at its limits."""
+    import ctypes as C
+    from phoonnx_amd import _ffi
+    from phoonnx_amd.session import SessionError
+    lib = sess._lib
+    ids = np.arange(3, 23, dtype=np.int64)
+    out = np.zeros((65, 8), np.int64)
+    n = np.zeros(65, np.int32)
+
+    def call(lens, B, max_length=8, start=0):
+        lens = np.asarray(lens, np.int32)
+        return lib.g2p_generate_batch(sess._h, _ffi.ptr(ids), _ffi.ptr(lens), B, max_length, start, 1, _ffi.ptr(out), _ffi.ptr(n))
+    assert call([20], 1) == 0
+    assert call([20], 0) < 0 and call([0], 1) < 0 and call([-3], 1) < 0          # no sequences / empty / negative length
+    assert call([1] * 65, 65) < 0                                                  # more than G2P_MAX_BATCH
+    assert call([20], 1, max_length=0) < 0 and call([20], 1, max_length=1024) < 0  # decoder positions: 1 .. 1023
+    assert call([20], 1, start=sess.hparam("vocab")) < 0
+    assert b"" != lib.g2p_last_error(sess._h)
+    # 64 one-byte inputs side by side, and one input of the longest length the tables cover
+    many = [np.array([3 + i], np.int64) for i in range(64)]
+    assert sess.generate_batch(many, max_length=3) == [sess.generate(x, max_length=3) for x in many]
+    long_in = np.random.default_rng(5).integers(3, 259, 1023).astype(np.int64)
+    assert sess.generate_batch([long_in, ids], max_length=4) == [sess.generate(long_in, max_length=4), sess.generate(ids, max_length=4)]
+    with pytest.raises(SessionError):
+        sess.generate(np.zeros(1024, np.int64) + 5, max_length=2)
