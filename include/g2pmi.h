@@ -42,8 +42,9 @@ const char *g2p_output_name(g2p_handle *h, int i);  /* "logits" */
 int g2p_bucket(g2p_handle *h, int decoder, int rel);
 
 /* What session.run returns (mul.py:210-211): logits [1, T, vocab] (host float32, T * vocab values) for
- * input_ids [1, S] and decoder_input_ids [1, T].  attention_mask may be NULL (all ones, what mul.py:187 builds);
- * a mask with zeros is rejected. */
+ * input_ids [1, S] and decoder_input_ids [1, T].  attention_mask may be NULL (all ones, what mul.py:187 builds) or
+ * right-padded (ones, then zeros: the padded positions are dropped, which is what masking them amounts to); a mask
+ * with holes is rejected. */
 int g2p_run(g2p_handle *h, const int64_t *input_ids, int S, const int64_t *attention_mask, const int64_t *decoder_input_ids,
             int T, float *logits);
 

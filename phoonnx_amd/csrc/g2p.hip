@@ -700,8 +700,17 @@ int g2p_run(g2p_handle *h, const int64_t *input_ids, int S, const int64_t *mask,
     if (S >= G2PModel::kMaxPos || T >= G2PModel::kMaxPos) return gfail(h, VITS_E_ARG, "sequence longer than %d", G2PModel::kMaxPos - 1);
     if (int rc = check_ids(h, input_ids, S, "input_ids")) return rc;
     if (int rc = check_ids(h, dec_ids, T, "decoder_input_ids")) return rc;
-    for (int i = 0; mask && i < S; i++)
-        if (mask[i] != 1) return gfail(h, VITS_E_ARG, "attention_mask with zeros is not supported (mul.py:187 passes all ones)");
+    if (mask) {
+        // mul.py:187 passes all ones.  A right-padded mask (ones, then zeros) is honoured by dropping the padding: no
+        // position attends to a masked key and the masked positions' own outputs are not part of the result, so the
+        // logits are those of the unpadded input.  Masks with holes are refused.
+        int n1 = 0;
+        while (n1 < S && mask[n1] == 1) n1++;
+        for (int i = n1; i < S; i++)
+            if (mask[i] != 0) return gfail(h, VITS_E_ARG, "attention_mask must be ones followed by zeros (right padding)");
+        if (n1 == 0) return gfail(h, VITS_E_ARG, "attention_mask masks every input position");
+        S = n1;
+    }
     const int L = S > T ? S : T;
     const size_t per = (size_t)(m.d_model > m.inner ? m.d_model : m.inner) * L * 4 + 512;
     const size_t need = 8 * per + 2 * ((size_t)m.d_ff * L * 4 + 512) + (size_t)m.vocab * T * 8 + (size_t)(S + T) * 8 + 4096 +

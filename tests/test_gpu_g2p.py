@@ -70,8 +70,13 @@ def test_g2p_bad_inputs_raise(sess):
     sess.run(None, ok)
     with pytest.raises(SessionError):
         sess.run(None, dict(ok, input_ids=np.array([[10, 5000]], np.int64)))
+    # a right-padded mask = the unpadded input; a mask with a hole (or nothing left) is refused
+    padded = dict(ok, input_ids=np.array([[10, 11, 0, 0]], np.int64), attention_mask=np.array([[1, 1, 0, 0]], np.int64))
+    assert np.array_equal(sess.run(None, padded)[0], sess.run(None, ok)[0])
     with pytest.raises(SessionError):
-        sess.run(None, dict(ok, attention_mask=np.array([[1, 0]], np.int64)))
+        sess.run(None, dict(ok, attention_mask=np.array([[0, 1]], np.int64)))
+    with pytest.raises(SessionError):
+        sess.run(None, dict(ok, attention_mask=np.array([[0, 0]], np.int64)))
     with pytest.raises(SessionError):
         sess.run(None, dict(ok, bogus=np.zeros(1)))
     with pytest.raises(SessionError):
