@@ -823,6 +823,7 @@ constexpr int kSxEpiInner = EPI_RES | SX_HAS_RAW | SX_HAS_PL | SX_PL_ACT;       
 constexpr int kSxEpiFirst = EPI_RES | SX_HAS_RAW;                                    // xs  = block output
 constexpr int kSxEpiAccum = EPI_RES | EPI_ACC | SX_HAS_RAW;                          // xs += block output
 constexpr int kSxEpiRaw = SX_HAS_RAW;                                                // raw only (raw-format stages)
+constexpr int kSxEpiStageOut = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_PL | SX_PL_ACT;  // x = (xs + block) / n as planes
 constexpr int kSxEpiGate = SX_GATE | SX_HAS_RAW;                                     // WN in-layer + gate -> planar acts
 
 template <int MW, int NW, int WM, int WN, int NP = 6>
@@ -835,6 +836,7 @@ inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t
         case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst, false, false, NP>(a, grid, lds, stream);
         case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum, false, false, NP>(a, grid, lds, stream);
         case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw, false, false, NP>(a, grid, lds, stream);  // flow WN convs
+        case kSxEpiStageOut: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiStageOut, false, false, NP>(a, grid, lds, stream);
         default: break;
     }
     if constexpr (WM == 2 && MW == 1) {  // 64-row tiles: the gated WN in-layer (per-utterance bias or not)
