@@ -227,6 +227,10 @@ def main():
     ap.add_argument("--parts", type=int, default=2,
                     help="render each batch as this many sub-batches on as many engine handles / HIP streams sharing "
                          "one weight arena (PipelinedSession); 1 = a single handle")
+    ap.add_argument("--also-parts", type=int, default=3,
+                    help="handles for the `also` (medium) measurement: that voice's token / frame-domain stages are half of "
+                         "its step, and three sub-batches hide more of them than two (573 vs 534 M samples/s; four or "
+                         "more handles per process fall off a cliff: 413 M)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -497,9 +501,10 @@ def main():
         try:
             mfirst = MiSession(voice_path("medium"), device_id=local_rank)
             km = max(5, a.steps)
-            dtm, nm, mp_, minputs = measure(mfirst, "medium", km, max(2, a.warmup), a.parts, a.lockstep, 1234 + rank)
+            dtm, nm, mp_, minputs = measure(mfirst, "medium", km, max(2, a.warmup), a.also_parts, a.lockstep, 1234 + rank)
             mroof, mstage, mrange = (None, None, None) if a.no_roofline else roofline_of(mfirst, "medium", minputs, 3)
             also = {"preset": "medium", "value": nm / dtm, "unit": "samples/s", "steps": km, "ms_per_step": dtm / km * 1e3,
+                    "pipeline_parts": len(mp_.parts),
                     "frames_per_id": nm / km / hop_of(mfirst) / (B * T), "roofline": mroof, "stages": mstage,
                     "f16_range": mrange,
                     "note": "measured in the same process after the headline voice's handles were closed"}
