@@ -28,6 +28,7 @@
 //   epilogue bias2, residual (x from registers; CHAIN: x1), multi-receptive-field accumulate / divide, fp32 raw store
 //            of the 256 - 2 P2 interior columns (P2 = c2's one-sided reach; columns nearer the tile edge saw garbage).
 #pragma once
+#include <cstdlib>
 #include "conv_sx_engine.hip.hpp"
 
 namespace vitsmi {
@@ -46,7 +47,7 @@ struct SxPairArgs {
     int K2, dil2, pad2;       // c2
     int LW1;                  // x tile width in cells = 256 + (K1 - 1) * dil1
     unsigned x_bytes;         // one chunk's x stage (2 planes x 2 halves x LW1 cells)
-    int LW2;                  // Y row width in cells (256 + 2 * pad2, rounded up)
+    int LW2;                  // Y row width in cells (256 + pad2, rounded up: see launch_conv_sx_pair)
     unsigned y_chunk_bytes;   // bytes of one chunk of Y = 4 * LW2 * 16
     int BNo, NT, B;           // kept output columns per tile, tiles along time, utterances
     int flags;                // EPI_ACC | EPI_DIV (the residual is always added)
@@ -447,7 +448,14 @@ inline bool sx_pair_supported(int C, int cfg, int K1, int dil1, int K2, int dil2
     if (2 * LW1 > 768) return false;                                      // x staging: three cells per thread
     const int halo2 = (K2 - 1) * dil2;
     if (halo2 % 2 || 256 - halo2 < 160) return false;                     // (> 37 % of a tile recomputed: not worth it)
-    const size_t lds_y = (size_t)(C / 16) * 4 * (size_t)((256 + halo2 + 7) / 8 * 8) * 16;
+    // 64 channels are matrix-heavier: a k = 7, dilation (3, 12) chain keeps 184 of 256 columns and measured 909 us fused
+    // against 472 + 399 as two launches (32 channels, HBM / latency-bound, still gain at that ratio)
+    static const int keep64 = [] {
+        const char *e = std::getenv("VITSMI_PAIR_MIN_KEEP64");  // A/B timing only
+        return e ? std::atoi(e) : 200;
+    }();
+    if (C == 64 && 256 - halo2 < keep64) return false;
+    const size_t lds_y = (size_t)(C / 16) * 4 * (size_t)((256 + halo2 / 2 + 7) / 8 * 8) * 16 + (size_t)(halo2 / 2) * 16;
     const size_t lds_x = (size_t)(C / 16) * 4 * LW1 * 16;                 // the whole x tile is resident
     return (lds_y > lds_x ? lds_y : lds_x) <= 80 * 1024 - 256;            // two workgroups per CU
 }
@@ -460,7 +468,11 @@ inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t 
     if (a.dil2 < 1) a.dil2 = 1;
     const int halo2 = (a.K2 - 1) * a.dil2;
     if (a.pad2 * 2 != halo2) return hipErrorInvalidValue;  // "same" padding
-    a.LW2 = (256 + halo2 + 7) / 8 * 8;  // Y is stored pad2 columns to the right; the margins only feed discarded outputs
+    // Y is stored pad2 columns to the right.  A row holds the 256 + pad2 columns phase 1 writes - all that the KEPT
+    // outputs (columns [pad2, 256 - pad2)) read; the outputs right of them read up to pad2 cells past the row's end, i.e.
+    // the next row's (or, for the last row, the slack's) bytes, and are discarded.  (With 256 + 2 pad2 cells per row a
+    // 64-channel k = 7, dilation 12 step did not fit two workgroups per CU.)
+    a.LW2 = (256 + a.pad2 + 7) / 8 * 8;
     a.y_chunk_bytes = (unsigned)(4 * a.LW2 * 16);
     a.BNo = 256 - halo2;
     a.NT = (a.T + a.BNo - 1) / a.BNo;
@@ -472,7 +484,7 @@ inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t 
     if (a.wscale2 == 0.f) a.wscale2 = 1.f;
     if ((long long)a.T * 64 + 64 >= (1ll << 32)) return hipErrorInvalidValue;
     // Y overlays the x stages (every chunk has its own)
-    const size_t lds_x = (size_t)a.nchunks * a.x_bytes, lds_y = (size_t)a.nchunks * a.y_chunk_bytes;
+    const size_t lds_x = (size_t)a.nchunks * a.x_bytes, lds_y = (size_t)a.nchunks * a.y_chunk_bytes + (size_t)a.pad2 * 16;
     const size_t lds = lds_x > lds_y ? lds_x : lds_y;
     if (lds > 80 * 1024 - 256 || !sx_pair_supported(a.C, cfg, a.K1, a.dil1, a.K2, a.dil2)) return hipErrorInvalidValue;
     const long long nb = (long long)a.NT * B;
