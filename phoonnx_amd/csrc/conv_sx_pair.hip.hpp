@@ -447,7 +447,11 @@ inline bool sx_pair_supported(int C, int cfg, int K1, int dil1, int K2, int dil2
     const int LW1 = 256 + (K1 - 1) * dil1;
     if (2 * LW1 > 768) return false;                                      // x staging: three cells per thread
     const int halo2 = (K2 - 1) * dil2;
-    if (halo2 % 2 || 256 - halo2 < 160) return false;                     // (> 37 % of a tile recomputed: not worth it)
+    static const int keep_min = [] {
+        const char *e = std::getenv("VITSMI_PAIR_MIN_KEEP");  // A/B timing only
+        return e ? std::atoi(e) : 160;
+    }();
+    if (halo2 % 2 || 256 - halo2 < keep_min) return false;                // (> 37 % of a tile recomputed: not worth it)
     // 64 channels are matrix-heavier: a k = 7, dilation (3, 12) chain keeps 184 of 256 columns and measured 909 us fused
     // against 472 + 399 as two launches (32 channels, HBM / latency-bound, still gain at that ratio)
     static const int keep64 = [] {
