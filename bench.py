@@ -54,34 +54,44 @@ def git_head():
         return None
 
 
-def pmc_traffic(preset, kernel_prefix):
-    """HBM bytes per launch of the dominant kernel family from the committed PMC passes of the SAME command
-    (profiles/*_<preset>_b32_pmc.json, written by tools/profile_gpu.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate
-    passes, per MI355X_MICROARCH.md).  Launch-weighted mean over the family's instantiations; None if absent."""
+def pmc_profile(preset):
+    """The newest committed PMC summary of the SAME command (profiles/*_<preset>_b32_pmc.json, written by
+    tools/profile_gpu.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate passes, per MI355X_MICROARCH.md) -> (doc, file name)."""
     import glob
-    # newest = highest (round, version) in the name rNN_vM_...: a fresh checkout gives every file the same mtime
     import re
 
+    # newest = highest (round, version) in the name rNN_vM_...: a fresh checkout gives every file the same mtime
     def ver(f):
         m = re.match(r"r(\d+)(?:_v(\d+))?_", os.path.basename(f))
         return (int(m.group(1)), int(m.group(2) or 0)) if m else (0, 0)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{preset}_b32_pmc.json")), key=ver)
     if not files:
-        return None
+        return None, None
     try:
-        doc = json.load(open(files[-1]))
-        ks = doc["kernels"]
+        return json.load(open(files[-1])), os.path.basename(files[-1])
     except Exception:
+        return None, None
+
+
+def kname_key(name):
+    """'void vitsmi::conv_sx_kernel<2, 4, 2, 2, 5120, false, false, 2>(vitsmi::SxArgs)' -> 'conv_sx_kernel<2,4,2,2,5120,false,false,2>'"""
+    return name.split("(")[0].replace("void ", "").replace("vitsmi::", "").replace(" ", "").strip()
+
+
+def pmc_traffic(preset, family):
+    """HBM bytes per launch of a kernel FAMILY (every instantiation whose name contains `family`: "conv_sx" covers
+    conv_sx_kernel AND conv_sx_pair_kernel), launch-weighted; None if no committed profile."""
+    doc, fname = pmc_profile(preset)
+    if not doc:
         return None
     tot = n = 0.0
-    for name, c in ks.items():
-        if kernel_prefix in name and "hbm_read_bytes_per_launch" in c and "hbm_write_bytes_per_launch" in c:
+    for name, c in doc.get("kernels", {}).items():
+        if family in name and "hbm_read_bytes_per_launch" in c and "hbm_write_bytes_per_launch" in c:
             tot += (c["hbm_read_bytes_per_launch"] + c["hbm_write_bytes_per_launch"]) * c["launches"]
             n += c["launches"]
     if not n:
         return None
-    return {"bytes_per_launch": tot / n, "source": os.path.basename(files[-1]), "commit": doc.get("commit"),
-            "length_scale": doc.get("length_scale")}
+    return {"bytes_per_launch": tot / n, "source": fname, "commit": doc.get("commit"), "length_scale": doc.get("length_scale")}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -109,7 +119,7 @@ def cpu_baseline(voice_path, preset, tokens, scales, seed, hop, budget_s=70.0):
         nz = rng.standard_normal((B, 192, tokens * 12)).astype(np.float32)
         return ids, lens, ndp, nz
 
-    def timed(name, infer, hop, threads):
+    def timed(name, infer, hop, threads, share=0.5):
         # one short warm-up call (thread pool, allocator, code paths), one utterance to learn the rate, then ONE batch
         # sized to fill what is left of this implementation's share of the budget (at most the bench batch, 32)
         ids, lens, ndp, nz = sample(1)
@@ -117,7 +127,7 @@ def cpu_baseline(voice_path, preset, tokens, scales, seed, hop, budget_s=70.0):
         t0 = time.perf_counter()
         r = infer(ids, lens, ndp, nz)
         t1 = time.perf_counter() - t0
-        B = int(max(1, min(32, (budget_s / 2 - t1) / max(t1, 1e-3) * 0.8)))
+        B = int(max(1, min(32, (budget_s * share - t1) / max(t1, 1e-3) * 0.8)))
         if B > 1:
             ids, lens, ndp, nz = sample(B)
             t0 = time.perf_counter()
@@ -131,7 +141,22 @@ def cpu_baseline(voice_path, preset, tokens, scales, seed, hop, budget_s=70.0):
         import torch
         from torch_baseline import TorchVits
         m = TorchVits(voice_path)
-        timed("torch_cpu", lambda i, l, a, b: m.infer(i, l, scales, None, a, b[:, :m.C]), m.hop, torch.get_num_threads())
+        # thread sweep: on a 2 x 64-core host the oneDNN / MKL kernels of these small convs do not scale to every core
+        # (round 2: 128 threads measured BELOW the survey's 8-thread figure).  One utterance per setting, the best
+        # setting then gets the sized batch; the sweep is reported.
+        ncpu = os.cpu_count() or 1
+        sweep = {}
+        ids1, lens1, ndp1, nz1 = sample(1)
+        for nt in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
+            torch.set_num_threads(nt)
+            m.infer(ids1[:, :64], np.full((1,), 64, np.int64), scales, None, ndp1[:, :, :64], nz1[:, :m.C])
+            t0 = time.perf_counter()
+            r1 = m.infer(ids1, lens1, scales, None, ndp1, nz1[:, :m.C])
+            sweep[nt] = int(np.asarray(r1["y_lengths"]).sum()) * m.hop / (time.perf_counter() - t0)
+        best_nt = max(sweep, key=sweep.get)
+        torch.set_num_threads(best_nt)
+        out["torch_thread_sweep"] = {"unit": "samples/s at B=1", **{str(k): v for k, v in sweep.items()}}
+        timed("torch_cpu", lambda i, l, a, b: m.infer(i, l, scales, None, a, b[:, :m.C]), m.hop, best_nt)
     except Exception as e:  # noqa: BLE001 - the baseline is a report, never the product
         out["torch_cpu_error"] = f"{type(e).__name__}: {e}"
     try:
@@ -141,7 +166,7 @@ def cpu_baseline(voice_path, preset, tokens, scales, seed, hop, budget_s=70.0):
         except Exception:  # noqa: BLE001
             o = vits_oracle.VitsOracle(voice_path, native=False)
         timed("c_openmp", lambda i, l, a, b: o.infer(i, l, scales, None, a, b[:, :o.inter_channels]), hop,
-              int(o.lib.vo_num_threads()))
+              int(o.lib.vo_num_threads()), share=0.25)
     except Exception as e:  # noqa: BLE001
         out["c_openmp_error"] = f"{type(e).__name__}: {e}"
     if not cands:
@@ -153,7 +178,8 @@ def cpu_baseline(voice_path, preset, tokens, scales, seed, hop, budget_s=70.0):
             "c_openmp": "C/OpenMP restatement (oracle/vits_oracle.c)"}[name]
     out.update(value=b["value"], cores=b["threads"], rtf=b["rtf"], implementation=name,
                sample=f"{impl}, B={b['B']} x {tokens} ids, same voice and scales, {b['samples']} samples in "
-                      f"{b['seconds']:.1f}s after a warm-up call (batch sized to a {budget_s / 2:.0f}s share of the budget)",
+                      f"{b['seconds']:.1f}s after a warm-up call (batch sized to its share of a {budget_s:.0f}s budget; "
+                      f"thread count = best of the sweep)",
                candidates={k: {"value": v["value"], "B": v["B"], "threads": v["threads"]} for k, v in cands.items()},
                host_cores=os.cpu_count())
     return out
@@ -366,11 +392,18 @@ def main():
         fl = ms = by = 0.0
         launches = 0
         agg = {}
+        per_k = {}
         s.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales, sid_ptr)  # (untimed: creates the handle's HIP events)
         s.stats()
         for _ in range(n_t):
             s.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales, sid_ptr)
             st = s.stats()
+            for r in s.launch_records():
+                e = per_k.setdefault(kname_key(r["kernel"]), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "stage": r["stage"]})
+                e["launches"] += 1
+                e["ms"] += r["ms"]
+                e["flops"] += r["flops"]
+                e["bytes"] += r["bytes"]
             fl += st["conv_flops"]
             by += st["conv_bytes"]
             ms += st["conv_ms"]
@@ -394,7 +427,30 @@ def main():
             kname = "conv_engine_kernel (implicit-GEMM Conv1d, v_mfma_f32_32x32x2_f32)"
             peak = FP32_PEAK_TFLOPS
         ach = kfl / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-        tr = pmc_traffic(preset, kname.split(" ")[0]) if (B, T) == (32, 256) else None
+        # (the whole family: conv_sx_kernel AND conv_sx_pair_kernel - launches_per_step counts both)
+        tr = pmc_traffic(preset, "conv_sx" if agg.get("sx_launches", 0) > 0 else "conv_engine") if (B, T) == (32, 256) else None
+        # the six instantiations with the most time: live HIP-event time and algorithmic work from this run, PMC columns
+        # (HBM bytes, matrix-pipe busy share, clock) joined by name from the committed profile of the same command
+        pdoc, pfile = pmc_profile(preset) if (B, T) == (32, 256) else (None, None)
+        pk = {kname_key(k): v for k, v in (pdoc or {}).get("kernels", {}).items()}
+        rows = []
+        for name, e in sorted(per_k.items(), key=lambda kv: -kv[1]["ms"])[:6]:
+            n_l = e["launches"]
+            is_sx = name.startswith("conv_sx")
+            k_peak = MFMA16_PEAK_TFLOPS / (3 if nprod == 2 else nprod) if is_sx else FP32_PEAK_TFLOPS
+            sec = e["ms"] * 1e-3
+            c = pk.get(name, {})
+            rd, wr = c.get("hbm_read_bytes_per_launch"), c.get("hbm_write_bytes_per_launch")
+            rows.append({
+                "name": name, "stage": ["enc", "dp", "flow", "dec"][e["stage"]] if 0 <= e["stage"] < 4 else None,
+                "launches_per_step": n_l / n_t, "avg_ms": e["ms"] / n_l, "share_of_conv_ms": e["ms"] / ms if ms > 0 else None,
+                "algorithmic_gbytes": e["bytes"] / n_l / 1e9, "algorithmic_gflop": e["flops"] / n_l / 1e9,
+                "mfma_frac": e["flops"] / sec / 1e12 / k_peak if sec > 0 else None,
+                "hbm_frac": e["bytes"] / sec / HBM_PEAK_BPS if sec > 0 else None,
+                "pmc_read_gbytes": None if rd is None else rd / 1e9, "pmc_write_gbytes": None if wr is None else wr / 1e9,
+                "pmc_over_algorithmic": None if rd is None or wr is None or not e["bytes"] else (rd + wr) / (e["bytes"] / n_l),
+                "mfma_util_pct": c.get("MfmaUtil_pct"), "clock_ghz": c.get("effective_clock_GHz")})
+            rows[-1]["frac"] = max(rows[-1]["mfma_frac"] or 0.0, rows[-1]["hbm_frac"] or 0.0)
         # Which roof bounds this kernel family on this voice: t_min = max(FLOPs / matrix peak, layer-granular bytes /
         # 8 TB/s).  The LJSpeech-size voice is matrix-bound (152 FLOP/B), phoonnx's default voice is
         # HBM-bound under the split arithmetic (60 FLOP/B against a ridge of 838.9 / 8 = 105).
@@ -410,6 +466,8 @@ def main():
                 "algorithmic_gbytes_per_launch": kby / max(kn, 1) / 1e9,
                 "traffic": (tr or {}).get("bytes_per_launch"),
                 "traffic_source": (tr or {}).get("source"), "traffic_commit": (tr or {}).get("commit"),
+                "traffic_note": "launch-weighted mean over every conv_sx_kernel and conv_sx_pair_kernel instantiation",
+                "kernels": rows, "kernels_pmc_source": pfile,
                 "launches_per_step": kn // n_t, "avg_launch_ms": kms / max(kn, 1),
                 "algorithmic_gflop_per_launch": kfl / max(kn, 1) / 1e9,
                 "all_conv_launches_per_step": launches // n_t,
@@ -470,8 +528,20 @@ def main():
             per.append(time.perf_counter() - t0)
             n_s += int(r["y_lengths"].sum()) * hop
         host_io = {"value": n_s / sum(per), "unit": "samples/s", "ms_per_step": 1e3 * sum(per) / len(per),
-                   "note": "vits_run: host int64 ids in, pinned-host fp32 [B,1,1,S] out (H2D + D2H + a NumPy copy per part "
-                           "inside the timed region), what session.run returns"}
+                   "over_value": (n_s / sum(per)) / (samples / dt) if samples else None,
+                   "note": "PipelinedSession.synthesize_batch: host int64 ids in, ONE host fp32 [B,1,1,S] array out (what "
+                           "session.run returns): H2D of the ids, the run, D2H by the DMA engine straight into the "
+                           "returned (pinned) array, each part's copy-out under the other parts' render"}
+
+    # the schedule the roofline block describes (one handle, whole batch) as a throughput figure of its own, untimed
+    # by events: `value` is the pipelined schedule (config.pipeline_parts handles), the kernel rows are per launch and
+    # hold for both
+    one_handle = None
+    if extras and len(pipe.parts) > 1:
+        k1 = max(3, a.steps // 2)
+        dt1, n1, _p1, _ = measure(sess, a.preset, k1, 1, 1, True, 1234 + rank)  # (shares `sess`: closed with `pipe`)
+        one_handle = {"value": n1 / dt1, "unit": "samples/s", "steps": k1, "ms_per_step": dt1 / k1 * 1e3,
+                      "note": "the same batch on ONE engine handle / stream: the schedule of the `roofline` and `stages` blocks"}
 
     # the same workload once more with every fp32 product exact (bf16x6), after (outside) the headline's timed region
     exact = None
@@ -540,7 +610,7 @@ def main():
                        "samples_per_step": samples_all / a.steps,
                        "frames_per_id": samples_all / a.steps / hop / (float(lens_h.sum()) * world),
                        "weights": weights, "commit": git_head()},
-            "roofline": roofline, "cpu_baseline": cpu, "step_ms": step_pct, "host_io": host_io,
+            "roofline": roofline, "cpu_baseline": cpu, "step_ms": step_pct, "host_io": host_io, "one_handle": one_handle,
             "exact_arithmetic": exact, "also": also, "stages": stage, "f16_range": f16_range,
         }
         if cpu and cpu.get("value"):

@@ -149,6 +149,23 @@ int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int
              const int64_t *sid, const vits_noise *noise, vits_output *out);
 void vits_free_output(vits_handle *h, vits_output *out);
 
+/* vits_run without the wait at the end and without an output: host buffers in, the whole path enqueued on the
+ * handle's stream.  Returns once the input copies and the one mid-pipeline readback (frame counts:
+ * vits_last_y_lengths) are done, i.e. while the generator is still rendering; complete it with vits_fetch_output,
+ * vits_last_pcm16 or vits_sync (any of them reports VITS_E_RANGE). */
+int vits_run_async(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
+                   const int64_t *sid, const vits_noise *noise);
+
+/* The last run's waveform -> caller-owned host memory (pageable, or pinned memory from vits_host_alloc for full PCIe
+ * rate): row b of the [B, S] result goes to dst + b * row_elems (row_elems >= S; columns [S, row_elems) are zeroed),
+ * so that several handles - the sub-batches of one batch, rendered concurrently - can deliver into ONE [B,1,1,S_max]
+ * array without a gather on the host.  Typical use: vits_run(..., out = NULL), then vits_last_y_lengths() to size the
+ * array, then this.  Waits for the run; VITS_E_RANGE as vits_sync. */
+int vits_fetch_output(vits_handle *h, float *dst, size_t row_elems, size_t dst_elems);
+/* Pinned (page-locked) host memory for vits_fetch_output / input staging; NULL on failure. */
+void *vits_host_alloc(size_t bytes);
+void vits_host_free(void *p);
+
 /* Device-resident variant: every pointer (ids, lens, sid, noise arrays) is a device
  * pointer on the handle's GPU; `out->data` and `out->y_lengths` are device pointers into
  * the handle's workspace, valid until the next call on this handle.  Returns after the
@@ -224,6 +241,20 @@ typedef struct {
 /* Enable per-stage HIP-event timing (adds event records on the handle's stream). */
 int vits_set_timing(vits_handle *h, int enable);
 int vits_get_stats(vits_handle *h, vits_stats *out);
+
+/* One record per conv-engine launch of the last run made with timing enabled, in launch order (call after
+ * vits_get_stats, which reads the events): the kernel instantiation as rocprofv3 spells it (without "void vitsmi::"
+ * and the argument list), its HIP-event time, algorithmic FLOPs and layer-granular bytes (fp32 input read once +
+ * output written once), pipeline stage (0 encoder, 1 duration predictor, 2 flow, 3 generator), shape.  Writes min(n, count)
+ * records, returns count. */
+typedef struct {
+    char kernel[128];
+    double flops, bytes;
+    float ms;
+    int stage;
+    int cin, cout, k, dil, t;   /* the conv's shape (a fused pair: its first conv) and input length */
+} vits_launch_record;
+int vits_launch_records(vits_handle *h, vits_launch_record *buf, int n);
 
 /* The HIP stream the handle launches on (hipStream_t as void*), for callers that want
  * to order their own work or events against it. */

@@ -30,6 +30,11 @@ class VitsStats(C.Structure):
                 ("f16_saturated", C.c_int), ("sx_bytes", C.c_double)]
 
 
+class VitsLaunchRecord(C.Structure):
+    _fields_ = [("kernel", C.c_char * 128), ("flops", C.c_double), ("bytes", C.c_double), ("ms", C.c_float),
+                ("stage", C.c_int), ("cin", C.c_int), ("cout", C.c_int), ("k", C.c_int), ("dil", C.c_int), ("t", C.c_int)]
+
+
 class VitsOpenOptions(C.Structure):
     _fields_ = [("device_id", C.c_int), ("gen_precision", C.c_char_p), ("arena_dev", C.c_void_p),
                 ("arena_bytes", C.c_size_t), ("host_only", C.c_int), ("layout_only", C.c_int)]
@@ -49,7 +54,8 @@ EXPORTS = [
     "vits_tap",
     "vits_set_timing", "vits_get_stats", "vits_stream", "vits_test_conv1d", "vits_test_conv_transpose1d",
     "vits_test_attention", "vits_bench_conv1d", "vits_test_conv1d_sx", "vits_test_conv_transpose1d_sx",
-    "vits_bench_conv1d_sx", "vits_test_conv_pair_sx",
+    "vits_bench_conv1d_sx", "vits_test_conv_pair_sx", "vits_fetch_output", "vits_run_async", "vits_host_alloc", "vits_host_free",
+    "vits_launch_records",
 ]
 
 
@@ -96,6 +102,7 @@ def load():
     run_args = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.POINTER(VitsNoise), C.POINTER(VitsOutput)]
     lib.vits_run.argtypes = run_args
     lib.vits_run_device.argtypes = run_args
+    lib.vits_run_async.argtypes = run_args[:-1]
     lib.vits_free_output.argtypes = [vp, C.POINTER(VitsOutput)]
     lib.vits_free_output.restype = None
     lib.vits_sync.argtypes = [vp]
@@ -107,6 +114,12 @@ def load():
     lib.vits_get_stats.argtypes = [vp, C.POINTER(VitsStats)]
     lib.vits_stream.argtypes = [vp]
     lib.vits_stream.restype = vp
+    lib.vits_fetch_output.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+    lib.vits_host_alloc.argtypes = [C.c_size_t]
+    lib.vits_host_alloc.restype = vp
+    lib.vits_host_free.argtypes = [vp]
+    lib.vits_host_free.restype = None
+    lib.vits_launch_records.argtypes = [vp, C.POINTER(VitsLaunchRecord), C.c_int]
     lib.vits_test_conv1d.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_float, vp]
     lib.vits_test_conv_transpose1d.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int,

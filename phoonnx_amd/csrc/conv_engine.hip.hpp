@@ -38,6 +38,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
+
 #include "sx_split.hip.hpp"
 
 namespace vitsmi {
@@ -480,6 +482,8 @@ inline hipError_t launch_conv_k(const ConvArgs &a, dim3 grid, size_t lds, hipStr
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    if (g_launch_name_on)
+        snprintf(g_launch_name, sizeof g_launch_name, "conv_engine_kernel<%d, %d, %d, %d, %d, %d>", MW, NW, WM, WN, VEC, ACT);
     kern<<<grid, 256, lds, stream>>>(a);
     return hipGetLastError();
 }

@@ -43,6 +43,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <utility>
 
@@ -812,6 +813,9 @@ inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipSt
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    if (g_launch_name_on)
+        snprintf(g_launch_name, sizeof g_launch_name, "conv_sx_kernel<%d, %d, %d, %d, %d, %s, %s, %d>", MW, NW, WM, WN, EPI,
+                 PROF ? "true" : "false", RAWIN ? "true" : "false", NP);
     kern<<<grid, 256, lds, stream>>>(a);
     return hipGetLastError();
 }

@@ -458,12 +458,10 @@ struct LinJob {
     int64_t y_rs = 0, y_cs = 1;  // (0: the call's default row stride)
 };
 void linear(Run &r, std::initializer_list<LinJob> jobs, const float *x, int xp, int T, int64_t y_rs) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        r.note(hipFuncSetAttribute(reinterpret_cast<const void *>(g2p_linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   64 * 1024));
-        attr_set = true;
-    }
+    // (the attribute belongs to the (function, device) pair: handles on different GPUs each set it, and no flag is
+    // shared between their threads; the call is idempotent and costs ~1 us)
+    r.note(hipFuncSetAttribute(reinterpret_cast<const void *>(g2p_linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               64 * 1024));
     G2PLinArgs a{};
     int tiles = 0;
     for (const LinJob &j : jobs) {

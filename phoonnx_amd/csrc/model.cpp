@@ -8,6 +8,7 @@
 #include "model.hpp"
 #include "g2p_model.hpp"
 
+#include <cctype>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -99,13 +100,320 @@ void split_path(const std::string &node_name, std::string &mod, std::string &lea
     }
 }
 
+// ---- structure-keyed naming (SURVEY §7 "Weight lookup", App. B).  Node names carry module paths only in exports of
+// recent torch versions; older Piper-era exports name their nodes "Conv_123".  The ORDER of the nodes, though, is the
+// order SynthesizerTrn.infer executes its modules in (export_onnx.py:318-327 traces it), and every module is
+// recognisable by its position in that order plus the (Cout, Cin, kernel, group) of its convolution.  This walks the
+// Conv / ConvTranspose / Gather / LayerNorm Mul-Add / Pad / Sub / Exp nodes in graph order and gives each one the
+// module-path name the current exporter would have given it ("/flow/flows.6/enc/in_layers.0/Conv"); resolve() then
+// runs on those names.  When the graph has real module-path names the two must agree (cross-check).
+// Returns "" on success (paths[i] = synthetic name of node i or ""), else what did not fit.
+std::string structural_paths(const OnnxModel &om, std::vector<std::string> &paths) {
+    struct CV {
+        int node, Cout, Cin, K, group, dil;
+        bool T;
+    };
+    const int nn = int(om.nodes.size());
+    paths.assign(size_t(nn), std::string());
+    std::vector<CV> cv;
+    for (int i = 0; i < nn; i++) {
+        const OnnxNode &n = om.nodes[size_t(i)];
+        if ((n.op != "Conv" && n.op != "ConvTranspose") || n.inputs.size() < 2) continue;
+        const OnnxTensor *w = om.find_init(n.inputs[1]);
+        if (!w || w->dtype != 1 || w->dims.size() != 3 || !w->data()) return "a convolution without a rank-3 float weight (" + n.op + ")";
+        CV c;
+        c.node = i;
+        c.T = n.op == "ConvTranspose";
+        auto g = n.ints.find("group");
+        c.group = (g != n.ints.end() && !g->second.empty()) ? int(g->second[0]) : 1;
+        auto dl = n.ints.find("dilations");
+        c.dil = (dl != n.ints.end() && !dl->second.empty()) ? int(dl->second[0]) : 1;
+        c.K = int(w->dims[2]);
+        if (c.T) {
+            c.Cin = int(w->dims[0]);
+            c.Cout = int(w->dims[1]) * c.group;
+        } else {
+            c.Cout = int(w->dims[0]);
+            c.Cin = int(w->dims[1]) * c.group;
+        }
+        cv.push_back(c);
+    }
+    const size_t n = cv.size();
+    size_t p = 0;
+    auto softmax_between = [&](int a, int b) {
+        for (int i = a + 1; i < b; i++)
+            if (om.nodes[size_t(i)].op == "Softmax") return true;
+        return false;
+    };
+    auto put = [&](size_t pos, const std::string &mod) { paths[size_t(cv[pos].node)] = "/" + mod + (cv[pos].T ? "/ConvTranspose" : "/Conv"); };
+    auto is11 = [&](size_t pos) { return pos < n && !cv[pos].T && cv[pos].K == 1 && cv[pos].group == 1; };
+    bool gin = false;
+    for (const auto &in : om.inputs) gin = gin || in == "sid";
+    const std::string S = std::to_string(0);
+    (void)S;
+    // ---- text encoder: [conv_q conv_k conv_v (Softmax) conv_o | ffn conv_1 conv_2] per layer, then proj
+    int H = 0, layers = 0;
+    while (p + 6 < n && is11(p) && is11(p + 1) && is11(p + 2) && is11(p + 3) && cv[p].Cout == cv[p].Cin &&
+           cv[p + 1].Cout == cv[p].Cout && cv[p + 2].Cout == cv[p].Cout && cv[p + 1].Cin == cv[p].Cin &&
+           softmax_between(cv[p + 2].node, cv[p + 3].node)) {
+        const std::string a = "enc_p/encoder/attn_layers." + std::to_string(layers), f = "enc_p/encoder/ffn_layers." + std::to_string(layers);
+        H = cv[p].Cout;
+        put(p, a + "/conv_q");
+        put(p + 1, a + "/conv_k");
+        put(p + 2, a + "/conv_v");
+        put(p + 3, a + "/conv_o");
+        put(p + 4, f + "/conv_1");
+        put(p + 5, f + "/conv_2");
+        if (cv[p + 4].Cin != H || cv[p + 5].Cout != H || cv[p + 4].Cout != cv[p + 5].Cin) return "encoder layer " + std::to_string(layers) + ": unexpected FFN shape";
+        p += 6;
+        layers++;
+    }
+    if (!layers) return "no attention layer found at the head of the graph";
+    if (!is11(p) || cv[p].Cin != H || cv[p].Cout % 2) return "enc_p.proj not found after the encoder layers";
+    const int C = cv[p].Cout / 2;
+    put(p++, "enc_p/proj");
+    // ---- duration predictor
+    auto dds = [&](const std::string &base) -> bool {  // (convs_sep.i, convs_1x1.i) pairs
+        int i = 0;
+        while (p + 1 < n && cv[p].group > 1 && cv[p].group == cv[p].Cout && is11(p + 1)) {
+            put(p, base + "/convs_sep." + std::to_string(i));
+            put(p + 1, base + "/convs_1x1." + std::to_string(i));
+            p += 2;
+            i++;
+        }
+        return i > 0;
+    };
+    const size_t sep_at = p + 1 + (gin ? 1 : 0);
+    if (sep_at < n && cv[sep_at].group > 1) {  // stochastic duration predictor (models.py:63-70,108-117)
+        if (!is11(p) || cv[p].Cin != H) return "dp.pre not found";
+        put(p++, "dp/pre");
+        if (gin) put(p++, "dp/cond");
+        if (!dds("dp/convs")) return "dp.convs not found";
+        if (!is11(p)) return "dp.proj not found";
+        put(p++, "dp/proj");
+        // ConvFlows in execution order; numbered as models.py:109-110 leaves them: 2 k + 1 for k = count .. 1
+        std::vector<size_t> starts;
+        {
+            size_t q = p;
+            while (q < n && is11(q) && cv[q].Cin == 1 && cv[q].Cout > 1) {
+                starts.push_back(q);
+                q++;
+                while (q + 1 < n && cv[q].group > 1) q += 2;
+                q++;  // proj
+            }
+        }
+        if (starts.empty()) return "dp: no ConvFlow found";
+        for (size_t j = 0; j < starts.size(); j++) {
+            const std::string s = "dp/flows." + std::to_string(2 * (starts.size() - j) + 1);
+            if (p != starts[j]) return "dp: ConvFlow walk lost its place";
+            put(p++, s + "/pre");
+            if (!dds(s + "/convs")) return s + ": no DDSConv";
+            if (!is11(p)) return s + ": proj not found";
+            put(p++, s + "/proj");
+        }
+    } else {  // plain DurationPredictor (models.py:120-165): [cond] conv_1 conv_2 proj
+        if (gin) put(p++, "dp/cond");
+        if (p + 2 >= n || cv[p].Cin != H || cv[p + 2].Cout != 1) return "dp: neither a stochastic nor a plain duration predictor";
+        put(p, "dp/conv_1");
+        put(p + 1, "dp/conv_2");
+        put(p + 2, "dp/proj");
+        p += 3;
+    }
+    const size_t dp_end = p;
+    // ---- coupling flow (reverse order: flows 2(n-1), .., 2, 0): pre [cond_layer] (in_layers.i res_skip_layers.i)* post
+    {
+        std::vector<std::vector<size_t>> cps;
+        if (C % 2) return "odd inter_channels";
+        const int half = C / 2;
+        while (p < n && is11(p) && cv[p].Cin == half) {
+            std::vector<size_t> c;
+            const int Hf = cv[p].Cout;
+            c.push_back(p++);
+            if (gin) c.push_back(p++);
+            int i = 0;
+            while (p + 1 < n && !cv[p].T && cv[p].Cin == Hf && cv[p].Cout == 2 * Hf && is11(p + 1) && cv[p + 1].Cin == Hf &&
+                   !(cv[p].K == 1 && cv[p].Cout == half)) {
+                c.push_back(p);
+                c.push_back(p + 1);
+                p += 2;
+                i++;
+            }
+            if (!i || !is11(p) || cv[p].Cin != Hf || cv[p].Cout != half) return "flow: coupling layer without WN layers / post";
+            c.push_back(p++);
+            cps.push_back(c);
+        }
+        if (cps.empty()) return "flow: no coupling layer found";
+        for (size_t j = 0; j < cps.size(); j++) {
+            const std::string s = "flow/flows." + std::to_string(2 * (cps.size() - 1 - j));
+            const auto &c = cps[j];
+            size_t k = 0;
+            put(c[k++], s + "/pre");
+            if (gin) put(c[k++], s + "/enc/cond_layer");
+            for (int i = 0; k + 1 < c.size(); i++, k += 2) {
+                put(c[k], s + "/enc/in_layers." + std::to_string(i));
+                put(c[k + 1], s + "/enc/res_skip_layers." + std::to_string(i));
+            }
+            put(c[k], s + "/post");
+        }
+    }
+    // ---- generator: conv_pre [cond] (ups.s resblocks...)* conv_post
+    if (p >= n || cv[p].T || cv[p].Cin != C) return "dec.conv_pre not found";
+    put(p++, "dec/conv_pre");
+    if (gin) {
+        if (!is11(p)) return "dec.cond not found";
+        put(p++, "dec/cond");
+    }
+    {
+        int stage = 0, rb = 0;
+        while (p < n && cv[p].T) {
+            put(p++, "dec/ups." + std::to_string(stage++));
+            std::vector<size_t> st;
+            while (p < n && !cv[p].T && !(p == n - 1)) st.push_back(p++);
+            if (st.empty()) return "dec: an upsampling stage without residual blocks";
+            // split into residual blocks: a new block where the kernel size changes; equal kernels: by the period of the
+            // dilation sequence
+            std::vector<std::vector<size_t>> blocks;
+            bool kchange = false;
+            for (size_t i = 1; i < st.size(); i++) kchange = kchange || cv[st[i]].K != cv[st[0]].K;
+            if (kchange) {
+                for (size_t i = 0; i < st.size(); i++) {
+                    if (i == 0 || cv[st[i]].K != cv[st[i - 1]].K) blocks.emplace_back();
+                    blocks.back().push_back(st[i]);
+                }
+            } else {
+                size_t per = st.size();
+                for (size_t q = 1; q < st.size(); q++) {
+                    if (st.size() % q) continue;
+                    bool ok = true;
+                    for (size_t i = q; i < st.size() && ok; i++) ok = cv[st[i]].dil == cv[st[i - q]].dil;
+                    if (ok) {
+                        per = q;
+                        break;
+                    }
+                }
+                for (size_t i = 0; i < st.size(); i++) {
+                    if (i % per == 0) blocks.emplace_back();
+                    blocks.back().push_back(st[i]);
+                }
+            }
+            for (const auto &b : blocks) {
+                bool t1 = b.size() % 2 == 0;  // ResBlock1: (convs1.j, convs2.j) pairs, every convs2 undilated (modules.py:220-298)
+                for (size_t i = 1; i < b.size() && t1; i += 2) t1 = cv[b[i]].dil == 1;
+                const std::string r = "dec/resblocks." + std::to_string(rb++);
+                for (size_t i = 0; i < b.size(); i++)
+                    put(b[i], t1 ? r + (i % 2 ? "/convs2." : "/convs1.") + std::to_string(i / 2) : r + "/convs." + std::to_string(i));
+            }
+        }
+        if (!stage) return "dec: no upsampling stage";
+    }
+    if (p != n - 1 || cv[p].Cout != 1) return "dec.conv_post not found at the end of the graph";
+    put(p++, "dec/conv_post");
+    // ---- everything that hangs off a convolution's position: LayerNorm scale / shift, relative-position tables,
+    // embeddings, the ElementwiseAffine of the duration flow
+    std::string last_mod;
+    int last_ch = 0, gathers = 0;
+    bool got_g = false, got_b = false;
+    const int dp_end_node = dp_end > 0 ? cv[dp_end - 1].node : -1;
+    for (int i = 0; i < nn; i++) {
+        const OnnxNode &nd = om.nodes[size_t(i)];
+        if (!paths[size_t(i)].empty()) {
+            std::string mod, leaf;
+            split_path(paths[size_t(i)], mod, leaf);
+            last_mod = mod;
+            got_g = got_b = false;
+            for (const auto &c : cv)
+                if (c.node == i) last_ch = c.Cout;
+            continue;
+        }
+        if (nd.op == "Gather" && !nd.inputs.empty()) {
+            const OnnxTensor *t = om.find_init(nd.inputs[0]);
+            if (t && t->dtype == 1 && t->dims.size() == 2) {
+                if (gathers == 0) paths[size_t(i)] = "/enc_p/emb/Gather";
+                else if (gathers == 1 && gin) paths[size_t(i)] = "/emb_g/Gather";
+                gathers++;
+            }
+        } else if ((nd.op == "Mul" || nd.op == "Add") && !last_mod.empty()) {
+            const OnnxTensor *t = nullptr;
+            for (const auto &in : nd.inputs) {
+                const OnnxTensor *c = om.find_init(in);
+                if (c && c->dtype == 1 && c->dims.size() == 1 && c->dims[0] == last_ch && last_ch > 1) t = c;
+            }
+            if (!t) continue;
+            std::string norm;
+            auto tail = [&](const std::string &key, std::string &head, std::string &idx) {
+                const size_t at = last_mod.rfind(key);
+                if (at == std::string::npos) return false;
+                head = last_mod.substr(0, at);
+                idx = last_mod.substr(at + key.size());
+                return true;
+            };
+            std::string head, idx;
+            if (tail("attn_layers.", head, idx) && idx.size() > 7 && idx.compare(idx.size() - 7, 7, ".conv_o") == 0)
+                norm = head + "norm_layers_1." + idx.substr(0, idx.size() - 7);
+            else if (tail("ffn_layers.", head, idx) && idx.size() > 7 && idx.compare(idx.size() - 7, 7, ".conv_2") == 0)
+                norm = head + "norm_layers_2." + idx.substr(0, idx.size() - 7);
+            else if (tail("convs_sep.", head, idx)) norm = head + "norms_1." + idx;
+            else if (tail("convs_1x1.", head, idx)) norm = head + "norms_2." + idx;
+            else if (last_mod == "dp.conv_1") norm = "dp.norm_1";
+            else if (last_mod == "dp.conv_2") norm = "dp.norm_2";
+            if (norm.empty()) continue;
+            if (nd.op == "Mul" && !got_g) got_g = true;
+            else if (nd.op == "Add" && got_g && !got_b) got_b = true;
+            else continue;
+            for (auto &ch : norm)
+                if (ch == '.') ch = '/';
+            // (module paths use '/' between modules and '.' inside "name.index": restore the index dots)
+            for (size_t k = 0; k + 1 < norm.size(); k++)
+                if (norm[k] == '/' && std::isdigit((unsigned char)norm[k + 1])) norm[k] = '.';
+            paths[size_t(i)] = "/" + norm + "/" + nd.op;
+        } else if (nd.op == "Pad" && !nd.inputs.empty() && last_mod.find("attn_layers.") != std::string::npos) {
+            const OnnxTensor *t = om.find_init(nd.inputs[0]);
+            if (t && t->dtype == 1 && t->dims.size() == 3) {
+                std::string a = last_mod.substr(0, last_mod.rfind('.'));  // enc_p.encoder.attn_layers.N
+                for (auto &ch : a)
+                    if (ch == '.') ch = '/';
+                for (size_t k = 0; k + 1 < a.size(); k++)
+                    if (a[k] == '/' && std::isdigit((unsigned char)a[k + 1])) a[k] = '.';
+                paths[size_t(i)] = "/" + a + "/Pad";
+            }
+        } else if ((nd.op == "Sub" || nd.op == "Exp") && i > dp_end_node && dp_end_node >= 0 && last_mod.rfind("dp.", 0) == 0) {
+            for (const auto &in : nd.inputs) {
+                const OnnxTensor *t = om.find_init(in);
+                if (t && t->dtype == 1 && t->numel() == 2) paths[size_t(i)] = "/dp/flows.0/" + nd.op;
+            }
+        }
+    }
+    return "";
+}
+
 void resolve(const OnnxModel &om, Resolver &R) {
     auto init = [&](const std::string &n) -> const OnnxTensor * { return om.find_init(n); };
     std::map<std::string, int> pad_seen;
-    for (const auto &n : om.nodes) {
-        if (n.name.empty()) continue;
+    // names: the exporter's module paths where the graph has them, else the structural walk's; both present: they agree
+    bool named = false;
+    for (const auto &n : om.nodes)
+        named = named || ((n.op == "Conv" || n.op == "ConvTranspose") && n.name.size() > 1 && n.name[0] == '/' &&
+                          n.name.find('/', 1) != std::string::npos);
+    std::vector<std::string> sp;
+    const std::string serr = structural_paths(om, sp);
+    static const bool force_struct = std::getenv("VITSMI_RESOLVE_BY_STRUCTURE") != nullptr;  // tests
+    const bool use_struct = !named || force_struct;
+    if (use_struct && !serr.empty())
+        throw std::runtime_error("the graph's nodes carry no module-path names and its structure is not that of a VITS export: " + serr);
+    if (named && serr.empty()) {
+        for (size_t i = 0; i < om.nodes.size(); i++) {
+            const OnnxNode &n = om.nodes[i];
+            if ((n.op != "Conv" && n.op != "ConvTranspose") || sp[i].empty()) continue;
+            if (sp[i] != n.name)
+                throw std::runtime_error("node '" + n.name + "' sits where the graph's structure expects '" + sp[i] + "'");
+        }
+    }
+    for (size_t ni = 0; ni < om.nodes.size(); ni++) {
+        const auto &n = om.nodes[ni];
+        const std::string &nm = use_struct ? sp[ni] : n.name;
+        if (nm.empty()) continue;
         std::string mod, leaf;
-        split_path(n.name, mod, leaf);
+        split_path(nm, mod, leaf);
         if (n.op == "Conv" || n.op == "ConvTranspose") {
             if (n.inputs.size() > 1) R.put(mod + ".weight", init(n.inputs[1]));
             if (n.inputs.size() > 2 && !n.inputs[2].empty()) R.put(mod + ".bias", init(n.inputs[2]));
@@ -1186,7 +1494,8 @@ std::string G2PModel::build(const OnnxModel &om) {
         if (q0.dims[0] != d_model || heads <= 0 || q0.dims[1] % heads) throw std::runtime_error("unexpected attention shape");
         inner = int(q0.dims[1]);
         d_kv = inner / heads;
-        if (d_kv > 256 || num_buckets < 2 || num_buckets % 2) throw std::runtime_error("unsupported T5 attention geometry");
+        // (num_buckets >= 4: the bidirectional table halves it twice - max_exact = num_buckets / 4 must not be zero)
+        if (d_kv > 256 || num_buckets < 4 || num_buckets % 2 || num_buckets / 2 >= max_distance) throw std::runtime_error("unsupported T5 attention geometry");
         act = saw_tanh ? 0 : (saw_erf ? 2 : (saw_relu ? 1 : 0));
         if (lm_node) {  // a Mul between the decoder's final layer norm and lm_head = the tied-embedding output scale
             auto it = producer.find(lm_node->inputs[0]);

@@ -15,6 +15,11 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kSxPeakSlots = 64;
 constexpr float kF16Max = 65504.f;
 
+// Timing mode (vits_set_timing): every conv launcher notes which kernel instantiation it started, spelled as rocprofv3
+// prints it, so that the per-launch records of vits_launch_records() can be joined with a kernel trace by name.
+inline thread_local bool g_launch_name_on = false;
+inline thread_local char g_launch_name[128];
+
 // ---- f16 mode (NP = 2): an fp32 operand as TWO fp16 planes, round-to-nearest at each step:
 //     v ~ h0 + h1,   h0 = f16(v), h1 = f16(v - h0):   |v - h0 - h1| <= 2^-24 |v|  (11 + 11 bits and the sign of h1)
 // so a product needs only the three MFMAs h0g0 + h0g1 + h1g0 (the dropped h1g1 is <= 2^-24 |v||g|): the same

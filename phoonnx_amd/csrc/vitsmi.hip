@@ -67,6 +67,7 @@ struct vits_handle {
     vits_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;
     std::vector<char> conv_event_sx;  // 1: that launch went through the split-exact engine
+    std::vector<vits_launch_record> conv_recs;  // what each timed launch was (vits_launch_records)
     size_t conv_events_used = 0;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int cur_stage = 0;  // 0 enc, 1 dp, 2 flow, 3 dec
@@ -254,9 +255,32 @@ bool conv_event_begin(Ctx &c) {
         hipEventCreate(&e1);
         h->conv_events.push_back({e0, e1});
     }
-    if (h->conv_events_used < h->conv_event_sx.size()) h->conv_event_sx[h->conv_events_used] = 0;
+    if (h->conv_event_sx.size() < h->conv_events.size()) h->conv_event_sx.resize(h->conv_events.size(), 0);
+    if (h->conv_recs.size() < h->conv_events.size()) h->conv_recs.resize(h->conv_events.size());
+    h->conv_event_sx[h->conv_events_used] = 0;
+    g_launch_name[0] = 0;
     hipEventRecord(h->conv_events[h->conv_events_used].first, c.st);
     return true;
+}
+
+// ... and its end event, with what the launch was: the instantiation the launcher picked (g_launch_name), algorithmic
+// FLOPs and layer-granular bytes
+void conv_event_end(Ctx &c, bool sx, double flops, double bytes, const ConvDesc &d, int T) {
+    vits_handle *h = c.h;
+    const size_t i = h->conv_events_used++;
+    h->conv_event_sx[i] = sx ? 1 : 0;
+    vits_launch_record &r = h->conv_recs[i];
+    std::snprintf(r.kernel, sizeof r.kernel, "%s", g_launch_name);
+    r.flops = flops;
+    r.bytes = bytes;
+    r.stage = h->cur_stage;
+    r.ms = 0.f;
+    r.cin = d.Cin;
+    r.cout = d.Cout;
+    r.k = d.K;
+    r.dil = d.dil;
+    r.t = T;
+    hipEventRecord(h->conv_events[i].second, c.st);
 }
 
 // Launch one conv through the engine; accounts algorithmic FLOPs/bytes per stage.
@@ -310,7 +334,7 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
     }
     const bool ev = conv_event_begin(c);
     c.note(launch_conv(a, d.cfg, c.B, c.st));
-    if (ev) hipEventRecord(h->conv_events[h->conv_events_used++].second, c.st);
+    if (ev) conv_event_end(c, false, 2.0 * d.macs_per_t * (double)T * c.B, 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T), d, T);
     conv_account(c, d, T);
 }
 
@@ -365,11 +389,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
         else if (wgs0 <= 256) run_cfg = 1;
     }
     c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, d.f16 ? 2 : (h->cur_stage == 3 ? h->gen_nprod : 6), d.cfg));
-    if (ev) {
-        if (h->conv_event_sx.size() < h->conv_events.size()) h->conv_event_sx.resize(h->conv_events.size(), 0);
-        h->conv_event_sx[h->conv_events_used] = 1;
-        hipEventRecord(h->conv_events[h->conv_events_used++].second, c.st);
-    }
+    if (ev) conv_event_end(c, true, 2.0 * d.macs_per_t * (double)T * c.B, 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T), d, T);
     conv_account(c, d, T);
     h->stats.sx_flops += 2.0 * d.macs_per_t * (double)T * c.B;
     h->stats.sx_bytes += 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T);
@@ -414,11 +434,9 @@ void conv_sx_pair(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const float *x
     a.peak = range_slots(h, true);
     const bool ev = conv_event_begin(c);
     c.note(launch_conv_sx_pair(a, c1.cfg, c.B, c.st, chain));
-    if (ev) {
-        if (h->conv_event_sx.size() < h->conv_events.size()) h->conv_event_sx.resize(h->conv_events.size(), 0);
-        h->conv_event_sx[h->conv_events_used] = 1;
-        hipEventRecord(h->conv_events[h->conv_events_used++].second, c.st);
-    }
+    if (ev)
+        conv_event_end(c, true, 2.0 * (c1.macs_per_t + c2.macs_per_t) * (double)T * c.B,
+                       4.0 * c.B * ((double)(c1.Cin + c1.Cout) * T + (double)(c2.Cin + c2.Cout) * T), c1, T);
     conv_account(c, c1, T);
     conv_account(c, c2, T);
     h->stats.conv_launches--;  // (two convs, one launch)
@@ -1361,6 +1379,7 @@ static int run_device_locked(vits_handle *h, const int64_t *ids, const int64_t *
     if (h->model.gin && !sid) return fail(h, VITS_E_ARG, "Missing speaker id");
     std::memset(&h->stats, 0, sizeof h->stats);
     h->conv_events_used = 0;
+    g_launch_name_on = h->timing;
     h->B = B;
     h->T = T;
     h->range_failed = false;
@@ -1472,16 +1491,33 @@ static int stage_inputs(vits_handle *h, const int64_t *ids, const int64_t *lens,
     return rc;
 }
 
+// host inputs in; returns once everything is enqueued (the mid-pipeline frame-count readback has completed, and with it
+// the input copies: the caller's buffers are free)
+static int run_async_locked(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
+                            const int64_t *sid, const vits_noise *noise, vits_output *dev) {
+    if (!scales) return fail(h, VITS_E_ARG, "null argument");
+    Staged sg;
+    int rc = stage_inputs(h, ids, lens, B, T, sid, noise, sg);
+    if (rc == VITS_OK) rc = run_device_locked(h, sg.d_ids, sg.d_lens, B, T, scales, sg.d_sid, sg.has_noise ? &sg.dn : nullptr, dev);
+    if (rc != VITS_OK) hipStreamSynchronize(h->stream);  // the staging slab is reused by the next call
+    return rc;
+}
+
+int vits_run_async(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
+                   const int64_t *sid, const vits_noise *noise) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    vits_output dev{};
+    return run_async_locked(h, ids, lens, B, T, scales, sid, noise, &dev);
+}
+
 int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T, const float scales[3],
              const int64_t *sid, const vits_noise *noise, vits_output *out) {
     if (int rc = check_dev(h)) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
-    if (!scales) return fail(h, VITS_E_ARG, "null argument");  // (out == NULL: run only)
-    Staged sg;
-    int rc = stage_inputs(h, ids, lens, B, T, sid, noise, sg);
     hipStream_t st = h->stream;
     vits_output dev{};
-    if (rc == VITS_OK) rc = run_device_locked(h, sg.d_ids, sg.d_lens, B, T, scales, sg.d_sid, sg.has_noise ? &sg.dn : nullptr, &dev);
+    int rc = run_async_locked(h, ids, lens, B, T, scales, sid, noise, &dev);  // (out == NULL: run only)
     if (rc == VITS_OK && !out) {
         // run only: the caller fetches what it needs afterwards (vits_last_pcm16, vits_last_y_lengths, vits_tap)
         if (hipStreamSynchronize(st) != hipSuccess)
@@ -1507,8 +1543,8 @@ int vits_run(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int
             std::memcpy(out->dims, dev.dims, sizeof dev.dims);
             out->y_lengths = hy;
         }
+        if (rc != VITS_OK) hipStreamSynchronize(st);
     }
-    if (rc != VITS_OK) hipStreamSynchronize(st);  // the staging slab is reused by the next call
     return rc;
 }
 
@@ -1563,6 +1599,8 @@ int vits_last_pcm16(vits_handle *h, int normalize, float volume, int16_t *out, s
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_pcm, n * 2, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return fail(h, VITS_E_DEVICE, "pcm16 post-processing failed: %s", hipGetErrorString(e));
+    if (int rc = range_check(h)) return rc;  // (after vits_run_async this is the first synchronisation of that run)
+    if (h->range_failed) return fail(h, VITS_E_RANGE, "the last run left the range of the fp16 operand planes (see vits_get_stats)");
     return VITS_OK;
 }
 
@@ -1578,6 +1616,7 @@ static int vocoder_common(vits_handle *h, const float *z, int B, int F, const in
             return fail(h, VITS_E_ARG, "sid[%d]=%lld is out of range [0,%d)", b, (long long)sid[b], m.n_speakers);
     std::memset(&h->stats, 0, sizeof h->stats);
     h->conv_events_used = 0;
+    g_launch_name_on = h->timing;
     h->range_failed = false;
     const size_t nCF = (size_t)B * m.C * F;
     const int Fgen = sink && sink->chunk_frames + 2 * m.gen_rf_frames < F ? sink->chunk_frames + 2 * m.gen_rf_frames : F;
@@ -1695,6 +1734,7 @@ int vits_get_stats(vits_handle *h, vits_stats *out) {
             float ms = 0.f, tot = 0.f, tot_sx = 0.f;
             for (size_t i = 0; i < h->conv_events_used; i++) {
                 if (hipEventElapsedTime(&ms, h->conv_events[i].first, h->conv_events[i].second) != hipSuccess) continue;
+                h->conv_recs[i].ms = ms;
                 tot += ms;
                 if (i < h->conv_event_sx.size() && h->conv_event_sx[i]) tot_sx += ms;
             }
@@ -1713,6 +1753,44 @@ int vits_get_stats(vits_handle *h, vits_stats *out) {
         }
     }
     *out = h->stats;
+    return VITS_OK;
+}
+
+int vits_launch_records(vits_handle *h, vits_launch_record *buf, int n) {
+    if (!h) return VITS_E_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int have = (int)h->conv_events_used;
+    for (int i = 0; i < have && i < n && buf; i++) buf[i] = h->conv_recs[i];
+    return have;
+}
+
+void *vits_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1) == hipSuccess ? p : nullptr;
+}
+
+void vits_host_free(void *p) {
+    if (p) hipHostFree(p);
+}
+
+int vits_fetch_output(vits_handle *h, float *dst, size_t row_elems, size_t dst_elems) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int B = h->B, S = h->S;
+    if (!h->d_out || B <= 0 || S <= 0) return fail(h, VITS_E_ARG, "no completed run to fetch");
+    if (!dst || row_elems < (size_t)S || dst_elems < (size_t)B * row_elems)
+        return fail(h, VITS_E_ARG, "output buffer too small: rows of %zu (need %d), %zu elements (need %zu)", row_elems, S,
+                    dst_elems, (size_t)B * row_elems);
+    hipStream_t st = h->stream;
+    hipError_t e = row_elems == (size_t)S
+                       ? hipMemcpyAsync(dst, h->d_out, (size_t)B * S * 4, hipMemcpyDeviceToHost, st)
+                       : hipMemcpy2DAsync(dst, row_elems * 4, h->d_out, (size_t)S * 4, (size_t)S * 4, B, hipMemcpyDeviceToHost, st);
+    if (row_elems > (size_t)S)  // (host work while the copy runs: the tail columns belong to nobody else)
+        for (int b = 0; b < B; b++) std::memset(dst + (size_t)b * row_elems + S, 0, (row_elems - S) * 4);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(h, VITS_E_DEVICE, "device-to-host copy failed: %s", hipGetErrorString(e));
+    if (int rc = range_check(h)) return rc;
+    if (h->range_failed) return fail(h, VITS_E_RANGE, "the last run left the range of the fp16 operand planes (see vits_get_stats)");
     return VITS_OK;
 }
 

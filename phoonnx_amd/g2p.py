@@ -24,6 +24,82 @@ BYT5_LANGS = ['ca-ES', 'cy-GB', 'da-DK', 'de-DE', 'en-GB', 'en-US', 'es-ES', 'et
               'pt-BR', 'pt-PT', 'qu-PE', 'ro-RO', 'sr-RS', 'sv-SE', 'tr-TR', 'yue-CN', 'zh-CN']  # mul.py:31-33
 
 
+# ---- language matching.  The reference resolves a BCP-47 tag to a phonemizer's own tag list with langcodes'
+# tag_distance (`phonemizers/base.py:86-122` match_lang: exact tag, else the closest supported one within distance 10,
+# else ValueError).  langcodes is not a dependency here; its outcome for these two short lists is reproduced by
+# (language, region / script) comparison with CLDR's likely regions as the default.
+_ISO639_3_TO_1 = {
+    "afr": "af", "sqi": "sq", "amh": "am", "ara": "ar", "arg": "an", "arm": "hy", "hye": "hy", "aze": "az", "bak": "ba",
+    "eus": "eu", "baq": "eu", "bel": "be", "ben": "bn", "bos": "bs", "bul": "bg", "bur": "my", "mya": "my", "cat": "ca",
+    "zho": "zh", "chi": "zh", "cmn": "zh", "cze": "cs", "ces": "cs", "dan": "da", "dut": "nl", "nld": "nl", "eng": "en",
+    "epo": "eo", "est": "et", "fin": "fi", "fra": "fr", "fre": "fr", "gla": "gd", "geo": "ka", "kat": "ka", "ger": "de",
+    "deu": "de", "gre": "el", "ell": "el", "grn": "gn", "guj": "gu", "hin": "hi", "hun": "hu", "ido": "io", "ind": "id",
+    "ina": "ia", "ita": "it", "jpn": "ja", "kaz": "kk", "khm": "km", "kor": "ko", "kur": "ku", "lat": "la", "lit": "lt",
+    "ltz": "lb", "mac": "mk", "mkd": "mk", "mlt": "mt", "nob": "nb", "nor": "nb", "ori": "or", "fas": "fa", "per": "fa",
+    "pol": "pl", "por": "pt", "ron": "ro", "rum": "ro", "rus": "ru", "san": "sa", "srp": "sr", "hbs": "sh", "snd": "sd",
+    "slo": "sk", "slk": "sk", "slv": "sl", "spa": "es", "swa": "sw", "swe": "sv", "tgl": "tl", "tam": "ta", "tat": "tt",
+    "tha": "th", "tur": "tr", "tuk": "tk", "ukr": "uk", "vie": "vi", "wel": "cy", "cym": "cy", "ice": "is", "isl": "is",
+    "gle": "ga", "glg": "gl", "sme": "se", "hrv": "hr", "que": "qu", "min": "nan",
+    "no": "nb", "nn": "nb", "iw": "he", "in": "id", "tl": "tl", "fil": "tl",  # macro-language / legacy two-letter aliases
+}
+_SUBTAG = {  # tag-list spellings of a region / script / variant -> BCP-47 subtag
+    "uk": "GB", "us": "US", "po": "PT", "bz": "BR", "qu": "CA", "latin": "419", "me": "MX", "t": "Hant", "s": "Hans",
+    "latn": "Latn", "cyrl": "Cyrl",
+}
+_DEFAULT_REGION = {"en": "US", "pt": "BR", "es": "ES", "fr": "FR", "zh": "Hans", "sh": "Latn"}  # CLDR likely subtags
+_NEAR = {  # an unsupported region -> the supported one CLDR's matching puts closest
+    "en": lambda r: "US" if r in ("US", "CA", "PH", "PR", "UM", "VI") else "GB",
+    "pt": lambda r: "BR" if r == "BR" else "PT",
+    "es": lambda r: r if r in ("ES", "MX") else ("ES" if r in ("EA", "IC", "GQ") else "419"),
+    "fr": lambda r: "CA" if r == "CA" else "FR",
+    "zh": lambda r: "Hant" if r in ("TW", "HK", "MO", "Hant") else "Hans",
+}
+
+
+def _parse_tag(tag: str):
+    parts = tag.replace("_", "-").split("-")
+    lang = parts[0].lower()
+    lang = _ISO639_3_TO_1.get(lang, lang)
+    sub = None
+    for p in parts[1:]:
+        q = _SUBTAG.get(p.lower())
+        if q is None and (len(p) == 2 or (len(p) == 3 and p.isdigit())):
+            q = p.upper()
+        if q is None and len(p) == 4 and p.isalpha():
+            q = p.title()
+        if q is not None and sub is None:
+            sub = q
+    return lang, sub
+
+
+def match_lang(target_lang: str, valid_langs: Sequence[str]) -> str:
+    """`BasePhonemizer.match_lang` (phonemizers/base.py:86-122): the tag itself when supported, else the closest supported
+    tag, else ValueError("unsupported language code: ...")."""
+    if target_lang in valid_langs:
+        return target_lang
+    lang, sub = _parse_tag(target_lang)
+    cands = [(v,) + _parse_tag(v) for v in valid_langs]
+    cands = [(v, s) for v, l, s in cands if l == lang]
+    if not cands:
+        raise ValueError(f"unsupported language code: {target_lang}")
+    if lang == "zh" and sub in ("CN", "SG", "MY"):
+        sub = "Hans"
+    want = sub if sub is not None else _DEFAULT_REGION.get(lang)
+    for v, s in cands:  # same region / script (the ByT5 list spells Chinese as zh-CN)
+        if s == want or (lang == "zh" and {s, want} == {"CN", "Hans"}):
+            return v
+    if sub is not None and lang in _NEAR:
+        near = _NEAR[lang](sub)
+        for v, s in cands:
+            if s == near or (lang == "zh" and {s, near} == {"CN", "Hans"}):
+                return v
+    want = _DEFAULT_REGION.get(lang)
+    for v, s in cands:
+        if s == want or s is None:
+            return v
+    return cands[0][0]
+
+
 def encode_text(text: str, lang: str) -> np.ndarray:
     """`ByT5Phonemizer._encode_text` (mul.py:152-170): "<lang>: text" as UTF-8 bytes, shifted by the 3 special ids."""
     data = f"<{lang}>: {text}".encode("utf-8")
@@ -155,18 +231,17 @@ class ByT5Phonemizer(SimplePhonemizer):
 
     @staticmethod
     def get_lang(target_lang: str) -> str:
-        if target_lang in BYT5_LANGS:
-            return target_lang
-        base = target_lang.split("-")[0].lower()
-        for l in BYT5_LANGS:  # (the reference resolves through langcodes: closest supported tag)
-            if l.split("-")[0].lower() == base:
-                return l
-        raise ValueError(f"unsupported language {target_lang}")
+        """mul.py:111-125: the closest tag of BYT5_LANGS ('en' -> 'en-US', 'pt' -> 'pt-BR', 'en-AU' -> 'en-GB')."""
+        return match_lang(target_lang, BYT5_LANGS)
+
+    def _prefix_lang(self, lang: str) -> str:
+        """The tag written in front of the text, "<tag>: text" (mul.py:152-170)."""
+        return self.get_lang(lang)
 
     def _infer(self, text: str, lang: str, max_length: int = 512) -> str:
         if not text.strip():
             return ""
-        ids = encode_text(text, self.get_lang(lang))
+        ids = encode_text(text, self._prefix_lang(lang))
         if self.device_loop:
             return decode_phones(self.session.generate(ids[0], max_length), self.tokens)
         # the reference's loop, call for call (mul.py:192-230)
@@ -192,7 +267,7 @@ class ByT5Phonemizer(SimplePhonemizer):
         if not self.device_loop or len(chunks) < 2:
             return [self.phonemize_string(c, lang) for c in chunks]
         todo = [i for i, c in enumerate(chunks) if c.strip()]
-        gen = self.session.generate_batch([encode_text(chunks[i], self.get_lang(lang))[0] for i in todo], max_length)
+        gen = self.session.generate_batch([encode_text(chunks[i], self._prefix_lang(lang))[0] for i in todo], max_length)
         out = [""] * len(chunks)
         for i, ids in zip(todo, gen):
             out[i] = decode_phones(ids, self.tokens)
@@ -209,19 +284,37 @@ CHARSIU_LANGS = ['ady', 'afr', 'sqi', 'amh', 'ara', 'arg', 'arm-e', 'arm-w', 'az
                  'gle', 'enm', 'syc', 'glg', 'sme', 'egy']  # mul.py:248-256
 
 
+def _charsiu_to_bcp47(tag: str) -> str:
+    lang, sub = _parse_tag(tag)
+    return lang if sub is None else f"{lang}-{sub}"
+
+
 class CharsiuPhonemizer(ByT5Phonemizer):
     """Mirror of `phoonnx.phonemizers.mul.CharsiuPhonemizer` (mul.py:239-286): the same engine, Charsiu's language tags,
-    and - these models cannot handle whitespace - one G2P call per word."""
+    and - these models cannot handle whitespace - one G2P call per word.
+
+    reference_prefix: which tag goes in front of each word.  In the reference `_encode_text` is a staticmethod that
+    always calls `ByT5Phonemizer.get_lang` (mul.py:159), so a Charsiu model is fed "<en-US>: word" although
+    `CharsiuPhonemizer.get_lang` would say "eng-us", the tag those checkpoints were trained with.  True (default)
+    reproduces the reference's input ids exactly; False writes the Charsiu tag."""
+
+    def __init__(self, model: str, tokenizer_config: Optional[str] = None, device_id: int = 0, device_loop: bool = True,
+                 reference_prefix: bool = True):
+        super().__init__(model, tokenizer_config, device_id, device_loop)
+        self.reference_prefix = reference_prefix
 
     @staticmethod
     def get_lang(target_lang: str) -> str:
-        if target_lang in CHARSIU_LANGS:
-            return target_lang
-        base = target_lang.split("-")[0].lower()
-        for l in CHARSIU_LANGS:
-            if l.split("-")[0] == base:
-                return l
-        raise ValueError(f"unsupported language {target_lang}")
+        """mul.py:269-284: the closest Charsiu tag ('en-US' -> 'eng-us', 'pt-BR' -> 'por-bz', 'de' -> 'ger')."""
+        return match_lang(target_lang, CHARSIU_LANGS)
+
+    def _prefix_lang(self, lang: str) -> str:
+        if self.reference_prefix:
+            try:
+                return ByT5Phonemizer.get_lang(lang)          # mul.py:159, as the reference does
+            except ValueError:
+                return ByT5Phonemizer.get_lang(_charsiu_to_bcp47(self.get_lang(lang)))
+        return self.get_lang(lang)
 
     def phonemize_string(self, text: str, lang: str) -> str:
         return " ".join(self._infer(w, lang) for w in text.split())
@@ -234,6 +327,6 @@ class CharsiuPhonemizer(ByT5Phonemizer):
         flat = [w for ws in words for w in ws]
         if not flat:
             return ["" for _ in chunks]
-        gen = self.session.generate_batch([encode_text(w, self.get_lang(lang))[0] for w in flat], max_length)
+        gen = self.session.generate_batch([encode_text(w, self._prefix_lang(lang))[0] for w in flat], max_length)
         it = iter(decode_phones(ids, self.tokens) for ids in gen)
         return [" ".join(next(it) for _ in ws) for ws in words]

@@ -29,6 +29,54 @@ class RangeError(SessionError):
     call, so user code only sees this when the fallback is switched off or impossible (borrowed weight arena)."""
 
 
+class _PinnedPool:
+    """Page-locked host blocks handed out as NumPy arrays (the DMA engine writes a result straight into the array the
+    caller receives: no staging copy, no second copy into a fresh array).  A block goes back to the pool when the last
+    array viewing it has been garbage-collected; at most `keep_bytes` of idle blocks are retained."""
+
+    def __init__(self, keep_bytes=2 << 30):
+        import threading
+        self._free = {}
+        self._idle = 0
+        self._keep = keep_bytes
+        self._mu = threading.Lock()
+
+    @staticmethod
+    def _cap(nbytes):
+        return max(1 << 16, (int(nbytes) + (1 << 20) - 1) >> 20 << 20) if nbytes > (1 << 16) else 1 << 16
+
+    def _give(self, ptr, cap):
+        with self._mu:
+            if self._idle + cap <= self._keep:
+                self._free.setdefault(cap, []).append(ptr)
+                self._idle += cap
+                return
+        _ffi.load().vits_host_free(ptr)
+
+    def array(self, shape, dtype=np.float32):
+        import weakref
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        cap = self._cap(n)
+        ptr = None
+        with self._mu:
+            # an idle block of this size class, or the smallest one up to twice as large
+            for c in sorted(k for k, v in self._free.items() if v and cap <= k <= 2 * cap):
+                ptr, cap = self._free[c].pop(), c
+                self._idle -= c
+                break
+        if ptr is None:
+            ptr = _ffi.load().vits_host_alloc(cap)
+            if not ptr:
+                raise SessionError(f"cannot allocate {cap} bytes of pinned host memory")
+        buf = (C.c_char * max(n, 1)).from_address(ptr)
+        fin = weakref.finalize(buf, self._give, ptr, cap)
+        fin.atexit = False  # (at interpreter exit the driver reclaims it)
+        return np.frombuffer(buf, dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+_POOL = _PinnedPool()
+
+
 @dataclass
 class NodeArg:
     name: str
@@ -72,6 +120,7 @@ class MiSession:
         self._open_args = dict(arena_device_ptr=arena_device_ptr, arena_bytes=arena_bytes, host_only=self.host_only,
                                layout_only=layout_only)
         self._seed = 0
+        self.range_fallbacks = 0  # times this session reopened itself with bf16x6 after a RangeError (stats())
         self._open(gen_precision)
 
     def _open(self, gen_precision):
@@ -101,9 +150,11 @@ class MiSession:
         import logging
         if not self.range_fallback or self.hparam("gen_nprod") != 2:
             raise exc
-        logging.getLogger(__name__).warning("%s: %s - reopening with gen_precision='bf16x6'", self.path, exc)
+        logging.getLogger(__name__).warning("%s: %s - reopening with gen_precision='bf16x6' (1.8x slower; "
+                                            "stats()['range_fallbacks'] counts these)", self.path, exc)
         self.close()
         self._open("bf16x6")
+        self.range_fallbacks += 1
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -192,28 +243,36 @@ class MiSession:
                 raise SessionError(f"noise_z must be [B,inter,F], got {noise_z.shape}")
             noise.noise_z = noise_z.ctypes.data
             noise.noise_z_stride = noise_z.shape[2]
-        out = _ffi.VitsOutput()
-        rc = self._lib.vits_run(self._h, _ffi.ptr(ids), _ffi.ptr(lens), B, T, _ffi.ptr(scales), _ffi.ptr(sid),
-                                C.byref(noise), C.byref(out))
-        if rc == _ffi.VITS_E_RANGE:
-            try:
-                self._raise("vits_run", rc)
-            except RangeError as exc:
-                self._fall_back_to_bf16x6(exc)
-            return self.synthesize_batch(ids, lens, scales, sid, noise_dp, noise_z, taps)
-        if rc != 0:
-            self._raise("vits_run", rc)
         try:
-            dims = tuple(out.dims[i] for i in range(4))
-            n = int(np.prod(dims))
-            audio = np.ctypeslib.as_array(out.data, shape=(n,)).reshape(dims).copy()
-            ylen = np.ctypeslib.as_array(out.y_lengths, shape=(B,)).copy()
-        finally:
-            self._lib.vits_free_output(self._h, C.byref(out))
+            self._begin(ids, lens, scales, sid, noise)
+            ylen = self.last_y_lengths()
+            S = int(ylen.max()) * self.hparam("hop")
+            audio = _POOL.array((B, 1, 1, S))
+            self._fetch(audio, 0, B)
+        except RangeError as exc:
+            self._fall_back_to_bf16x6(exc)
+            return self.synthesize_batch(ids, lens, scales, sid, noise_dp, noise_z, taps)
         res = {"output": audio, "y_lengths": ylen}
         for t in taps:
             res[t] = self.tap(t)
         return res
+
+    def _begin(self, ids, lens, scales, sid, noise):
+        """vits_run_async: validated host arrays in, the whole path enqueued; frame counts are known on return."""
+        B, T = ids.shape
+        rc = self._lib.vits_run_async(self._h, _ffi.ptr(ids), _ffi.ptr(lens), B, T, _ffi.ptr(scales), _ffi.ptr(sid),
+                                      C.byref(noise))
+        if rc != 0:
+            self._raise("vits_run", rc)
+
+    def _fetch(self, out, row0, rows):
+        """vits_fetch_output: this handle's [rows, S] waveform -> rows [row0, row0 + rows) of `out` [B,1,1,S_out]
+        (pinned or pageable host memory), zero-filled past S.  Waits for the run."""
+        S_out = out.shape[3]
+        dst = out.ctypes.data + row0 * S_out * 4
+        rc = self._lib.vits_fetch_output(self._h, C.c_void_p(dst), S_out, rows * S_out)
+        if rc != 0:
+            self._raise("vits_run", rc)
 
     def vocoder(self, z, sid=None):
         z = np.ascontiguousarray(z, np.float32)
@@ -243,38 +302,57 @@ class MiSession:
         engine hands chunks over: the consumer works on chunk i while chunk i + 1 renders."""
         import queue
         import threading
-        q = queue.Queue()
+        q = queue.Queue(maxsize=2)  # the engine renders at most two chunks ahead of the consumer
+        stop = threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return
+                except queue.Full:
+                    pass
 
         @_ffi.CHUNK_FN
         def on_chunk(user, samples, B, first, n, total):
-            q.put((int(first), np.ctypeslib.as_array(samples, shape=(B * n,)).reshape(B, n).copy(), int(total)))
-            return 0
+            if stop.is_set():
+                return 1  # the consumer is gone: end the run (vits_chunk_fn's "stop" return)
+            put((int(first), np.ctypeslib.as_array(samples, shape=(B * n,)).reshape(B, n).copy(), int(total)))
+            return 1 if stop.is_set() else 0
 
         def work():
             try:
                 rc = start(on_chunk)
-                q.put(None if rc == 0 else (rc, self._err()))
+                put(None if rc == 0 or stop.is_set() else (rc, self._err()))
             except BaseException as e:  # noqa: BLE001 - re-raised on the consumer's thread
-                q.put(e)
+                put(e)
 
         t = threading.Thread(target=work, daemon=True)
         t.start()
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            if len(item) == 2:
-                cls = RangeError if item[0] == _ffi.VITS_E_RANGE else SessionError
-                raise cls(f"chunked run failed [{item[0]}]: {item[1]}")
-            yield item
-        t.join()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                if len(item) == 2:
+                    cls = RangeError if item[0] == _ffi.VITS_E_RANGE else SessionError
+                    raise cls(f"chunked run failed [{item[0]}]: {item[1]}")
+                yield item
+        finally:
+            # generator closed early (break / GeneratorExit) or failed: tell the engine to stop after the chunk in
+            # flight, so that the handle's mutex is released and the next call does not queue behind a dead render
+            stop.set()
+            t.join()
 
     def synthesize_stream(self, ids, lens, scales, sid=None, chunk_frames: int = 64, noise_dp=None, noise_z=None):
         """The whole path with the waveform delivered in chunks of `chunk_frames` frames (hop samples each): yields
         (first_sample, float32 [B, n], total_samples).  Concatenated, the chunks are bit-identical to
-        synthesize_batch(...)["output"][:, 0, 0, :]; frame counts afterwards from last_y_lengths()."""
+        synthesize_batch(...)["output"][:, 0, 0, :]; frame counts afterwards from last_y_lengths().  Chunks are handed out
+        as they finish, so a range violation of the f16x3 arithmetic cannot be repaired by a silent re-run: it raises
+        RangeError at the end (no bf16x6 fallback here; reopen with gen_precision="bf16x6").  Closing the generator
+        early stops the engine after the chunk in flight."""
         ids = np.ascontiguousarray(ids, np.int64)
         lens = np.ascontiguousarray(lens, np.int64)
         scales = np.ascontiguousarray(scales, np.float32)
@@ -333,7 +411,20 @@ class MiSession:
     def stats(self):
         s = _ffi.VitsStats()
         self._lib.vits_get_stats(self._h, C.byref(s))
-        return {k: getattr(s, k) for k, _ in _ffi.VitsStats._fields_}
+        d = {k: getattr(s, k) for k, _ in _ffi.VitsStats._fields_}
+        d["range_fallbacks"] = self.range_fallbacks
+        return d
+
+    def launch_records(self):
+        """Per conv-engine launch of the last run made with set_timing(True) (call stats() first: it reads the events):
+        [{"kernel", "ms", "flops", "bytes", "stage"}] in launch order."""
+        n = self._lib.vits_launch_records(self._h, None, 0)
+        if n <= 0:
+            return []
+        buf = (_ffi.VitsLaunchRecord * n)()
+        self._lib.vits_launch_records(self._h, buf, n)
+        return [{"kernel": r.kernel.decode(), "ms": r.ms, "flops": r.flops, "bytes": r.bytes, "stage": r.stage,
+                 "cin": r.cin, "cout": r.cout, "k": r.k, "dil": r.dil, "t": r.t} for r in buf]
 
     def arena_bytes(self):
         return self._lib.vits_arena_bytes(self._h)
@@ -427,12 +518,51 @@ class PipelinedSession:
         if parts < 1:
             raise SessionError("parts must be >= 1")
         self.parts = [first]
-        # the borrowed arena is packed for `first`'s arithmetic: the other handles must lay it out the same way
+        # `first` owns the weight arena the other handles borrow: it must never close and reopen itself under them
+        # (MiSession's own fallback would free the arena while the borrowers run on it).  The fallback happens HERE,
+        # for all handles together (_fall_back).
+        self.range_fallback = first.range_fallback
+        first.range_fallback = False
+        self.range_fallbacks = 0
+        self._n_parts = parts
+        self._borrow()
+        self.set_seed(first._seed)
+
+    def _borrow(self):
+        """(Re)create the handles that share parts[0]'s arena (laid out for ITS arithmetic)."""
+        first = self.parts[0]
         precision = {2: "f16x3", 6: "bf16x6", 3: "bf16x3", 1: "bf16"}[int(first.hparam("gen_nprod"))]
-        for _ in range(parts - 1):
+        for _ in range(self._n_parts - 1):
             self.parts.append(MiSession(first.path, device_id=first.device_id, arena_device_ptr=first.arena_device(),
                                         arena_bytes=first.arena_bytes(), gen_precision=precision))
-        self.set_seed(first._seed)
+
+    def _fall_back(self, exc):
+        """After a RangeError on any part: every borrower is synchronised and closed, THEN the owner reopens with the
+        six-product arithmetic (bf16 planes: fp32 range), then the borrowers are recreated on the new arena."""
+        import logging
+        first = self.parts[0]
+        if not self.range_fallback or first.hparam("gen_nprod") != 2:
+            raise exc
+        logging.getLogger(__name__).warning("%s: %s - reopening all %d handles with gen_precision='bf16x6'", first.path, exc,
+                                            len(self.parts))
+        for s in reversed(self.parts[1:]):
+            try:
+                s.sync()
+            except SessionError:
+                pass
+            s.close()
+        del self.parts[1:]
+        try:
+            first.sync()
+        except SessionError:
+            pass
+        seed = first._seed
+        first.close()
+        first._open("bf16x6")
+        first.range_fallbacks += 1
+        self.range_fallbacks += 1
+        self._borrow()
+        self.set_seed(seed)
 
     @classmethod
     def open(cls, path, device_id: int = 0, parts: int = 2):
@@ -508,29 +638,67 @@ class PipelinedSession:
         return np.concatenate([self.parts[i].last_y_lengths() for i in range(n)])
 
     def synthesize_batch(self, ids, lens, scales, sid=None):
-        """Host arrays in, host arrays out, like MiSession.synthesize_batch; the sub-batches run concurrently from
-        worker threads (the C calls release the GIL).  Output rows are zero-padded to the longest utterance."""
-        from concurrent.futures import ThreadPoolExecutor
+        """Host arrays in, host arrays out, like MiSession.synthesize_batch.  One worker thread per sub-batch (the C
+        calls release the GIL): each enqueues its part (vits_run_async), learns its frame counts, meets the others at a
+        barrier where the ONE [B,1,1,S_max] result array (pinned host memory) is sized, then waits for its own render
+        and lets the DMA engine write its rows straight into that array (vits_fetch_output) - the copy-out of a part
+        that finishes early runs under the render of the others, and no byte is copied twice on the host."""
+        import threading
         ids = np.ascontiguousarray(ids)
         lens = np.ascontiguousarray(lens)
+        scales = np.ascontiguousarray(scales)
+        if ids.dtype != np.int64 or lens.dtype != np.int64 or ids.ndim != 2 or lens.shape != (ids.shape[0],):
+            raise SessionError("Unexpected input: 'input' int64 [B,T], 'input_lengths' int64 [B]")
+        if scales.dtype != np.float32 or scales.shape != (3,):
+            raise SessionError("Unexpected input: 'scales' must be float32 of shape [3]")
         B = ids.shape[0]
+        if sid is not None:
+            sid = np.ascontiguousarray(sid)
+            if sid.dtype != np.int64 or sid.shape != (B,):
+                raise SessionError("Unexpected input: 'sid' must be int64 of shape [batch_size]")
         bnd = self.bounds(B)
         n = len(bnd) - 1
+        hop = self.hparam("hop")
+        ylen = np.zeros(B, np.int64)
+        box = {}
+
+        def size_output():  # (barrier action: runs once, in one thread, when every part knows its frame counts)
+            box["out"] = _POOL.array((B, 1, 1, int(ylen.max()) * hop))
+
+        bar = threading.Barrier(n, action=size_output)
+        errors = []
 
         def work(i):
             b0, b1 = bnd[i], bnd[i + 1]
-            return self.parts[i].synthesize_batch(ids[b0:b1], lens[b0:b1], scales, None if sid is None else sid[b0:b1])
+            p = self.parts[i]
+            try:
+                noise = _ffi.VitsNoise()
+                noise.seed = p._seed
+                p._begin(ids[b0:b1], lens[b0:b1], scales, None if sid is None else sid[b0:b1], noise)
+                ylen[b0:b1] = p.last_y_lengths()
+                bar.wait()
+                p._fetch(box["out"], b0, b1 - b0)
+            except threading.BrokenBarrierError:
+                pass  # another part failed; its error is reported
+            except Exception as e:  # noqa: BLE001 - re-raised on the caller's thread
+                errors.append(e)
+                bar.abort()
 
         if n == 1:
-            res = [work(0)]
+            work(0)
         else:
-            with ThreadPoolExecutor(n) as ex:
-                res = list(ex.map(work, range(n)))
-        S = max(r["output"].shape[3] for r in res)
-        out = np.zeros((B, 1, 1, S), np.float32)
-        for i, r in enumerate(res):
-            out[bnd[i]:bnd[i + 1], :, :, :r["output"].shape[3]] = r["output"]
-        return {"output": out, "y_lengths": np.concatenate([r["y_lengths"] for r in res])}
+            th = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if errors:
+            rng = [e for e in errors if isinstance(e, RangeError)]
+            if rng:
+                self._fall_back(rng[0])
+                return self.synthesize_batch(ids, lens, scales, sid)
+            raise errors[0]
+        return {"output": box["out"], "y_lengths": ylen}
 
     def sync(self):
         for s in self.parts:

@@ -4,6 +4,7 @@ walker.  No compute calls (no GPU here)."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -262,3 +263,62 @@ print("survived", ok, err)
     assert r.returncode == 0 and "survived" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-500:])
     n_ok, n_err = (int(v) for v in r.stdout.split()[-2:])
     assert n_ok + n_err == len(cases) and n_err > len(cases) // 2, (n_ok, n_err)
+
+
+# ---- structure-keyed weight resolution (SURVEY §7 "Weight lookup", App. B)
+def _renamed(tmp_path, preset, strip):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from rename_nodes import rename
+    out = tmp_path / f"{preset}{'_strip' if strip else ''}.onnx"
+    out.write_bytes(rename(open(os.path.join(GOLDEN, preset + ".onnx"), "rb").read(), strip=strip))
+    return str(out)
+
+
+@pytest.mark.parametrize("preset", ALL_PRESETS)
+@pytest.mark.parametrize("strip", [False, True])
+def test_graphs_without_module_path_node_names_resolve_by_structure(tmp_path, preset, strip):
+    """Older (Piper-era) exports name their nodes `Conv_123`, or not at all.  With every node of a fixture renamed to
+    `<op>_<n>` (or its name removed) the loader walks Conv / ConvTranspose / Gather / LayerNorm / Pad nodes in graph order
+    and recognises each module by position and (Cout, Cin, kernel, group): the packed weight arena and every derived
+    hyper-parameter must equal those of the file with module-path names - which itself is only accepted because the
+    structural walk and its names agree (model.cpp resolve: cross-check)."""
+    a = MiSession(os.path.join(GOLDEN, preset + ".onnx"), host_only=True)
+    b = MiSession(_renamed(tmp_path, preset, strip), host_only=True)
+    assert a.arena_bytes() == b.arena_bytes()
+    assert np.array_equal(a.arena_host(), b.arena_host())
+    for k in ("hidden", "inter", "filter", "n_heads", "n_layers", "n_vocab", "n_speakers", "gin", "use_sdp", "hop", "n_ups",
+              "resblock", "gen_sx", "gen_rf_frames", "dec_macs_per_frame", "flow_macs_per_frame"):
+        assert a.hparam(k) == b.hparam(k), k
+    a.close()
+    b.close()
+
+
+def test_structure_that_is_not_a_vits_export_is_rejected_with_a_reason(tmp_path):
+    """No names AND an unexpected node order (here: the graph truncated after the encoder's convs) -> an error that says
+    what did not fit, not a crash and not a half-resolved model."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rename_nodes as rn
+    src = open(os.path.join(GOLDEN, "tiny_rb1.onnx"), "rb").read()
+    # drop the last Conv node (dec.conv_post) from the renamed graph
+    out = bytearray()
+    for fn, wt, f0, a, b in rn._fields(src, 0, len(src)):
+        if fn != 7 or wt != 2:
+            out += src[f0:b]
+            continue
+        nodes = [(g0, ga, gb) for gfn, gwt, g0, ga, gb in rn._fields(src, a, b) if gfn == 1 and gwt == 2]
+        last_conv = max(i for i, (g0, ga, gb) in enumerate(nodes)
+                        if any(nfn == 4 and bytes(src[na:nb]) == b"Conv" for nfn, nwt, n0, na, nb in rn._fields(src, ga, gb)))
+        g = bytearray()
+        k = 0
+        for gfn, gwt, g0, ga, gb in rn._fields(src, a, b):
+            if gfn == 1 and gwt == 2:
+                if k != last_conv:
+                    g += src[g0:gb]
+                k += 1
+            else:
+                g += src[g0:gb]
+        out += rn._ld(7, bytes(g))
+    bad = tmp_path / "cut.onnx"
+    bad.write_bytes(rn.rename(bytes(out)))
+    with pytest.raises(SessionError, match="structure|conv_post|not found"):
+        MiSession(str(bad), host_only=True)

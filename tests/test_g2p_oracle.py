@@ -80,3 +80,24 @@ def test_g2p_abi_surface_and_model_description(G):
     s.close()
     with pytest.raises(SessionError):   # a VITS graph is not a T5 graph
         MiG2PSession(os.path.join(GOLDEN, "tiny_dp.onnx"), host_only=True)
+
+
+def test_language_tags_resolve_like_the_reference_match_lang():
+    """TTSVoice hands BCP-47 tags (config.lang_code) to the phonemizer; the reference resolves them to the
+    phonemizer's own list through langcodes (phonemizers/base.py:86-122).  Expected values = langcodes' answers for the
+    reference's lists (mul.py:31-33, 248-256)."""
+    from phoonnx_amd.g2p import ByT5Phonemizer as B, CharsiuPhonemizer as Ch
+    byt5 = {"en-US": "en-US", "en": "en-US", "en-GB": "en-GB", "en-AU": "en-GB", "pt": "pt-BR", "pt-PT": "pt-PT",
+            "de": "de-DE", "de-AT": "de-DE", "zh": "zh-CN", "no": "nb-NO", "yue": "yue-CN", "fr-CA": "fr-FR"}
+    charsiu = {"en-US": "eng-us", "en": "eng-us", "en-GB": "eng-uk", "pt-BR": "por-bz", "pt": "por-bz", "pt-PT": "por-po",
+               "de": "ger", "de-DE": "ger", "nl-NL": "dut", "cs": "cze", "el-GR": "gre", "zh-TW": "zho-t", "zh-CN": "zho-s",
+               "es-MX": "spa-me", "es-AR": "spa-latin", "es": "spa", "fr-CA": "fra-qu", "fr": "fra", "eng-us": "eng-us",
+               "fa-IR": "fas", "is": "ice", "cy": "wel-nw", "vi": "vie-n"}
+    for t, want in byt5.items():
+        assert B.get_lang(t) == want, (t, B.get_lang(t), want)
+    for t, want in charsiu.items():
+        assert Ch.get_lang(t) == want, (t, Ch.get_lang(t), want)
+    for bad in ("xx-YY", "tlh", ""):
+        for cls in (B, Ch):
+            with pytest.raises(ValueError):
+                cls.get_lang(bad)
