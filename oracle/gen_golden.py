@@ -243,7 +243,7 @@ def frames_for(torch, m, kw, ids, lens, scales, sid, noise_dp):
     return int(r["y_lengths"].max())
 
 
-def make_cases(torch, m, kw, rng, big=False):
+def make_cases(torch, m, kw, rng, big=False, long_case=False):
     nv = kw["n_vocab"]
     C = kw["inter_channels"]
     cases = {}
@@ -298,6 +298,13 @@ def make_cases(torch, m, kw, rng, big=False):
     add("b1_t3_noise", ids, lens, [0.5, 1.7, 0.6], sids(1), True)
     ids, lens = padded([1, 5])
     add("b2_t1_t5_noise", ids, lens, [0.667, 1.0, 0.8], sids(2), True)
+    if long_case:
+        # (added last: the earlier cases draw the same random numbers as before)  >= 200 frames: with upsample rates
+        # (4, 4, 2) the 128-channel plane-format stage is then >= 800 columns = several 256-column tiles wide, the 64- and
+        # 32-channel raw-format stages 3200 / 6400 columns: tile seams, halos and the fused pair / chain kernels' overlap
+        # columns are all inside the tensor, against the reference itself
+        ids, lens = padded([128, 93])
+        add("b2_long_noise", ids, lens, [0.667, 1.6, 0.8], sids(2), True)
     return cases
 
 
@@ -319,7 +326,7 @@ def main():
         export_onnx(torch, m, kw, path, name)
         print("   wrote", path, os.path.getsize(path), "bytes")
         rng = np.random.default_rng(4321)
-        cases = make_cases(torch, m, kw, rng, big=bool(a.big))
+        cases = make_cases(torch, m, kw, rng, big=bool(a.big), long_case=name.startswith("sx_"))
         flat = {}
         for cname, c in cases.items():
             for k, v in c.items():
