@@ -302,7 +302,8 @@ def main():
 
     # weights: rank 0 reads + packs, RCCL broadcast of the arena (checksum-verified), every rank opens on its GPU
     t_load = time.perf_counter()
-    sess, arena_keepalive = open_sharded(voice, local_rank, dist, force_broadcast=a.force_dist)
+    open_stats = {}
+    sess, arena_keepalive = open_sharded(voice, local_rank, dist, force_broadcast=a.force_dist, stats=open_stats)
     t_load = time.perf_counter() - t_load
     weights = {"mode": "local pack", "load_s": t_load}
     if arena_keepalive is not None:
@@ -317,30 +318,53 @@ def main():
             sys.exit(f"rank {rank}: broadcast weight arena differs from a local pack ({got:#x} vs {local_sum:#x})")
         weights = {"mode": "RCCL broadcast of the packed arena from rank 0", "bytes": int(arena_keepalive.numel()),
                    "checksum": f"{got & (2**64 - 1):#018x}", "verified_equal_to_local_pack_on_every_rank": True,
-                   "load_s": t_load}
+                   "load_s": t_load, "pack_s_rank0": open_stats.get("pack_s"), "broadcast_s": open_stats.get("bcast_s"),
+                   "layout_open_s": open_stats.get("open_s")}
     hop = sess.hparam("hop")
     gen_nprod = int(sess.hparam("gen_nprod"))
 
-    if a.total_batch:
-        if a.total_batch % world:
-            sys.exit(f"--total-batch {a.total_batch} does not divide over {world} GPUs")
-        B = a.total_batch // world
-    else:
-        B = a.batch
+    from phoonnx_amd.sharding import partition
     T = a.tokens
+    shard_info = None
 
-    def make_inputs(seed, Bn=B):
+    def global_batch(seed, n):
         g = torch.Generator(device="cpu").manual_seed(seed)
-        ids = torch.randint(0, 256, (Bn, T), generator=g, dtype=torch.int64)
-        lens = torch.full((Bn,), T, dtype=torch.int64)
+        ids = torch.randint(0, 256, (n, T), generator=g, dtype=torch.int64)
+        lens = torch.full((n,), T, dtype=torch.int64)
         if a.mixed_lengths:  # ragged lengths, zero-padded ids, padding mask in play
             g2 = torch.Generator(device="cpu").manual_seed(1235 + seed)
-            lens = torch.randint(max(1, T // 4), T + 1, (Bn,), generator=g2, dtype=torch.int64)
+            lens = torch.randint(max(1, T // 4), T + 1, (n,), generator=g2, dtype=torch.int64)
             lens[0] = T
             ids = ids * (torch.arange(T)[None, :] < lens[:, None])
         return ids, lens
 
-    def make_sid(seed, first, Bn=B):
+    if a.total_batch:
+        # strong scaling (BASELINE config 5): ONE request of total_batch utterances, the same on every rank (same seed),
+        # dealt to the ranks by sharding.partition (length-sorted snake deal: equal work per rank, little padding inside
+        # a shard); this rank renders its shard, padded to the shard's own longest utterance
+        ids_all, lens_all = global_batch(1234, a.total_batch)
+        shards, _inv = partition(lens_all.numpy(), world)
+        mine = torch.from_numpy(np.ascontiguousarray(shards[rank]))
+        lens_mine = lens_all[mine]
+        Tm = int(lens_mine.max()) if len(mine) else 1
+        ids_mine = ids_all[mine][:, :Tm].contiguous()
+        B, T = int(len(mine)), Tm
+        if B == 0:
+            sys.exit(f"rank {rank}: --total-batch {a.total_batch} leaves this rank without an utterance")
+        shard_info = {"path": "sharding.partition (length-sorted snake deal)", "total_batch": a.total_batch,
+                      "rank0_rows": B, "rank0_padded_tokens": T, "rank0_tokens": int(lens_mine.sum()),
+                      "tokens_per_rank": [int(lens_all[torch.from_numpy(np.ascontiguousarray(sh))].sum()) for sh in shards],
+                      "rows_per_rank": [int(len(sh)) for sh in shards]}
+    else:
+        B = a.batch
+
+    def make_inputs(seed, Bn=None):
+        if a.total_batch:
+            return ids_mine, lens_mine
+        return global_batch(seed, B if Bn is None else Bn)
+
+    def make_sid(seed, first, Bn=None):
+        Bn = B if Bn is None else Bn
         if int(first.hparam("n_speakers")) <= 1:
             return None
         g = torch.Generator(device="cpu").manual_seed(77 + seed)
@@ -487,12 +511,19 @@ def main():
     # ---------------------------------------------------------------- the headline measurement
     dt, samples, pipe, inputs = measure(sess, a.preset, a.steps, a.warmup, a.parts, a.lockstep, 1234 + rank)
     tot = torch.tensor([dt, float(samples)], dtype=torch.float64, device="cuda")
+    per_rank = None
     if dist:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt_max, samples_all = float(mx[0]), float(sm[1])
+        # every rank's own numbers, for rank 0's line (outside the timed region; a few hundred bytes over the host path)
+        mine_rec = {"rank": rank, "device": local_rank, "rows": B, "padded_tokens": T, "ms_per_step": dt / a.steps * 1e3,
+                    "samples_per_step": samples / a.steps, "load_s": t_load, "broadcast_s": open_stats.get("bcast_s"),
+                    "layout_open_s": open_stats.get("open_s"), "arena_checksum": weights.get("checksum")}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_rec)
     else:
         dt_max, samples_all = dt, float(samples)
 
@@ -601,14 +632,16 @@ def main():
             "rtf": dt_max / (samples_all / world / 22050.0) if samples_all else None,
             "config": {"workload": f"VITS full pipeline (encoder+duration+flow+HiFi-GAN), preset={a.preset}"
                                    f"{'' if a.speakers <= 1 else f', {a.speakers} speakers (sid per utterance)'}, "
-                                   f"batch={B}/GPU x {T} phoneme ids"
+                                   f"batch={f'{a.total_batch} over {world} GPU(s)' if a.total_batch else f'{B}/GPU'} x {a.tokens} phoneme ids"
                                    f"{' (lengths uniform in [T/4, T], zero-padded)' if a.mixed_lengths else ''}, "
                                    f"scales=[0.667,{scales[1]:.2f},0.8], device Philox noise, seeded synthetic weights",
-                       "preset": a.preset, "batch_per_gpu": B, "global_batch": B * world, "tokens": T, "hop": hop,
+                       "preset": a.preset, "batch_per_gpu": B, "global_batch": a.total_batch or B * world, "tokens": a.tokens, "hop": hop,
                        "pipeline_parts": n_parts,
                        "pipeline_host": "lockstep" if (a.lockstep or n_parts == 1) else "one free-running host thread per part",
                        "samples_per_step": samples_all / a.steps,
-                       "frames_per_id": samples_all / a.steps / hop / (float(lens_h.sum()) * world),
+                       "frames_per_id": samples_all / a.steps / hop /
+                                        (float(lens_all.sum()) if a.total_batch else float(lens_h.sum()) * world),
+                       "sharding": shard_info, "ranks": per_rank,
                        "weights": weights, "commit": git_head()},
             "roofline": roofline, "cpu_baseline": cpu, "step_ms": step_pct, "host_io": host_io, "one_handle": one_handle,
             "exact_arithmetic": exact, "also": also, "stages": stage, "f16_range": f16_range,

@@ -282,7 +282,8 @@ int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, in
  * 2 bf16 (the declared reduced-precision vocoder modes), 3 f16x3 (two fp16 planes, three products: the generator's
  * default, VITSMI_GEN_PRECISION).  vits_test_conv_transpose1d_sx: a negative stride selects f16x3.
  * vits_bench_conv1d_sx dbg bits: 1 no DMA after the first step, 2 no epilogue, 8 residual epilogue, 16 in-kernel
- * cycle breakdown (128-row tiles only), 32 / 64 bf16x3 / bf16, 128 f16x3.  ms_out holds 8 floats: [0] ms per launch, [1] tile config, [3..7] with
+ * cycle breakdown (128-row tiles only), 32 / 64 bf16x3 / bf16, 128 f16x3, 256 the v_mfma_f32_32x32x16 main loop even where
+ * the 16x16x32 one applies.  ms_out holds 8 floats: [0] ms per launch, [1] tile config, [3..7] with
  * bit 16: s_memtime ticks per pipeline step spent in {LDS wait, DMA wait, barrier, DMA issue, loads + MFMA}. */
 int vits_test_conv1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
                         int Cout, int K, int dil, int pad_l, int flags, float slope, float *out);

@@ -83,8 +83,11 @@ struct SxArgs {
     int Cin, Cout, Cr;    // Cout = virtual rows (Cr * ups)
     int K, dil, padL, nchunks, ups;
     int LW;               // x tile width in cells                       ( " )
+    int RS;               // cells between the rows of an x stage (>= LW) ( " )
+    int s16;              // the weights are packed for the 16x16x32 main loop (ConvDesc::s16; f16x3, plane input)
     unsigned magic;       // ceil(2^32 / LW)                             ( " )
     unsigned x_bytes;     // bytes of one x stage                        ( " )
+    unsigned lds_bytes;   // dynamic LDS of the launch (two x stages)    ( " )
     int NT, MT, B;        // tiles along time / along rows, utterances   ( " )
     int flags;            // EPI_RES | EPI_ACC | EPI_DIV | DBG_*
     float div, oslope, oslope2;
@@ -197,9 +200,15 @@ constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL 
 // NP = plane products per fp32 product: 6 = exact (default); 3 (w0x0 + w0x1 + w1x0, ~2^-16 relative) and
 // 1 (w0x0, plain bf16) are the declared reduced-precision vocoder modes (VITSMI_GEN_PRECISION, BASELINE config 4):
 // they read only the planes they use.
-template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false, int NP = 6>
+// SH = MFMA shape of the main loop: 32 = v_mfma_f32_32x32x16 (one step = one tap of a 16-channel chunk), 16 =
+// v_mfma_f32_16x16x32 (one step = one tap of a 32-channel chunk; f16x3 arithmetic, plane input only).  Same products,
+// same accumulation order per output element up to the chunk grouping; the chip holds a higher clock on the 16x16x32
+// shape under its power cap (tools/mfma_shape_probe.hip: 1.13-1.15x the FLOP/s at equal cycles per FLOP).
+template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false, int NP = 6, int SH = 32>
 __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxArgs a) {
     constexpr int BM = MW * WM * 32, BN = NW * WN * 32, MB = BM / 32;
+    constexpr bool S16 = SH == 16;
+    static_assert(SH == 32 || (SH == 16 && NP == 2 && !RAWIN && !PROF), "16x16x32: f16x3 arithmetic on plane inputs");
     static_assert(NP == 6 || NP == 3 || NP == 1 || NP == 2, "plane products");
     constexpr bool F16 = NP == 2;                          // two fp16 planes, three products
     constexpr int NPROD = F16 ? 3 : NP;
@@ -223,15 +232,19 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     if (tile_nb >= a.NT * a.B) return;                 // padding workgroups of the last round (uniform exit)
     const int b = tile_nb / a.NT, t0 = (tile_nb - b * a.NT) * BN;
     const int T = a.T, LW = a.LW, K = a.K, CG = a.Cin >> 3;
+    const int RS = S16 ? a.RS : a.LW;          // cells between the rows of an x stage (16x16x32: rounded up, see launch_conv_sx)
+    constexpr int XG = S16 ? 4 : 2;            // channel groups of 8 per chunk: rows of a stage = planes x XG
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_sx;
     const uint32_t XB = a.x_bytes;
     const u32x4 *xb = a.xp + (int64_t)b * a.x_bstride;
     const int64_t pstride = (int64_t)CG * T;  // cells per plane
     // packed weights of one step (one tap of one 16-channel chunk): the tile height they were packed for
-    const int STEPBYTES = (MB << a.wshift) * NPW * 1024;
+    // (16x16x32: a step is k = 32, i.e. twice the bytes per 32-row block: [16-row sub-block][plane] x 1 KiB)
+    constexpr int BLKBYTES = (S16 ? 2 : 1) * NPW * 1024;
+    const int STEPBYTES = (MB << a.wshift) * BLKBYTES;
     // this wave's A rows of step 0 (uniform address: lives in SGPRs)
     const char *wbase = reinterpret_cast<const char *>(a.wp) + (int64_t)(mt >> a.wshift) * a.nchunks * K * STEPBYTES +
-                        (mt & ((1 << a.wshift) - 1)) * (MB * NPW * 1024) + wm * (MW * NPW * 1024);
+                        (mt & ((1 << a.wshift) - 1)) * (MB * BLKBYTES) + wm * (MW * BLKBYTES);
     const int nit = a.x_bytes >> 12;           // DMA rounds of 256 cells per x tile (the stage is padded to 4 KiB)
     float pk = 0.f;                            // f16 mode: largest |value| this thread split into fp16 planes
 
@@ -240,9 +253,10 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     // scalar.  So the per-lane byte offsets and the validity masks are computed once per tile (the general path spends
     // ~25 VALU operations, eight of them quarter-rate multiplies, in front of every DMA, next to a saturated matrix
     // pipe); lanes whose cell is padding are masked off and their LDS cells are zeroed once, below.
-    constexpr int MAXIT = 6;
-    const bool fastx = F16 && !RAWIN && nit <= MAXIT && !(a.flags & DBG_NO_DMA) &&
-                       (2 * pstride + 2 * (int64_t)T) * 16 < (1ll << 32);  // 32-bit byte offsets inside an utterance
+    constexpr int MAXIT = S16 ? 10 : 6;
+    // (16x16x32: launch_conv_sx admits only what the fast path covers)
+    const bool fastx = S16 || (F16 && !RAWIN && nit <= MAXIT && !(a.flags & DBG_NO_DMA) &&
+                               (2 * pstride + 2 * (int64_t)T) * 16 < (1ll << 32));  // 32-bit byte offsets inside an utterance
     uint32_t xoffs[MAXIT];
     bool xok[MAXIT];
     int nx_issued = 0;  // DMAs this wave really issues per x tile (a round whose 64 cells are all padding is skipped)
@@ -251,25 +265,25 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
 #pragma unroll
             for (int it = 0; it < MAXIT; it++) {
                 const int i = it * 256 + wave * 64 + lane;
-                const int row = (int)__umulhi((unsigned)i, a.magic);
-                const int col = i - row * LW;
+                const int row = (int)__umulhi((unsigned)i, a.magic);  // (magic = ceil(2^32 / RS))
+                const int col = i - row * RS;
                 const int t = t0 - a.padL + col;
-                xok[it] = it < nit && row < 2 * NPL && t >= 0 && t < T;
-                xoffs[it] = (uint32_t)(((int64_t)(row >> 1) * pstride + (int64_t)(row & 1) * T + t) * 16);
+                xok[it] = it < nit && row < XG * NPL && col < LW && t >= 0 && t < T;
+                xoffs[it] = (uint32_t)(((int64_t)(row / XG) * pstride + (int64_t)(row % XG) * T + t) * 16);
                 nx_issued += __builtin_amdgcn_ballot_w64(xok[it]) != 0 ? 1 : 0;
             }
             if (t0 - a.padL < 0 || t0 - a.padL + LW > T) {  // (uniform) only edge tiles have padding columns
                 const u32x4 z = {0u, 0u, 0u, 0u};
-                for (uint32_t o = (uint32_t)tid * 16u; o < 2u * XB; o += 4096u) ds_write128(lds0 + o, z);
+                for (uint32_t o = (uint32_t)tid * 16u; o < a.lds_bytes; o += 4096u) ds_write128(lds0 + o, z);
                 __syncthreads();  // the zeros are in place before the first DMA can land on a neighbouring cell
             }
         }
     }
     // x tile of one chunk -> LDS: rows (plane, channel-group half) x LW cells; every wave issues `nit` DMAs
-    auto issue_x = [&](int chunk, uint32_t xoff) {
+    auto issue_x = [&](int chunk, uint32_t xoff) __attribute__((always_inline)) {
         if constexpr (F16 && !RAWIN) {
             if (fastx) {
-                const char *cb = reinterpret_cast<const char *>(xb) + (int64_t)(2 * chunk) * T * 16;
+                const char *cb = reinterpret_cast<const char *>(xb) + (int64_t)(XG * chunk) * T * 16;
 #pragma unroll
                 for (int it = 0; it < MAXIT; it++) {
                     if (it < nit) {  // (uniform) every wave issues the same count, masked-off rounds included
@@ -280,6 +294,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
                 return;
             }
         }
+        if constexpr (S16) return;
         for (int it = 0; it < nit; it++) {
             const int base = it * 256 + wave * 64;
             const int i = base + lane;
@@ -385,13 +400,183 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     };
 
     f32x16 acc[MW][NW];
+    if constexpr (!S16) {
+#pragma unroll
+        for (int m = 0; m < MW; m++)
+#pragma unroll
+            for (int n = 0; n < NW; n++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
+    }
+    constexpr bool PRE = RAWIN && EPI >= 0 && (EPI & SX_RES_EARLY) != 0;
+    constexpr int NRND_ = MW * (NW / 2);
+    f32x4 pre[PRE ? NRND_ : 1][2][4];
+
+    if constexpr (S16) {
+    // ================================================================== main loop, v_mfma_f32_16x16x32_f16
+    // A wave's 64 x 128 (MW x NW blocks of 32 x 32) tile as 2 MW x 2 NW blocks of 16 x 16.  One step = one tap of a
+    // 32-channel chunk (k = 32): lane (c = lane & 15, g = lane >> 4) holds weights W[row c of its 16-row block][channels 8 g ..
+    // 8 g + 7] and activations x[channels 8 g ..][column c of its 16-column block].  96 MFMAs of 16 cycles per step and wave
+    // (MW = 2), issued as 2 half-steps (one 32-row block each) x NW quarters (one 32-column block each) x 12.
+    //   A (weights): L2 -> registers, two half-step buffers of 16 registers, requested one half-step (48 MFMAs = 768
+    //                cycles, the lead the 32x32x16 loop has) ahead; (three buffers, a whole step ahead, do not fit: 128
+    //                accumulator + 48 + 32 operand registers and the compiler spilled 80)
+    //   B (x tile):  LDS -> registers per quarter (4 ds_read_b128 = 16 registers), two quarter buffers, a quarter ahead;
+    //                both row halves of a step read the same quarters (the x tile is re-read from LDS once per 32 rows).
+    // The 16-row sub-blocks' rows were permuted at pack time (model.cpp pack_conv_sx, s16) so that after ONE
+    // v_permlane16_swap per accumulator pair every lane holds exactly what the 32 x 32 accumulator layout of the epilogue
+    // expects: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of column lane & 31 in register r.
+    constexpr int HPS = MW;                 // half-steps per step
+    constexpr int NQ = NW;                  // quarters per half-step
+    struct AHalf {
+        u32x4 f[2][2];                      // [16-row sub-block][plane]
+    };
+    f32x4 c16[MW][2][NW][2];                // [32-row block][sub-block a][32-column block][sub-block b]
+#pragma unroll
+    for (int m = 0; m < MW; m++)
+#pragma unroll
+        for (int aa = 0; aa < 2; aa++)
+#pragma unroll
+            for (int n = 0; n < NW; n++)
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++) c16[m][aa][n][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int S = a.nchunks * K, H = S * HPS;
+    const uint32_t voff0 = (uint32_t)lane * 16u;
+    auto load_ah = [&](AHalf &f, int hs) __attribute__((always_inline)) {  // half-step hs = (step, 32-row block m)
+        const int st = hs / HPS, m = hs - st * HPS;
+        // (readfirstlane on both halves: the address must be provably wave-uniform for the scalar-base load)
+        const uint64_t pa = reinterpret_cast<uint64_t>(wbase) + (uint64_t)((int64_t)st * STEPBYTES + m * BLKBYTES);
+        const char *sb = reinterpret_cast<const char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) |
+                                                        (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)pa));
+        f.f[0][0] = global_read128<0>(voff0, sb);
+        f.f[0][1] = global_read128<1024>(voff0, sb);
+        f.f[1][0] = global_read128<2048>(voff0, sb);
+        f.f[1][1] = global_read128<3072>(voff0, sb);
+    };
+    const uint32_t b_lane = lds0 + (uint32_t)((lane >> 4) * RS + wn * (NW * 32) + (lane & 15)) * 16u;
+    const uint32_t plane_b = (uint32_t)(4 * RS) * 16u;
+    u32x4 bq[2][2][2];                      // [buffer][sub-block b][plane]
+    auto load_bq = [&](auto BUF, auto Q, uint32_t bb0) __attribute__((always_inline)) {
+        constexpr int bf = decltype(BUF)::value, q = decltype(Q)::value;
+        bq[bf][0][0] = ds_read128<q * 512>(bb0);
+        bq[bf][0][1] = ds_read128<q * 512>(bb0 + plane_b);
+        bq[bf][1][0] = ds_read128<q * 512 + 256>(bb0);
+        bq[bf][1][1] = ds_read128<q * 512 + 256>(bb0 + plane_b);
+    };
+    auto mma_q = [&](const AHalf &f, auto M, auto BUF, auto Q) __attribute__((always_inline)) {
+        constexpr int m = decltype(M)::value, bf = decltype(BUF)::value, q = decltype(Q)::value;
+        // products in the order of the 32x32x16 loop: g1*h0, g0'*h1', g0*h0; consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int aa = 0; aa < 2; aa++)
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++) {
+                    const f16x8 ga = c == 0 ? __builtin_bit_cast(f16x8, f.f[aa][1])
+                                            : (c == 1 ? __builtin_bit_cast(f16x8, f.f[aa][0]) * (_Float16)0.00048828125f
+                                                      : __builtin_bit_cast(f16x8, f.f[aa][0]));
+                    c16[m][aa][q][bb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga, __builtin_bit_cast(f16x8, bq[bf][bb][c == 1 ? 1 : 0]),
+                                                                               c16[m][aa][q][bb], 0, 0, 0);
+                }
+    };
+    auto wait_vm16 = [&](int n) __attribute__((always_inline)) {  // at most n of this wave's vector-memory operations still in flight
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;  // (nx_issued <= MAXIT = 10)
+        }
+    };
+    const std::integral_constant<int, 0> I0{};
+    const std::integral_constant<int, 1> I1{};
+    // prologue: the first x tile, then the first two half-steps' weights (vector-memory operations retire in order:
+    // whoever waits for A(0) has waited for x(0))
+    issue_x(0, 0);
+    AHalf ab[2];
+    load_ah(ab[0], 0);
+    int chunk = 0, tap = 0;
+    int x_age = 99;  // half-steps since this wave issued the DMAs of an x tile (they sit behind that half-step's A request)
+    auto half_step = [&](AHalf &fc, AHalf &fload, auto M, int hs) __attribute__((always_inline)) {
+        constexpr int m = decltype(M)::value;
+        // in flight behind A(hs) (requested by the previous half-step): the x DMAs if that half-step issued them
+        if (x_age == 0) wait_vm16(nx_issued);  // (once per chunk)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool chunk_start = m == 0 && tap == 0;
+        const bool more_x = chunk + 1 < a.nchunks;
+        if (chunk_start) {
+            __builtin_amdgcn_s_barrier();  // x(chunk) is complete in LDS; everyone is done with the other stage
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (hs + 1 < H) load_ah(fload, hs + 1);
+        x_age++;
+        if (chunk_start && more_x) {
+            issue_x(chunk + 1, ((chunk + 1) & 1) * XB);
+            x_age = 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t bb0 = b_lane + (uint32_t)(chunk & 1) * XB + (uint32_t)(tap * a.dil) * 16u;
+        // does the half-step after this one read the same stage?  (it does unless it opens the next chunk: then its first
+        // quarter can only be requested behind that chunk's barrier)
+        const bool last_of_chunk = m == HPS - 1 && tap == K - 1;
+        const uint32_t bnext = m == HPS - 1 ? bb0 + (uint32_t)a.dil * 16u : bb0;  // next half-step: next tap, or the other rows
+        if (chunk_start) load_bq(I0, I0, bb0);  // (every other half-step found its first quarter requested by its predecessor)
+        static_for<NQ>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            constexpr int bf = q & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (q + 1 < NQ) {
+                load_bq(std::integral_constant<int, (q + 1) & 1>{}, std::integral_constant<int, q + 1>{}, bb0);
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // quarter q has landed, q + 1 is in flight
+            } else {
+                if (!last_of_chunk && hs + 1 < H) {
+                    load_bq(std::integral_constant<int, NQ & 1>{}, I0, bnext);
+                    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                } else
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_q(fc, M, std::integral_constant<int, bf>{}, Q);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        if (m == HPS - 1 && ++tap == K) {
+            tap = 0;
+            chunk++;
+        }
+    };
+    static_assert(NQ % 2 == 0, "the first quarter of a half-step always lands in quarter buffer 0");
+    // unrolled by two half-steps: the A buffers alternate, the row half has period MW - both static inside the body
+    constexpr int U = 2;
+    int hs = 0;
+    for (; hs + U <= H; hs += U)
+        static_for<U>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            half_step(ab[i % 2], ab[(i + 1) % 2], std::integral_constant<int, i % HPS>{}, hs + i);
+        });
+    // (no exit from the middle of the unrolled body: see the 32x32x16 loop; MW = 2: H is even and there is no tail)
+    if (hs < H) half_step(ab[0], ab[1], std::integral_constant<int, 0>{}, hs);
+    // 16 x 16 -> 32 x 32 accumulator layout: lanes with lane & 16 hold the right rows of the WRONG 16-column half for one
+    // accumulator of each (sub-block b = 0, b = 1) pair; one half-row swap per register pair puts every value in place
 #pragma unroll
     for (int m = 0; m < MW; m++)
 #pragma unroll
         for (int n = 0; n < NW; n++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
-
+            for (int aa = 0; aa < 2; aa++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(c16[m][aa][n][0][rr]),
+                                                                     __float_as_uint(c16[m][aa][n][1][rr]), false, false);
+                    acc[m][n][8 * aa + rr] = __uint_as_float(sw[0]);
+                    acc[m][n][8 * aa + 4 + rr] = __uint_as_float(sw[1]);
+                }
+    } else {
     // Register sets: A fragments ping-pong between two sets (global loads are slow: a whole step ahead); the B
     // fragments have ONE set whose two halves (block columns [0, NH) and [NH, NW)) are refilled as soon as the
     // MFMAs that read them have been issued, i.e. half a step ahead.
@@ -488,9 +673,6 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
         load_a(f0, 0);
     }
     // SX_RES_EARLY: all residual operands of this wave, requested now (same addressing as the epilogue's issue_adds)
-    constexpr bool PRE = RAWIN && EPI >= 0 && (EPI & SX_RES_EARLY) != 0;
-    constexpr int NRND_ = MW * (NW / 2);
-    f32x4 pre[PRE ? NRND_ : 1][2][4];
     if constexpr (PRE) {
         const int Tout_ = T * a.ups;  // (ups == 1 here: a residual conv)
         const float *resb_ = a.res + (int64_t)b * a.raw_bstride;
@@ -593,6 +775,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
             atomicAdd(a.prof + 7, __builtin_amdgcn_s_memrealtime() - prt0);     // ... per 100 MHz ticks = clock
         }
     }
+    }  // (32x32x16 main loop)
 
     // ---- epilogue.  C/D layout of a 32x32 block: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5):
     // register quad q holds 4 consecutive channels 8q + 4*hi .. +3 of one time step = half a cell.
@@ -793,20 +976,24 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
         }
     });
     if constexpr (F16) {
-        if (a.peak) sx_publish_peak(a.peak, (int)blockIdx.x, pk);  // (uniform branch)
+        if (a.peak) {  // (uniform branch)
+            if constexpr (S16) sx_publish_peak_at(a.peak, (int)blockIdx.x, pk, reinterpret_cast<float *>(lds_sx));
+            else sx_publish_peak(a.peak, (int)blockIdx.x, pk);
+        }
     }
 }
 
 // sx tile configs: index -> (BM, BN, waves WM x WN, blocks per wave MW x NW):
 //   0: 128x256 (2x2 waves of 64x128)   1: 64x256 (2x2 waves of 32x128)   2: 32x256 (1x4 waves of 32x64)
 // All are 256 columns wide: the weights of a step then serve 4 (2) block columns per register load.
-inline int sx_tile_m(int cfg) { return cfg == 0 ? 128 : (cfg == 1 ? 64 : 32); }
-inline int sx_tile_n(int) { return 256; }
+// 3: 64x128 (2x2 waves of 32x64), run-time choice for short grids of 64-row layers (same packed weights as 1)
+inline int sx_tile_m(int cfg) { return cfg == 0 ? 128 : ((cfg == 1 || cfg == 3) ? 64 : 32); }
+inline int sx_tile_n(int cfg) { return cfg == 3 ? 128 : 256; }
 
-template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false, int NP = 6>
+template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false, int NP = 6, int SH = 32>
 inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
-    auto kern = conv_sx_kernel<MW, NW, WM, WN, EPI, PROF, RAWIN, NP>;
+    auto kern = conv_sx_kernel<MW, NW, WM, WN, EPI, PROF, RAWIN, NP, SH>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kSxMaxDynLds);
@@ -814,8 +1001,8 @@ inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipSt
         attr_set = true;
     }
     if (g_launch_name_on)
-        snprintf(g_launch_name, sizeof g_launch_name, "conv_sx_kernel<%d, %d, %d, %d, %d, %s, %s, %d>", MW, NW, WM, WN, EPI,
-                 PROF ? "true" : "false", RAWIN ? "true" : "false", NP);
+        snprintf(g_launch_name, sizeof g_launch_name, "conv_sx_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %d>", MW, NW, WM, WN, EPI,
+                 PROF ? "true" : "false", RAWIN ? "true" : "false", NP, SH);
     kern<<<grid, 256, lds, stream>>>(a);
     return hipGetLastError();
 }
@@ -830,24 +1017,26 @@ constexpr int kSxEpiRaw = SX_HAS_RAW;                                           
 constexpr int kSxEpiStageOut = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_PL | SX_PL_ACT;  // x = (xs + block) / n as planes
 constexpr int kSxEpiGate = SX_GATE | SX_HAS_RAW;                                     // WN in-layer + gate -> planar acts
 
-template <int MW, int NW, int WM, int WN, int NP = 6>
+template <int MW, int NW, int WM, int WN, int NP = 6, int SH = 32>
 inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
-    if (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, NP>(a, grid, lds, stream);
+    if constexpr (SH == 32) {
+        if (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, NP>(a, grid, lds, stream);
+    }
     switch (epi) {
-        case kSxEpiPlanes: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiPlanes, false, false, NP>(a, grid, lds, stream);
-        case kSxEpiUp: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiUp, false, false, NP>(a, grid, lds, stream);
-        case kSxEpiInner: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiInner, false, false, NP>(a, grid, lds, stream);
-        case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst, false, false, NP>(a, grid, lds, stream);
-        case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum, false, false, NP>(a, grid, lds, stream);
-        case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw, false, false, NP>(a, grid, lds, stream);  // flow WN convs
-        case kSxEpiStageOut: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiStageOut, false, false, NP>(a, grid, lds, stream);
+        case kSxEpiPlanes: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiPlanes, false, false, NP, SH>(a, grid, lds, stream);
+        case kSxEpiUp: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiUp, false, false, NP, SH>(a, grid, lds, stream);
+        case kSxEpiInner: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiInner, false, false, NP, SH>(a, grid, lds, stream);
+        case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst, false, false, NP, SH>(a, grid, lds, stream);
+        case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum, false, false, NP, SH>(a, grid, lds, stream);
+        case kSxEpiRaw: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiRaw, false, false, NP, SH>(a, grid, lds, stream);  // flow WN convs
+        case kSxEpiStageOut: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiStageOut, false, false, NP, SH>(a, grid, lds, stream);
         default: break;
     }
     if constexpr (WM == 2 && MW == 1) {  // 64-row tiles: the gated WN in-layer (per-utterance bias or not)
-        if ((epi & ~SX_HAS_BIASB) == kSxEpiGate) return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiGate, false, false, NP>(a, grid, lds, stream);
+        if ((epi & ~SX_HAS_BIASB) == kSxEpiGate) return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiGate, false, false, NP, SH>(a, grid, lds, stream);
     }
     if (epi & SX_GATE) return hipErrorInvalidValue;  // (no generic form of the gate epilogue)
-    return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, NP>(a, grid, lds, stream);
+    return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, NP, SH>(a, grid, lds, stream);
 }
 
 // raw-input kernels (tensors of <= 64 channels): outputs are raw only
@@ -897,12 +1086,30 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
         while ((BM << a.wshift) < PM) a.wshift++;
     }
     a.LW = BN + (a.K - 1) * a.dil;
-    a.magic = (unsigned)((0x100000000ull + a.LW - 1) / a.LW);
+    a.RS = a.LW;
     // an x stage is padded to whole DMA rounds (256 cells = 4 KiB), so that every wave issues the same count
     // (rows = 2 channel-group halves x the planes the mode reads: 3 bf16 planes, 2 in the fp16 / bf16x3 modes, 1 in bf16)
-    const int xrows = nprod == 6 ? 6 : (nprod == 1 ? 2 : 4);
-    a.x_bytes = (unsigned)(((size_t)xrows * a.LW * 16 + 4095) / 4096 * 4096);
-    const size_t lds = 2 * (size_t)a.x_bytes;  // two x stages; the weights never touch LDS
+    int xrows = nprod == 6 ? 6 : (nprod == 1 ? 2 : 4);
+    const bool s16 = a.s16 != 0;
+    if (cfg == 3 && !s16) return hipErrorInvalidValue;  // (64 x 128 tiles exist for the 16x16x32 loop only)
+    if (s16) {
+        // weights packed for the 16x16x32 main loop: chunks of 32 channels (4 channel groups x 2 planes = 8 rows per stage)
+        if (nprod != 2 || rawin || a.prof || (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) || a.Cin % 32) return hipErrorInvalidValue;
+        xrows = 8;
+        // rows 16 cells apart modulo 16: the ds_read_b128 of a B fragment (lanes 16 apart = the next channel group) is then
+        // free of bank conflicts; where that does not fit two workgroups per CU the rows stay packed (mild conflicts)
+        // (two workgroups per CU = 80 KiB each, all of it dynamic: the 16x16x32 kernels have no static LDS)
+        const int rs16 = (a.LW + 15) / 16 * 16;
+        if (((size_t)8 * rs16 * 16 + 4095) / 4096 * 4096 + (size_t)8 * rs16 * 16 <= (size_t)80 * 1024) a.RS = rs16;
+    }
+    a.magic = (unsigned)((0x100000000ull + a.RS - 1) / a.RS);
+    a.x_bytes = (unsigned)(((size_t)xrows * a.RS * 16 + 4095) / 4096 * 4096);
+    if (s16 && (a.x_bytes > 10 * 4096 || ((long long)(2 * (a.Cin / 8) + 2) * a.T) * 16 >= (1ll << 32))) return hipErrorInvalidValue;
+    // two x stages; the weights never touch LDS.  (16x16x32: the second stage ends with its last row - the DMA rounds are
+    // whole 4 KiB but lanes past the last row are masked off - which keeps the 50-cell halo of a k = 11, dilation 5 conv
+    // inside 80 KiB)
+    const size_t lds = s16 ? (size_t)a.x_bytes + (size_t)xrows * a.RS * 16 : 2 * (size_t)a.x_bytes;
+    a.lds_bytes = (unsigned)lds;
     // (pack_conv_sx pads narrower kernels to 3 taps; model.cpp sx_supported() mirrors the size limits)
     if (lds > (size_t)kSxMaxDynLds || a.x_bytes > 12 * 4096 || a.K < 3) return hipErrorInvalidValue;
     if (rawin && (cfg == 0 || 2 * a.LW > 768 || !a.xr || (long long)a.T * 64 + 64 >= (1ll << 32))) return hipErrorInvalidValue;
@@ -924,8 +1131,8 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     if (a.out_pl) epi |= SX_HAS_PL | (a.oslope2 != 1.f ? SX_PL_ACT : 0);
     if (a.bias_b) epi |= SX_HAS_BIASB;
     if (a.flags & SX_GATE) {
-        if (rawin || cfg != 1 || (nprod != 2 && nprod != 6) || a.ups != 1 || !a.out_raw || a.out_pl || (a.Cr & 63) ||
-            lds < (size_t)2 * 4 * 4 * 1024)
+        if (rawin || (cfg != 1 && cfg != 3) || (nprod != 2 && nprod != 6) || a.ups != 1 || !a.out_raw || a.out_pl || (a.Cr & 63) ||
+            lds < (size_t)2 * (sx_tile_n(cfg) / 64) * 4 * 1024)
             return hipErrorInvalidValue;
         epi |= SX_GATE;
     }
@@ -943,6 +1150,14 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
         if (rawin)
             return cfg == 1 ? launch_conv_sx_rawin<1, 4, 2, 2, 2>(a, epi, grid, lds, stream)
                             : launch_conv_sx_rawin<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
+        if (s16) {
+            switch (cfg) {
+                case 0: return launch_conv_sx_epi<2, 4, 2, 2, 2, 16>(a, epi, grid, lds, stream);
+                case 1: return launch_conv_sx_epi<1, 4, 2, 2, 2, 16>(a, epi, grid, lds, stream);
+                case 3: return launch_conv_sx_epi<1, 2, 2, 2, 2, 16>(a, epi, grid, lds, stream);
+                default: return launch_conv_sx_epi<1, 2, 1, 4, 2, 16>(a, epi, grid, lds, stream);
+            }
+        }
         if (a.prof && cfg == 0) return launch_conv_sx_k<2, 4, 2, 2, -1, true, false, 2>(a, grid, lds, stream);
         switch (cfg) {
 #if SX_CFG0_WIDE

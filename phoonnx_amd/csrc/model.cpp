@@ -556,6 +556,7 @@ void pick_tiling(int Cin, int Cout, int K, int dil, int padL, int hint, int &cfg
 thread_local int t_hint = 0;  // size class of the layers being packed (set by Model::build)
 thread_local bool t_sx_f16 = false;  // pack_conv_sx: two scaled fp16 planes instead of three bf16 planes
 thread_local int t_sx_min_cfg = 0;   // pack_conv_sx: smallest tile index allowed (1 = no 128-row tiles)
+thread_local bool t_sx_shape32 = false;  // pack_conv_sx: never the 16x16x32 packing (bench / ablation hooks)
 
 // W is addressed through a functor so that permutations / transposed-conv rewrites need no copies:
 // w(co, ci, tap) for co < Cout, ci < Cin, tap < K.
@@ -703,7 +704,18 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     d.mblocks = Cout / 32;
     const int MB = sx_tile_m(d.cfg) / 32;
     const int npw = t_sx_f16 ? 2 : 3;                              // planes per 32-row block
-    const int64_t kib = int64_t(d.mblocks) * d.nchunks * K * npw;  // 1 KiB = one (block, plane) fragment set
+    // 16x16x32 main loop (f16x3, plane input, 32-channel chunks): when the x stage of a 32-channel chunk (8 rows of
+    // 256 + halo cells) fits ten DMA rounds, i.e. two workgroups per CU
+    static const bool shape32_only = [] {
+        const char *e = std::getenv("VITSMI_SX_SHAPE");  // "32": A/B timing against the v_mfma_f32_32x32x16 loop
+        return e && std::string(e) == "32";
+    }();
+    d.s16 = t_sx_f16 && !d.rawin && !shape32_only && !t_sx_shape32 && Cin % 32 == 0 && (size_t)8 * (256 + (K - 1) * dil) * 16 <= (size_t)10 * 4096;
+    if (d.s16) {
+        d.CK = 32;
+        d.nchunks = Cin / 32;
+    }
+    const int64_t kib = int64_t(d.mblocks) * (Cin / 16) * K * npw;  // 1 KiB = one (block, plane) fragment set of k = 16
     d.w_off = P.alloc(kib * 256);
     if (bias_virtual) d.b_off = P.put(bias_virtual, Cout);
     d.macs_per_t = double(Cin) * Cout * Kreal;
@@ -726,6 +738,25 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     }
     if (P.dry) return d;
     uint16_t *dst = reinterpret_cast<uint16_t *>(P.arena.data() + d.w_off);
+    if (d.s16) {
+        // [m-tile][chunk of 32 ci][tap][32-row block][sub-block a][plane][lane][8]: 4 KiB per (32-row block, step)
+        for (int mb = 0; mb < d.mblocks; mb++)
+            for (int chunk = 0; chunk < d.nchunks; chunk++)
+                for (int tap = 0; tap < K; tap++) {
+                    const int64_t base = ((((int64_t)(mb / MB) * d.nchunks + chunk) * K + tap) * MB + (mb % MB)) * 4;
+                    for (int sub = 0; sub < 2; sub++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            const int i16 = lane & 15, q = i16 >> 2;
+                            const int row32 = (i16 & 3) + 8 * (2 * sub + (q & 1)) + 4 * (q >> 1);
+                            for (int i = 0; i < 8; i++) {
+                                uint16_t p[3];
+                                split2h_host(wz(mb * 32 + row32, chunk * 32 + 8 * (lane >> 4) + i, tap) * wmul, p);
+                                for (int pl = 0; pl < 2; pl++) dst[(base + sub * 2 + pl) * 512 + lane * 8 + i] = p[pl];
+                            }
+                        }
+                }
+        return d;
+    }
     for (int mb = 0; mb < d.mblocks; mb++)
         for (int chunk = 0; chunk < d.nchunks; chunk++)
             for (int tap = 0; tap < K; tap++) {
@@ -918,6 +949,7 @@ void split2h_host(float v, uint16_t p[3]) {
 }
 
 void set_sx_f16(bool on) { t_sx_f16 = on; }
+void set_sx_shape32(bool on) { t_sx_shape32 = on; }
 
 // Arithmetic of the split-operand convs for the opens that follow on this thread: an explicit choice
 // (vits_open_opts) wins over VITSMI_GEN_PRECISION in the environment; nullptr / "" = the default (f16x3).

@@ -36,6 +36,11 @@ struct ConvDesc {
     // wscale = 2^-k is applied to the accumulators (conv_sx_engine.hip.hpp, f16 mode)
     bool f16 = false;
     float wscale = 1.f;
+    // sx + f16 only: packed for the v_mfma_f32_16x16x32_f16 main loop: chunks of 32 input channels, per 32-row block and
+    // step [16-row sub-block a][plane][lane][8] with lane = (row c = lane & 15, channel group g = lane >> 4) and the rows
+    // of a sub-block permuted (row 4 q + r of sub-block a = row r + 8 (2 a + (q & 1)) + 4 (q >> 1) of the 32-row block)
+    // so that the accumulators reach the epilogue's 32 x 32 layout with one half-row swap (conv_sx_engine.hip.hpp)
+    bool s16 = false;
     // sx only (flow WN in-layers): rows packed as [32 tanh | 32 sigmoid] per 64-row tile, the conv's epilogue applies
     // the gate and writes planar acts (conv_sx_engine.hip.hpp SX_GATE)
     bool gate = false;
@@ -162,6 +167,7 @@ uint16_t f16_rne(float f);
 float f16_to_f32(uint16_t h);
 void split2h_host(float v, uint16_t p[3]);
 void set_sx_f16(bool on);  // pack_conv_sx format for the calls that follow on this thread (test hooks)
+void set_sx_shape32(bool on);  // ... never the 16x16x32 (s16) packing (bench hooks: ablation flags, A/B of the MFMA shapes)
 // generator arithmetic for the Model::build calls that follow on this thread: explicit name, or nullptr = take
 // VITSMI_GEN_PRECISION from the environment (default f16x3)
 void set_gen_precision_override(const char *name);

@@ -54,6 +54,21 @@ __device__ __forceinline__ void split2h_pair_pk(float x, float y, unsigned &w0, 
 constexpr int kSxPeakStride = 32;  // uints between slots: one 128-byte line each
 // (sx_publish_peak's four floats are static LDS: the dynamic part a kernel may ask for is the CU's 160 KiB less that)
 constexpr int kSxMaxDynLds = 160 * 1024 - 256;
+// ... with the four floats in caller-provided LDS (a kernel whose dynamic LDS must be the whole of the CU's share: no
+// static allocation beside it).  `s_pk` may alias memory other waves are still reading: a barrier comes first.
+__device__ __forceinline__ void sx_publish_peak_at(unsigned *slots, int slot_idx, float pk, float *s_pk) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pk = __builtin_fmaxf(pk, __shfl_xor(pk, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_pk[threadIdx.x >> 6] = pk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pk = __builtin_fmaxf(__builtin_fmaxf(s_pk[0], s_pk[1]), __builtin_fmaxf(s_pk[2], s_pk[3]));
+        unsigned *slot = slots + (slot_idx & (kSxPeakSlots - 1)) * kSxPeakStride;
+        const unsigned bits = __float_as_uint(pk);
+        if (bits > __builtin_nontemporal_load(slot)) atomicMax(slot, bits);
+    }
+}
 __device__ __forceinline__ void sx_publish_peak(unsigned *slots, int slot_idx, float pk) {
     __shared__ float s_pk[4];
 #pragma unroll

@@ -376,6 +376,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.oslope = oslope;
     a.oslope2 = oslope2;
     a.wscale = d.wscale;
+    a.s16 = d.s16 ? 1 : 0;
     vits_handle *h = c.h;
     a.peak = range_slots(h, d.f16 && (d.rawin || out_pl));  // launches that split values into fp16 planes
     const bool ev = conv_event_begin(c);
@@ -387,6 +388,16 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
         const long long wgs0 = (long long)((T + 255) / 256) * c.B * (d.Cout / 128);
         if (wgs0 <= 128) run_cfg = 2;
         else if (wgs0 <= 256) run_cfg = 1;
+    }
+    // 64-row layers on the 16x16x32 loop: 128-column tiles where the grid of 256-column ones fills the chip badly (the
+    // flow's WN in-layers at batch 32: 768 workgroups on 512 slots = two rounds of which the second is half empty, and 24 %
+    // padding columns; as 1344 half-size workgroups on 768 slots: the time of one full round).  Same arithmetic.
+    static const bool no_narrow = std::getenv("VITSMI_SX_NO_NARROW_TILES") != nullptr;  // A/B timing only
+    if (d.cfg == 1 && d.s16 && !d.rawin && !no_narrow) {
+        const long long mt = d.Cout / 64;
+        const long long w256 = ((long long)((T + 255) / 256) * c.B + 7) / 8 * 8 * mt, w128 = ((long long)((T + 127) / 128) * c.B + 7) / 8 * 8 * mt;
+        const long long r256 = (w256 + 511) / 512 * 2, r128 = (w128 + 767) / 768;  // rounds, in units of a 128-column tile
+        if (r128 < r256) run_cfg = 3;
     }
     c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, d.f16 ? 2 : (h->cur_stage == 3 ? h->gen_nprod : 6), d.cfg));
     if (ev) conv_event_end(c, true, 2.0 * d.macs_per_t * (double)T * c.B, 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T), d, T);
@@ -1945,6 +1956,7 @@ static void fill_sx_args(SxArgs &a, const ConvDesc &d, const float *dA, int T) {
     a.Cin = d.Cin; a.Cout = d.Cout; a.Cr = Cr; a.K = d.K; a.dil = d.dil; a.padL = d.padL;
     a.nchunks = d.nchunks; a.ups = d.ups;
     a.div = 1.f;
+    a.s16 = d.s16 ? 1 : 0;
 }
 
 static int run_test_conv_sx(const ConvDesc &d, const std::vector<float> &arena, const float *x, int B, int T, int flags,
@@ -2099,8 +2111,10 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
     ConvDesc d;
     std::vector<float> arena;
     set_sx_f16((dbg & 128) != 0);
+    set_sx_shape32((dbg & (1 | 2 | 16 | 256)) != 0);  // ablation / cycle-breakdown builds exist for the 32x32x16 loop only
     std::string e = pack_test_conv(w.data(), nullptr, Cin, Cout, K, dil, dil * (K - 1) / 2, 3, &d, &arena);
     set_sx_f16(false);
+    set_sx_shape32(false);
     if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
     float *dA = nullptr, *dx = nullptr, *draw = nullptr, *dres = nullptr;
     uint16_t *dxp = nullptr, *dop = nullptr;

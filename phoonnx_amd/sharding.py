@@ -53,13 +53,17 @@ def arena_checksum(arena) -> int:
     return int(arena[:n].view(torch.int32).sum(dtype=torch.int64).item())
 
 
-def broadcast_arena(path: str, dist, device: Optional[int], src: int = 0, verify: bool = True):
+def broadcast_arena(path: str, dist, device: Optional[int], src: int = 0, verify: bool = True, stats: Optional[dict] = None):
     """Rank `src` parses + packs the .onnx on the host; the packed arena is broadcast to every
     rank (device tensors over RCCL when `device` is not None, host tensors otherwise, e.g. gloo).
     verify: every rank compares the checksum of what it received with rank `src`'s (a second, 8-byte broadcast) and
-    raises on a mismatch.  Returns a uint8 torch tensor holding the arena on this rank."""
+    raises on a mismatch.  Returns a uint8 torch tensor holding the arena on this rank.
+    stats (optional dict) receives pack_s (rank `src`: parse + pack), bcast_s (header + arena broadcast, synchronised),
+    bytes, checksum."""
+    import time
     import torch
     rank = dist.get_rank()
+    t0 = time.perf_counter()
     dev = torch.device("cuda", device) if device is not None else torch.device("cpu")
     hdr = torch.zeros(2, dtype=torch.int64, device=dev)  # [bytes, checksum]
     host = None
@@ -70,29 +74,44 @@ def broadcast_arena(path: str, dist, device: Optional[int], src: int = 0, verify
         hdr[1] = arena_checksum(arena)
         arena = arena.to(dev)
         host.close()
+    t1 = time.perf_counter()
     dist.broadcast(hdr, src)
     nbytes, want = int(hdr[0].item()), int(hdr[1].item())
     if rank != src:
         arena = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     dist.broadcast(arena, src)  # ~64-119 MB once; 7 xGMI links x ~153 GB/s -> sub-millisecond class
-    if verify:
-        got = arena_checksum(arena)
-        if got != want:
-            raise RuntimeError(f"rank {rank}: weight arena checksum {got:#x} differs from rank {src}'s {want:#x}")
+    got = arena_checksum(arena) if verify else None  # (.item(): also waits for the broadcast on a device tensor)
+    if device is not None:
+        torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
+    if stats is not None:
+        stats.update(pack_s=t1 - t0, bcast_s=t2 - t1, bytes=nbytes, checksum=want, verified=bool(verify))
+    if verify and got != want:
+        raise RuntimeError(f"rank {rank}: weight arena checksum {got:#x} differs from rank {src}'s {want:#x}")
     return arena
 
 
-def open_sharded(path: str, device_id: int, dist=None, src: int = 0, force_broadcast: bool = False, verify: bool = True):
+def open_sharded(path: str, device_id: int, dist=None, src: int = 0, force_broadcast: bool = False, verify: bool = True,
+                 stats: Optional[dict] = None):
     """Open one engine handle per rank.  With a process group, weights arrive by broadcast and the handle adopts the
     device arena (vits_open_with_arena: the file is parsed for the model description and the arena LAYOUT only - no
     rank but `src` packs a weight); without one this is a plain open.  force_broadcast takes the broadcast path even at
     world size 1 (exercises the N > 1 code on a one-GPU box).
-    Returns (session, arena_tensor_or_None) - keep the tensor alive as long as the session."""
+    Returns (session, arena_tensor_or_None) - keep the tensor alive as long as the session.  stats: as
+    broadcast_arena, plus open_s (layout-only open on the adopted arena)."""
+    import time
     if dist is None or (dist.get_world_size() == 1 and not force_broadcast):
-        return MiSession(path, device_id=device_id), None
-    arena = broadcast_arena(path, dist, device_id, src, verify)
+        t0 = time.perf_counter()
+        sess = MiSession(path, device_id=device_id)
+        if stats is not None:
+            stats.update(open_s=time.perf_counter() - t0)
+        return sess, None
+    arena = broadcast_arena(path, dist, device_id, src, verify, stats)
     # (every rank resolves the arithmetic the same way rank `src` did when it packed: VITSMI_GEN_PRECISION / default)
+    t0 = time.perf_counter()
     sess = MiSession(path, device_id=device_id, arena_device_ptr=arena.data_ptr(), arena_bytes=arena.numel())
+    if stats is not None:
+        stats.update(open_s=time.perf_counter() - t0)
     return sess, arena
 
 
@@ -100,11 +119,18 @@ class ShardedSynthesizer:
     """Batched-utterance front: `synthesize(utterances)` runs this rank's shard and (optionally)
     gathers the waveforms of all ranks on the host in the original order."""
 
-    def __init__(self, path: str, device_id: int, dist=None, force_broadcast: bool = False):
+    def __init__(self, path: str, device_id: int, dist=None, force_broadcast: bool = False, session=None):
+        """session: an already opened engine session for this rank (anything with synthesize_batch(ids, lens, scales,
+        sid) -> {"output", "y_lengths"} and hparam("hop")); default: open_sharded(path, device_id, dist)."""
         self.dist = dist
         self.rank = dist.get_rank() if dist else 0
         self.world = dist.get_world_size() if dist else 1
-        self.session, self._arena = open_sharded(path, device_id, dist, force_broadcast=force_broadcast)
+        self.open_stats = {}
+        if session is not None:
+            self.session, self._arena = session, None
+        else:
+            self.session, self._arena = open_sharded(path, device_id, dist, force_broadcast=force_broadcast,
+                                                     stats=self.open_stats)
         self.hop = self.session.hparam("hop")
 
     def synthesize(self, utterances: Sequence[Sequence[int]], scales, sids: Optional[Sequence[int]] = None,

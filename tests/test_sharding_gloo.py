@@ -101,6 +101,84 @@ def test_arena_broadcast_two_ranks_gloo(voice, tmp_path):
     assert sorted(got[0][3][0] + got[0][3][1]) == [0, 1, 2, 3, 4] and got[0][3] == got[1][3]
 
 
+class _StubSession:
+    """Stands in for MiSession on a CPU box: a deterministic "waveform" per utterance that depends on its ids only
+    (so any rank renders the same thing for the same utterance), frame count = token count."""
+    HOP = 4
+
+    def hparam(self, key):
+        assert key == "hop"
+        return self.HOP
+
+    def synthesize_batch(self, ids, lens, scales, sid=None):
+        B, T = ids.shape
+        S = int(lens.max()) * self.HOP
+        out = np.zeros((B, 1, 1, S), np.float32)
+        for b in range(B):
+            n = int(lens[b]) * self.HOP
+            seed = int(ids[b, :lens[b]].sum()) + (0 if sid is None else 1000 * int(sid[b]))
+            out[b, 0, 0, :n] = np.sin(np.arange(n, dtype=np.float32) * 0.01 * (seed % 97 + 1)) * float(scales[1])
+        return {"output": out, "y_lengths": lens.astype(np.int64)}
+
+    def close(self):
+        pass
+
+
+def _request(seed=5, n=11):
+    rng = np.random.default_rng(seed)
+    utts = [rng.integers(1, 50, size=int(k)).tolist() for k in rng.integers(1, 40, size=n)]
+    sids = rng.integers(0, 4, size=n).tolist()
+    return utts, sids
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from phoonnx_amd.sharding import ShardedSynthesizer
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = ShardedSynthesizer("unused.onnx", 0, dist, session=_StubSession())
+        utts, sids = _request()
+        scales = np.array([0.667, 1.5, 0.8], np.float32)
+        mine = sh.synthesize(utts, scales, sids)                 # this rank's shard: [(original index, waveform)]
+        everything = sh.synthesize(utts, scales, sids, gather=True)
+        q.put((rank, [i for i, _ in mine], [w.tolist() for w in everything]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_synthesize_gathers_in_the_original_order_two_ranks_gloo():
+    """ShardedSynthesizer.synthesize(gather=True) end to end over a real process group (gloo, two
+    ranks, stub engine): snake partition -> per-rank padded batch -> all_gather_object -> restore order.  Every rank must
+    hold every utterance's waveform at its ORIGINAL index, equal to what one process renders."""
+    import torch.multiprocessing as mp
+    from phoonnx_amd.sharding import ShardedSynthesizer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    utts, sids = _request()
+    solo = ShardedSynthesizer("unused.onnx", 0, None, session=_StubSession())
+    want = [w for _, w in sorted(solo.synthesize(utts, np.array([0.667, 1.5, 0.8], np.float32), sids))]
+    assert sorted(got[0][1] + got[1][1]) == list(range(len(utts)))       # shards: disjoint, complete
+    assert abs(len(got[0][1]) - len(got[1][1])) <= 1
+    for rank, _, everything in got:
+        assert len(everything) == len(utts)
+        for i, w in enumerate(everything):
+            assert len(w) == len(utts[i]) * _StubSession.HOP, (rank, i)
+            np.testing.assert_array_equal(np.asarray(w, np.float32), want[i])
+
+
 def test_arena_checksum_detects_corruption():
     import torch
     from phoonnx_amd import MiSession

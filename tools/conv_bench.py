@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--prof", action="store_true", help="with --sx: per-step cycle breakdown of the 128x128 kernel")
     ap.add_argument("--sx", action="store_true", help="benchmark the split-operand engine instead (f16x3 arithmetic)")
     ap.add_argument("--bf16x6", action="store_true", help="with --sx: the six-product exact arithmetic")
+    ap.add_argument("--shapes", action="store_true",
+                    help="with --sx: A/B of the two MFMA shapes of the main loop (16x16x32 where it applies vs 32x32x16), "
+                         "interleaved rounds in one process")
     a = ap.parse_args()
     lib = _ffi.load()
     F, B = a.frames, a.batch
@@ -59,6 +62,23 @@ def main():
     if a.sx:  # split-exact bf16 engine: generator shapes only (Cin % 16 == 0, Cout % 32 == 0)
         from phoonnx_amd.session import bench_conv1d_sx
         mode = 0 if a.bf16x6 else 128
+        if a.shapes:
+            for name, Cin, Cout, T, K, dil, hint in shapes:
+                if hint == 2 or Cin % 32 or Cout % 32 or Cin <= 64:
+                    continue
+                res = {0: [], 256: []}
+                for rnd in range(3):
+                    for sh in (0, 256):
+                        for dbg in (0, 8):
+                            ms, cfg = bench_conv1d_sx(B, Cin, Cout, T, K, dil, dbg | mode | sh, a.iters)
+                            res[sh].append((dbg, ms))
+                def best(sh, dbg):
+                    return min(ms for d, ms in res[sh] if d == dbg)
+                fl = 2.0 * B * Cin * Cout * K * T / 1e9
+                print(f"{name:24s} T={T:7d} cfg{cfg}  planes: 16x16x32 {best(0, 0):7.3f} ms {fl / best(0, 0):5.0f} TF | 32x32x16 "
+                      f"{best(256, 0):7.3f} ms {fl / best(256, 0):5.0f} TF | x{best(256, 0) / best(0, 0):.3f}    res+raw+planes: "
+                      f"{best(0, 8):7.3f} vs {best(256, 8):7.3f} ms x{best(256, 8) / best(0, 8):.3f}", flush=True)
+            return
         for name, Cin, Cout, T, K, dil, hint in shapes:
             if hint != 0:
                 continue
