@@ -120,15 +120,23 @@ __device__ __forceinline__ float lrelu_f(float v, float slope) {
 // 160 KiB, the widest (k = 11) take 2 x 38 KiB (two workgroups).  This is safe only because every LDS read of
 // the main loop is inline asm: for compiler-visible reads hipcc could not prove the stages disjoint and would
 // wait `vmcnt(0)` (drain the prefetch) in front of them.
-template <int MW, int NW, int WM, int WN, int VEC, int ACT>
+// KS > 1 (token-domain layers): the workgroup's four waves SPLIT THE REDUCTION of one small output tile (MW x NW blocks,
+// WM = WN = 1) instead of owning a block each: wave w takes the k-groups w, w + KS, .. of every chunk, the partial tiles
+// meet in LDS and are summed in wave order (a fixed order: results do not depend on the batch), then wave e finishes
+// block e.  Token-domain grids are short (B x 256 columns): as 64 x 64 tiles of four whole-K blocks the 768 -> 192, k = 3
+// FFN conv of the encoder is 384 workgroups of 1152 dependent MFMAs per wave (1.5 per CU: 127 us at batch 32, 84 us at
+// batch 1, 12 workgroups); as 32 x 64 tiles with the reduction split four ways it is 768 workgroups of 576.
+template <int MW, int NW, int WM, int WN, int VEC, int ACT, int KS = 1>
 __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kernel(ConvArgs a) {
     constexpr int BM = WM * MW * 32, BN = WN * NW * 32, MB = BM / 32;
+    static_assert(WM * WN * KS == 4, "four waves per workgroup");
+    static_assert(KS == 1 || MW * NW <= 4, "a wave per output block finishes the tile");
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     float *const stageP = lds_dyn;
     float *const stageQ = lds_dyn + a.stage_floats;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = KS > 1 ? 0 : wave / WN, wn = KS > 1 ? 0 : wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z;
     const int t0 = blockIdx.x * BN;
@@ -293,6 +301,89 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // ---- the same loop for one wave's share of the k-groups (KS > 1): groups wave, wave + KS, ..
+    auto compute_ks = [&](const float *stage) {
+        const uint32_t sbase = (uint32_t)(uintptr_t)stage;
+        auto read_a = [&](int m, int grp) {
+            f32x4 r;
+            const uint32_t ad = sbase + a_byte0 + (uint32_t)((m * spc + grp) * 1024);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(ad) : "memory");
+            return r;
+        };
+        auto read_b = [&](uint32_t ad, float *dst) {
+            if constexpr (NW == 1) {
+                float r;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(r) : "v"(ad) : "memory");
+                dst[0] = r;
+            } else {
+                f32x2 r;
+                asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(r) : "v"(ad) : "memory");
+                dst[0] = r.x;
+                dst[1] = r.y;
+                if constexpr (NW == 4) {
+                    f32x2 q;
+                    asm volatile("ds_read2_b32 %0, %1 offset0:64 offset1:96" : "=v"(q) : "v"(ad) : "memory");
+                    dst[2] = q.x;
+                    dst[3] = q.y;
+                }
+            }
+        };
+        // group gi = (tap, g): g_per_tap = CK / 8 is a power of two
+        const int gsh = g_per_tap == 4 ? 2 : (g_per_tap == 2 ? 1 : 0);
+        auto baddr = [&](int gi) {
+            const int tp = gi >> gsh, g = gi & (g_per_tap - 1);
+            return sbase + (uint32_t)((g * 8 + hi) * LW + tp * a.dil + col0) * 4u;
+        };
+        int gi = wave;
+        if (gi >= ngroups) return;  // (uniform per wave: a chunk with fewer groups than waves)
+        uint32_t bbyte = baddr(gi);
+        f32x4 av_n[MW];
+        float bv_n[NW];
+#pragma unroll
+        for (int m = 0; m < MW; m++) av_n[m] = read_a(m, gi);
+        read_b(bbyte, bv_n);
+        for (; gi < ngroups; gi += KS) {
+            const bool more = gi + KS < ngroups;
+            const int gnext = more ? gi + KS : gi;
+            const uint32_t bbyte2 = more ? baddr(gnext) : bbyte;
+            f32x4 av[MW];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                float bv[NW];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) {
+#pragma unroll
+                    for (int m = 0; m < MW; m++) av[m] = av_n[m];
+                }
+#pragma unroll
+                for (int n = 0; n < NW; n++) bv[n] = bv_n[n];
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) {
+#pragma unroll
+                    for (int m = 0; m < MW; m++) av_n[m] = read_a(m, gnext);
+                }
+                read_b(j < 3 ? bbyte + (uint32_t)(j + 1) * lw2b : bbyte2, bv_n);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ACT) {
+#pragma unroll
+                    for (int n = 0; n < NW; n++) bv[n] = lrelu_f(bv[n], slope);
+                }
+#pragma unroll
+                for (int m = 0; m < MW; m++) {
+                    const float aval = j == 0 ? av[m].x : (j == 1 ? av[m].y : (j == 2 ? av[m].z : av[m].w));
+#pragma unroll
+                    for (int n = 0; n < NW; n++)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bv[n], acc[m][n], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bbyte = bbyte2;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     // ---- per-lane epilogue constants, computed up front so their loads hide behind the main loop.
     // C/D layout of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
     const int flags = a.flags;
@@ -303,7 +394,11 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
     const float *biasp = a.bias ? a.bias : a.zeros;
     const float *bbp = a.bias_b ? a.bias_b + (int64_t)b * a.bias_b_stride : a.zeros;
     const int bb_on = a.bias_b ? 1 : 0, b_on = a.bias ? 1 : 0;
-    const int mblk0 = mblk_base + wm * MW;
+    // KS > 1: after the reduction wave e finishes block e = (e / NW, e % NW) of the tile as a one-block wave
+    constexpr int EM = KS > 1 ? 1 : MW, EN = KS > 1 ? 1 : NW;  // blocks per wave in the epilogue
+    const bool e_live = KS == 1 || wave < MW * NW;
+    const int e_m = (KS > 1 && e_live) ? wave / NW : 0, e_n = (KS > 1 && e_live) ? wave % NW : 0;
+    const int mblk0 = mblk_base + wm * MW + e_m;
     // element offset of (co, t = 0) inside the utterance, recomputed where needed (2 VALU ops) rather than
     // kept in 32 registers across the main loop; -1 = row out of range
     auto row_off = [&](int m, int r) -> int {
@@ -316,17 +411,43 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
     const bool dbg_nodma = a.flags & DBG_NO_DMA;
     issue(0, stageP);
     // (no exit from the middle of the unrolled pair: a mid-loop break makes hipcc copy the accumulators)
+    auto run = [&](const float *stage) {
+        if constexpr (KS > 1) compute_ks(stage);
+        else compute(stage);
+    };
     for (int chunk = 0; chunk + 1 < nchunks; chunk += 2) {
         __syncthreads();  // own DMA drained (vmcnt(0)) + everyone done reading stageQ
         if (!(dbg_nodma && chunk > 0)) issue(chunk + 1, stageQ);
-        compute(stageP);
+        run(stageP);
         __syncthreads();
         if (chunk + 2 < nchunks && !dbg_nodma) issue(chunk + 2, stageP);
-        compute(stageQ);
+        run(stageQ);
     }
     if (nchunks & 1) {
         __syncthreads();
-        compute(stageP);
+        run(stageP);
+    }
+    // ---- KS > 1: the four partial tiles meet in LDS (the stages are dead) and are summed in wave order; wave e then
+    // owns block e in acc[0][0]
+    if constexpr (KS > 1) {
+        constexpr int NBLK = MW * NW;
+        __syncthreads();
+        float *part = lds_dyn;  // [wave][block][register][lane]
+#pragma unroll
+        for (int m = 0; m < MW; m++)
+#pragma unroll
+            for (int n = 0; n < NW; n++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) part[((wave * NBLK + m * NW + n) * 16 + r) * 64 + lane] = acc[m][n][r];
+        __syncthreads();
+        const int eb = e_live ? wave : 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float sum = part[((0 * NBLK + eb) * 16 + r) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < KS; w++) sum += part[((w * NBLK + eb) * 16 + r) * 64 + lane];
+            acc[0][0][r] = sum;
+        }
     }
 
     // ---- epilogue: branch-free per element (absent bias pointers read the zero page, flags become
@@ -352,7 +473,8 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
     const float *addp = (flags & EPI_RES) ? rb : ob;
     const bool has_add = flags & (EPI_RES | EPI_ACC | EPI_COUPLING);
 #pragma unroll
-    for (int m = 0; m < MW; m++) {
+    for (int m = 0; m < EM; m++) {
+        if (!e_live) break;  // (KS > 1: the waves beyond the tile's blocks only took part in the reduction)
         int orow_m[16];
         float brow_m[16];
         // EPI_WN: this 32-row block is either residual rows (-> out, added to it) or skip rows (-> out2)
@@ -370,20 +492,20 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
             const int cc = co < a.Cout ? co : 0;
             brow_m[r] = biasp[cc * b_on] + bbp[cc * bb_on];
         }
-        constexpr int NB = NW >= 4 ? 2 : NW;  // tiles whose add-operands are in flight together (register budget)
+        constexpr int NB = EN >= 4 ? 2 : EN;  // tiles whose add-operands are in flight together (register budget)
         float ad[NB][16];
 #pragma unroll
-        for (int n = 0; n < NW; n++) {
+        for (int n = 0; n < EN; n++) {
             if (has_add_m && (n % NB) == 0) {
 #pragma unroll
                 for (int q = 0; q < NB; q++) {
-                    const int tq = t0 + wn * (NW * 32) + (n + q) * 32 + l31;
+                    const int tq = t0 + wn * (NW * 32) + (n + q + e_n) * 32 + l31;
                     const int ttq = tq * ups;
 #pragma unroll
                     for (int r = 0; r < 16; r++) ad[q][r] = (orow_m[r] >= 0 && tq < T) ? addm[orow_m[r] + ttq] : 0.f;
                 }
             }
-            const int t = t0 + wn * (NW * 32) + n * 32 + l31;
+            const int t = t0 + wn * (NW * 32) + (n + e_n) * 32 + l31;
             if (t >= T) {
                 if (ups == 1 && t < a.out_cstride && !(flags & EPI_NO_PADFILL)) {  // row padding up to the pitch: zeros (see x_cstride)
 #pragma unroll
@@ -451,7 +573,7 @@ __global__ __launch_bounds__(256, (MW * NW >= 4) ? 3 : 4) void conv_engine_kerne
 }
 
 // tile configs: index -> (BM, BN)
-//   0: 32x512   1: 64x256   2: 128x128   3: 64x64   4: 32x128
+//   0: 32x512   1: 64x256   2: 128x128   3: 64x64   4: 32x128   5: 32x64, the four waves split the reduction (KS = 4)
 inline int conv_tile_m(int cfg) { return cfg == 2 ? 128 : ((cfg == 1 || cfg == 3) ? 64 : 32); }
 inline int conv_tile_n(int cfg) {
     switch (cfg) {
@@ -459,6 +581,7 @@ inline int conv_tile_n(int cfg) {
         case 1: return 256;
         case 2: return 128;
         case 3: return 64;
+        case 5: return 64;
         default: return 128;
     }
 }
@@ -469,13 +592,14 @@ inline int conv_stage_floats(int cfg) {
         const char *e = std::getenv("VITSMI_STAGE_CAP_SMALL");  // tuning experiments only (model.cpp stage_capacity)
         return e ? std::atoi(e) : 4864;
     }();
+    if (cfg == 5) return 6144;
     return cfg <= 2 ? 9728 : cap3;
 }
 
-template <int MW, int NW, int WM, int WN, int VEC, int ACT>
+template <int MW, int NW, int WM, int WN, int VEC, int ACT, int KS = 1>
 inline hipError_t launch_conv_k(const ConvArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;  // allow > 64 KiB of dynamic LDS, once per instantiation
-    auto kern = conv_engine_kernel<MW, NW, WM, WN, VEC, ACT>;
+    auto kern = conv_engine_kernel<MW, NW, WM, WN, VEC, ACT, KS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSxMaxDynLds);
@@ -483,15 +607,15 @@ inline hipError_t launch_conv_k(const ConvArgs &a, dim3 grid, size_t lds, hipStr
         attr_set = true;
     }
     if (g_launch_name_on)
-        snprintf(g_launch_name, sizeof g_launch_name, "conv_engine_kernel<%d, %d, %d, %d, %d, %d>", MW, NW, WM, WN, VEC, ACT);
+        snprintf(g_launch_name, sizeof g_launch_name, "conv_engine_kernel<%d, %d, %d, %d, %d, %d, %d>", MW, NW, WM, WN, VEC, ACT, KS);
     kern<<<grid, 256, lds, stream>>>(a);
     return hipGetLastError();
 }
 
-template <int MW, int NW, int WM, int WN>
+template <int MW, int NW, int WM, int WN, int KS = 1>
 inline hipError_t launch_conv_t(const ConvArgs &a, dim3 grid, bool vec4, bool act, size_t lds, hipStream_t stream) {
-    if (vec4) return act ? launch_conv_k<MW, NW, WM, WN, 4, 1>(a, grid, lds, stream) : launch_conv_k<MW, NW, WM, WN, 4, 0>(a, grid, lds, stream);
-    return act ? launch_conv_k<MW, NW, WM, WN, 1, 1>(a, grid, lds, stream) : launch_conv_k<MW, NW, WM, WN, 1, 0>(a, grid, lds, stream);
+    if (vec4) return act ? launch_conv_k<MW, NW, WM, WN, 4, 1, KS>(a, grid, lds, stream) : launch_conv_k<MW, NW, WM, WN, 4, 0, KS>(a, grid, lds, stream);
+    return act ? launch_conv_k<MW, NW, WM, WN, 1, 1, KS>(a, grid, lds, stream) : launch_conv_k<MW, NW, WM, WN, 1, 0, KS>(a, grid, lds, stream);
 }
 
 // Launch on `stream`; LW / padLa / xs_floats / magic are filled in here.
@@ -523,7 +647,8 @@ inline hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
     const size_t stage = (size_t)a.xs_floats + (size_t)(BM / 32) * (a.K * a.CK / 8) * 256;
     if (stage > (size_t)conv_stage_floats(cfg)) return hipErrorInvalidValue;  // pick_tiling guarantees this never fires
     a.stage_floats = (int)((stage + 63) / 64 * 64);
-    const size_t lds = 2 * (size_t)a.stage_floats * sizeof(float);
+    size_t lds = 2 * (size_t)a.stage_floats * sizeof(float);
+    if (cfg == 5 && lds < (size_t)4 * 2 * 16 * 64 * 4) lds = (size_t)4 * 2 * 16 * 64 * 4;  // the four partial 32 x 64 tiles
     if ((int64_t)a.Cout * (a.ups == 1 ? a.out_cstride : a.T) >= (int64_t)1 << 31) return hipErrorInvalidValue;  // 32-bit element offsets per utterance
     if ((int64_t)a.CK * a.x_cstride + a.T >= (int64_t)1 << 31) return hipErrorInvalidValue;  // ... and inside a chunk of the input
     switch (cfg) {
@@ -531,6 +656,7 @@ inline hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
         case 1: return launch_conv_t<2, 2, 1, 4>(a, grid, vec4, act, lds, stream);
         case 2: return launch_conv_t<2, 2, 2, 2>(a, grid, vec4, act, lds, stream);
         case 3: return launch_conv_t<1, 1, 2, 2>(a, grid, vec4, act, lds, stream);
+        case 5: return launch_conv_t<1, 2, 1, 1, 4>(a, grid, vec4, act, lds, stream);
         default: return launch_conv_t<1, 1, 1, 4>(a, grid, vec4, act, lds, stream);
     }
 }

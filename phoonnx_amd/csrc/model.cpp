@@ -492,10 +492,11 @@ struct Packer {
 };
 
 // ---- tile / chunk selection (mirrors conv_engine.hip.hpp; kept here so model.cpp stays HIP-free)
-// cfg: 0: 32x512, 1: 64x256, 2: 128x128 (long sequences), 3: 64x64, 4: 32x128 (short sequences)
+// cfg: 0: 32x512, 1: 64x256, 2: 128x128 (long sequences), 3: 64x64, 4: 32x128 (short sequences), 5: 32x64 with the
+// reduction split over the workgroup's four waves (token domain)
 int tile_m(int cfg) { return cfg == 2 ? 128 : ((cfg == 1 || cfg == 3) ? 64 : 32); }
 int tile_n(int cfg) {
-    static const int n[5] = {512, 256, 128, 64, 128};
+    static const int n[6] = {512, 256, 128, 64, 128, 64};
     return n[cfg];
 }
 // floats of ONE pipeline stage (x tile + A slab) in the 16-byte-DMA layout (the larger one)
@@ -512,6 +513,7 @@ size_t stage_capacity(int cfg) {  // conv_engine.hip.hpp conv_stage_floats
         const char *e = std::getenv("VITSMI_STAGE_CAP_SMALL");  // tuning experiments only
         return e ? std::atol(e) : 4864l;
     }();
+    if (cfg == 5) return 6144;  // (its workgroups hold >= 32 KiB for the partial tiles anyway: room for 32-channel chunks)
     return cfg <= 2 ? 9728 : size_t(cap3);
 }
 
@@ -526,7 +528,11 @@ void pick_tiling(int Cin, int Cout, int K, int dil, int padL, int hint, int &cfg
         return;
     }
     std::vector<int> cands;
-    if (hint == 2) cands = {Cout <= 32 ? 4 : 3};
+    static const bool no_splitk = std::getenv("VITSMI_NO_SPLITK") != nullptr;  // A/B timing only
+    // token domain: deep reductions into few rows (the encoder's 768 -> 192, k = 3 FFN conv: 2304 products per output)
+    // split the reduction over the workgroup's waves (cfg 5); wide, shallow layers keep a block per wave (measured at
+    // batch 32: 127 -> 98 us for the former, 94 -> 104 us for the 192 -> 768 conv)
+    if (hint == 2) cands = {Cout <= 32 ? 4 : ((!no_splitk && Cin * K >= 1024) ? 5 : 3)};
     else if (hint == 1 && Cout % 128 != 0) cands = {Cout <= 32 ? 4 : 3};
     // long-sequence tiles, also the fallback when a wide kernel does not fit a small tile's LDS stage
     if (Cout <= 32) cands.push_back(0);

@@ -114,7 +114,7 @@ def main():
             line += "  | ablate TF/s: " + " ".join(parts)
         if a.sweep:
             best = []
-            for c in range(5):
+            for c in range(6):
                 for k in (8, 16, 32, 64, 96, 192):
                     rr = bench(lib, B, Cin, Cout, T, K, dil, hint, a.iters, c, k)
                     if rr:
