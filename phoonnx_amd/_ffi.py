@@ -64,7 +64,8 @@ G2P_EXPORTS = ["g2p_open", "g2p_close", "g2p_last_error", "g2p_hparam", "g2p_num
 
 
 def lib_path():
-    return os.path.join(_HERE, "libvitsmi.so")
+    # VITSMI_LIB: another build of the library (kernel experiments: variants compiled with -D switches side by side)
+    return os.environ.get("VITSMI_LIB") or os.path.join(_HERE, "libvitsmi.so")
 
 
 def load():

@@ -211,57 +211,63 @@ struct DdsLayerArgs {
     int CK, nchunks, MB;   // packing geometry of pw: chunk depth, chunks, 32-row blocks per m-tile
 };
 
+// NBLK = C / 32 at compile time: every channel loop is straight-line code (the run-time form branched around each
+// depthwise tap, each LDS read and each group of four MFMAs: every MFMA waited for its own predicated ds_read_b32, and
+// the 1x1 conv ran at a third of the matrix pipe's issue rate; 55 -> see DESIGN §5.3).
+template <int NBLK>
 __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
     typedef float f32x16_ __attribute__((ext_vector_type(16)));
-    __shared__ float y1[256 * 32];   // [ci][tl]: B operand of the 1x1 conv
+    constexpr int C = NBLK * 32;
+    __shared__ float y1[C * 32];   // [ci][tl]: B operand of the 1x1 conv
     __shared__ float red[8][32];
     __shared__ float stat[2][32];
     const int tid = threadIdx.x, tl = tid & 31, cg = tid >> 5;
     const int lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
     const int t0 = blockIdx.x * 32, t = t0 + tl, b = blockIdx.y;
-    const int C = a.C, T = a.T;
+    const int T = a.T;
     const int L = a.len ? a.len[b] : T;
     const bool tv = t < T;
     const float *p = a.in + (int64_t)b * C * T;
     float *o = a.out + (int64_t)b * C * T;
     // packed 1x1 weights: float4 group gi of block mb = k-steps 4 gi .. 4 gi + 3 (two input channels each) of its 32 rows
-    const int nblk = C >> 5;
     const int spc = a.CK >> 3;           // float4 groups per (block, chunk)
-    const int ngroups = C >> 3;          // groups per block
-    constexpr int MAXB = 2;              // blocks per wave: C <= 256 -> 8 blocks over 4 waves
-    constexpr int MAXG = 32;
-    float4 wa[MAXG];
+    constexpr int NG = C >> 3;           // groups per block
+    constexpr int MAXB = (NBLK + 3) / 4; // blocks per wave
+    float4 wa[NG];
     auto load_w = [&](int mb) {
 #pragma unroll
-        for (int gi = 0; gi < MAXG; gi++) {
-            if (gi < ngroups) {
-                const int ch = gi / spc, g = gi - ch * spc;
-                wa[gi] = reinterpret_cast<const float4 *>(a.pw)[(((int64_t)((mb / a.MB) * a.nchunks + ch) * a.MB + (mb % a.MB)) * spc + g) * 64 + lane];
-            }
+        for (int gi = 0; gi < NG; gi++) {
+            const int ch = gi / spc, g = gi - ch * spc;
+            wa[gi] = reinterpret_cast<const float4 *>(a.pw)[(((int64_t)((mb / a.MB) * a.nchunks + ch) * a.MB + (mb % a.MB)) * spc + g) * 64 + lane];
         }
     };
-    if (wave < nblk) load_w(wave);
+    if (wave < NBLK) load_w(wave);
     // ---- stage 1: depthwise conv (k = 3) of x * mask, LayerNorm over channels, GELU -> y1 (thread: channels cg + 8 i)
-    constexpr int CPT = 32;
+    constexpr int CPT = C / 8;
     {
         float v[CPT];
         const int pad = a.dil;  // (3 * dil - dil) / 2
         float s = 0.f;
+        // the three taps' validity does not depend on the channel
+        bool ok[3];
+        int tt[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            tt[k] = t + k * a.dil - pad;
+            ok[k] = tv && tt[k] >= 0 && tt[k] < T && tt[k] < L;
+            tt[k] = ok[k] ? tt[k] : 0;
+        }
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int c = cg + 8 * i;
-            float x = 0.f;
-            if (c < C && tv) {
-                x = a.dw_b[c];
+            float x = a.dw_b[c];
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const int tt = t + k * a.dil - pad;
-                    const float xv = (tt >= 0 && tt < T && tt < L) ? p[(int64_t)c * T + tt] : 0.f;
-                    x += a.dw_w[c * 3 + k] * xv;
-                }
+            for (int k = 0; k < 3; k++) {
+                const float xv = p[(int64_t)c * T + tt[k]];  // (always inside the row; masked taps multiply by zero below)
+                x += a.dw_w[c * 3 + k] * (ok[k] ? xv : 0.f);
             }
-            v[i] = x;
-            s += x;
+            v[i] = tv ? x : 0.f;
+            s += v[i];
         }
         red[cg][tl] = s;
         __syncthreads();
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
-            const float d = (cg + 8 * i < C) ? v[i] - mean : 0.f;
+            const float d = v[i] - mean;
             q += d * d;
         }
         red[cg][tl] = q;
@@ -286,47 +292,58 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int c = cg + 8 * i;
-            if (c < C) y1[c * 32 + tl] = tv ? gelu_erf((v[i] - mean) * rs * a.ln1_g[c] + a.ln1_b[c]) : 0.f;
+            y1[c * 32 + tl] = tv ? gelu_erf((v[i] - mean) * rs * a.ln1_g[c] + a.ln1_b[c]) : 0.f;
         }
     }
     __syncthreads();
     // ---- stage 2: 1x1 conv on the matrix cores.  Block rows (32 output channels each) are dealt to the waves round-robin.
-    // (the weights of this wave's first block were requested before stage 1 and arrived under it; all loads of a block are
-    // issued together: fetched one group at a time in front of its four MFMAs, 48 dependent L2 round trips made this
-    // kernel as slow as the three launches it replaces)
+    // Group gi covers input channels 8 gi .. 8 gi + 7 (chunks are consecutive): this lane's B values of its four k-steps
+    // sit at compile-time offsets from one base, so the reads of a whole block are plain loads the compiler batches ahead
+    // of the MFMA chain.
     f32x16_ acc[MAXB];
 #pragma unroll
     for (int j = 0; j < MAXB; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    const float *yb = y1 + hi * 32 + (lane & 31);
 #pragma unroll
     for (int j = 0; j < MAXB; j++) {
         const int mb = wave + 4 * j;
-        if (mb < nblk) {  // (uniform per wave)
+        if (mb < NBLK) {  // (uniform per wave)
             if (j > 0) load_w(mb);
 #pragma unroll
-            for (int gi = 0; gi < MAXG; gi++) {
-                if (gi < ngroups) {
-                    const float wv[4] = {wa[gi].x, wa[gi].y, wa[gi].z, wa[gi].w};
-                    const int ch = gi / spc, g = gi - ch * spc;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int ci = ch * a.CK + 2 * (4 * g + k) + hi;  // this lane's k index of the step
-                        const float bv = ci < C ? y1[ci * 32 + (lane & 31)] : 0.f;
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[k], bv, acc[j], 0, 0, 0);
-                    }
-                }
+            for (int gi = 0; gi < NG; gi++) {
+                const float b0 = yb[(8 * gi + 0) * 32], b1 = yb[(8 * gi + 2) * 32], b2 = yb[(8 * gi + 4) * 32], b3 = yb[(8 * gi + 6) * 32];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[gi].x, b0, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[gi].y, b1, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[gi].z, b2, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[gi].w, b3, acc[j], 0, 0, 0);
             }
         }
     }
     // ---- stage 3: + bias, LayerNorm over channels (column = lane & 31, rows spread over registers, `hi`, blocks, waves),
     // GELU, residual, mask.  C/D layout: row = (r & 3) + 8 * (r >> 2) + 4 * hi, col = lane & 31.
     const int col = lane & 31;
+    const int tc = t0 + col;
+    const bool tcv = tc < T;
+    // the residual operands travel while the statistics are formed
+    float resv[MAXB][16];
+#pragma unroll
+    for (int j = 0; j < MAXB; j++) {
+        const int mb = wave + 4 * j;
+        if (mb < NBLK) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int c = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                resv[j][r] = p[(int64_t)c * T + (tcv ? tc : 0)];
+            }
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXB; j++) {
         const int mb = wave + 4 * j;
-        if (mb < nblk) {
+        if (mb < NBLK) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 acc[j][r] += a.pw_bias[mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
 #pragma unroll
     for (int j = 0; j < MAXB; j++) {
         const int mb = wave + 4 * j;
-        if (mb < nblk) {
+        if (mb < NBLK) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const float d = acc[j][r] - mean;
@@ -359,18 +376,17 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
     if (tid < 32) stat[1][tid] = 1.0f / sqrtf((red[4][tid] + red[5][tid] + red[6][tid] + red[7][tid]) / (float)C + 1e-5f);
     __syncthreads();
     const float rs = stat[1][col];
-    const int tc = t0 + col;
-    if (tc >= T) return;
+    if (!tcv) return;
     const float mk = (!a.mask_out || tc < L) ? 1.f : 0.f;
 #pragma unroll
     for (int j = 0; j < MAXB; j++) {
         const int mb = wave + 4 * j;
-        if (mb < nblk) {
+        if (mb < NBLK) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int c = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const float y = gelu_erf((acc[j][r] - mean) * rs * a.ln2_g[c] + a.ln2_b[c]);
-                o[(int64_t)c * T + tc] = (p[(int64_t)c * T + tc] + y) * mk;
+                o[(int64_t)c * T + tc] = (resv[j][r] + y) * mk;
             }
         }
     }

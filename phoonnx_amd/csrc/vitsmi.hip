@@ -496,7 +496,8 @@ void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const 
 // DDSConv (modules.py:117-129) in place on h [B,C,T]; y,y2 are scratch of the same size.
 void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const int *len, int C, int T) {
     static const bool unfused = std::getenv("VITSMI_DDS_UNFUSED") != nullptr;  // A/B timing only
-    if (!unfused && C <= 256 && C % 32 == 0 && d.K == 3 && d.n_layers > 0) {
+    const int nblk = C / 32;
+    if (!unfused && C <= 256 && C % 32 == 0 && nblk != 5 && nblk != 7 && d.K == 3 && d.n_layers > 0) {
         // one launch per layer (dds_layer_kernel), ping-ponging between the three buffers so that the result of the
         // last layer lands in hbuf: each layer must write a buffer other than the one it reads
         float *bufs[3] = {hbuf, y, y2};
@@ -527,7 +528,15 @@ void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const i
             a.CK = L.pw.CK;
             a.nchunks = L.pw.nchunks;
             a.MB = (L.pw.cfg == 2 ? 128 : ((L.pw.cfg == 1 || L.pw.cfg == 3) ? 64 : 32)) / 32;
-            dds_layer_kernel<<<dim3((T + 31) / 32, c.B), 256, 0, c.st>>>(a);
+            const dim3 dg((T + 31) / 32, c.B);
+            switch (nblk) {  // (channel count at compile time: straight-line channel loops)
+                case 1: dds_layer_kernel<1><<<dg, 256, 0, c.st>>>(a); break;
+                case 2: dds_layer_kernel<2><<<dg, 256, 0, c.st>>>(a); break;
+                case 3: dds_layer_kernel<3><<<dg, 256, 0, c.st>>>(a); break;
+                case 4: dds_layer_kernel<4><<<dg, 256, 0, c.st>>>(a); break;
+                case 6: dds_layer_kernel<6><<<dg, 256, 0, c.st>>>(a); break;
+                default: dds_layer_kernel<8><<<dg, 256, 0, c.st>>>(a); break;
+            }
             c.note(hipGetLastError());
             c.h->stats.total_launches++;
             {   // the 1x1 conv's algorithmic work, as conv() would account it
