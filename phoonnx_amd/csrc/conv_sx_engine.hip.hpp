@@ -88,6 +88,10 @@ struct SxArgs {
     int Cin, Cout, Cr;    // Cout = virtual rows (Cr * ups)
     int K, dil, padL, nchunks, ups;
     int LW;               // x tile width in cells                       ( " )
+    // SX_WN_RMW: valid lengths, second planar tensor, first row that goes to it, rows that also get planes
+    const int *len;
+    float *out_raw2;
+    int row_split, pl_rows;
     int RS;               // cells between the rows of an x stage (>= LW) ( " )
     int s16;              // the weights are packed for the 16x16x32 main loop (ConvDesc::s16; f16x3, plane input)
     unsigned magic;       // ceil(2^32 / LW)                             ( " )
@@ -193,7 +197,12 @@ enum : int {
     // channels H + 32 m ..).  The sigmoid waves hand their values to the tanh waves through LDS; the output is
     // acts = tanh(a) * sigmoid(b) as a PLANAR fp32 tensor [H][T] (what the res_skip conv on the f32 engine reads).
     // out_raw = acts, raw_bstride = H * T, Cr = 2 H; bias_b indexes ORIGINAL rows.  64-row tiles only.
-    SX_GATE = 1 << 15
+    SX_GATE = 1 << 15,
+    // The flow's res_skip conv (modules.py:200-209) with its update folded in, generic epilogue only: the value, masked
+    // by t < len[b], is ADDED into planar fp32 tensors [rows][T] - rows [0, row_split) into out_raw (x = (x + res) * mask:
+    // x is masked already), rows [row_split, Cout) into out_raw2 (skip += ...), row index less row_split - and the new
+    // rows [0, pl_rows) are written once more as the fp16 operand planes of the next in-layer (out_pl).
+    SX_WN_RMW = 1 << 16
 };
 constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB | SX_RES_EARLY |
                            SX_GATE;
@@ -854,13 +863,82 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
                     const f32x4 other = __builtin_bit_cast(f32x4, got[k][q]);
                     const f32x4 own = wm == 0 ? mine[k][q] : mine[NW / 2 + k][q];
                     if (t < T) {
+                        if (a.out_pl) {
+                            // acts as the fp16 operand planes of the res_skip conv on this engine (|acts| < 1: no range issue)
+                            unsigned wa[2], wb[2];
+                            split2h_pair(own[0] * other[0], own[1] * other[1], wa[0], wa[1]);
+                            split2h_pair(own[2] * other[2], own[3] * other[3], wb[0], wb[1]);
+                            uint16_t *pl = a.out_pl + (int64_t)b * a.pl_bstride;
+                            const int64_t cell = ((int64_t)((ch0 >> 3) + q) * T + t) * 8 + 4 * hi;
+                            *reinterpret_cast<u32x2 *>(pl + cell) = u32x2{wa[0], wb[0]};
+                            *reinterpret_cast<u32x2 *>(pl + (int64_t)(H >> 3) * T * 8 + cell) = u32x2{wa[1], wb[1]};
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) actb[(int64_t)(ch0 + 8 * q + 4 * hi + e) * T + t] = own[e] * other[e];
+                            for (int e = 0; e < 4; e++) actb[(int64_t)(ch0 + 8 * q + 4 * hi + e) * T + t] = own[e] * other[e];
+                        }
                     }
                 }
             }
         }
         return;
+    }
+    if constexpr (EPI < 0) {
+        if (a.flags & SX_WN_RMW) {
+            const int Lb = a.len ? a.len[b] : T;
+            const float wsc = a.wscale;
+            const float *biasp = a.bias ? a.bias : a.zeros;
+            const int b_on = a.bias ? 1 : 0;
+            const int xrows = a.row_split, srows = a.Cout - a.row_split;
+            uint16_t *plb = a.out_pl ? a.out_pl + (int64_t)b * a.pl_bstride : nullptr;
+            const int64_t plane_elems = (int64_t)(a.pl_rows >> 3) * T * 8;
+#pragma unroll
+            for (int m = 0; m < MW; m++) {
+                const int row0 = mt * BM + (wm * MW + m) * 32;
+                const bool to_x = row0 < xrows;   // (a 32-row block lies on one side: both counts are multiples of 32)
+                float *ob = to_x ? a.out_raw + (int64_t)b * xrows * T : a.out_raw2 + (int64_t)b * srows * T;
+                const int r0 = to_x ? row0 : row0 - xrows;
+                const bool planes = plb && to_x && row0 < a.pl_rows;
+                f32x4 bq[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
+#pragma unroll
+                for (int n = 0; n < NW; n++) {
+                    const int t = t0 + (wn * NW + n) * 32 + l31;
+                    const int tl = t < T ? t : T - 1;
+                    const float mk = t < Lb ? 1.f : 0.f;
+                    float old[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) old[r] = ob[(int64_t)(r0 + (r & 3) + 8 * (r >> 2) + 4 * hi) * T + tl];
+                    if (t >= T) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            // register 4 q + e = row e + 8 q + 4 hi of the block
+                            const float v = __builtin_fmaf(acc[m][n][4 * q + e], wsc, bq[q][e]);
+                            o[e] = old[4 * q + e] + v * mk;
+                            ob[(int64_t)(r0 + e + 8 * q + 4 * hi) * T + t] = o[e];
+                        }
+                        if (planes) {
+                            unsigned wa[2], wb[2];
+                            split2h_pair_pk(o[0], o[1], wa[0], wa[1], pk);
+                            split2h_pair_pk(o[2], o[3], wb[0], wb[1], pk);
+                            const int64_t cell = ((int64_t)((row0 >> 3) + q) * T + t) * 8 + 4 * hi;
+                            *reinterpret_cast<u32x2 *>(plb + cell) = u32x2{wa[0], wb[0]};
+                            *reinterpret_cast<u32x2 *>(plb + plane_elems + cell) = u32x2{wa[1], wb[1]};
+                        }
+                    }
+                }
+            }
+            if constexpr (F16) {
+                if (a.peak) {
+                    if constexpr (S16) sx_publish_peak_at(a.peak, (int)blockIdx.x, pk, reinterpret_cast<float *>(lds_sx));
+                    else sx_publish_peak(a.peak, (int)blockIdx.x, pk);
+                }
+            }
+            return;
+        }
     }
     const int u = a.ups, Cr = a.Cr, Tout = T * u, CGo = Cr >> 3;
     float *rawb = a.out_raw + (int64_t)b * a.raw_bstride;     // (only dereferenced when the flags say so)
@@ -1024,6 +1102,7 @@ constexpr int kSxEpiGate = SX_GATE | SX_HAS_RAW;                                
 
 template <int MW, int NW, int WM, int WN, int NP = 6, int SH = 32>
 inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+    if (epi == -2) return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, NP, SH>(a, grid, lds, stream);  // SX_WN_RMW
     if constexpr (SH == 32) {
         if (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, NP>(a, grid, lds, stream);
     }
@@ -1116,7 +1195,7 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     const size_t lds = s16 ? (size_t)a.x_bytes + (size_t)xrows * a.RS * 16 : 2 * (size_t)a.x_bytes;
     a.lds_bytes = (unsigned)lds;
     // (pack_conv_sx pads narrower kernels to 3 taps; model.cpp sx_supported() mirrors the size limits)
-    if (lds > (size_t)kSxMaxDynLds || a.x_bytes > 12 * 4096 || a.K < 3) return hipErrorInvalidValue;
+    if (lds > (size_t)kSxMaxDynLds || a.x_bytes > 12 * 4096 || (a.K < 3 && !s16)) return hipErrorInvalidValue;
     if (rawin && (cfg == 0 || 2 * a.LW > 768 || !a.xr || (long long)a.T * 64 + 64 >= (1ll << 32))) return hipErrorInvalidValue;
     if (a.oslope == 0.f) a.oslope = 1.f;
     if (a.oslope2 == 0.f) a.oslope2 = 1.f;
@@ -1133,23 +1212,33 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     // epilogue description (see the SX_* bits): derived from the arguments, then matched against the instantiations
     int epi = a.flags & (EPI_RES | EPI_ACC | EPI_DIV);
     if (a.out_raw && !(a.flags & SX_NO_RAW_STORE)) epi |= SX_HAS_RAW | (a.oslope != 1.f ? SX_RAW_ACT : 0);
-    if (a.out_pl) epi |= SX_HAS_PL | (a.oslope2 != 1.f ? SX_PL_ACT : 0);
+    if (a.out_pl && !(a.flags & SX_GATE)) epi |= SX_HAS_PL | (a.oslope2 != 1.f ? SX_PL_ACT : 0);
     if (a.bias_b) epi |= SX_HAS_BIASB;
+    if (a.flags & SX_WN_RMW) {
+        // (its own epilogue block in the generic instantiation: force that one)
+        if (rawin || nprod != 2 || a.ups != 1 || !a.out_raw2 || (a.row_split && !a.out_raw) || a.row_split % 32 || a.Cout % 32 ||
+            a.pl_rows % 32 || a.pl_rows > a.row_split || a.bias_b || (a.flags & SX_GATE))
+            return hipErrorInvalidValue;
+        epi = -2;
+    }
     if (a.flags & SX_GATE) {
-        if (rawin || (cfg != 1 && cfg != 3) || (nprod != 2 && nprod != 6) || a.ups != 1 || !a.out_raw || a.out_pl || (a.Cr & 63) ||
+        if (rawin || (cfg != 1 && cfg != 3) || (nprod != 2 && nprod != 6) || a.ups != 1 || (!a.out_raw && !a.out_pl) || (a.Cr & 63) ||
             lds < (size_t)2 * (sx_tile_n(cfg) / 64) * 4 * 1024)
             return hipErrorInvalidValue;
-        epi |= SX_GATE;
+        epi |= SX_GATE | SX_HAS_RAW;  // (one instantiation: planar acts to out_raw, or operand planes to out_pl)
     }
     // (SX_RES_EARLY has compile-time instantiations only: where none matches, the residual is read in the epilogue)
     // (bf16x6 on the 64-row tile has no registers left for it: 256 VGPRs and a spill)
     const bool early_ok = rawin && (nprod == 2 || (nprod == 6 && cfg == 2)) && (a.flags & EPI_RES) && !(a.flags & (DBG_NO_DMA | DBG_NO_EPI)) &&
                           a.res == a.xr && a.ups == 1 && a.out_raw && !(a.flags & SX_NO_RAW_STORE) && !a.out_pl && !a.bias_b &&
                           a.oslope == 1.f && (!(a.flags & EPI_DIV) || (a.flags & EPI_ACC));
-    if (early_ok) epi |= SX_RES_EARLY;
-    if ((epi & EPI_RES) && !a.res) return hipErrorInvalidValue;
-    if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
-    a.flags = (a.flags & ~kSxEpiMask) | epi;
+    if (early_ok && epi != -2) epi |= SX_RES_EARLY;
+    if (epi != -2) {
+        if ((epi & EPI_RES) && !a.res) return hipErrorInvalidValue;
+        if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
+        a.flags = (a.flags & ~kSxEpiMask) | epi;
+    } else
+        a.flags = SX_WN_RMW;
     if (nprod == 2) {  // two fp16 planes, three products (fp32-grade): the same specialised epilogues
         if (a.wscale == 0.f) a.wscale = 1.f;
         if (rawin)

@@ -691,9 +691,16 @@ int sx_pick_cfg(int Cout) {
 template <class WF>
 ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF w, const float *bias_virtual) {
     if (!sx_supported(Cin, Cout, Cout, K, dil)) throw std::runtime_error("conv shape not supported by the sx engine");
-    // the engine's pipeline needs >= 3 taps per chunk: narrower kernels get zero taps appended on the right
+    // the 32x32x16 pipeline needs >= 3 taps per chunk: narrower kernels get zero taps appended on the right.  (The
+    // 16x16x32 loop waits for everything at each chunk start and takes a 1 x 1 conv as it is: decided below.)
     const int Kreal = K;
-    if (K < 3) K = 3;
+    static const bool shape32_only = [] {
+        const char *e = std::getenv("VITSMI_SX_SHAPE");  // "32": A/B timing against the v_mfma_f32_32x32x16 loop
+        return e && std::string(e) == "32";
+    }();
+    const bool want16 = t_sx_f16 && !sx_raw_format(Cin) && !shape32_only && !t_sx_shape32 && Cin % 32 == 0 &&
+                        (size_t)8 * (256 + (Kreal - 1) * dil) * 16 <= (size_t)10 * 4096;
+    if (K < 3 && !want16) K = 3;
     auto wz = [&](int co, int ci, int tap) { return tap < Kreal ? w(co, ci, tap) : 0.f; };
     ConvDesc d;
     d.sx = true;
@@ -712,11 +719,7 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     const int npw = t_sx_f16 ? 2 : 3;                              // planes per 32-row block
     // 16x16x32 main loop (f16x3, plane input, 32-channel chunks): when the x stage of a 32-channel chunk (8 rows of
     // 256 + halo cells) fits ten DMA rounds, i.e. two workgroups per CU
-    static const bool shape32_only = [] {
-        const char *e = std::getenv("VITSMI_SX_SHAPE");  // "32": A/B timing against the v_mfma_f32_32x32x16 loop
-        return e && std::string(e) == "32";
-    }();
-    d.s16 = t_sx_f16 && !d.rawin && !shape32_only && !t_sx_shape32 && Cin % 32 == 0 && (size_t)8 * (256 + (K - 1) * dil) * 16 <= (size_t)10 * 4096;
+    d.s16 = want16;
     if (d.s16) {
         d.CK = 32;
         d.nchunks = Cin / 32;
@@ -1223,6 +1226,19 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
                     } else
                         cd.wn[i].in = pack_named(P, R, in, dil, same_pad(k, dil));
                     cd.wn[i].rs = pack_named(P, R, s + ".enc.res_skip_layers." + std::to_string(i), 1, 0);
+                    {
+                        // ... and for the split-operand engine, where the gated in-layer runs on its 16x16x32 loop: the 1 x 1
+                        // conv then reads the acts as operand planes and folds the x / skip update into its epilogue
+                        // (SX_WN_RMW).  VITSMI_FLOW_RS_F32 keeps it on the f32 engine (A/B timing).
+                        static const bool rs_f32 = std::getenv("VITSMI_FLOW_RS_F32") != nullptr;
+                        const auto &inl = cd.wn[i].in;
+                        if (!rs_f32 && inl.sx && inl.f16 && inl.gate && inl.s16 && flow_H % 32 == 0) {
+                            t_sx_f16 = true;
+                            ConvDesc r2 = pack_named_sx(P, R, s + ".enc.res_skip_layers." + std::to_string(i), 1, 0);
+                            t_sx_f16 = false;
+                            if (r2.s16 && r2.K == 1) cd.wn[i].rs_sx = r2;
+                        }
+                    }
                     if (cd.wn[i].rs.Cin != flow_H || cd.wn[i].rs.K != 1 ||
                         (cd.wn[i].rs.Cout != flow_H && cd.wn[i].rs.Cout != 2 * flow_H))
                         throw std::runtime_error(s + ": unexpected res_skip shape");

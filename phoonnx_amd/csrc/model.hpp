@@ -76,6 +76,9 @@ struct CouplingDesc {  // one ResidualCouplingLayer with the preceding Flip fold
     int n_wn = 0;
     struct {
         ConvDesc in, rs;
+        // the res_skip conv once more for the split-operand engine (16x16x32 loop, K = 1; used when the in-layer is gated
+        // on that engine and hands its acts over as operand planes): rs_sx.sx says whether it exists
+        ConvDesc rs_sx;
     } wn[8];
     int64_t cond_w = -1, cond_b = -1;  // [2*H*n_wn, gin]
     bool swapped = false;  // true: x0 is the physical upper half, x1 the lower

@@ -342,9 +342,15 @@ void conv(Ctx &c, const ConvDesc &d, const float *x, int64_t x_bstride, int T, f
 // batches in the engine's layouts: input planes [B][3][Cin/8][T][8], outputs raw [B][Cr/8][T*u][8] and/or
 // planes [B][3][Cr/8][T*u][8]; `res` has the raw layout of the output.
 // `x` is the plane tensor, or (d.rawin) the fp32 raw tensor, to which the kernel applies leaky_relu(islope).
+struct SxWn {               // SX_WN_RMW arguments of conv_sx()
+    const int *len = nullptr;
+    float *out_raw2 = nullptr;
+    int row_split = 0, pl_rows = 0;
+};
+
 void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, uint16_t *out_pl, int flags,
              const float *res = nullptr, const float *bias_b = nullptr, int bias_b_stride = 0, float div = 1.f,
-             float oslope = 1.f, float oslope2 = 1.f, float islope = 1.f) {
+             float oslope = 1.f, float oslope2 = 1.f, float islope = 1.f, const SxWn *wn = nullptr) {
     SxArgs a{};
     const int Cr = d.Cout / d.ups;
     const int64_t Tout = (int64_t)T * d.ups;
@@ -360,7 +366,14 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.out_raw = out_raw;
     a.raw_bstride = (flags & SX_GATE) ? (int64_t)(Cr / 2) * Tout : (int64_t)Cr * Tout;  // (gate: planar acts [H][T])
     a.out_pl = out_pl;
-    a.pl_bstride = (int64_t)3 * Cr * Tout;
+    a.pl_bstride = (flags & SX_GATE) ? (int64_t)3 * (Cr / 2) * Tout : (int64_t)3 * Cr * Tout;  // (gate: planes of the H acts)
+    if (wn) {  // SX_WN_RMW: planes of the first pl_rows rows only
+        a.len = wn->len;
+        a.out_raw2 = wn->out_raw2;
+        a.row_split = wn->row_split;
+        a.pl_rows = wn->pl_rows;
+        a.pl_bstride = (int64_t)3 * wn->pl_rows * Tout;
+    }
     a.res = res;
     a.zeros = c.P(c.m.zeros_off);
     a.Cin = d.Cin;
@@ -1116,6 +1129,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     uint16_t *hx_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, nHF * 2));  // planes of hx (sx in-layers)
     const int half = C / 2;
     const int64_t sCF = (int64_t)C * F, sHF = (int64_t)Hf * F;
+    uint16_t *acts_pl = reinterpret_cast<uint16_t *>(a2);  // (a2 is unused where the gate writes operand planes)
     for (auto &cd : m.flow) {
         float *gc = nullptr;
         const int gc_rows = 2 * Hf * cd.n_wn;
@@ -1150,7 +1164,23 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
                                                                                              range_slots(h, cd.wn[i].in.f16));
                     h->stats.total_launches++;
                 }
-                if (cd.wn[i].in.gate) {  // tanh * sigmoid in the conv's epilogue: acts directly
+                if (cd.wn[i].in.gate && cd.wn[i].rs_sx.sx) {
+                    // gate in the in-layer's epilogue, acts handed over as fp16 operand planes; the res_skip 1 x 1 conv on
+                    // the same engine reads them and folds the update in: x += res * mask (+ the next in-layer's planes),
+                    // skip += .. (skip was zeroed when the coupling started)
+                    if (i == 0) c.note(hipMemsetAsync(skip, 0, nHF * 4, st));
+                    conv_sx(c, cd.wn[i].in, hx_pl, F, nullptr, acts_pl, SX_GATE, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr,
+                            gc_rows);
+                    SxWn w;
+                    w.len = ylen;
+                    w.out_raw2 = skip;
+                    w.row_split = last ? 0 : Hf;
+                    const bool np = !last && cd.wn[i + 1].in.sx && cd.wn[i + 1].in.f16 && Hf % 32 == 0;
+                    w.pl_rows = np ? Hf : 0;
+                    conv_sx(c, cd.wn[i].rs_sx, acts_pl, F, hx, np ? hx_pl : nullptr, SX_WN_RMW, nullptr, nullptr, 0, 1.f, 1.f, 1.f,
+                            1.f, &w);
+                    continue;
+                } else if (cd.wn[i].in.gate) {  // tanh * sigmoid in the conv's epilogue: acts directly
                     conv_sx(c, cd.wn[i].in, hx_pl, F, acts, nullptr, SX_GATE, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr,
                             gc_rows);
                     h->stats.total_launches--;  // (no gate launch: undo the increment below)
