@@ -202,7 +202,7 @@ enum : int {
     // by t < len[b], is ADDED into planar fp32 tensors [rows][T] - rows [0, row_split) into out_raw (x = (x + res) * mask:
     // x is masked already), rows [row_split, Cout) into out_raw2 (skip += ...), row index less row_split - and the new
     // rows [0, pl_rows) are written once more as the fp16 operand planes of the next in-layer (out_pl).
-    SX_WN_RMW = 1 << 16
+    SX_WN_RMW = 1 << 19  // (bits 16-18: DBG_NO_DMA, DBG_NO_EPI, EPI_NO_PADFILL of conv_engine.hip.hpp)
 };
 constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB | SX_RES_EARLY |
                            SX_GATE;
@@ -520,9 +520,11 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     auto half_step = [&](AHalf &fc, AHalf &fload, auto M, int hs) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value;
         // in flight behind A(hs) (requested by the previous half-step): the x DMAs if that half-step issued them
-        if (x_age == 0) wait_vm16(nx_issued);  // (once per chunk)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... unless this half-step opens a chunk whose x tile was issued by the previous one (K = 1 and one half-step per
+        // step): the barrier below publishes that tile, so this wave's share of it must have landed
         const bool chunk_start = m == 0 && tap == 0;
+        if (x_age == 0 && !chunk_start) wait_vm16(nx_issued);  // (once per chunk)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const bool more_x = chunk + 1 < a.nchunks;
         if (chunk_start) {
             __builtin_amdgcn_s_barrier();  // x(chunk) is complete in LDS; everyone is done with the other stage
