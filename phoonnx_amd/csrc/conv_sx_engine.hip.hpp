@@ -52,6 +52,12 @@
 #ifndef SX_CFG0_WIDE
 #define SX_CFG0_WIDE 0  // 128 x 256 tile as four 32-row waves x 256 columns (half the weight bytes per workgroup)
 #endif
+#ifndef SX16_SPREAD
+#define SX16_SPREAD 0  // (experiment) x-tile DMA rounds spread behind the quarters of the chunk-opening half-step
+#endif
+#ifndef SX16_PRIO
+#define SX16_PRIO 0  // (experiment) raised wave priority around each quarter's MFMAs
+#endif
 #ifndef SX16_WIDE
 #define SX16_WIDE 1  // 16x16x32 loop, 128 x 256 tile as four waves of 32 rows x 256 columns: each wave streams its own weight rows (half
                      // the L2 -> CU weight bytes of the 2 x 2 arrangement, a whole step of lead), the x tile is read once per wave
@@ -480,6 +486,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     auto mma_q = [&](const AHalf &f, auto M, auto BUF, auto Q) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value, bf = decltype(BUF)::value, q = decltype(Q)::value;
         // products in the order of the 32x32x16 loop: g1*h0, g0'*h1', g0*h0; consecutive MFMAs hit different accumulators
+        if constexpr (SX16_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -492,6 +499,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
                     c16[m][aa][q][bb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga, __builtin_bit_cast(f16x8, bq[bf][bb][c == 1 ? 1 : 0]),
                                                                                c16[m][aa][q][bb], 0, 0, 0);
                 }
+        if constexpr (SX16_PRIO) __builtin_amdgcn_s_setprio(0);
     };
     auto wait_vm16 = [&](int n) __attribute__((always_inline)) {  // at most n of this wave's vector-memory operations still in flight
         switch (n) {
@@ -532,8 +540,9 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
         __builtin_amdgcn_sched_barrier(0);
         if (hs + 1 < H && !(SX_NOA && hs > 0)) load_ah(fload, hs + 1);
         x_age++;
-        if (chunk_start && more_x) {
-            issue_x(chunk + 1, ((chunk + 1) & 1) * XB);
+        const bool do_x = chunk_start && more_x;
+        if (do_x) {
+            if constexpr (!SX16_SPREAD) issue_x(chunk + 1, ((chunk + 1) & 1) * XB);
             x_age = 0;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -559,6 +568,18 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
             }
             __builtin_amdgcn_sched_barrier(0);
             mma_q(fc, M, std::integral_constant<int, bf>{}, Q);
+            if constexpr (SX16_SPREAD) {
+                // the next chunk's x tile, a few DMA rounds behind each quarter's MFMAs instead of one burst in front of them
+                if (do_x) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const char *cb = reinterpret_cast<const char *>(xb) + (int64_t)(XG * (chunk + 1)) * T * 16;
+                    const uint32_t xoff = ((chunk + 1) & 1) * XB;
+#pragma unroll
+                    for (int it = q; it < MAXIT; it += NQ)
+                        if (it < nit && xok[it])
+                            lds_dma<16>(cb + xoffs[it], reinterpret_cast<float *>(lds_sx + xoff + (it * 256 + wave * 64) * 16));
+                }
+            }
         });
         __builtin_amdgcn_sched_barrier(0);
         if (m == HPS - 1 && ++tap == K) {

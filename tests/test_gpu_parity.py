@@ -117,6 +117,11 @@ SX_CASES = [
     (1, 64, 64, 5, 7, 1),       # sequence shorter than the kernel (raw-input path, everything is halo)
     (2, 128, 128, 31, 3, 1),    # sequence much shorter than the 256-column tile (plane-input path)
     (1, 128, 128, 400, 11, 13), # receptive field wider than any VITS layer: 7 DMA rounds per x tile, the general DMA path
+    # round 3, the 16x16x32 main loop (f16x3, plane input, Cin % 32 == 0): its tile shapes and pipeline corners
+    (2, 192, 384, 700, 1, 1),   # 1 x 1 conv taken as it is: every step opens a chunk (the flow's res_skip conv)
+    (1, 192, 192, 260, 1, 1),   # ... on 64-row tiles
+    (2, 256, 256, 530, 11, 5),  # widest halo of the headline voice: x stage rows of 320 cells, 2 x 80 KiB of LDS per CU
+    (1, 96, 160, 300, 5, 2),    # three 32-channel chunks, Cout % 64 != 0 (32-row tiles)
 ]
 
 
