@@ -204,10 +204,13 @@ enum : int {
     // acts = tanh(a) * sigmoid(b) as a PLANAR fp32 tensor [H][T] (what the res_skip conv on the f32 engine reads).
     // out_raw = acts, raw_bstride = H * T, Cr = 2 H; bias_b indexes ORIGINAL rows.  64-row tiles only.
     SX_GATE = 1 << 15,
-    // The flow's res_skip conv (modules.py:200-209) with its update folded in, generic epilogue only: the value, masked
-    // by t < len[b], is ADDED into planar fp32 tensors [rows][T] - rows [0, row_split) into out_raw (x = (x + res) * mask:
-    // x is masked already), rows [row_split, Cout) into out_raw2 (skip += ...), row index less row_split - and the new
-    // rows [0, pl_rows) are written once more as the fp16 operand planes of the next in-layer (out_pl).
+    // Planar epilogue (generic instantiation only): o = old + act(value) * mask goes to PLANAR fp32 tensors [rows][T] - rows
+    // [0, row_split) to out_raw, rows [row_split, Cout) to out_raw2 (row index less row_split) - and the new rows
+    // [0, pl_rows) once more as fp16 operand planes (out_pl; out_raw may then be absent).  old = the output itself
+    // (EPI_ACC), the planar tensor res (EPI_RES; rows of out_raw only) or nothing; act = ReLU with EPI_RELU; mask =
+    // t < len[b] with EPI_MASK.  Users: the flow's res_skip conv (modules.py:200-209: x = (x + res) * mask, skip += ..,
+    // planes of x for the next in-layer) and the text encoder's 1 x 1 / FFN convs (attentions.py:66-75, 419-427), whose
+    // neighbours (attention, LayerNorm) work on planar tensors.
     SX_WN_RMW = 1 << 19  // (bits 16-18: DBG_NO_DMA, DBG_NO_EPI, EPI_NO_PADFILL of conv_engine.hip.hpp)
 };
 constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB | SX_RES_EARLY |
@@ -907,7 +910,11 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     }
     if constexpr (EPI < 0) {
         if (a.flags & SX_WN_RMW) {
-            const int Lb = a.len ? a.len[b] : T;
+            // planar epilogue: o = old + act(acc * wscale + bias) * mask, stored as [B][rows][T] fp32 and / or as operand planes.
+            //   old: the output itself (EPI_ACC), the planar tensor `res` (EPI_RES, x rows only), or nothing
+            //   act: ReLU with EPI_RELU; mask: t < len[b] with EPI_MASK
+            const bool p_acc = (a.flags & EPI_ACC) != 0, p_res = (a.flags & EPI_RES) != 0, p_relu = (a.flags & EPI_RELU) != 0;
+            const int Lb = ((a.flags & EPI_MASK) && a.len) ? a.len[b] : T;
             const float wsc = a.wscale;
             const float *biasp = a.bias ? a.bias : a.zeros;
             const int b_on = a.bias ? 1 : 0;
@@ -918,7 +925,8 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
             for (int m = 0; m < MW; m++) {
                 const int row0 = mt * BM + (wm * MW + m) * 32;
                 const bool to_x = row0 < xrows;   // (a 32-row block lies on one side: both counts are multiples of 32)
-                float *ob = to_x ? a.out_raw + (int64_t)b * xrows * T : a.out_raw2 + (int64_t)b * srows * T;
+                float *ob = to_x ? (a.out_raw ? a.out_raw + (int64_t)b * xrows * T : nullptr) : a.out_raw2 + (int64_t)b * srows * T;
+                const float *oldp = p_acc ? ob : (p_res && to_x ? a.res + (int64_t)b * xrows * T : nullptr);
                 const int r0 = to_x ? row0 : row0 - xrows;
                 const bool planes = plb && to_x && row0 < a.pl_rows;
                 f32x4 bq[4];
@@ -930,8 +938,13 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
                     const int tl = t < T ? t : T - 1;
                     const float mk = t < Lb ? 1.f : 0.f;
                     float old[16];
+                    if (oldp) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++) old[r] = ob[(int64_t)(r0 + (r & 3) + 8 * (r >> 2) + 4 * hi) * T + tl];
+                        for (int r = 0; r < 16; r++) old[r] = oldp[(int64_t)(r0 + (r & 3) + 8 * (r >> 2) + 4 * hi) * T + tl];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) old[r] = 0.f;
+                    }
                     if (t >= T) continue;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
@@ -939,9 +952,13 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
                             // register 4 q + e = row e + 8 q + 4 hi of the block
-                            const float v = __builtin_fmaf(acc[m][n][4 * q + e], wsc, bq[q][e]);
+                            float v = __builtin_fmaf(acc[m][n][4 * q + e], wsc, bq[q][e]);
+                            if (p_relu) v = __builtin_fmaxf(v, 0.f);
                             o[e] = old[4 * q + e] + v * mk;
-                            ob[(int64_t)(r0 + e + 8 * q + 4 * hi) * T + t] = o[e];
+                        }
+                        if (ob) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) ob[(int64_t)(r0 + e + 8 * q + 4 * hi) * T + t] = o[e];
                         }
                         if (planes) {
                             unsigned wa[2], wb[2];
@@ -1239,8 +1256,11 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
     if (a.bias_b) epi |= SX_HAS_BIASB;
     if (a.flags & SX_WN_RMW) {
         // (its own epilogue block in the generic instantiation: force that one)
-        if (rawin || nprod != 2 || a.ups != 1 || !a.out_raw2 || (a.row_split && !a.out_raw) || a.row_split % 32 || a.Cout % 32 ||
-            a.pl_rows % 32 || a.pl_rows > a.row_split || a.bias_b || (a.flags & SX_GATE))
+        const bool p_acc = (a.flags & EPI_ACC) != 0;
+        if (rawin || nprod != 2 || a.ups != 1 || (a.row_split < a.Cout && !a.out_raw2) ||
+            (a.row_split && !a.out_raw && (p_acc || !a.out_pl)) || a.row_split % 32 || a.Cout % 32 || a.row_split > a.Cout ||
+            a.pl_rows % 32 || a.pl_rows > a.row_split || (a.pl_rows && !a.out_pl) || a.bias_b || (a.flags & SX_GATE) ||
+            ((a.flags & EPI_RES) && (!a.res || p_acc)) || ((a.flags & EPI_MASK) && !a.len))
             return hipErrorInvalidValue;
         epi = -2;
     }
@@ -1261,7 +1281,7 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
         if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
         a.flags = (a.flags & ~kSxEpiMask) | epi;
     } else
-        a.flags = SX_WN_RMW;
+        a.flags = SX_WN_RMW | (a.flags & (EPI_ACC | EPI_RES | EPI_MASK | EPI_RELU));
     if (nprod == 2) {  // two fp16 planes, three products (fp32-grade): the same specialised epilogues
         if (a.wscale == 0.f) a.wscale = 1.f;
         if (rawin)

@@ -112,11 +112,16 @@ __global__ void dds_dw_ln_gelu_kernel(const float *x, float *y, const float *w, 
 // two 128-byte rows per instruction, and B*T/32 workgroups fill the chip where the one-lane-per-(b,t)
 // kernels above ran on 128 wavefronts.  DW = 1 computes the DDSConv depthwise conv of x*mask on the fly
 // (modules.py:121-122) instead of reading `in` directly.
-template <int DW>
+// PL: the result is written once more as the two fp16 operand planes of the split-operand conv engine ([C/8][T][8] cells
+// per plane, batch stride 3 planes; conv_sx_engine.hip.hpp), transposed through LDS so that every cell leaves as one
+// 16-byte store; `peak` = that engine's range-guard slots (C % 8 == 0).
+template <int DW, bool PL = false>
 __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *out, const float *gamma,
                                                       const float *beta, const int *len, int C, int T, int flags,
-                                                      const float *dw_w, const float *dw_b, int K, int dil) {
+                                                      const float *dw_w, const float *dw_b, int K, int dil,
+                                                      uint16_t *planes = nullptr, unsigned *peak = nullptr) {
     __shared__ float red[8][32];
+    __shared__ __attribute__((aligned(16))) uint16_t cells[PL ? 2 : 1][PL ? 32 * 32 * 8 : 8];  // [plane][channel group][t][8]
     const int tid = threadIdx.x, tl = tid & 31, cg = tid >> 5;
     const int t = blockIdx.x * 32 + tl, b = blockIdx.y;
     const int L = len ? len[b] : T;
@@ -179,16 +184,41 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
     var /= (float)C;
     const float rs = 1.0f / sqrtf(var + 1e-5f);
     const float mk = (!(flags & LN_MASK) || t < L) ? 1.f : 0.f;
-    if (!tv) return;
+    if (!PL && !tv) return;
+    float pk = 0.f;
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
         const int c = cg + 8 * i;
-        if (c < C) {
+        if (c < C && tv) {
             float y = (v[i] - mean) * rs * gamma[c] + beta[c];
             if (flags & LN_GELU) y = gelu_erf(y);
             if (flags & LN_ACCUM) y += o[(int64_t)c * T + t];
-            o[(int64_t)c * T + t] = y * mk;
+            y *= mk;
+            o[(int64_t)c * T + t] = y;
+            if constexpr (PL) {
+                pk = !(__builtin_fabsf(y) <= kF16Max) ? __builtin_inff() : __builtin_fmaxf(pk, __builtin_fabsf(y));
+                const float yc = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
+                const _Float16 h0 = (_Float16)yc, h1 = (_Float16)((yc - (float)h0) * 2048.f);
+                cells[0][(i * 32 + tl) * 8 + cg] = __builtin_bit_cast(unsigned short, h0);
+                cells[1][(i * 32 + tl) * 8 + cg] = __builtin_bit_cast(unsigned short, h1);
+            }
         }
+    }
+    if constexpr (PL) {
+        __syncthreads();
+        const int CG = C >> 3;
+        uint16_t *pb = planes + (int64_t)b * 3 * CG * T * 8;
+        const int tb = blockIdx.x * 32;
+        for (int cell = tid; cell < CG * 32; cell += 256) {
+            const int g = cell >> 5, tt = tb + (cell & 31);
+            if (tt < T) {
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+                    *reinterpret_cast<u32x4 *>(pb + (((int64_t)pl * CG + g) * T + tt) * 8) =
+                        *reinterpret_cast<const u32x4 *>(&cells[pl][cell * 8]);
+            }
+        }
+        if (peak) sx_publish_peak(peak, (int)(blockIdx.x + blockIdx.y), pk);
     }
 }
 
@@ -860,7 +890,8 @@ __global__ void fill_normal_kernel(float *out, int64_t n, uint64_t seed, uint64_
 template <int DKB>  // ceil(dk/32)
 __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv, float *out, const float *relk,
                                                                const float *relv, const int *len, int Hc, int T,
-                                                               int dk, int win) {
+                                                               int dk, int win, uint16_t *planes = nullptr,
+                                                               unsigned *peak = nullptr) {
     // 4 wavefronts = 4 consecutive 32-query blocks of one (utterance, head); every 32-key block of K and V
     // is staged ONCE in LDS (coalesced 128-byte rows) and shared by the four waves.
     // K block transposed: kt[key j][d], d contiguous (row pitch KP), so that a lane's A values of four consecutive
@@ -1059,29 +1090,58 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
         relv_s[e] = d < dk ? relv[m * dk + d] : 0.f;
     }
     __syncthreads();
+    // planes (optional; dk % 8 == 0): the output once more as the fp16 operand planes of conv_o on the split-operand engine
+    // ([Hc/8][T][8] cells per plane): a lane holds four consecutive channels of each group of eight = half a cell
+    uint16_t *pb = planes ? planes + (int64_t)b * 3 * Hc * T : nullptr;
+    const int64_t plane_elems = (int64_t)Hc * T;
+    float pk = 0.f;
     if (!active) {
         for (int d = hi; d < dk; d += 2)
             if (i < T) o[(int64_t)d * T + i] = 0.f;
-        return;
-    }
-#pragma unroll
-    for (int m = 0; m < 9; m++) wrel[m] += __shfl_xor(wrel[m], 32);
-    const bool qvalid = i < L;
-    const float rl = 1.f / lrun;
-    if (i >= T) return;  // (no barrier follows)
-#pragma unroll
-    for (int db = 0; db < DKB; db++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (full || d < dk) {
-                float val = oacc[db][r];
-#pragma unroll
-                for (int m = 0; m < 9; m++)
-                    if (m < nrel) val += wrel[m] * relv_s[m * (DKB * 32) + d];
-                o[(int64_t)d * T + i] = qvalid ? val * rl : 0.f;
+        if (pb && i < T)
+            for (int d = 4 * hi; d < dk; d += 8) {
+                const int64_t cell = ((int64_t)((h * dk + d) >> 3) * T + i) * 8 + 4 * hi;
+                *reinterpret_cast<u32x2 *>(pb + cell) = u32x2{0u, 0u};
+                *reinterpret_cast<u32x2 *>(pb + plane_elems + cell) = u32x2{0u, 0u};
             }
+    } else {
+#pragma unroll
+        for (int m = 0; m < 9; m++) wrel[m] += __shfl_xor(wrel[m], 32);
+        const bool qvalid = i < L;
+        const float rl = 1.f / lrun;
+        if (i < T) {
+#pragma unroll
+            for (int db = 0; db < DKB; db++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float ov[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int r = 4 * q + e;
+                        const int d = db * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        ov[e] = 0.f;
+                        if (full || d < dk) {
+                            float val = oacc[db][r];
+#pragma unroll
+                            for (int m = 0; m < 9; m++)
+                                if (m < nrel) val += wrel[m] * relv_s[m * (DKB * 32) + d];
+                            ov[e] = qvalid ? val * rl : 0.f;
+                            o[(int64_t)d * T + i] = ov[e];
+                        }
+                    }
+                    const int d0 = db * 32 + 8 * q + 4 * hi;
+                    if (pb && (full || d0 < dk)) {
+                        unsigned wa[2], wb[2];
+                        split2h_pair_pk(ov[0], ov[1], wa[0], wa[1], pk);
+                        split2h_pair_pk(ov[2], ov[3], wb[0], wb[1], pk);
+                        const int64_t cell = ((int64_t)((h * dk + d0) >> 3) * T + i) * 8 + 4 * hi;
+                        *reinterpret_cast<u32x2 *>(pb + cell) = u32x2{wa[0], wb[0]};
+                        *reinterpret_cast<u32x2 *>(pb + plane_elems + cell) = u32x2{wa[1], wb[1]};
+                    }
+                }
         }
+    }
+    if (pb && peak) sx_publish_peak(peak, (int)(blockIdx.x + blockIdx.y + blockIdx.z), pk);  // (uniform: every thread is here)
 }
 
 }  // namespace vitsmi

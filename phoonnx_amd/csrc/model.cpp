@@ -8,6 +8,7 @@
 #include "model.hpp"
 #include "g2p_model.hpp"
 
+#include <functional>
 #include <cctype>
 #include <cmath>
 #include <cstdlib>
@@ -1055,6 +1056,30 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
         n_vocab = int(embw.dims[0]);
         H = int(embw.dims[1]);
         emb = P.put(embw);
+        // The encoder's convs once more for the split-operand engine (same arithmetic as the generator's default: two fp16
+        // planes, three products, 16x16x32 loop): 3-5 x the f32 matrix cores' rate at batch 32, and a shorter dependent
+        // chain per workgroup at batch 1.  Taken when the generator runs f16x3 (the exact mode keeps the f32 engine here:
+        // it is what a range-guard fallback falls back to); VITSMI_ENC_ENGINE=f32 for A/B timing.
+        bool enc_want_sx = false;
+        {
+            const char *ge = std::getenv("VITSMI_GEN_ENGINE"), *ee = std::getenv("VITSMI_ENC_ENGINE");
+            const char *pe = gen_precision_name();
+            enc_want_sx = !(ge && std::string(ge) == "f32") && !(ee && std::string(ee) == "f32") &&
+                          (!pe || !*pe || std::string(pe) == "f16x3") && H % 32 == 0;
+        }
+        bool enc_all_sx = enc_want_sx;
+        auto sx_twin = [&](const ConvDesc &f, const std::function<ConvDesc()> &mk) {
+            ConvDesc d;
+            if (!enc_want_sx || f.Cin % 32 || f.Cout % 32 || !sx_supported(f.Cin, f.Cout, f.Cout, f.K, f.dil)) {
+                enc_all_sx = false;
+                return d;
+            }
+            t_sx_f16 = true;
+            d = mk();
+            t_sx_f16 = false;
+            if (!d.sx || !d.f16 || !d.s16 || d.K != f.K) enc_all_sx = false;
+            return d;
+        };
         for (int l = 0;; l++) {
             std::string a = "enc_p.encoder.attn_layers." + std::to_string(l);
             if (!R.get(a + ".conv_q.weight")) break;
@@ -1076,6 +1101,8 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
             std::memcpy(b3.data() + 2 * H, bv.p, size_t(H) * 4);
             L.qkv = pack_conv(P, H, 3 * H, 1, 1, 0, wf, b3.data());
             L.o = pack_named(P, R, a + ".conv_o", 1, 0);
+            L.qkv_sx = sx_twin(L.qkv, [&] { return pack_conv_sx(P, H, 3 * H, 1, 1, 0, wf, b3.data()); });
+            L.o_sx = sx_twin(L.o, [&] { return pack_named_sx(P, R, a + ".conv_o", 1, 0); });
             const TRef &rk = R.need(a + ".emb_rel_k", 3);
             if (rk.dims[0] != 1) throw std::runtime_error("per-head relative embeddings are unsupported");
             if (rk.dims[1] % 2 != 1) throw std::runtime_error(a + ".emb_rel_k: expected 2*window+1 rows");
@@ -1100,6 +1127,8 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
             L.ffn1 = pack_named(P, R, f + ".conv_1", 1, (fk - 1) / 2);  // attentions.py:419-427
             L.ffn2 = pack_named(P, R, f + ".conv_2", 1, (fk - 1) / 2);
             if (L.ffn1.Cin != H || L.ffn2.Cin != FF || L.ffn2.Cout != H) throw std::runtime_error(f + ": unexpected FFN shape");
+            L.ffn1_sx = sx_twin(L.ffn1, [&] { return pack_named_sx(P, R, f + ".conv_1", 1, (fk - 1) / 2); });
+            L.ffn2_sx = sx_twin(L.ffn2, [&] { return pack_named_sx(P, R, f + ".conv_2", 1, (fk - 1) / 2); });
             enc.push_back(L);
         }
         n_layers = int(enc.size());
@@ -1107,6 +1136,8 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
         enc_proj = pack_named(P, R, "enc_p.proj", 1, 0);
         if (enc_proj.Cin != H || enc_proj.K != 1 || enc_proj.Cout % 2) throw std::runtime_error("enc_p.proj: unexpected shape");
         C = enc_proj.Cout / 2;
+        enc_proj_sx = sx_twin(enc_proj, [&] { return pack_named_sx(P, R, "enc_p.proj", 1, 0); });
+        enc_sx = enc_all_sx;
 
         // ---------------- speaker embedding (models.py:614-615)
         if (R.get("emb_g.weight")) {

@@ -67,6 +67,8 @@ struct ConvFlowDesc {  // modules.py:469-527
 
 struct EncLayerDesc {
     ConvDesc qkv, o, ffn1, ffn2;
+    // the same four convs packed for the split-operand engine (16x16x32 loop, planar epilogue): read when Model::enc_sx
+    ConvDesc qkv_sx, o_sx, ffn1_sx, ffn2_sx;
     int64_t rel_k = -1, rel_v = -1;  // [2w+1, dk]
     int64_t ln1_g = -1, ln1_b = -1, ln2_g = -1, ln2_b = -1;
 };
@@ -109,6 +111,8 @@ struct Model {
     int64_t emb = -1;
     std::vector<EncLayerDesc> enc;
     ConvDesc enc_proj;
+    ConvDesc enc_proj_sx;  // (split-operand engine, see EncLayerDesc)
+    bool enc_sx = false;   // the encoder's convs run on the split-operand engine (f16x3; VITSMI_ENC_ENGINE=f32 keeps the f32 engine)
 
     // ---- speaker conditioning
     int64_t emb_g = -1;

@@ -420,6 +420,26 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     h->stats.sx_launches++;
 }
 
+// A token- / frame-domain conv on the split-operand engine with the planar epilogue (SX_WN_RMW): x_pl = fp16 operand planes
+// of the input; out (may be nullptr when out_pl is given) = planar fp32 [B][Cout][T]; out_pl = operand planes of the output
+// for the next conv; flags = EPI_RELU | EPI_MASK | EPI_ACC | EPI_RES (res: planar, the shape of out).
+void conv_sx_planar(Ctx &c, const ConvDesc &d, const uint16_t *x_pl, int T, float *out, uint16_t *out_pl, int flags,
+                    const int *len = nullptr, const float *res = nullptr) {
+    SxWn w;
+    w.len = len;
+    w.row_split = d.Cout;
+    w.pl_rows = out_pl ? d.Cout : 0;
+    conv_sx(c, d, x_pl, T, out, out_pl, SX_WN_RMW | flags, res, nullptr, 0, 1.f, 1.f, 1.f, 1.f, &w);
+}
+
+// planar fp32 [B][C][T] (masked by len when given) -> fp16 operand planes of the split-operand engine
+void split_planes(Ctx &c, const float *x, uint16_t *pl, int C, int T, const int *len) {
+    sx_split_planes_kernel<<<dim3((T + 255) / 256, C / 8, c.B), 256, 0, c.st>>>(x, (int64_t)C * T, T, len, pl, C, T, 1,
+                                                                                range_slots(c.h, true));
+    c.note(hipGetLastError());
+    c.h->stats.total_launches++;
+}
+
 // Two dependent convs of a ResBlock as ONE launch (conv_sx_pair.hip.hpp), raw-format stages only (x, out: fp32 raw
 // [B][C/8][T][8]): a ResBlock1 step, out = c2(lrelu(c1(lrelu(x)))) + x, or (chain) two ResBlock2 steps,
 // x1 = c1(lrelu(x)) + x, out = c2(lrelu(x1)) + x1; then [+ out] [/ div].
@@ -496,14 +516,20 @@ void pinned_put(vits_handle *h, void *q) {
     else hipHostFree(q);
 }
 
-void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const int *len, int C, int T, int flags) {
-    if (C <= 256)
+// planes (optional): the result once more as fp16 operand planes of the split-operand engine (see split_planes)
+void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const int *len, int C, int T, int flags,
+               uint16_t *planes = nullptr) {
+    if (C <= 256 && planes && C % 8 == 0)
+        ln_tile_kernel<0, true><<<dim3((T + 31) / 32, c.B), 256, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags, nullptr,
+                                                                            nullptr, 1, 1, planes, range_slots(c.h, true));
+    else if (C <= 256)
         ln_tile_kernel<0><<<dim3((T + 31) / 32, c.B), 256, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags, nullptr,
                                                                       nullptr, 1, 1);
     else
         layernorm_c_kernel<<<dim3((T + 63) / 64, c.B), 64, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags);
     c.note(hipGetLastError());
     c.h->stats.total_launches++;
+    if (planes && !(C <= 256 && C % 8 == 0)) split_planes(c, out, planes, C, T, nullptr);
 }
 
 // DDSConv (modules.py:117-129) in place on h [B,C,T]; y,y2 are scratch of the same size.
@@ -598,6 +624,7 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     need += al(nHT) * 4;                                   // x, attn out, embedding, spare
     need += al((size_t)B * 3 * H * T);                     // qkv
     need += al((size_t)B * m.FF * T);                      // ffn hidden
+    if (m.enc_sx) need += 2 * al(nHT * 3 / 2 + 64) + al((size_t)B * m.FF * T * 3 / 2 + 64);  // operand planes: x, attn out, ffn hidden
     need += al((size_t)B * 2 * C * T) + 2 * al((size_t)B * C * T);  // stats, m_p, logs_p
     need += al((size_t)B * Cdp * T) * 5;                   // dp buffers
     int pr_rows = 32;  // spline parameters per position: 3 * bins - 1 (29 for the reference's 10 bins, up to 47)
@@ -637,7 +664,41 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     h->stats.total_launches += 2;
     const int64_t sHT = (int64_t)H * T;
     const float *xin = xe;  // layer input: the embedding for layer 0, x afterwards
+    // split-operand engine (Model::enc_sx): every conv reads fp16 operand planes and writes planar fp32 (what attention,
+    // LayerNorm and the duration predictor read) or planes for the next conv
+    uint16_t *x_pl = nullptr, *att_pl = nullptr, *ff_pl = nullptr;
+    if (m.enc_sx) {
+        x_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, nHT * 3 / 2 + 64));
+        att_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, nHT * 3 / 2 + 64));
+        ff_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, (size_t)B * m.FF * T * 3 / 2 + 64));
+        split_planes(c, xe, x_pl, H, T, len);
+    }
     for (auto &L : m.enc) {
+        if (m.enc_sx) {
+            conv_sx_planar(c, L.qkv_sx, x_pl, T, qkv, nullptr, 0);
+            dim3 ag((T + 127) / 128, m.n_heads, B);
+            int dkb = (m.dk + 31) / 32;
+            // (the attention kernel writes its output as conv_o's operand planes too when head widths are whole cells)
+            uint16_t *apl = m.dk % 8 == 0 ? att_pl : nullptr;
+            unsigned *apk = apl ? range_slots(h, true) : nullptr;
+            switch (dkb) {
+                case 1: attention_relpos_kernel<1><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window, apl, apk); break;
+                case 2: attention_relpos_kernel<2><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window, apl, apk); break;
+                case 3: attention_relpos_kernel<3><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window, apl, apk); break;
+                default: attention_relpos_kernel<4><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window, apl, apk); break;
+            }
+            c.note(hipGetLastError());
+            h->stats.total_launches++;
+            h->stats.enc_flops += 2.0 * B * m.n_heads * (2.0 * m.dk * T * (double)T);
+            if (!apl) split_planes(c, att, att_pl, H, T, nullptr);
+            conv_sx_planar(c, L.o_sx, att_pl, T, x, nullptr, EPI_RES, nullptr, xin);
+            xin = x;
+            layernorm(c, x, x, L.ln1_g, L.ln1_b, len, H, T, LN_MASK, x_pl);
+            conv_sx_planar(c, L.ffn1_sx, x_pl, T, nullptr, ff_pl, EPI_RELU | EPI_MASK, len);
+            conv_sx_planar(c, L.ffn2_sx, ff_pl, T, x, nullptr, EPI_MASK | EPI_ACC, len);
+            layernorm(c, x, x, L.ln2_g, L.ln2_b, len, H, T, LN_MASK, x_pl);
+            continue;
+        }
         // q|k|v = 1x1 convs (attentions.py:216-218), fused into one [3H,H] GEMM
         conv(c, L.qkv, xin, sHT, T, qkv, 3 * sHT, 0);
         dim3 ag((T + 127) / 128, m.n_heads, B);
@@ -666,7 +727,8 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     // x = x * mask ; stats = proj(x) * mask (models.py:205-208)
     mask_kernel<<<dim3((T + 255) / 256, H, B), 256, 0, st>>>(x, len, H, T);
     h->stats.total_launches++;
-    conv(c, m.enc_proj, x, sHT, T, stats, (int64_t)2 * C * T, EPI_MASK, len);
+    if (m.enc_sx) conv_sx_planar(c, m.enc_proj_sx, x_pl, T, stats, nullptr, EPI_MASK, len);
+    else conv(c, m.enc_proj, x, sHT, T, stats, (int64_t)2 * C * T, EPI_MASK, len);
     h->d_mp = stats;                       // [B, 2C, T] : m_p = rows [0,C), logs_p = rows [C,2C)
     h->d_logs = stats + (int64_t)C * T;    // batch stride 2*C*T for both
 
@@ -1177,7 +1239,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
                     w.row_split = last ? 0 : Hf;
                     const bool np = !last && cd.wn[i + 1].in.sx && cd.wn[i + 1].in.f16 && Hf % 32 == 0;
                     w.pl_rows = np ? Hf : 0;
-                    conv_sx(c, cd.wn[i].rs_sx, acts_pl, F, hx, np ? hx_pl : nullptr, SX_WN_RMW, nullptr, nullptr, 0, 1.f, 1.f, 1.f,
+                    conv_sx(c, cd.wn[i].rs_sx, acts_pl, F, hx, np ? hx_pl : nullptr, SX_WN_RMW | EPI_ACC | EPI_MASK, nullptr, nullptr, 0, 1.f, 1.f, 1.f,
                             1.f, &w);
                     continue;
                 } else if (cd.wn[i].in.gate) {  // tanh * sigmoid in the conv's epilogue: acts directly

@@ -148,7 +148,7 @@ class MiSession:
     def _fall_back_to_bf16x6(self, exc):
         """After a RangeError: reopen this voice with the exact six-product arithmetic (bf16 planes: fp32 range)."""
         import logging
-        if not self.range_fallback or self.hparam("gen_nprod") != 2:
+        if not self.range_fallback or self.gen_precision == "bf16x6":  # (only fp16 planes raise it: encoder, flow, generator)
             raise exc
         logging.getLogger(__name__).warning("%s: %s - reopening with gen_precision='bf16x6' (1.8x slower; "
                                             "stats()['range_fallbacks'] counts these)", self.path, exc)
@@ -531,7 +531,9 @@ class PipelinedSession:
     def _borrow(self):
         """(Re)create the handles that share parts[0]'s arena (laid out for ITS arithmetic)."""
         first = self.parts[0]
-        precision = {2: "f16x3", 6: "bf16x6", 3: "bf16x3", 1: "bf16"}[int(first.hparam("gen_nprod"))]
+        # the arithmetic the owner was opened with, as it was asked for: the layout of every split-operand conv (encoder,
+        # flow, generator) follows the request, also where this voice's generator cannot use that engine
+        precision = first.gen_precision
         for _ in range(self._n_parts - 1):
             self.parts.append(MiSession(first.path, device_id=first.device_id, arena_device_ptr=first.arena_device(),
                                         arena_bytes=first.arena_bytes(), gen_precision=precision))
@@ -541,7 +543,7 @@ class PipelinedSession:
         six-product arithmetic (bf16 planes: fp32 range), then the borrowers are recreated on the new arena."""
         import logging
         first = self.parts[0]
-        if not self.range_fallback or first.hparam("gen_nprod") != 2:
+        if not self.range_fallback or first.gen_precision == "bf16x6":
             raise exc
         logging.getLogger(__name__).warning("%s: %s - reopening all %d handles with gen_precision='bf16x6'", first.path, exc,
                                             len(self.parts))
