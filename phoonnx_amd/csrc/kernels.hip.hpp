@@ -10,7 +10,30 @@
 
 namespace vitsmi {
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// erf without branches (both ranges evaluated, one select; < 1 ulp against double erf over the whole range): the library
+// erff branches on |x|, and a branch per element splits an unrolled loop into basic blocks - the loads of each
+// element's parameters then wait for their own round trip instead of travelling together
+__device__ __forceinline__ float erf_nb(float a) {
+    const float t = __builtin_fabsf(a), s = a * a;
+    float r = __builtin_fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = __builtin_fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = __builtin_fmaf(r, s, u);
+    r = __builtin_fmaf(r, t, -1.06777877e-1f);
+    r = __builtin_fmaf(r, t, -6.34846687e-1f);
+    r = __builtin_fmaf(r, t, -1.28717512e-1f);
+    r = __builtin_fmaf(r, t, -t);
+    r = 1.0f - __expf(r);  // (r <= 0: exp2 of a scaled argument, no range cases)
+    r = __builtin_copysignf(r, a);
+    float q = -5.96761703e-4f;
+    q = __builtin_fmaf(q, s, 4.99119423e-3f);
+    q = __builtin_fmaf(q, s, -2.67681349e-2f);
+    q = __builtin_fmaf(q, s, 1.12819925e-1f);
+    q = __builtin_fmaf(q, s, -3.76125336e-1f);
+    q = __builtin_fmaf(q, s, 1.28379166e-1f);
+    q = __builtin_fmaf(q, a, a);
+    return t > 0.927734375f ? r : q;
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erf_nb(v * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + expf(-v)); }
 __device__ __forceinline__ float softplus_f(float v) { return v > 20.0f ? v : log1pf(expf(v)); }
 
@@ -132,11 +155,33 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
     float v[CPT];
     const int pad = (K * dil - dil) / 2;
     float s = 0.f;
+    // Every per-channel operand is requested up front with a clamped (always valid) address and selected afterwards: a
+    // predicate per element makes each load its own basic block, i.e. one exposed round trip per channel (the plain
+    // LayerNorm spent 20 us on 32 of them).  gv / bv: gamma, beta; av: the LN_ACCUM operand.
+    float gv[CPT], bv[CPT], av[CPT];
+    const int tcl = tv ? t : T - 1;
+#pragma unroll
+    for (int i = 0; i < CPT; i++) {
+        const int c = cg + 8 * i, cc = c < C ? c : cg;
+        gv[i] = gamma[cc];
+        bv[i] = beta[cc];
+        if (DW == 0) v[i] = p[(int64_t)cc * T + tcl];
+    }
+    if (flags & LN_ACCUM) {  // (uniform; `in` and `out` may be the same tensor: read before anything is stored)
+#pragma unroll
+        for (int i = 0; i < CPT; i++) av[i] = o[(int64_t)(cg + 8 * i < C ? cg + 8 * i : cg) * T + tcl];
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) av[i] = 0.f;
+    }
+    const float relu_floor = (flags & LN_RELU_IN) ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
         const int c = cg + 8 * i;
         float x = 0.f;
-        if (c < C && tv) {
+        if (DW == 0) {
+            x = (c < C && tv) ? fmaxf(v[i], relu_floor) : 0.f;
+        } else if (c < C && tv) {
             if (DW > 1) {
                 // tap count known at compile time (DW = K; 3 in every DDSConv): the loads of all taps and channels are
                 // in flight together instead of one round trip per (channel, tap)
@@ -154,9 +199,6 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
                     const float xv = (tt >= 0 && tt < T && tt < L) ? p[(int64_t)c * T + tt] : 0.f;
                     x += dw_w[c * K + k] * xv;
                 }
-            } else {
-                x = p[(int64_t)c * T + t];
-                if (flags & LN_RELU_IN) x = fmaxf(x, 0.f);
             }
         }
         v[i] = x;
@@ -186,14 +228,19 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
     const float mk = (!(flags & LN_MASK) || t < L) ? 1.f : 0.f;
     if (!PL && !tv) return;
     float pk = 0.f;
+    float yv[CPT];
+    if (flags & LN_GELU) {  // (uniform, outside the element loop)
+#pragma unroll
+        for (int i = 0; i < CPT; i++) yv[i] = (gelu_erf((v[i] - mean) * rs * gv[i] + bv[i]) + av[i]) * mk;
+    } else {
+#pragma unroll
+        for (int i = 0; i < CPT; i++) yv[i] = ((v[i] - mean) * rs * gv[i] + bv[i] + av[i]) * mk;
+    }
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
         const int c = cg + 8 * i;
         if (c < C && tv) {
-            float y = (v[i] - mean) * rs * gamma[c] + beta[c];
-            if (flags & LN_GELU) y = gelu_erf(y);
-            if (flags & LN_ACCUM) y += o[(int64_t)c * T + t];
-            y *= mk;
+            const float y = yv[i];
             o[(int64_t)c * T + t] = y;
             if constexpr (PL) {
                 pk = !(__builtin_fabsf(y) <= kF16Max) ? __builtin_inff() : __builtin_fmaxf(pk, __builtin_fabsf(y));
@@ -263,15 +310,33 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
     const int spc = a.CK >> 3;           // float4 groups per (block, chunk)
     constexpr int NG = C >> 3;           // groups per block
     constexpr int MAXB = (NBLK + 3) / 4; // blocks per wave
-    float4 wa[NG];
-    auto load_w = [&](int mb) {
+    // (all of this wave's blocks are requested here, ahead of stage 1: their round trip is hidden behind it)
+    float4 wa[MAXB][NG];
 #pragma unroll
-        for (int gi = 0; gi < NG; gi++) {
-            const int ch = gi / spc, g = gi - ch * spc;
-            wa[gi] = reinterpret_cast<const float4 *>(a.pw)[(((int64_t)((mb / a.MB) * a.nchunks + ch) * a.MB + (mb % a.MB)) * spc + g) * 64 + lane];
+    for (int j = 0; j < MAXB; j++) {
+        const int mb = wave + 4 * j;
+        if (mb < NBLK) {
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) {
+                const int ch = gi / spc, g = gi - ch * spc;
+                wa[j][gi] = reinterpret_cast<const float4 *>(a.pw)[(((int64_t)((mb / a.MB) * a.nchunks + ch) * a.MB + (mb % a.MB)) * spc + g) * 64 + lane];
+            }
         }
-    };
-    if (wave < NBLK) load_w(wave);
+    }
+    // per-channel parameters of all three stages: one coalesced batch into LDS (read per element from global memory, inside
+    // loops the GELU used to split into basic blocks, every element waited for its own round trip: ~25 of the layer's 50 us)
+    __shared__ float prm[9][C];  // dw_b, dw_w tap 0..2, ln1_g, ln1_b, pw_bias, ln2_g, ln2_b
+    for (int e = tid; e < C; e += 256) {
+        prm[0][e] = a.dw_b[e];
+        prm[1][e] = a.dw_w[e * 3];
+        prm[2][e] = a.dw_w[e * 3 + 1];
+        prm[3][e] = a.dw_w[e * 3 + 2];
+        prm[4][e] = a.ln1_g[e];
+        prm[5][e] = a.ln1_b[e];
+        prm[6][e] = a.pw_bias[e];
+        prm[7][e] = a.ln2_g[e];
+        prm[8][e] = a.ln2_b[e];
+    }
     // ---- stage 1: depthwise conv (k = 3) of x * mask, LayerNorm over channels, GELU -> y1 (thread: channels cg + 8 i)
     constexpr int CPT = C / 8;
     {
@@ -287,15 +352,20 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
             ok[k] = tv && tt[k] >= 0 && tt[k] < T && tt[k] < L;
             tt[k] = ok[k] ? tt[k] : 0;
         }
+        // all 3 * CPT loads travel together (always inside the row; masked taps are zeroed below) ...
+        float xr[CPT][3];
+#pragma unroll
+        for (int i = 0; i < CPT; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) xr[i][k] = p[(int64_t)(cg + 8 * i) * T + tt[k]];
+        __builtin_amdgcn_sched_barrier(0);  // ... (the scheduler otherwise sinks each load to its use, three in flight at a time)
+        __syncthreads();                    // prm is in LDS
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int c = cg + 8 * i;
-            float x = a.dw_b[c];
+            float x = prm[0][c];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float xv = p[(int64_t)c * T + tt[k]];  // (always inside the row; masked taps multiply by zero below)
-                x += a.dw_w[c * 3 + k] * (ok[k] ? xv : 0.f);
-            }
+            for (int k = 0; k < 3; k++) x += prm[1 + k][c] * (ok[k] ? xr[i][k] : 0.f);
             v[i] = tv ? x : 0.f;
             s += v[i];
         }
@@ -322,7 +392,7 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
 #pragma unroll
         for (int i = 0; i < CPT; i++) {
             const int c = cg + 8 * i;
-            y1[c * 32 + tl] = tv ? gelu_erf((v[i] - mean) * rs * a.ln1_g[c] + a.ln1_b[c]) : 0.f;
+            y1[c * 32 + tl] = tv ? gelu_erf((v[i] - mean) * rs * prm[4][c] + prm[5][c]) : 0.f;
         }
     }
     __syncthreads();
@@ -330,33 +400,10 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
     // Group gi covers input channels 8 gi .. 8 gi + 7 (chunks are consecutive): this lane's B values of its four k-steps
     // sit at compile-time offsets from one base, so the reads of a whole block are plain loads the compiler batches ahead
     // of the MFMA chain.
-    f32x16_ acc[MAXB];
-#pragma unroll
-    for (int j = 0; j < MAXB; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
-    const float *yb = y1 + hi * 32 + (lane & 31);
-#pragma unroll
-    for (int j = 0; j < MAXB; j++) {
-        const int mb = wave + 4 * j;
-        if (mb < NBLK) {  // (uniform per wave)
-            if (j > 0) load_w(mb);
-#pragma unroll
-            for (int gi = 0; gi < NG; gi++) {
-                const float b0 = yb[(8 * gi + 0) * 32], b1 = yb[(8 * gi + 2) * 32], b2 = yb[(8 * gi + 4) * 32], b3 = yb[(8 * gi + 6) * 32];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[gi].x, b0, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[gi].y, b1, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[gi].z, b2, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[gi].w, b3, acc[j], 0, 0, 0);
-            }
-        }
-    }
-    // ---- stage 3: + bias, LayerNorm over channels (column = lane & 31, rows spread over registers, `hi`, blocks, waves),
-    // GELU, residual, mask.  C/D layout: row = (r & 3) + 8 * (r >> 2) + 4 * hi, col = lane & 31.
+    // (stage 3's column and its residual operands, requested ahead of the MFMA chain)
     const int col = lane & 31;
     const int tc = t0 + col;
     const bool tcv = tc < T;
-    // the residual operands travel while the statistics are formed
     float resv[MAXB][16];
 #pragma unroll
     for (int j = 0; j < MAXB; j++) {
@@ -369,6 +416,28 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
             }
         }
     }
+    f32x16_ acc[MAXB];
+#pragma unroll
+    for (int j = 0; j < MAXB; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    const float *yb = y1 + hi * 32 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < MAXB; j++) {
+        const int mb = wave + 4 * j;
+        if (mb < NBLK) {  // (uniform per wave)
+#pragma unroll
+            for (int gi = 0; gi < NG; gi++) {
+                const float b0 = yb[(8 * gi + 0) * 32], b1 = yb[(8 * gi + 2) * 32], b2 = yb[(8 * gi + 4) * 32], b3 = yb[(8 * gi + 6) * 32];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j][gi].x, b0, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j][gi].y, b1, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j][gi].z, b2, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j][gi].w, b3, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- stage 3: + bias, LayerNorm over channels (column = lane & 31, rows spread over registers, `hi`, blocks, waves),
+    // GELU, residual, mask.  C/D layout: row = (r & 3) + 8 * (r >> 2) + 4 * hi, col = lane & 31.
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < MAXB; j++) {
@@ -376,7 +445,7 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
         if (mb < NBLK) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                acc[j][r] += a.pw_bias[mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+                acc[j][r] += prm[6][mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
                 s += acc[j][r];
             }
         }
@@ -415,7 +484,7 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int c = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float y = gelu_erf((acc[j][r] - mean) * rs * a.ln2_g[c] + a.ln2_b[c]);
+                const float y = gelu_erf((acc[j][r] - mean) * rs * prm[7][c] + prm[8][c]);
                 o[(int64_t)c * T + tc] = (resv[j][r] + y) * mk;
             }
         }
@@ -1085,9 +1154,11 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
     // dependent global loads in the epilogue
     __syncthreads();
     float *relv_s = kt;  // (32 * KP >= 9 * DKB * 32 floats)
-    for (int e = tid; e < nrel * DKB * 32; e += 256) {
+    // (all nine rows, zeros beyond 2 win + 1: the epilogue's nine terms per element then need no predicate - as 432
+    // branch + LDS read + wait triples they cost ~18 us of this kernel's ~95)
+    for (int e = tid; e < 9 * DKB * 32; e += 256) {
         const int m = e / (DKB * 32), d = e - m * (DKB * 32);
-        relv_s[e] = d < dk ? relv[m * dk + d] : 0.f;
+        relv_s[e] = (m < nrel && d < dk) ? relv[m * dk + d] : 0.f;
     }
     __syncthreads();
     // planes (optional; dk % 8 == 0): the output once more as the fp16 operand planes of conv_o on the split-operand engine
@@ -1123,8 +1194,7 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
                         if (full || d < dk) {
                             float val = oacc[db][r];
 #pragma unroll
-                            for (int m = 0; m < 9; m++)
-                                if (m < nrel) val += wrel[m] * relv_s[m * (DKB * 32) + d];
+                            for (int m = 0; m < 9; m++) val += wrel[m] * relv_s[m * (DKB * 32) + d];  // (wrel[m >= nrel] = 0)
                             ov[e] = qvalid ? val * rl : 0.f;
                             o[(int64_t)d * T + i] = ov[e];
                         }
