@@ -956,8 +956,12 @@ __global__ void fill_normal_kernel(float *out, int64_t n, uint64_t seed, uint64_
 //   + sum_{|j-i|<=w} p[i,j] * E_v[j-i+w] (attentions.py:261-268); everything divided by the row sum.
 // Query columns live on lanes (lane&31) in both products, so the softmax statistics are per-lane
 // scalars and the only cross-lane traffic is one lane^32 exchange per block.
-template <int DKB>  // ceil(dk/32)
-__global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv, float *out, const float *relk,
+// KH = 2: the key blocks of an utterance are dealt to two halves of 4 waves each (first / second half of the blocks, own
+// K/V staging buffers), whose online-softmax states (m, l, O, relative-value weights) meet in LDS at the end: the
+// dependent chain of a wave - 2 x DKB x 16 64-cycle MFMAs plus a softmax per key block, one wave per SIMD - halves, and a
+// batch of 32 fills 1024 instead of 512 of the chip's wave slots.  The split depends on the utterance's length only.
+template <int DKB, int KH = 2>  // ceil(dk/32), key halves
+__global__ __launch_bounds__(256 * KH) void attention_relpos_kernel(const float *qkv, float *out, const float *relk,
                                                                const float *relv, const int *len, int Hc, int T,
                                                                int dk, int win, uint16_t *planes = nullptr,
                                                                unsigned *peak = nullptr) {
@@ -967,9 +971,14 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
     // k-steps (d = 2 st + hi) are one 32-byte read; V block vs[d][key j] (row pitch VP): the four keys a lane needs
     // per accumulator quad are one 16-byte read.  Pitches = 4 mod 32 floats: 16-byte reads of 8 lanes tile the banks.
     constexpr int KP = DKB * 32 + 4, VP = 36;
-    __shared__ __attribute__((aligned(16))) float kt[32 * KP];
-    __shared__ __attribute__((aligned(16))) float vs[DKB * 32 * VP];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    constexpr int HALF_FLOATS = 32 * KP + DKB * 32 * VP;      // one half's K and V staging
+    constexpr int MERGE_ITEMS = 2 + DKB * 16 + 9;             // m, l, O accumulators, relative-value weights
+    constexpr int SMEM = KH * HALF_FLOATS > 256 * MERGE_ITEMS || KH == 1 ? KH * HALF_FLOATS : 256 * MERGE_ITEMS;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    __shared__ float s_pk8[4];
+    const int half = KH == 1 ? 0 : (int)(threadIdx.x >> 8);
+    float *kt = smem + half * HALF_FLOATS, *vs = kt + 32 * KP;
+    const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int i0 = (blockIdx.x * 4 + wave) * 32, h = blockIdx.y, b = blockIdx.z;
     const int L = len[b] < T ? len[b] : T;
     const int i = i0 + l31;
@@ -1036,6 +1045,7 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
         for (int r = 0; r < 16; r++) oacc[db][r] = 0.f;
 
     const int nkb = (L + 31) / 32;
+    const int nkb_h = (nkb + KH - 1) / KH, kb0 = half * nkb_h;  // this half: blocks kb0 .. kb0 + nkb_h - 1 (those < nkb)
     const int srow = tid >> 5, scol = tid & 31;  // staging: 8 rows x 32 columns per pass
     // K/V block kb+1 is fetched into registers while block kb is being consumed from LDS (the global latency of a
     // block would otherwise sit in front of every one of its 2 x DKB x 16 MFMAs)
@@ -1063,8 +1073,10 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
             vreg[r] = ok ? v[(int64_t)d * T + j] : 0.f;
         }
     };
-    if (nkb > 0) fetch(0);
-    for (int kb = 0; kb < nkb; kb++) {
+    if (kb0 < nkb) fetch(kb0);
+    for (int it = 0; it < nkb_h; it++) {
+        const int kb = kb0 + it;
+        const bool kvalid = kb < nkb;  // (uniform per half; both halves pass the same barriers)
         const int j0 = kb * 32;
         __syncthreads();
 #pragma unroll
@@ -1073,9 +1085,9 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
             kt[scol * KP + d] = kreg[r];
             vs[d * VP + scol] = vreg[r];
         }
-        if (kb + 1 < nkb) fetch(kb + 1);
+        if (it + 1 < nkb_h && kb + 1 < nkb) fetch(kb + 1);
         __syncthreads();
-        if (!active) continue;
+        if (!active || !kvalid) continue;
         // two accumulators: the STEPS MFMAs are one dependent chain otherwise (16 passes each)
         f32x16 s, s2;
 #pragma unroll
@@ -1150,13 +1162,41 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[db][e], s[4 * q4 + e], oacc[db], 0, 0, 0);
         }
     }
+    if constexpr (KH == 2) {
+        // the second half's state -> LDS ([item][lane of the half]: conflict free) -> folded into the first half's
+        __syncthreads();  // (both halves are done with their staging buffers)
+        if (half == 1) {
+            smem[0 * 256 + tid] = mrun;
+            smem[1 * 256 + tid] = lrun;
+#pragma unroll
+            for (int db = 0; db < DKB; db++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) smem[(2 + db * 16 + r) * 256 + tid] = oacc[db][r];
+#pragma unroll
+            for (int m = 0; m < 9; m++) smem[(2 + DKB * 16 + m) * 256 + tid] = wrel[m];
+        }
+        __syncthreads();
+        if (half == 0 && active) {
+            const float m1 = smem[0 * 256 + tid], l1 = smem[1 * 256 + tid];
+            const float mnew = fmaxf(mrun, m1);  // (mrun is finite: an active wave's first half holds key block 0)
+            const float a0 = __expf(mrun - mnew), a1 = __expf(m1 - mnew);
+            lrun = lrun * a0 + l1 * a1;
+            mrun = mnew;
+#pragma unroll
+            for (int db = 0; db < DKB; db++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) oacc[db][r] = oacc[db][r] * a0 + smem[(2 + db * 16 + r) * 256 + tid] * a1;
+#pragma unroll
+            for (int m = 0; m < 9; m++) wrel[m] = wrel[m] * a0 + smem[(2 + DKB * 16 + m) * 256 + tid] * a1;
+        }
+    }
     // relative-value embeddings E_v staged once (as E_k was): nine values per output element otherwise come as
     // dependent global loads in the epilogue
     __syncthreads();
-    float *relv_s = kt;  // (32 * KP >= 9 * DKB * 32 floats)
+    float *relv_s = smem;  // (32 * KP >= 9 * DKB * 32 floats)
     // (all nine rows, zeros beyond 2 win + 1: the epilogue's nine terms per element then need no predicate - as 432
     // branch + LDS read + wait triples they cost ~18 us of this kernel's ~95)
-    for (int e = tid; e < 9 * DKB * 32; e += 256) {
+    for (int e = threadIdx.x; e < 9 * DKB * 32; e += 256 * KH) {
         const int m = e / (DKB * 32), d = e - m * (DKB * 32);
         relv_s[e] = (m < nrel && d < dk) ? relv[m * dk + d] : 0.f;
     }
@@ -1166,7 +1206,9 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
     uint16_t *pb = planes ? planes + (int64_t)b * 3 * Hc * T : nullptr;
     const int64_t plane_elems = (int64_t)Hc * T;
     float pk = 0.f;
-    if (!active) {
+    if (half != 0) {
+        // (the first half writes the result)
+    } else if (!active) {
         for (int d = hi; d < dk; d += 2)
             if (i < T) o[(int64_t)d * T + i] = 0.f;
         if (pb && i < T)
@@ -1211,7 +1253,18 @@ __global__ __launch_bounds__(256) void attention_relpos_kernel(const float *qkv,
                 }
         }
     }
-    if (pb && peak) sx_publish_peak(peak, (int)(blockIdx.x + blockIdx.y + blockIdx.z), pk);  // (uniform: every thread is here)
+    if (pb && peak) {  // (uniform: every thread is here; the first half's four waves carry the peak)
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) pk = __builtin_fmaxf(pk, __shfl_xor(pk, o2, 64));
+        if (half == 0 && lane == 0) s_pk8[wave] = pk;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            pk = __builtin_fmaxf(__builtin_fmaxf(s_pk8[0], s_pk8[1]), __builtin_fmaxf(s_pk8[2], s_pk8[3]));
+            unsigned *slot = peak + ((blockIdx.x + blockIdx.y + blockIdx.z) & (kSxPeakSlots - 1)) * kSxPeakStride;
+            const unsigned bits = __float_as_uint(pk);
+            if (bits > __builtin_nontemporal_load(slot)) atomicMax(slot, bits);
+        }
+    }
 }
 
 }  // namespace vitsmi

@@ -420,6 +420,28 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     h->stats.sx_launches++;
 }
 
+// a3: relative-position attention core, one launch (kernels.hip.hpp).  Two key halves per workgroup unless
+// VITSMI_ATT_NOSPLIT is set (A/B timing only).
+void launch_attention(hipStream_t st, int B, int T, int n_heads, int dk, int window, const float *qkv, float *att,
+                      const float *rel_k, const float *rel_v, const int *len, int H, uint16_t *planes = nullptr,
+                      unsigned *peak = nullptr) {
+    static const bool nosplit = std::getenv("VITSMI_ATT_NOSPLIT") != nullptr;
+    dim3 ag((T + 127) / 128, n_heads, B);
+    const int dkb = (dk + 31) / 32;
+#define VITSMI_ATT(DKB)                                                                                                       \
+    do {                                                                                                                      \
+        if (nosplit) attention_relpos_kernel<DKB, 1><<<ag, 256, 0, st>>>(qkv, att, rel_k, rel_v, len, H, T, dk, window, planes, peak); \
+        else attention_relpos_kernel<DKB, 2><<<ag, 512, 0, st>>>(qkv, att, rel_k, rel_v, len, H, T, dk, window, planes, peak);         \
+    } while (0)
+    switch (dkb) {
+        case 1: VITSMI_ATT(1); break;
+        case 2: VITSMI_ATT(2); break;
+        case 3: VITSMI_ATT(3); break;
+        default: VITSMI_ATT(4); break;
+    }
+#undef VITSMI_ATT
+}
+
 // A token- / frame-domain conv on the split-operand engine with the planar epilogue (SX_WN_RMW): x_pl = fp16 operand planes
 // of the input; out (may be nullptr when out_pl is given) = planar fp32 [B][Cout][T]; out_pl = operand planes of the output
 // for the next conv; flags = EPI_RELU | EPI_MASK | EPI_ACC | EPI_RES (res: planar, the shape of out).
@@ -676,17 +698,10 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     for (auto &L : m.enc) {
         if (m.enc_sx) {
             conv_sx_planar(c, L.qkv_sx, x_pl, T, qkv, nullptr, 0);
-            dim3 ag((T + 127) / 128, m.n_heads, B);
-            int dkb = (m.dk + 31) / 32;
             // (the attention kernel writes its output as conv_o's operand planes too when head widths are whole cells)
             uint16_t *apl = m.dk % 8 == 0 ? att_pl : nullptr;
-            unsigned *apk = apl ? range_slots(h, true) : nullptr;
-            switch (dkb) {
-                case 1: attention_relpos_kernel<1><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window, apl, apk); break;
-                case 2: attention_relpos_kernel<2><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window, apl, apk); break;
-                case 3: attention_relpos_kernel<3><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window, apl, apk); break;
-                default: attention_relpos_kernel<4><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window, apl, apk); break;
-            }
+            launch_attention(st, B, T, m.n_heads, m.dk, m.window, qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, apl,
+                             apl ? range_slots(h, true) : nullptr);
             c.note(hipGetLastError());
             h->stats.total_launches++;
             h->stats.enc_flops += 2.0 * B * m.n_heads * (2.0 * m.dk * T * (double)T);
@@ -701,14 +716,7 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
         }
         // q|k|v = 1x1 convs (attentions.py:216-218), fused into one [3H,H] GEMM
         conv(c, L.qkv, xin, sHT, T, qkv, 3 * sHT, 0);
-        dim3 ag((T + 127) / 128, m.n_heads, B);
-        int dkb = (m.dk + 31) / 32;
-        switch (dkb) {
-            case 1: attention_relpos_kernel<1><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
-            case 2: attention_relpos_kernel<2><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
-            case 3: attention_relpos_kernel<3><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
-            default: attention_relpos_kernel<4><<<ag, 256, 0, st>>>(qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, T, m.dk, m.window); break;
-        }
+        launch_attention(st, B, T, m.n_heads, m.dk, m.window, qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H);
         c.note(hipGetLastError());
         h->stats.total_launches++;
         h->stats.enc_flops += 2.0 * B * m.n_heads * (2.0 * m.dk * T * (double)T);
@@ -2303,13 +2311,7 @@ int vits_test_attention(int device_id, const float *qkv, int B, int C, int T, in
     TCHECK(hipMemcpy(drk, rel_k, nr * 4, hipMemcpyHostToDevice));
     TCHECK(hipMemcpy(drv, rel_v, nr * 4, hipMemcpyHostToDevice));
     TCHECK(hipMemcpy(dlen, l32.data(), B * 4, hipMemcpyHostToDevice));
-    dim3 ag((T + 127) / 128, n_heads, B);
-    switch ((dk + 31) / 32) {
-        case 1: attention_relpos_kernel<1><<<ag, 256>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
-        case 2: attention_relpos_kernel<2><<<ag, 256>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
-        case 3: attention_relpos_kernel<3><<<ag, 256>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
-        default: attention_relpos_kernel<4><<<ag, 256>>>(dq, dout, drk, drv, dlen, C, T, dk, window); break;
-    }
+    launch_attention(nullptr, B, T, n_heads, dk, window, dq, dout, drk, drv, dlen, C);
     TCHECK(hipGetLastError());
     TCHECK(hipDeviceSynchronize());
     TCHECK(hipMemcpy(out, dout, no * 4, hipMemcpyDeviceToHost));
