@@ -53,6 +53,17 @@ struct SxPairArgs {
     int flags;                // EPI_ACC | EPI_DIV (the residual is always added)
     float div;
     unsigned *peak;           // f16 range guard slots (SxArgs::peak), may be nullptr
+    // NCH > 1 (multi-receptive-field fusion, see conv_sx_pair_kernel): the chains after the first.  Chain 0 is described
+    // by the fields above; K1 / dil1 / pad1 and pad2 above are then the LARGEST reaches (the tile geometry), and xoff /
+    // yoff are what a chain with a shorter reach adds to its operand columns (pad1 - its own pad1, pad2 - its own pad2).
+    struct Chain {
+        const u32x4 *wp1, *wp2;
+        const float *bias1, *bias2;
+        float wscale1, wscale2;
+        int K1, dil1, K2, dil2;
+        int xoff, yoff;
+    } ch[3];
+    int nchain;
 };
 
 // (the 32-channel variant needs ~165 registers and <= 40 KiB of LDS: three workgroups per CU hide more of each
@@ -69,9 +80,16 @@ struct SxPairArgs {
 #ifndef SX_PAIR_EARLY32
 #define SX_PAIR_EARLY32 1
 #endif
-template <int MW, int NW, int WM, int WN, int EPI, bool CHAIN>
-__global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC) ? 3 : 2) void conv_sx_pair_kernel(SxPairArgs a) {
+// NCH > 1: the multi-receptive-field sum of a ResBlock2 stage, xs = (rb_0(x) + rb_1(x) + ..) / n (models.py:356-363), as ONE
+// launch: the x tile (widest halo of the chains) is loaded and split ONCE and stays in LDS (Y no longer overlays it), the
+// chains run one after the other over the same 256 columns - a chain with a shorter reach reads its operands xoff / yoff
+// cells further right - and their results meet in registers, in the order the separate launches added them (bit-identical).
+// As three launches the stage's tensor is read 3 + 2 times (x three times, the running sum twice) and written three
+// times; here once each.
+template <int MW, int NW, int WM, int WN, int EPI, bool CHAIN, int NCH = 1>
+__global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 3 : 2) void conv_sx_pair_kernel(SxPairArgs a) {
     constexpr int BN = NW * WN * 32, NH = NW / 2;
+    static_assert(NCH == 1 || (CHAIN && NW == 2 && (EPI & EPI_ACC) == 0), "fused chains: 32 channels, no external running sum");
     // 32-channel variant: the residual is requested in the prologue, right behind the x tile, and waits in registers
     // (its lines are in flight at that moment; after phase 1 they have left the L2: PMC showed the re-read going to
     // the fabric).  The running sum (EPI_ACC) is NOT: with it the variant needs 188 registers, loses the third
@@ -307,13 +325,55 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC) ? 3 : 2) void 
         });
     };
 
+    // per-chain parameters: the argument's own fields, or (fused chains) entry ci of a.ch
+    struct ChainPar {
+        const char *wb1, *wb2;
+        const float *bias1, *bias2;
+        float ws1, ws2;
+        int K1, dil1, K2, dil2;
+        uint32_t xoff, yoff;
+    };
+    auto chain_par = [&](int ci) {
+        ChainPar c;
+        if constexpr (NCH == 1) {
+            c = ChainPar{wbase1, wbase2, a.bias1, a.bias2, a.wscale1, a.wscale2, a.K1, a.dil1, a.K2, a.dil2, 0u, 0u};
+        } else {
+            const auto &h = a.ch[ci];
+            c = ChainPar{reinterpret_cast<const char *>(h.wp1) + wm * (MW * NPW * 1024),
+                         reinterpret_cast<const char *>(h.wp2) + wm * (MW * NPW * 1024),
+                         h.bias1, h.bias2, h.wscale1, h.wscale2, h.K1, h.dil1, h.K2, h.dil2, (uint32_t)h.xoff, (uint32_t)h.yoff};
+        }
+        return c;
+    };
+    static_assert(NCH == 1 || EARLY, "fused chains keep x in registers from the prologue on");
+    // Y: over the x stages (one chain: x is dead after phase 1), or behind them (fused chains: x is every chain's input)
+    const uint32_t ylds = NCH > 1 ? lds0 + (uint32_t)a.nchunks * XB : lds0;
+    // (xkeep = x in the accumulator layout, saved at the first hand-over: `pre` is still in flight here - it was requested
+    // by the prologue's asm loads and is only known to have landed once phase 1 has waited for its last weights)
+    f32x4 xkeep[NCH > 1 ? NW / 2 : 1][2][4], tot[NCH > 1 ? NW / 2 : 1][2][4];
+    ASet f1s[DEPTH + 1], f2s[DEPTH + 1];
+#pragma unroll 1
+    for (int ci = 0; ci < NCH; ci++) {
+    const ChainPar cp = chain_par(ci);
+    if constexpr (NCH > 1) {
+        if (ci > 0) {
+#pragma unroll
+            for (int rr = 0; rr < NW / 2; rr++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) pre[rr][j][q] = xkeep[rr][j][q];
+            zero_acc();
+        }
+    }
     // =================================================================== phase 1: c1 over columns [t1, t1 + 256)
-    ASet f1s[DEPTH + 1];
-    load_a(f1s[0], wbase1, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // the x tile is complete
+    load_a(f1s[0], cp.wb1, 0);
+    if (ci == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // the x tile is complete
+    }
     __builtin_amdgcn_sched_barrier(0);
-    run_conv(f1s, wbase1, a.K1, a.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31) * 16u, XB,
+    run_conv(f1s, cp.wb1, cp.K1, cp.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31 + (int)cp.xoff) * 16u, XB,
              (uint32_t)(2 * LW) * 16u);
 
     // ---- the residual (64-channel variant): the tile's lines were fetched a phase or two ago; CHAIN needs them now
@@ -322,15 +382,15 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC) ? 3 : 2) void 
     if constexpr (CHAIN && !EARLY) load_pre();
 
     // =================================================================== hand-over: c1's output -> Y (fp16 planes in LDS)
-    ASet f2s[DEPTH + 1];
-    load_a(f2s[0], wbase2, 0);  // first weights of c2 travel meanwhile
+    load_a(f2s[0], cp.wb2, 0);  // first weights of c2 travel meanwhile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave has finished reading the x stages Y is about to overwrite
+    // every wave has finished reading what Y is about to overwrite: the x stages (one chain), the previous chain's Y
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     {
-        const float wsc = a.wscale1, msl = a.mslope;
-        const float *biasp = a.bias1 ? a.bias1 : a.zeros;
-        const int b_on = a.bias1 ? 1 : 0;
+        const float wsc = cp.ws1, msl = a.mslope;
+        const float *biasp = cp.bias1 ? cp.bias1 : a.zeros;
+        const int b_on = cp.bias1 ? 1 : 0;
         const uint32_t YC = a.y_chunk_bytes, LW2 = (uint32_t)a.LW2;
         const int row0 = wm * 32;
         f32x4 bq[4];
@@ -348,6 +408,9 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC) ? 3 : 2) void 
                 for (int e = 0; e < 4; e++) {
                     float v = __builtin_fmaf(acc[n][4 * q + e], wsc, bq[q][e]);
                     if constexpr (CHAIN) {  // x1 = c1(lrelu(x)) + x: c2's input and, kept in `pre`, its residual
+                        if constexpr (NCH > 1) {
+                            if (ci == 0) xkeep[n / 2][n % 2][q][e] = pre[n / 2][n % 2][q][e];
+                        }
                         v += pre[n / 2][n % 2][q][e];
                         pre[n / 2][n % 2][q][e] = v;
                     }
@@ -358,7 +421,7 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC) ? 3 : 2) void 
                 split2h_pair_pk(o[2], o[3], wb[0], wb[1], pk);
                 // channel group g = 4 * wm + q -> chunk g / 2, half g % 2; 4 channels = 8 bytes of the 16-byte cell
                 const int g = 4 * wm + q;
-                const uint32_t cell = lds0 + (uint32_t)(g >> 1) * YC + ((uint32_t)(g & 1) * LW2 + (uint32_t)(col + a.pad2)) * 16u + 8u * hi;
+                const uint32_t cell = ylds + (uint32_t)(g >> 1) * YC + ((uint32_t)(g & 1) * LW2 + (uint32_t)(col + a.pad2)) * 16u + 8u * hi;
                 asm volatile("ds_write_b64 %0, %1" ::"v"(cell), "v"(u32x2{wa[0], wb[0]}) : "memory");
                 asm volatile("ds_write_b64 %0, %1" ::"v"(cell + 2u * LW2 * 16u), "v"(u32x2{wa[1], wb[1]}) : "memory");
             }
@@ -370,17 +433,17 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC) ? 3 : 2) void 
     __builtin_amdgcn_sched_barrier(0);
 
     // =================================================================== phase 2: c2 over Y
-    run_conv(f2s, wbase2, a.K2, a.dil2, lds0 + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31) * 16u, a.y_chunk_bytes,
-             (uint32_t)(2 * a.LW2) * 16u);
+    run_conv(f2s, cp.wb2, cp.K2, cp.dil2, ylds + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31 + (int)cp.yoff) * 16u,
+             a.y_chunk_bytes, (uint32_t)(2 * a.LW2) * 16u);
     if constexpr (!CHAIN && !EARLY) load_pre();
 
     // =================================================================== epilogue: bias2 + x [+ xs] [/ n] -> raw
     {
         constexpr int flags = EPI;
         float *rawb = a.out_raw + (int64_t)b * a.C * T;
-        const float wsc = a.wscale2, rdiv = a.div;
-        const float *biasp = a.bias2 ? a.bias2 : a.zeros;
-        const int b_on = a.bias2 ? 1 : 0;
+        const float wsc = cp.ws2, rdiv = a.div;
+        const float *biasp = cp.bias2 ? cp.bias2 : a.zeros;
+        const int b_on = cp.bias2 ? 1 : 0;
         const int row0 = wm * 32;
         f32x4 bq[4];
 #pragma unroll
@@ -403,13 +466,22 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC) ? 3 : 2) void 
                 const int n = rr * 2 + j;
                 const int col = (wn * NW + n) * 32 + l31;
                 const int t = t1 + col;
-                if (col < a.pad2 || col >= a.pad2 + a.BNo || t >= T) continue;  // overlap columns belong to the neighbours
+                const bool kept = !(col < a.pad2 || col >= a.pad2 + a.BNo || t >= T);  // overlap columns belong to the neighbours
+                if constexpr (NCH == 1) {
+                    if (!kept) continue;
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = __builtin_fmaf(acc[n][4 * q + e], wsc, bq[q][e]);
                     v += pre[rr][j][q];
+                    if constexpr (NCH > 1) {
+                        // (the order of the separate launches: this chain's result + the running sum)
+                        if (ci > 0) v += tot[rr][j][q];
+                        tot[rr][j][q] = v;
+                        if (ci < NCH - 1 || !kept) continue;
+                    }
                     if constexpr ((flags & EPI_ACC) != 0) {
                         if constexpr (EARLY && ACC) v += ad[rr][j][q];
                         else v += adl[j][q];
@@ -423,13 +495,14 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC) ? 3 : 2) void 
             }
         });
     }
+    }  // chains
     if (a.peak) sx_publish_peak(a.peak, (int)blockIdx.x, pk);  // (uniform branch; every thread arrives)
 }
 
-template <int MW, int NW, int WM, int WN, int EPI, bool CHAIN>
+template <int MW, int NW, int WM, int WN, int EPI, bool CHAIN, int NCH = 1>
 inline hipError_t launch_conv_sx_pair_k(const SxPairArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
-    auto kern = conv_sx_pair_kernel<MW, NW, WM, WN, EPI, CHAIN>;
+    auto kern = conv_sx_pair_kernel<MW, NW, WM, WN, EPI, CHAIN, NCH>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kSxMaxDynLds);
@@ -437,8 +510,8 @@ inline hipError_t launch_conv_sx_pair_k(const SxPairArgs &a, dim3 grid, size_t l
         attr_set = true;
     }
     if (g_launch_name_on)
-        snprintf(g_launch_name, sizeof g_launch_name, "conv_sx_pair_kernel<%d, %d, %d, %d, %d, %s>", MW, NW, WM, WN, EPI,
-                 CHAIN ? "true" : "false");
+        snprintf(g_launch_name, sizeof g_launch_name, NCH > 1 ? "conv_sx_pair_kernel<%d, %d, %d, %d, %d, %s, %d>" : "conv_sx_pair_kernel<%d, %d, %d, %d, %d, %s>",
+                 MW, NW, WM, WN, EPI, CHAIN ? "true" : "false", NCH);
     kern<<<grid, 256, lds, stream>>>(a);
     return hipGetLastError();
 }
@@ -518,6 +591,73 @@ inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t 
     }
     SX_PAIR_CASES(1, 2, 1, 4, false)
 #undef SX_PAIR_CASES
+}
+
+// Fused multi-receptive-field stage (conv_sx_pair_kernel<.., NCH>): n = 2 or 3 two-step ResBlock2 chains of a 32-channel
+// stage, out = (sum of the chains) / div.  K1 / dil1 / K2 / dil2 per chain ("same" padding on both convs).
+struct SxMrfGeom {
+    int pad1, pad2, LW1, LW2;
+    size_t lds;
+};
+inline bool sx_mrf_geom(int C, int n, const int *K1, const int *dil1, const int *K2, const int *dil2, SxMrfGeom *g) {
+    if (C != 32 || n < 2 || n > 3) return false;
+    int p1 = 0, p2 = 0;
+    for (int i = 0; i < n; i++) {
+        if (K1[i] < 3 || K2[i] < 3 || !(K1[i] & 1) || !(K2[i] & 1) || dil1[i] < 1 || dil2[i] < 1) return false;
+        const int a1 = (K1[i] - 1) / 2 * dil1[i], a2 = (K2[i] - 1) / 2 * dil2[i];
+        p1 = a1 > p1 ? a1 : p1;
+        p2 = a2 > p2 ? a2 : p2;
+    }
+    const int LW1 = 256 + 2 * p1;
+    if (2 * LW1 > 768) return false;       // x staging: three cells per thread
+    if (256 - 2 * p2 < 160) return false;  // (as sx_pair_supported: more than 37 % of a tile recomputed)
+    const int LW2 = (256 + p2 + 7) / 8 * 8;
+    const size_t lds = (size_t)(C / 16) * 4 * LW1 * 16 + (size_t)(C / 16) * 4 * LW2 * 16 + (size_t)p2 * 16;
+    if (lds > 80 * 1024 - 256) return false;  // two workgroups per CU
+    if (g) *g = SxMrfGeom{p1, p2, LW1, LW2, lds};
+    return true;
+}
+
+// a: xr, islope, mslope, T, out_raw, zeros, C, div, peak and ch[0 .. nchain) (wp / bias / wscale / K / dil; xoff, yoff are
+// filled in here)
+inline hipError_t launch_conv_sx_mrf(SxPairArgs a, int B, hipStream_t stream) {
+    int K1[3], d1[3], K2[3], d2[3];
+    if (a.nchain < 2 || a.nchain > 3) return hipErrorInvalidValue;
+    for (int i = 0; i < a.nchain; i++) {
+        K1[i] = a.ch[i].K1;
+        d1[i] = a.ch[i].dil1;
+        K2[i] = a.ch[i].K2;
+        d2[i] = a.ch[i].dil2;
+    }
+    SxMrfGeom g;
+    if (!sx_mrf_geom(a.C, a.nchain, K1, d1, K2, d2, &g)) return hipErrorInvalidValue;
+    for (int i = 0; i < a.nchain; i++) {
+        a.ch[i].xoff = g.pad1 - (K1[i] - 1) / 2 * d1[i];
+        a.ch[i].yoff = g.pad2 - (K2[i] - 1) / 2 * d2[i];
+        if (a.ch[i].wscale1 == 0.f) a.ch[i].wscale1 = 1.f;
+        if (a.ch[i].wscale2 == 0.f) a.ch[i].wscale2 = 1.f;
+    }
+    a.pad1 = g.pad1;
+    a.pad2 = g.pad2;
+    a.LW1 = g.LW1;
+    a.x_bytes = (unsigned)((size_t)4 * a.LW1 * 16);
+    a.LW2 = g.LW2;
+    a.y_chunk_bytes = (unsigned)(4 * a.LW2 * 16);
+    a.BNo = 256 - 2 * g.pad2;
+    a.NT = (a.T + a.BNo - 1) / a.BNo;
+    a.B = B;
+    a.nchunks = a.C / 16;
+    if (a.islope == 0.f) a.islope = 1.f;
+    if (a.mslope == 0.f) a.mslope = 1.f;
+    if ((long long)a.T * 64 + 64 >= (1ll << 32)) return hipErrorInvalidValue;
+    const long long nb = (long long)a.NT * B;
+    if (nb == 0) return hipSuccess;
+    const long long wgs = (nb + 7) / 8 * 8;
+    if (wgs >= (1ll << 31)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)wgs, 1, 1);
+    a.flags = EPI_DIV;
+    if (a.nchain == 2) return launch_conv_sx_pair_k<1, 2, 1, 4, EPI_DIV, true, 2>(a, grid, g.lds, stream);
+    return launch_conv_sx_pair_k<1, 2, 1, 4, EPI_DIV, true, 3>(a, grid, g.lds, stream);
 }
 
 }  // namespace vitsmi

@@ -512,6 +512,73 @@ void conv_sx_pair(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const float *x
     h->stats.sx_launches++;
 }
 
+// The multi-receptive-field sum of a 32-channel ResBlock2 stage, xs = (rb_0(x) + .. + rb_{n-1}(x)) / n with every rb a
+// two-step chain (models.py:356-363, modules.py:355-364), as ONE launch (conv_sx_pair_kernel<.., NCH = n>): can it?
+bool sx_mrf_ok(const vits_handle *h, const UpStageDesc &stg) {
+    // Opt-in (VITSMI_SX_MRF=1, read per run): measured on the default voice, the fused stage moves 4x fewer bytes and takes
+    // the same time on one handle (2.39 vs 2.46 ms: the 32-row tiles are bound by their own dependent chains, not by HBM) and
+    // loses 4-10 % of the step under the three-handle schedule (two long workgroups per CU instead of three short ones).
+    const bool off = std::getenv("VITSMI_SX_MRF") == nullptr;
+    const int n = (int)stg.rbs.size();
+    if (off || n < 2 || n > 3) return false;
+    int K1[3], d1[3], K2[3], d2[3];
+    for (int j = 0; j < n; j++) {
+        const auto &rb = stg.rbs[j];
+        if (rb.type1 || rb.n != 2 || !sx_pair_ok(h, rb.c1[0], rb.c1[1]) || rb.c1[0].padL * 2 != (rb.c1[0].K - 1) * rb.c1[0].dil)
+            return false;
+        K1[j] = rb.c1[0].K;
+        d1[j] = rb.c1[0].dil;
+        K2[j] = rb.c1[1].K;
+        d2[j] = rb.c1[1].dil;
+    }
+    return sx_mrf_geom(stg.rbs[0].c1[0].Cin, n, K1, d1, K2, d2, nullptr);
+}
+
+void conv_sx_mrf(Ctx &c, const UpStageDesc &stg, const float *x, int T, float *out, float slope) {
+    const int n = (int)stg.rbs.size();
+    SxPairArgs a{};
+    a.xr = x;
+    a.islope = slope;
+    a.mslope = slope;
+    a.T = T;
+    a.out_raw = out;
+    a.zeros = c.P(c.m.zeros_off);
+    a.C = stg.rbs[0].c1[0].Cin;
+    a.div = (float)n;
+    a.nchain = n;
+    double macs = 0, bytes = 0;
+    for (int j = 0; j < n; j++) {
+        const ConvDesc &c1 = stg.rbs[j].c1[0], &c2 = stg.rbs[j].c1[1];
+        auto &ch = a.ch[j];
+        ch.wp1 = reinterpret_cast<const u32x4 *>(c.P(c1.w_off));
+        ch.wp2 = reinterpret_cast<const u32x4 *>(c.P(c2.w_off));
+        ch.bias1 = c.P(c1.b_off);
+        ch.bias2 = c.P(c2.b_off);
+        ch.wscale1 = c1.wscale;
+        ch.wscale2 = c2.wscale;
+        ch.K1 = c1.K;
+        ch.dil1 = c1.dil;
+        ch.K2 = c2.K;
+        ch.dil2 = c2.dil;
+        macs += c1.macs_per_t + c2.macs_per_t;
+        bytes += 4.0 * ((double)(c1.Cin + c1.Cout) + (double)(c2.Cin + c2.Cout));  // (layer-granular, as the separate launches)
+    }
+    vits_handle *h = c.h;
+    a.peak = range_slots(h, true);
+    const bool ev = conv_event_begin(c);
+    c.note(launch_conv_sx_mrf(a, c.B, c.st));
+    if (ev) conv_event_end(c, true, 2.0 * macs * (double)T * c.B, bytes * T * c.B, stg.rbs[n - 1].c1[0], T);
+    for (int j = 0; j < n; j++) {
+        conv_account(c, stg.rbs[j].c1[0], T);
+        conv_account(c, stg.rbs[j].c1[1], T);
+    }
+    h->stats.conv_launches -= 2 * n - 1;  // (2 n convs, one launch)
+    h->stats.total_launches -= 2 * n - 1;
+    h->stats.sx_flops += 2.0 * macs * (double)T * c.B;
+    h->stats.sx_bytes += bytes * T * c.B;
+    h->stats.sx_launches++;
+}
+
 // Pinned output buffer of `bytes` bytes: the handle's pool when it is free (grown on demand), else a fresh
 // allocation (the caller still holds an earlier output).  Released by pinned_put().
 void *pinned_get(vits_handle *h, size_t bytes) {
@@ -907,6 +974,13 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
         uint16_t *xs_pl = stage_in[(si + 1) & 1];
         const int nk = (int)stg.rbs.size();
         const bool last_stage = si == nst - 1;
+        if (fr && sx_mrf_ok(h, stg)) {
+            // every ResBlock2 of the stage in one launch: x read once, the sum formed in registers, one store
+            conv_sx_mrf(c, stg, y_raw, T, xs_raw, S);
+            xa_is_raw = true;
+            xa = xs_raw;
+            continue;
+        }
         for (int j = 0; j < nk; j++) {
             const auto &rbk = stg.rbs[j];
             const float *cur = y_raw;          // residual operand

@@ -483,6 +483,30 @@ def test_sx_generator_matches_reference_goldens(monkeypatch, preset, precision, 
     s.close()
 
 
+def test_fused_mrf_stage_is_bit_identical_to_separate_chains(monkeypatch):
+    """The 32-channel ResBlock2 stage as ONE launch (conv_sx_pair_kernel<.., NCH>: every chain from one resident x tile,
+    the multi-receptive-field sum in registers; opt-in, VITSMI_SX_MRF=1) against the default chain-per-launch form: same
+    products, same order of additions - the same bits.  sx_rb2_ms: kernels (3, 5, 7), dilations (1, 2) / (2, 6) / (3, 12),
+    290 frames = several tiles per utterance, ragged lengths."""
+    g = np.load(os.path.join(GOLDEN, "sx_rb2_ms.npz"))
+    outs = []
+    monkeypatch.setenv("VITSMI_SX_MRF", "1")
+    for off in (False, True):
+        if off:
+            monkeypatch.delenv("VITSMI_SX_MRF")
+        s = _session("sx_rb2_ms")
+        res = []
+        for c in golden_cases(g):
+            r = s.synthesize_batch(case_get(g, c, "ids"), case_get(g, c, "lens"), case_get(g, c, "scales"),
+                                   case_get(g, c, "sid"), case_get(g, c, "noise_dp"), case_get(g, c, "noise_z"))
+            res.append(r["output"])
+        outs.append((res, s.stats()["total_launches"]))
+        s.close()
+    assert outs[0][1] < outs[1][1], "the fused form was not taken"
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.abs(a).max() > 0.02 and np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("preset", SX_PRESETS)
 def test_sx_vocoder_only_matches_reference_z(preset):
     """BASELINE config 2 (vocoder only) on an sx voice: feed the reference's own z (already masked) to
