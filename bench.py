@@ -442,7 +442,7 @@ def main():
         kby = by
         if agg.get("sx_launches", 0) > 0:
             kfl, kms, kn, kby = agg["sx_flops"], agg["sx_ms"], int(agg["sx_launches"]), agg["sx_bytes"]
-            kname = ("conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 2 fp16 planes, 3 x v_mfma_f32_32x32x16_f16 per product)"
+            kname = ("conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 2 fp16 planes, 3 x v_mfma_f32_16x16x32_f16 per product)"
                      if nprod == 2 else
                      "conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 3 bf16 planes, v_mfma_f32_32x32x16_bf16 plane products)")
             peak = MFMA16_PEAK_TFLOPS / (3 if nprod == 2 else nprod)
