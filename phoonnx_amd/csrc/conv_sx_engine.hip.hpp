@@ -862,7 +862,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const float v = F16 ? __builtin_fmaf(acc[0][n][4 * q + e], wsc, bq[q][e]) : acc[0][n][4 * q + e] + bq[q][e];
-                    mine[n][q][e] = wm == 0 ? tanhf(v) : 1.0f / (1.0f + expf(-v));
+                    mine[n][q][e] = wm == 0 ? tanh_nb(v) : sigmoid_nb(v);
                 }
                 const bool send = (wm == 1) == (n < NW / 2);  // (uniform per wave)
                 if (send) ds_write128(exch + (uint32_t)(n * 4 + q) * 1024u, __builtin_bit_cast(u32x4, mine[n][q]));

@@ -77,6 +77,10 @@ struct SxPairArgs {
 #ifndef SX_PAIR_EARLY_ACC
 #define SX_PAIR_EARLY_ACC 0
 #endif
+#ifndef SX_PAIR_WGS32
+#define SX_PAIR_WGS32 3  // workgroups per CU the 32-channel variant is compiled for (4 = 128 registers: 116-172 bytes of scratch
+                         // per lane, the three chains of the default voice 551 / 767 / 1125 -> 688 / 1064 / 1336 us)
+#endif
 #ifndef SX_PAIR_EARLY32
 #define SX_PAIR_EARLY32 1
 #endif
@@ -87,7 +91,7 @@ struct SxPairArgs {
 // As three launches the stage's tensor is read 3 + 2 times (x three times, the running sum twice) and written three
 // times; here once each.
 template <int MW, int NW, int WM, int WN, int EPI, bool CHAIN, int NCH = 1>
-__global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 3 : 2) void conv_sx_pair_kernel(SxPairArgs a) {
+__global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? SX_PAIR_WGS32 : 2) void conv_sx_pair_kernel(SxPairArgs a) {
     constexpr int BN = NW * WN * 32, NH = NW / 2;
     static_assert(NCH == 1 || (CHAIN && NW == 2 && (EPI & EPI_ACC) == 0), "fused chains: 32 channels, no external running sum");
     // 32-channel variant: the residual is requested in the prologue, right behind the x tile, and waits in registers

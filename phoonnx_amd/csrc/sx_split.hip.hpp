@@ -83,4 +83,23 @@ __device__ __forceinline__ void sx_publish_peak(unsigned *slots, int slot_idx, f
     }
 }
 
+// tanh / sigmoid without branches or library range handling (|error| < 1e-7 absolute, 2.5e-7 relative for tanh): the WN
+// gate's epilogue applies 32 of them per lane next to a matrix loop that is ~40 % busy; the library tanhf alone is ~50
+// instructions with branches.  v_exp_f32 saturates the way the functions need (exp2(+big) = inf -> 1 - 2/inf = 1).
+__device__ __forceinline__ float tanh_nb(float v) {
+    const float t = __builtin_fabsf(v), s = v * v;
+    float p = 62.0f / 2835.0f;
+    p = __builtin_fmaf(p, s, -17.0f / 315.0f);
+    p = __builtin_fmaf(p, s, 2.0f / 15.0f);
+    p = __builtin_fmaf(p, s, -1.0f / 3.0f);
+    p = __builtin_fmaf(p * s, v, v);
+    const float e = __builtin_amdgcn_exp2f(t * 2.8853900817779268f);  // exp(2 |v|)
+    float r = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+    r = __builtin_copysignf(r, v);
+    return t < 0.3f ? p : r;
+}
+__device__ __forceinline__ float sigmoid_nb(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
+}
+
 }  // namespace vitsmi

@@ -401,6 +401,9 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
         const long long wgs0 = (long long)((T + 255) / 256) * c.B * (d.Cout / 128);
         if (wgs0 <= 128) run_cfg = 2;
         else if (wgs0 <= 256) run_cfg = 1;
+        // token- / frame-domain convs with the planar epilogue (short reductions, bound by their prologue / epilogue
+        // latencies): 64 x 128 tiles put 4-7x the workgroups on the chip (res_skip 51 -> 42 us, FFN conv_1 43 -> 36 us)
+        if (d.s16 && (flags & SX_WN_RMW) && wgs0 > 128 && wgs0 <= 1024) run_cfg = 3;
     }
     // 64-row layers on the 16x16x32 loop: 128-column tiles where the grid of 256-column ones fills the chip badly (the
     // flow's WN in-layers at batch 32: 768 workgroups on 512 slots = two rounds of which the second is half empty, and 24 %
@@ -411,6 +414,13 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
         const long long w256 = ((long long)((T + 255) / 256) * c.B + 7) / 8 * 8 * mt, w128 = ((long long)((T + 127) / 128) * c.B + 7) / 8 * 8 * mt;
         const long long r256 = (w256 + 511) / 512 * 2, r128 = (w128 + 767) / 768;  // rounds, in units of a 128-column tile
         if (r128 < r256) run_cfg = 3;
+    }
+    {
+        // (experiments only: VITSMI_SX_FORCE_CFG=<stage><cfg>, e.g. 22 = the flow's plane-input convs on the 32-row tile)
+        static const int force = [] { const char *e = std::getenv("VITSMI_SX_FORCE_CFG"); return e ? std::atoi(e) : -1; }();
+        if (force >= 0 && d.s16 && !d.rawin && h->cur_stage == force / 10 && (!(flags & SX_GATE) || force % 10 == 1 || force % 10 == 3) &&
+            sx_tile_m(force % 10) <= sx_tile_m(d.cfg) && d.Cout % sx_tile_m(force % 10) == 0)
+            run_cfg = force % 10;
     }
     c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, d.f16 ? 2 : (h->cur_stage == 3 ? h->gen_nprod : 6), d.cfg));
     if (ev) conv_event_end(c, true, 2.0 * d.macs_per_t * (double)T * c.B, 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T), d, T);
