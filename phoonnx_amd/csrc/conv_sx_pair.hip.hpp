@@ -64,10 +64,17 @@ struct SxPairArgs {
         int xoff, yoff;
     } ch[3];
     int nchain;
+    unsigned long long *prof;  // (SX_PAIR_PROF builds) 8 counters of this launch: six phase sums in shader cycles, -, workgroups
 };
 
 // (the 32-channel variant needs ~165 registers and <= 40 KiB of LDS: three workgroups per CU hide more of each
 // other's load / hand-over / store phases than two; the 64-channel one holds 64 accumulators + 64 residual registers)
+#ifndef SX_PAIR_PROF
+#define SX_PAIR_PROF 0  // diagnostic build: s_memtime stamps at the phase boundaries, summed per launch into SxPairArgs::prof
+#endif
+#ifndef SX_PAIR_ALIAS
+#define SX_PAIR_ALIAS 0
+#endif
 #ifndef SX_PAIR_DEPTH32
 #define SX_PAIR_DEPTH32 2
 #endif
@@ -160,6 +167,17 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
     // like conv_sx_kernel: with K = 3 a chunk is three steps of matrix work, an HBM round trip is ten, and - vector
     // loads return in order - every weight load behind an x load waits for it: ~2.5 us of stall per chunk, 25 of the
     // 31 us a 64-channel k = 3 tile took.)  A thread owns cells i = it*256 + tid of a chunk's [2 halves][LW] cells.
+#if SX_PAIR_PROF
+    auto stamp = [&]() {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t;
+    };
+    unsigned long long tp[8];
+    tp[0] = stamp();
+#endif
     constexpr int NXC = 3;
     {
         u32x4 xst[MAXCH][NXC][2];
@@ -198,6 +216,9 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
                 asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if SX_PAIR_PROF
+        tp[1] = stamp();  // the x tile has arrived
+#endif
         const float isl = a.islope;
         static_for<MAXCH>([&](auto CH) {
             constexpr int ch = decltype(CH)::value;
@@ -355,7 +376,14 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
     // (xkeep = x in the accumulator layout, saved at the first hand-over: `pre` is still in flight here - it was requested
     // by the prologue's asm loads and is only known to have landed once phase 1 has waited for its last weights)
     f32x4 xkeep[NCH > 1 ? NW / 2 : 1][2][4], tot[NCH > 1 ? NW / 2 : 1][2][4];
+#if SX_PAIR_ALIAS
+    // one set of weight registers for both phases (phase 2's first weights are requested when phase 1 has consumed its
+    // last): the look-ahead can be twice as deep for the same register count
+    ASet f1s[DEPTH + 1];
+    ASet(&f2s)[DEPTH + 1] = f1s;
+#else
     ASet f1s[DEPTH + 1], f2s[DEPTH + 1];
+#endif
 #pragma unroll 1
     for (int ci = 0; ci < NCH; ci++) {
     const ChainPar cp = chain_par(ci);
@@ -374,7 +402,13 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
     load_a(f1s[0], cp.wb1, 0);
     if (ci == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if SX_PAIR_PROF
+        tp[2] = stamp();  // converted and written to LDS
+#endif
         __builtin_amdgcn_s_barrier();  // the x tile is complete
+#if SX_PAIR_PROF
+        tp[3] = stamp();
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     run_conv(f1s, cp.wb1, cp.K1, cp.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31 + (int)cp.xoff) * 16u, XB,
@@ -383,6 +417,9 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
     // ---- the residual (64-channel variant): the tile's lines were fetched a phase or two ago; CHAIN needs them now
     // (x1 = c1(..) + x at the hand-over), PAIR only in the epilogue and requests them there, so that they do not occupy
     // registers during phase 2.
+#if SX_PAIR_PROF
+    tp[4] = stamp();  // phase 1 done
+#endif
     if constexpr (CHAIN && !EARLY) load_pre();
 
     // =================================================================== hand-over: c1's output -> Y (fp16 planes in LDS)
@@ -435,10 +472,16 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // Y is complete
     __builtin_amdgcn_sched_barrier(0);
+#if SX_PAIR_PROF
+    tp[5] = stamp();  // hand-over done
+#endif
 
     // =================================================================== phase 2: c2 over Y
     run_conv(f2s, cp.wb2, cp.K2, cp.dil2, ylds + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31 + (int)cp.yoff) * 16u,
              a.y_chunk_bytes, (uint32_t)(2 * a.LW2) * 16u);
+#if SX_PAIR_PROF
+    tp[6] = stamp();  // phase 2 done
+#endif
     if constexpr (!CHAIN && !EARLY) load_pre();
 
     // =================================================================== epilogue: bias2 + x [+ xs] [/ n] -> raw
@@ -500,6 +543,14 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
         });
     }
     }  // chains
+#if SX_PAIR_PROF
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tp[7] = stamp();  // stores have left
+    if (a.prof && tid == 0) {
+        for (int i = 0; i < 7; i++) atomicAdd(a.prof + i, tp[i + 1] - tp[i]);
+        atomicAdd(a.prof + 7, 1ull);
+    }
+#endif
     if (a.peak) sx_publish_peak(a.peak, (int)blockIdx.x, pk);  // (uniform branch; every thread arrives)
 }
 

@@ -508,6 +508,31 @@ void conv_sx_pair(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const float *x
     a.div = div;
     vits_handle *h = c.h;
     a.peak = range_slots(h, true);
+#if SX_PAIR_PROF
+    {
+        // diagnostic build: one row of 8 counters per pair launch of a run, printed by the next launch_table / bench run
+        static unsigned long long *rows = nullptr;
+        static int idx = 0;
+        if (!rows) {
+            hipMalloc((void **)&rows, 64 * 8 * sizeof(unsigned long long));
+            hipMemset(rows, 0, 64 * 8 * sizeof(unsigned long long));
+        }
+        if (h->stats.sx_launches == 0 || idx >= 64) idx = 0;
+        a.prof = rows + (idx++ % 64) * 8;
+        if (std::getenv("VITSMI_PAIR_PROF_DUMP") && idx == 1) {
+            unsigned long long hrows[64 * 8];
+            hipDeviceSynchronize();
+            hipMemcpy(hrows, rows, sizeof hrows, hipMemcpyDeviceToHost);
+            for (int r = 0; r < 64; r++)
+                if (hrows[r * 8 + 7]) {
+                    fprintf(stderr, "pairprof row %d wgs %llu:", r, hrows[r * 8 + 7]);
+                    for (int i = 0; i < 7; i++) fprintf(stderr, " %.0f", (double)hrows[r * 8 + i] / (double)hrows[r * 8 + 7]);
+                    fprintf(stderr, "\n");
+                }
+            hipMemset(rows, 0, sizeof hrows);
+        }
+    }
+#endif
     const bool ev = conv_event_begin(c);
     c.note(launch_conv_sx_pair(a, c1.cfg, c.B, c.st, chain));
     if (ev)
