@@ -64,6 +64,7 @@ struct SxPairArgs {
         int xoff, yoff;
     } ch[3];
     int nchain;
+    unsigned a_ring;          // (32-channel variant) byte offset of the shared weight ring in LDS: 3 groups x 2 steps x 2 KiB
     unsigned long long *prof;  // (SX_PAIR_PROF builds) 8 counters of this launch: six phase sums in shader cycles, -, workgroups
 };
 
@@ -71,6 +72,10 @@ struct SxPairArgs {
 // other's load / hand-over / store phases than two; the 64-channel one holds 64 accumulators + 64 residual registers)
 #ifndef SX_PAIR_PROF
 #define SX_PAIR_PROF 0  // diagnostic build: s_memtime stamps at the phase boundaries, summed per launch into SxPairArgs::prof
+#endif
+#ifndef SX_PAIR_SHARED_A
+#define SX_PAIR_SHARED_A 0  // 32-channel variant: weights through a workgroup-shared LDS ring (run_conv_sha): built, bit-identical,
+                           // measured neutral to slower (k3 / k5 / k7 chains 547 / 764 / 1131 -> 543 / 746 / 1232 us): off
 #endif
 #ifndef SX_PAIR_ALIAS
 #define SX_PAIR_ALIAS 0
@@ -178,6 +183,14 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
     unsigned long long tp[8];
     tp[0] = stamp();
 #endif
+    if constexpr (NW == 2 && WM == 1 && NCH == 1 && SX_PAIR_SHARED_A != 0)
+        // (shared weight ring, see run_conv_sha: c1's first groups are requested ahead of the x tile)
+        for (int g = 0; g < 3; g++)
+            if (g < ((a.nchunks * a.K1) >> 1)) {
+                const int sub = wave >> 1, pl = wave & 1;
+                lds_dma<16>(wbase1 + (int64_t)(2 * g + sub) * STEPBYTES + pl * 1024 + lane * 16,
+                            reinterpret_cast<float *>(lds_sx + a.a_ring + (unsigned)((g * 2 + sub) * 2048 + pl * 1024)));
+            }
     constexpr int NXC = 3;
     {
         u32x4 xst[MAXCH][NXC][2];
@@ -350,6 +363,93 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
         });
     };
 
+    // ---- (experiment, SX_PAIR_SHARED_A) 32-channel variant: the four waves of a workgroup use the SAME weight rows (one
+    // block row); as four private register streams the weights cost a quarter of these launches' time by ablation (no
+    // re-fetch = -25..32 %), and deeper private look-ahead makes it worse.  Here a step's weights cross the L2 -> CU path
+    // once: a ring of RG groups of two steps in LDS, each wave fetching a quarter of a group with one 1 KiB LDS-DMA (step
+    // 2 g + (wave >> 1), plane wave & 1), two groups ahead; one barrier per group publishes it (and says that everyone is
+    // done with the group before).  A fragments then come from LDS like B's.  Measured: no gain (the barrier per two
+    // steps costs what the shared fetch saves) - kept for the record, off by default.
+    constexpr bool SHA = NW == 2 && WM == 1 && NCH == 1 && SX_PAIR_SHARED_A != 0;
+    constexpr int RG = 3;
+    auto sha_dma = [&](const char *wb, int g) {  // this wave's quarter of group g
+        const int sub = wave >> 1, pl = wave & 1;
+        const char *src = wb + (int64_t)(2 * g + sub) * STEPBYTES + pl * 1024 + lane * 16;
+        lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + a.a_ring + (unsigned)(((g % RG) * 2 + sub) * 2048 + pl * 1024)));
+    };
+    auto sha_prefetch = [&](const char *wb, int K) {  // the first RG groups of a conv (the ring must be free)
+        const int NG = (a.nchunks * K) >> 1;
+#pragma unroll
+        for (int g = 0; g < RG; g++)
+            if (g < NG) sha_dma(wb, g);
+    };
+    auto wait_vm_le = [&](int n) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        }
+    };
+    auto run_conv_sha = [&](ASet &fa0, ASet &fa1, const char *wb, int K, int dil, uint32_t rows0, uint32_t chunk_bytes,
+                            uint32_t pstride) {
+        const int S = a.nchunks * K, NG = S >> 1;  // (two 16-channel chunks: S is even)
+        const uint32_t alds = lds0 + a.a_ring + (uint32_t)lane * 16u;
+        auto read_a = [&](ASet &f, int st) {
+            const uint32_t ad = alds + (uint32_t)((((st >> 1) % RG) * 2 + (st & 1)) * 2048);
+            f.fa[0] = ds_read128<0>(ad);
+            f.fa[1] = ds_read128<1024>(ad);
+        };
+        int chunk = 0, tap = 0;
+        // group 0: this wave's quarter has landed when only its younger prefetches are in flight; the barrier publishes it
+        wait_vm_le((NG < RG ? NG : RG) - 1);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(fa0, 0);
+        load_b_half(H0, rows0, pstride);
+        load_b_half(H1, rows0, pstride);
+        auto step = [&](ASet &fc, ASet &fload, int st, bool boundary) {
+            int ntap = tap + 1, nchunk = chunk;
+            if (ntap == K) {
+                ntap = 0;
+                nchunk++;
+            }
+            const bool more = st + 1 < S;
+            const uint32_t next = rows0 + (uint32_t)nchunk * chunk_bytes + (uint32_t)(ntap * dil) * 16u;
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lds_older_half();  // in flight, oldest first: A(st), B half 0, B half 1 -> the first two have landed
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(fc, H0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                if (boundary) {
+                    // the next step opens group g + 1: my quarter of it is back when only the groups behind it are in
+                    // flight; after the barrier everyone has read group g for the last time, its slot takes group g + RG
+                    const int g = st >> 1;
+                    const int last = g + RG - 1 < NG - 1 ? g + RG - 1 : NG - 1;
+                    wait_vm_le(last - (g + 1));
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + RG < NG) sha_dma(wb, g + RG);
+                }
+                read_a(fload, st + 1);
+                load_b_half(H0, next, pstride);
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // B half 1 of this step has landed
+            } else
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mma_half(fc, H1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) load_b_half(H1, next, pstride);
+            __builtin_amdgcn_sched_barrier(0);
+            tap = ntap;
+            chunk = nchunk;
+        };
+        for (int g = 0; g < NG; g++) {
+            step(fa0, fa1, 2 * g, false);
+            step(fa1, fa0, 2 * g + 1, true);
+        }
+    };
+
     // per-chain parameters: the argument's own fields, or (fused chains) entry ci of a.ch
     struct ChainPar {
         const char *wb1, *wb2;
@@ -399,7 +499,7 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
         }
     }
     // =================================================================== phase 1: c1 over columns [t1, t1 + 256)
-    load_a(f1s[0], cp.wb1, 0);
+    if constexpr (!SHA) load_a(f1s[0], cp.wb1, 0);
     if (ci == 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if SX_PAIR_PROF
@@ -411,8 +511,12 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
 #endif
     }
     __builtin_amdgcn_sched_barrier(0);
-    run_conv(f1s, cp.wb1, cp.K1, cp.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31 + (int)cp.xoff) * 16u, XB,
-             (uint32_t)(2 * LW) * 16u);
+    if constexpr (SHA)
+        run_conv_sha(f1s[0], f1s[1], cp.wb1, cp.K1, cp.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31 + (int)cp.xoff) * 16u,
+                     XB, (uint32_t)(2 * LW) * 16u);
+    else
+        run_conv(f1s, cp.wb1, cp.K1, cp.dil1, lds0 + (uint32_t)(hi * LW + wn * (NW * 32) + l31 + (int)cp.xoff) * 16u, XB,
+                 (uint32_t)(2 * LW) * 16u);
 
     // ---- the residual (64-channel variant): the tile's lines were fetched a phase or two ago; CHAIN needs them now
     // (x1 = c1(..) + x at the hand-over), PAIR only in the epilogue and requests them there, so that they do not occupy
@@ -423,11 +527,12 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
     if constexpr (CHAIN && !EARLY) load_pre();
 
     // =================================================================== hand-over: c1's output -> Y (fp16 planes in LDS)
-    load_a(f2s[0], cp.wb2, 0);  // first weights of c2 travel meanwhile
+    if constexpr (!SHA) load_a(f2s[0], cp.wb2, 0);  // first weights of c2 travel meanwhile
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // every wave has finished reading what Y is about to overwrite: the x stages (one chain), the previous chain's Y
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SHA) sha_prefetch(cp.wb2, cp.K2);  // (... and the weight ring: c2's first groups travel during the hand-over)
     {
         const float wsc = cp.ws1, msl = a.mslope;
         const float *biasp = cp.bias1 ? cp.bias1 : a.zeros;
@@ -477,8 +582,12 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
 #endif
 
     // =================================================================== phase 2: c2 over Y
-    run_conv(f2s, cp.wb2, cp.K2, cp.dil2, ylds + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31 + (int)cp.yoff) * 16u,
-             a.y_chunk_bytes, (uint32_t)(2 * a.LW2) * 16u);
+    if constexpr (SHA)
+        run_conv_sha(f2s[0], f2s[1], cp.wb2, cp.K2, cp.dil2, ylds + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31 + (int)cp.yoff) * 16u,
+                     a.y_chunk_bytes, (uint32_t)(2 * a.LW2) * 16u);
+    else
+        run_conv(f2s, cp.wb2, cp.K2, cp.dil2, ylds + (uint32_t)(hi * a.LW2 + wn * (NW * 32) + l31 + (int)cp.yoff) * 16u,
+                 a.y_chunk_bytes, (uint32_t)(2 * a.LW2) * 16u);
 #if SX_PAIR_PROF
     tp[6] = stamp();  // phase 2 done
 #endif
@@ -620,8 +729,12 @@ inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t 
     if ((long long)a.T * 64 + 64 >= (1ll << 32)) return hipErrorInvalidValue;
     // Y overlays the x stages (every chunk has its own)
     const size_t lds_x = (size_t)a.nchunks * a.x_bytes, lds_y = (size_t)a.nchunks * a.y_chunk_bytes + (size_t)a.pad2 * 16;
-    const size_t lds = lds_x > lds_y ? lds_x : lds_y;
+    size_t lds = lds_x > lds_y ? lds_x : lds_y;
     if (lds > 80 * 1024 - 256 || !sx_pair_supported(a.C, cfg, a.K1, a.dil1, a.K2, a.dil2)) return hipErrorInvalidValue;
+    if (cfg != 1 && SX_PAIR_SHARED_A) {  // 32 channels: the shared weight ring behind the tile (3 groups x 2 steps x 2 KiB)
+        a.a_ring = (unsigned)((lds + 1023) / 1024 * 1024);
+        lds = a.a_ring + 3 * 4096;
+    }
     const long long nb = (long long)a.NT * B;
     if (nb == 0) return hipSuccess;
     const long long wgs = (nb + 7) / 8 * 8;
