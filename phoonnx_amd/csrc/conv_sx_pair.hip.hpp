@@ -75,7 +75,7 @@ struct SxPairArgs {
 #endif
 #ifndef SX_PAIR_SHARED_A
 #define SX_PAIR_SHARED_A 0  // 32-channel variant: weights through a workgroup-shared LDS ring (run_conv_sha): built, bit-identical,
-                           // measured neutral to slower (k3 / k5 / k7 chains 547 / 764 / 1131 -> 543 / 746 / 1232 us): off
+                           // measured neutral (k3 / k5 / k7 chains 540 / 763 / 1129 -> 539 / 753 / 1198 us): off
 #endif
 #ifndef SX_PAIR_ALIAS
 #define SX_PAIR_ALIAS 0
@@ -368,8 +368,9 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
     // re-fetch = -25..32 %), and deeper private look-ahead makes it worse.  Here a step's weights cross the L2 -> CU path
     // once: a ring of RG groups of two steps in LDS, each wave fetching a quarter of a group with one 1 KiB LDS-DMA (step
     // 2 g + (wave >> 1), plane wave & 1), two groups ahead; one barrier per group publishes it (and says that everyone is
-    // done with the group before).  A fragments then come from LDS like B's.  Measured: no gain (the barrier per two
-    // steps costs what the shared fetch saves) - kept for the record, off by default.
+    // done with the group before; none when the conv fits the ring).  A fragments then come from LDS like B's.  Measured:
+    // no gain, also where the conv is resident before the phase starts (k = 3) - the weight fetch is not what bounds these
+    // phases (the ablation's gain is a clock effect of stale operands).  Kept for the record, off by default.
     constexpr bool SHA = NW == 2 && WM == 1 && NCH == 1 && SX_PAIR_SHARED_A != 0;
     constexpr int RG = 3;
     auto sha_dma = [&](const char *wb, int g) {  // this wave's quarter of group g
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
             mma_half(fc, H0);
             __builtin_amdgcn_sched_barrier(0);
             if (more) {
-                if (boundary) {
+                if (boundary && NG > RG) {  // (a conv of at most RG groups is resident from the start: no hand-shake)
                     // the next step opens group g + 1: my quarter of it is back when only the groups behind it are in
                     // flight; after the barrier everyone has read group g for the last time, its slot takes group g + RG
                     const int g = st >> 1;
