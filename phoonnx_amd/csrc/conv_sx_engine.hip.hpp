@@ -1003,8 +1003,12 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     f32x4 adb[PIPE ? 2 : 1][2][4], ad2[2][4];
     auto geom = [&](int m, int n, int &co0, int &r, int &t) {
         const int row0 = mt * BM + (wm * MW + m) * 32;
-        r = u == 1 ? 0 : row0 / Cr;
-        co0 = row0 - r * Cr;
+        // virtual rows of a transposed conv: (block of 32 channels, output phase r, channel) - the 32-row blocks of a tile
+        // are the phases of the SAME channels, so a workgroup writes whole 64- / 128-byte runs of an output line (as
+        // r-major rows, one phase per tile, PMC showed 1.9x the bytes at the fabric: the phases of a line came from
+        // different workgroups and the 8- / 16-byte pieces of a sector left the L2 separately)
+        r = u == 1 ? 0 : (row0 >> 5) % u;
+        co0 = u == 1 ? row0 : (row0 / (32 * u)) * 32;
         t = t0 + (wn * NW + n) * 32 + l31;
     };
     auto cell_at = [&](int co0, int r, int t, int q) -> int64_t {

@@ -829,14 +829,22 @@ ConvTGeom convt_geom(const Resolver &R, const std::string &name) {
     return g;
 }
 
-// Same rewrite as pack_convT, but virtual rows are r-major (row = r*Cout + co): a 32-row block then holds
-// 32 consecutive real channels of ONE output phase r, which is what the sx epilogue's cell stores need.
+// Same rewrite as pack_convT, but virtual rows are ordered (block of 32 channels, phase r, channel): a 32-row block
+// holds 32 consecutive real channels of ONE output phase r, which is what the sx epilogue's cell stores need, and the
+// blocks of a tile are the phases of the same channels, so that a workgroup writes whole runs of an output line
+// (conv_sx_engine.hip.hpp, geom).
 ConvDesc pack_convT_sx(Packer &P, const Resolver &R, const std::string &name) {
     const ConvTGeom g = convt_geom(R, name);
     const float *wp = R.req(name + ".weight").p;
     const int Kv = g.o_max - g.o_min + 1;
+    auto row_of = [&](int cov, int &r, int &co) {
+        const int cb = cov / (32 * g.u), rem = cov % (32 * g.u);
+        r = rem / 32;
+        co = cb * 32 + rem % 32;
+    };
     auto wf = [&](int cov, int ci, int tapv) -> float {
-        int r = cov / g.Cout, co = cov % g.Cout;
+        int r, co;
+        row_of(cov, r, co);
         int j0 = (r + g.p) % g.u, e = (r + g.p) / g.u;
         int m = e - g.o_min - tapv;
         int j = j0 + m * g.u;
@@ -847,7 +855,11 @@ ConvDesc pack_convT_sx(Packer &P, const Resolver &R, const std::string &name) {
     const TRef *b = R.bias_of(name + ".bias", g.Cout);
     if (b) {
         bv.resize(size_t(g.Cout) * g.u);
-        for (int c = 0; c < g.Cout * g.u; c++) bv[c] = b->p[c % g.Cout];
+        for (int c = 0; c < g.Cout * g.u; c++) {
+            int r, co;
+            row_of(c, r, co);
+            bv[c] = b->p[co];
+        }
     }
     if (g.Cout % 32) throw std::runtime_error(name + ": sx transposed conv needs Cout % 32 == 0");
     ConvDesc d = pack_conv_sx(P, g.Cin, g.Cout * g.u, Kv, 1, -g.o_min, wf, b ? bv.data() : nullptr);
