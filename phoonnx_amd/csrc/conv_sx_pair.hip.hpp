@@ -675,8 +675,8 @@ inline hipError_t launch_conv_sx_pair_k(const SxPairArgs &a, dim3 grid, size_t l
         attr_set = true;
     }
     if (g_launch_name_on)
-        snprintf(g_launch_name, sizeof g_launch_name, NCH > 1 ? "conv_sx_pair_kernel<%d, %d, %d, %d, %d, %s, %d>" : "conv_sx_pair_kernel<%d, %d, %d, %d, %d, %s>",
-                 MW, NW, WM, WN, EPI, CHAIN ? "true" : "false", NCH);
+        snprintf(g_launch_name, sizeof g_launch_name, "conv_sx_pair_kernel<%d, %d, %d, %d, %d, %s, %d>", MW, NW, WM, WN, EPI,
+                 CHAIN ? "true" : "false", NCH);
     kern<<<grid, 256, lds, stream>>>(a);
     return hipGetLastError();
 }
