@@ -58,6 +58,11 @@
 #ifndef SX16_PRIO
 #define SX16_PRIO 0  // (experiment) raised wave priority around each quarter's MFMAs
 #endif
+#ifndef SX16_NA_SMALL
+#define SX16_NA_SMALL 2  // weight register sets of the 16x16x32 loop's tiles with 32 x 64 outputs per wave (see half_step); 3 = two
+                         // half-steps of look-ahead: parity-tested, measured equal at batch 1 and 32 (the weight fetch is not what
+                         // a step of these tiles waits for)
+#endif
 #ifndef SX16_WIDE
 #define SX16_WIDE 1  // 16x16x32 loop, 128 x 256 tile as four waves of 32 rows x 256 columns: each wave streams its own weight rows (half
                      // the L2 -> CU weight bytes of the 2 x 2 arrangement, a whole step of lead), the x tile is read once per wave
@@ -228,7 +233,7 @@ constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL 
 // same accumulation order per output element up to the chunk grouping; the chip holds a higher clock on the 16x16x32
 // shape under its power cap (tools/mfma_shape_probe.hip: 1.13-1.15x the FLOP/s at equal cycles per FLOP).
 template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false, int NP = 6, int SH = 32>
-__global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxArgs a) {
+__global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2 && !RAWIN) ? 3 : 2)) void conv_sx_kernel(SxArgs a) {
     constexpr int BM = MW * WM * 32, BN = NW * WN * 32, MB = BM / 32;
     constexpr bool S16 = SH == 16;
     static_assert(SH == 32 || (SH == 16 && NP == 2 && !RAWIN && !PROF), "16x16x32: f16x3 arithmetic on plane inputs");
@@ -523,30 +528,63 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
     const std::integral_constant<int, 1> I1{};
     // prologue: the first x tile, then the first two half-steps' weights (vector-memory operations retire in order:
     // whoever waits for A(0) has waited for x(0))
+    // NA weight sets, NA - 1 half-steps ahead.  Two for the wide tiles (128 accumulators leave no room; a half-step is
+    // 768 cycles of MFMAs there).  Where a wave holds 32 x 64 outputs (a half-step is 24 MFMAs = 384 cycles; the
+    // instantiations short grids run on) three fit - and measured no different from two (SX16_NA_SMALL).
+    constexpr int NA = NW == 2 ? SX16_NA_SMALL : 2;
+    static_assert(NA >= 2 && NA <= 4, "");
     issue_x(0, 0);
-    AHalf ab[2];
-    load_ah(ab[0], 0);
+    AHalf ab[NA];
+    static_for<NA - 1>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if (i < H) load_ah(ab[i], i);
+    });
     int chunk = 0, tap = 0;
-    int x_age = 99;  // half-steps since this wave issued the DMAs of an x tile (they sit behind that half-step's A request)
+    // vector-memory bookkeeping (operations retire in order).  iss[j] / xct[j]: operations / x DMAs this wave issued in the
+    // half-step j + 1 back; a_since_x: weight loads issued after the DMAs of the x tile the next chunk start will publish
+    int iss[NA - 1], xct[NA - 1];
+#pragma unroll
+    for (int j = 0; j < NA - 1; j++) {
+        iss[j] = 4;  // (the prologue's weight requests, youngest first; x(0) went out before all of them)
+        xct[j] = 0;
+    }
+    int a_since_x = 4 * (NA - 1);
     auto half_step = [&](AHalf &fc, AHalf &fload, auto M, int hs) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value;
         // in flight behind A(hs) (requested by the previous half-step): the x DMAs if that half-step issued them
         // ... unless this half-step opens a chunk whose x tile was issued by the previous one (K = 1 and one half-step per
         // step): the barrier below publishes that tile, so this wave's share of it must have landed
         const bool chunk_start = m == 0 && tap == 0;
-        if (x_age == 0 && !chunk_start) wait_vm16(nx_issued);  // (once per chunk)
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // A(hs) was the FIRST request of the half-step NA - 1 back: in flight behind it may stay that half-step's x DMAs and
+        // everything the half-steps since have issued.  A half-step that opens a chunk also needs that chunk's x tile (the
+        // barrier below publishes it): behind its DMAs only the weight requests made since may stay.
+        int allow = xct[NA - 2];
+#pragma unroll
+        for (int j = 0; j < NA - 2; j++) allow += iss[j];
+        if (chunk_start && a_since_x < allow) allow = a_since_x;
+        wait_vm16(allow);
         const bool more_x = chunk + 1 < a.nchunks;
         if (chunk_start) {
             __builtin_amdgcn_s_barrier();  // x(chunk) is complete in LDS; everyone is done with the other stage
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (hs + 1 < H && !(SX_NOA && hs > 0)) load_ah(fload, hs + 1);
-        x_age++;
+#pragma unroll
+        for (int j = NA - 2; j > 0; j--) {
+            iss[j] = iss[j - 1];
+            xct[j] = xct[j - 1];
+        }
+        iss[0] = xct[0] = 0;
+        if (hs + NA - 1 < H && !(SX_NOA && hs > 0)) {
+            load_ah(fload, hs + NA - 1);
+            iss[0] = 4;
+            a_since_x += 4;
+        }
         const bool do_x = chunk_start && more_x;
         if (do_x) {
             if constexpr (!SX16_SPREAD) issue_x(chunk + 1, ((chunk + 1) & 1) * XB);
-            x_age = 0;
+            iss[0] += nx_issued;
+            xct[0] = nx_issued;
+            a_since_x = 0;
         }
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t bb0 = b_lane + (uint32_t)(chunk & 1) * XB + (uint32_t)(tap * a.dil) * 16u;
@@ -591,16 +629,20 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : 2) void conv_sx_kernel(SxA
         }
     };
     static_assert(NQ % 2 == 0, "the first quarter of a half-step always lands in quarter buffer 0");
-    // unrolled by two half-steps: the A buffers alternate, the row half has period MW - both static inside the body
-    constexpr int U = 2;
+    // unrolled by the period of (weight set, row half) - both static inside the body
+    constexpr int U = NA * HPS / (NA % HPS == 0 ? HPS : 1) / (HPS % NA == 0 && NA != HPS ? NA : 1);
+    static_assert(U % NA == 0 && U % HPS == 0, "one period of weight sets and row halves");
     int hs = 0;
     for (; hs + U <= H; hs += U)
         static_for<U>([&](auto I) {
             constexpr int i = decltype(I)::value;
-            half_step(ab[i % 2], ab[(i + 1) % 2], std::integral_constant<int, i % HPS>{}, hs + i);
+            half_step(ab[i % NA], ab[(i + NA - 1) % NA], std::integral_constant<int, i % HPS>{}, hs + i);
         });
-    // (no exit from the middle of the unrolled body: see the 32x32x16 loop; MW = 2: H is even and there is no tail)
-    if (hs < H) half_step(ab[0], ab[1], std::integral_constant<int, 0>{}, hs);
+    // (no exit from the middle of the unrolled body: see the 32x32x16 loop)
+    static_for<U - 1>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if (hs + i < H) half_step(ab[i % NA], ab[(i + NA - 1) % NA], std::integral_constant<int, i % HPS>{}, hs + i);
+    });
     // 16 x 16 -> 32 x 32 accumulator layout: lanes with lane & 16 hold the right rows of the WRONG 16-column half for one
     // accumulator of each (sub-block b = 0, b = 1) pair; one half-row swap per register pair puts every value in place
 #pragma unroll
