@@ -562,7 +562,10 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
 #pragma unroll
         for (int j = 0; j < NA - 2; j++) allow += iss[j];
         if (chunk_start && a_since_x < allow) allow = a_since_x;
-        wait_vm16(allow);
+        // (the common case first: the switch below is a tree of scalar branches, ~100 cycles at one wave per SIMD)
+        // (its own asm text: identical statements would be merged back into the switch's case 0)
+        if (__builtin_expect(allow == 0, 1)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(15)" ::: "memory");
+        else wait_vm16(allow);
         const bool more_x = chunk + 1 < a.nchunks;
         if (chunk_start) {
             __builtin_amdgcn_s_barrier();  // x(chunk) is complete in LDS; everyone is done with the other stage
