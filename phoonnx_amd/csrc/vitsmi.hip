@@ -1567,6 +1567,7 @@ int vits_hparam(vits_handle *h, const char *key, int64_t *out) {
     else if (k == "gin") *out = m.gin;
     else if (k == "gen_sx") *out = m.gen_sx ? 1 : 0;
     else if (k == "gen_nprod") *out = h->gen_nprod;
+    else if (k == "enc_sx") *out = m.enc_sx ? 1 : 0;
     else if (k == "use_sdp") *out = m.use_sdp;
     else if (k == "hop") *out = m.hop;
     else if (k == "n_ups") *out = (int64_t)m.ups.size();

@@ -90,6 +90,37 @@ def test_generator_engines_agree(monkeypatch):
     np.testing.assert_allclose(a["output"], b["output"], atol=2e-5, rtol=0)
 
 
+@pytest.mark.parametrize("preset", ["medium", "high"])
+def test_encoder_engines_agree(monkeypatch, preset):
+    """The text encoder's convs on the split-operand engine (default: f16x3 products, planar epilogue, operand planes
+    written by LayerNorm / attention / the first FFN conv) against VITSMI_ENC_ENGINE=f32 (the f32-MFMA engine): the same
+    fp32 arithmetic to rounding - durations equal, every tap in front of the generator within the stage tolerance."""
+    from phoonnx_amd import MiSession
+    path = _voice(preset)
+    rng = np.random.default_rng(11)
+    B, T = 5, 200
+    ids = rng.integers(0, 256, (B, T)).astype(np.int64)
+    lens = np.array([T, T - 17, T // 2, 3, T - 1], np.int64)
+    sc = np.array([0.667, 1.3, 0.8], np.float32)
+    ndp = rng.standard_normal((B, 2, T)).astype(np.float32)
+    nz = rng.standard_normal((B, 192, T * 8)).astype(np.float32)
+    taps = ("x", "m_p", "logs_p", "logw", "w_ceil", "z_p", "z")
+    s1 = MiSession(path)
+    assert s1.hparam("enc_sx") == 1
+    a = s1.synthesize_batch(ids, lens, sc, None, ndp, nz, taps=taps)
+    s1.close()
+    monkeypatch.setenv("VITSMI_ENC_ENGINE", "f32")
+    s2 = MiSession(path)
+    assert s2.hparam("enc_sx") == 0
+    b = s2.synthesize_batch(ids, lens, sc, None, ndp, nz, taps=taps)
+    s2.close()
+    assert np.array_equal(a["w_ceil"], b["w_ceil"]) and np.array_equal(a["y_lengths"], b["y_lengths"])
+    for k in ("x", "m_p", "logs_p", "logw", "z_p", "z"):
+        assert np.abs(b[k]).max() > 0.05
+        np.testing.assert_allclose(a[k], b[k], atol=2e-5, rtol=2e-5, err_msg=k)
+    np.testing.assert_allclose(a["output"], b["output"], atol=5e-5, rtol=0)
+
+
 @pytest.mark.parametrize("preset,B,T", [("medium", 4, 128), ("high", 2, 96)])
 def test_generator_f16_mode_agrees_with_exact_mode(monkeypatch, preset, B, T):
     """The default generator arithmetic (f16x3: operands as two fp16 planes, three MFMA products per fp32 product,
