@@ -58,6 +58,9 @@
 #ifndef SX16_PRIO
 #define SX16_PRIO 0  // (experiment) raised wave priority around each quarter's MFMAs
 #endif
+#ifndef SX16_ABL
+#define SX16_ABL 0  // timing-only ablations of the 16x16x32 loop (wrong results): 1 no MFMAs, 2 no B reads, 4 no chunk barrier
+#endif
 #ifndef SX16_NA_SMALL
 #define SX16_NA_SMALL 2  // weight register sets of the 16x16x32 loop's tiles with 32 x 64 outputs per wave (see half_step); 3 = two
                          // half-steps of look-ahead: parity-tested, measured equal at batch 1 and 32 (the weight fetch is not what
@@ -486,6 +489,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
     u32x4 bq[2][2][2];                      // [buffer][sub-block b][plane]
     auto load_bq = [&](auto BUF, auto Q, uint32_t bb0) __attribute__((always_inline)) {
         constexpr int bf = decltype(BUF)::value, q = decltype(Q)::value;
+        if constexpr ((SX16_ABL & 2) != 0) return;
         bq[bf][0][0] = ds_read128<q * 512>(bb0);
         bq[bf][0][1] = ds_read128<q * 512>(bb0 + plane_b);
         bq[bf][1][0] = ds_read128<q * 512 + 256>(bb0);
@@ -494,6 +498,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
     auto mma_q = [&](const AHalf &f, auto M, auto BUF, auto Q) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value, bf = decltype(BUF)::value, q = decltype(Q)::value;
         // products in the order of the 32x32x16 loop: g1*h0, g0'*h1', g0*h0; consecutive MFMAs hit different accumulators
+        if constexpr ((SX16_ABL & 1) != 0) return;
         if constexpr (SX16_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int c = 0; c < 3; c++)
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
         if (__builtin_expect(allow == 0, 1)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(15)" ::: "memory");
         else wait_vm16(allow);
         const bool more_x = chunk + 1 < a.nchunks;
-        if (chunk_start) {
+        if (chunk_start && !(SX16_ABL & 4)) {
             __builtin_amdgcn_s_barrier();  // x(chunk) is complete in LDS; everyone is done with the other stage
         }
         __builtin_amdgcn_sched_barrier(0);
