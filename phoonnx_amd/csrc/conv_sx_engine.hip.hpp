@@ -106,6 +106,9 @@ struct SxArgs {
     const int *len;
     float *out_raw2;
     int row_split, pl_rows;
+    int pl_of2;               // the planes are those of out_raw2's rows (the WN skip sum after its last layer) instead of out_raw's
+    int64_t planar_bstride;   // batch stride of out_raw / res in the planar epilogue (0: row_split * T; the coupling's x1 rows
+                              // live inside z: C * F)
     int RS;               // cells between the rows of an x stage (>= LW) ( " )
     int s16;              // the weights are packed for the 16x16x32 main loop (ConvDesc::s16; f16x3, plane input)
     unsigned magic;       // ceil(2^32 / LW)                             ( " )
@@ -219,7 +222,9 @@ enum : int {
     // t < len[b] with EPI_MASK.  Users: the flow's res_skip conv (modules.py:200-209: x = (x + res) * mask, skip += ..,
     // planes of x for the next in-layer) and the text encoder's 1 x 1 / FFN convs (attentions.py:66-75, 419-427), whose
     // neighbours (attention, LayerNorm) work on planar tensors.
-    SX_WN_RMW = 1 << 19  // (bits 16-18: DBG_NO_DMA, DBG_NO_EPI, EPI_NO_PADFILL of conv_engine.hip.hpp)
+    SX_WN_RMW = 1 << 19,  // (bits 16-18: DBG_NO_DMA, DBG_NO_EPI, EPI_NO_PADFILL of conv_engine.hip.hpp)
+    SX_PLANAR_STORE2 = 1 << 20,  // planar epilogue with EPI_ACC: rows of out_raw2 are stored, not accumulated
+    SX_PLANAR_COUPLING = 1 << 21  // planar epilogue with EPI_ACC: o = (old - value * mask) * mask (modules.py:464, mean_only)
 };
 constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB | SX_RES_EARLY |
                            SX_GATE;
@@ -975,10 +980,13 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
             for (int m = 0; m < MW; m++) {
                 const int row0 = mt * BM + (wm * MW + m) * 32;
                 const bool to_x = row0 < xrows;   // (a 32-row block lies on one side: both counts are multiples of 32)
-                float *ob = to_x ? (a.out_raw ? a.out_raw + (int64_t)b * xrows * T : nullptr) : a.out_raw2 + (int64_t)b * srows * T;
-                const float *oldp = p_acc ? ob : (p_res && to_x ? a.res + (int64_t)b * xrows * T : nullptr);
+                const int64_t xbs = a.planar_bstride ? a.planar_bstride : (int64_t)xrows * T;
+                float *ob = to_x ? (a.out_raw ? a.out_raw + (int64_t)b * xbs : nullptr) : a.out_raw2 + (int64_t)b * srows * T;
+                // (SX_PLANAR_STORE2: the rows of the second tensor are stored, not accumulated - the first WN layer's skip)
+                const float *oldp = p_acc && !(!to_x && (a.flags & SX_PLANAR_STORE2)) ? ob : (p_res && to_x ? a.res + (int64_t)b * xbs : nullptr);
                 const int r0 = to_x ? row0 : row0 - xrows;
-                const bool planes = plb && to_x && row0 < a.pl_rows;
+                const bool planes = plb && (a.pl_of2 ? !to_x : to_x) && r0 < a.pl_rows;
+                const bool coupling = (a.flags & SX_PLANAR_COUPLING) != 0;
                 f32x4 bq[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
@@ -1004,7 +1012,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
                             // register 4 q + e = row e + 8 q + 4 hi of the block
                             float v = __builtin_fmaf(acc[m][n][4 * q + e], wsc, bq[q][e]);
                             if (p_relu) v = __builtin_fmaxf(v, 0.f);
-                            o[e] = old[4 * q + e] + v * mk;
+                            o[e] = coupling ? (old[4 * q + e] - v * mk) * mk : old[4 * q + e] + v * mk;
                         }
                         if (ob) {
 #pragma unroll
@@ -1014,7 +1022,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
                             unsigned wa[2], wb[2];
                             split2h_pair_pk(o[0], o[1], wa[0], wa[1], pk);
                             split2h_pair_pk(o[2], o[3], wb[0], wb[1], pk);
-                            const int64_t cell = ((int64_t)((row0 >> 3) + q) * T + t) * 8 + 4 * hi;
+                            const int64_t cell = ((int64_t)((r0 >> 3) + q) * T + t) * 8 + 4 * hi;
                             *reinterpret_cast<u32x2 *>(plb + cell) = u32x2{wa[0], wb[0]};
                             *reinterpret_cast<u32x2 *>(plb + plane_elems + cell) = u32x2{wa[1], wb[1]};
                         }
@@ -1313,7 +1321,8 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
         const bool p_acc = (a.flags & EPI_ACC) != 0;
         if (rawin || nprod != 2 || a.ups != 1 || (a.row_split < a.Cout && !a.out_raw2) ||
             (a.row_split && !a.out_raw && (p_acc || !a.out_pl)) || a.row_split % 32 || a.Cout % 32 || a.row_split > a.Cout ||
-            a.pl_rows % 32 || a.pl_rows > a.row_split || (a.pl_rows && !a.out_pl) || a.bias_b || (a.flags & SX_GATE) ||
+            a.pl_rows % 32 || a.pl_rows > (a.pl_of2 ? a.Cout - a.row_split : a.row_split) || (a.pl_rows && !a.out_pl) || a.bias_b ||
+            (a.flags & SX_GATE) || ((a.flags & SX_PLANAR_COUPLING) && !p_acc) ||
             ((a.flags & EPI_RES) && (!a.res || p_acc)) || ((a.flags & EPI_MASK) && !a.len))
             return hipErrorInvalidValue;
         epi = -2;
@@ -1335,7 +1344,7 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
         if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
         a.flags = (a.flags & ~kSxEpiMask) | epi;
     } else
-        a.flags = SX_WN_RMW | (a.flags & (EPI_ACC | EPI_RES | EPI_MASK | EPI_RELU));
+        a.flags = SX_WN_RMW | (a.flags & (EPI_ACC | EPI_RES | EPI_MASK | EPI_RELU | SX_PLANAR_STORE2 | SX_PLANAR_COUPLING));
     if (nprod == 2) {  // two fp16 planes, three products (fp32-grade): the same specialised epilogues
         if (a.wscale == 0.f) a.wscale = 1.f;
         if (rawin)

@@ -1291,6 +1291,37 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
                     throw std::runtime_error(s + ": WN stack must end in a skip-only layer");
                 for (int i = 0; i + 1 < cd.n_wn; i++)
                     if (cd.wn[i].rs.Cout != 2 * flow_H) throw std::runtime_error(s + ": unexpected res_skip shape");
+                {
+                    // pre / post on the split-operand engine too when the whole WN stack runs there: pre reads the planes
+                    // the previous coupling's post wrote (x1 of one coupling is x0 of the next), post reads the planes of
+                    // the skip sum the last res_skip conv wrote.  VITSMI_FLOW_PREPOST_F32 keeps the f32 engine (A/B timing).
+                    static const bool pp_f32 = std::getenv("VITSMI_FLOW_PREPOST_F32") != nullptr;
+                    bool all_sx = !pp_f32 && half % 32 == 0 && flow_H % 32 == 0;
+                    for (int i = 0; i < cd.n_wn; i++)
+                        all_sx = all_sx && cd.wn[i].in.sx && cd.wn[i].in.f16 && cd.wn[i].in.gate && cd.wn[i].in.s16 && cd.wn[i].rs_sx.sx;
+                    if (all_sx && sx_supported(half, flow_H, flow_H, 1, 1) && sx_supported(flow_H, half, half, 1, 1)) {
+                        const TRef &wpre = R.need(s + ".pre.weight", 3), &wpost = R.need(s + ".post.weight", 3);
+                        const TRef *bpre = R.bias_of(s + ".pre.bias", flow_H), *bpost = R.bias_of(s + ".post.bias", half);
+                        const bool sw = cd.swapped;
+                        auto wf_pre = [&](int co, int ci, int) { return wpre.p[int64_t(co) * half + (sw ? rev[ci] : ci)]; };
+                        auto wf_post = [&](int co, int ci, int) { return wpost.p[int64_t(sw ? rev[co] : co) * flow_H + ci]; };
+                        std::vector<float> bperm;
+                        const float *bp = bpost ? bpost->p : nullptr;
+                        if (bpost && sw) {
+                            bperm.resize(half);
+                            for (int c = 0; c < half; c++) bperm[c] = bpost->p[rev[c]];
+                            bp = bperm.data();
+                        }
+                        t_sx_f16 = true;
+                        ConvDesc a = pack_conv_sx(P, half, flow_H, 1, 1, 0, wf_pre, bpre ? bpre->p : nullptr);
+                        ConvDesc b = pack_conv_sx(P, flow_H, half, 1, 1, 0, wf_post, bp);
+                        t_sx_f16 = false;
+                        if (a.s16 && b.s16 && a.K == 1 && b.K == 1) {
+                            cd.pre_sx = a;
+                            cd.post_sx = b;
+                        }
+                    }
+                }
                 if (gin) {
                     const int64_t rows = int64_t(2) * flow_H * cd.n_wn;
                     cd.cond_w = P.put(R.need(s + ".enc.cond_layer.weight", 3, rows * gin));

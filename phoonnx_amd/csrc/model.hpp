@@ -75,6 +75,9 @@ struct EncLayerDesc {
 
 struct CouplingDesc {  // one ResidualCouplingLayer with the preceding Flip folded in
     ConvDesc pre, post;
+    // pre / post once more for the split-operand engine (planar epilogue; taken when every WN layer of the coupling runs
+    // there): pre_sx.sx says whether they exist
+    ConvDesc pre_sx, post_sx;
     int n_wn = 0;
     struct {
         ConvDesc in, rs;

@@ -346,6 +346,8 @@ struct SxWn {               // SX_WN_RMW arguments of conv_sx()
     const int *len = nullptr;
     float *out_raw2 = nullptr;
     int row_split = 0, pl_rows = 0;
+    bool pl_of2 = false;          // planes of out_raw2's rows instead of out_raw's
+    int64_t planar_bstride = 0;   // batch stride of out_raw / res (0: row_split * T)
 };
 
 void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, uint16_t *out_pl, int flags,
@@ -373,6 +375,8 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
         a.row_split = wn->row_split;
         a.pl_rows = wn->pl_rows;
         a.pl_bstride = (int64_t)3 * wn->pl_rows * Tout;
+        a.pl_of2 = wn->pl_of2 ? 1 : 0;
+        a.planar_bstride = wn->planar_bstride;
     }
     a.res = res;
     a.zeros = c.P(c.m.zeros_off);
@@ -1270,6 +1274,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + al(nHF * 2) + gen_ws_bytes(m, B, Fgen) + (1 << 16);
     for (auto &cd : m.flow) need += al((size_t)B * 2 * Hf * cd.n_wn);
     need += al((size_t)B * m.C0);
+    need += al(nCF) + al(nHF * 2);  // operand planes of a coupling's x0 and of its skip sum (pre / post on the split-operand engine)
     if (int rc = slab_reserve(h, h->frm, need)) return rc;
     Slab &s = h->frm;
     s.used = 0;
@@ -1309,7 +1314,15 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     const int half = C / 2;
     const int64_t sCF = (int64_t)C * F, sHF = (int64_t)Hf * F;
     uint16_t *acts_pl = reinterpret_cast<uint16_t *>(a2);  // (a2 is unused where the gate writes operand planes)
-    for (auto &cd : m.flow) {
+    // pre / post on the split-operand engine (CouplingDesc::pre_sx): planes of x0 (written by the previous coupling's post:
+    // its x1 is this one's x0; split here for the first) and of the skip sum (written by the last res_skip conv)
+    uint16_t *x0_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, nCF));
+    uint16_t *skip_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, nHF * 2));
+    bool x0_planes_ready = false;
+    for (size_t ci = 0; ci < m.flow.size(); ci++) {
+        const auto &cd = m.flow[ci];
+        const bool pp = cd.pre_sx.sx && cd.post_sx.sx && half % 32 == 0;
+        const bool pp_next = ci + 1 < m.flow.size() && m.flow[ci + 1].pre_sx.sx && m.flow[ci + 1].post_sx.sx;
         float *gc = nullptr;
         const int gc_rows = 2 * Hf * cd.n_wn;
         if (m.gin) {
@@ -1329,7 +1342,16 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
         ex0.out_pl = planes0 ? hx_pl : nullptr;
         ex0.pl_rows = Hf;
         // h = pre(x0) * mask
-        conv(c, cd.pre, x0, sCF, F, hx, sHF, EPI_MASK, ylen, nullptr, 0, nullptr, 0, 0.1f, 1.f, 1.f, nullptr, 1.f, 0, 0, &ex0);
+        if (pp) {
+            if (!x0_planes_ready) {
+                sx_split_planes_kernel<<<dim3((F + 255) / 256, half / 8, B), 256, 0, st>>>(x0, sCF, F, nullptr, x0_pl, half, F, 1,
+                                                                                        range_slots(h, true));
+                h->stats.total_launches++;
+            }
+            conv_sx_planar(c, cd.pre_sx, x0_pl, F, hx, planes0 ? hx_pl : nullptr, EPI_MASK, ylen);
+        } else
+            conv(c, cd.pre, x0, sCF, F, hx, sHF, EPI_MASK, ylen, nullptr, 0, nullptr, 0, 0.1f, 1.f, 1.f, nullptr, 1.f, 0, 0, &ex0);
+        x0_planes_ready = false;
         for (int i = 0; i < cd.n_wn; i++) {
             const bool last = i == cd.n_wn - 1;
             // x_in = in_layer(h) + g_l ; acts = tanh * sigmoid ; rs = res_skip(acts)
@@ -1346,8 +1368,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
                 if (cd.wn[i].in.gate && cd.wn[i].rs_sx.sx) {
                     // gate in the in-layer's epilogue, acts handed over as fp16 operand planes; the res_skip 1 x 1 conv on
                     // the same engine reads them and folds the update in: x += res * mask (+ the next in-layer's planes),
-                    // skip += .. (skip was zeroed when the coupling started)
-                    if (i == 0) c.note(hipMemsetAsync(skip, 0, nHF * 4, st));
+                    // skip += .. (the first layer stores it)
                     conv_sx(c, cd.wn[i].in, hx_pl, F, nullptr, acts_pl, SX_GATE, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr,
                             gc_rows);
                     SxWn w;
@@ -1356,8 +1377,15 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
                     w.row_split = last ? 0 : Hf;
                     const bool np = !last && cd.wn[i + 1].in.sx && cd.wn[i + 1].in.f16 && Hf % 32 == 0;
                     w.pl_rows = np ? Hf : 0;
-                    conv_sx(c, cd.wn[i].rs_sx, acts_pl, F, hx, np ? hx_pl : nullptr, SX_WN_RMW | EPI_ACC | EPI_MASK, nullptr, nullptr, 0, 1.f, 1.f, 1.f,
-                            1.f, &w);
+                    uint16_t *rs_pl = np ? hx_pl : nullptr;
+                    if (last && pp) {  // the finished skip sum as post's operand planes
+                        w.pl_rows = Hf;
+                        w.pl_of2 = true;
+                        rs_pl = skip_pl;
+                    }
+                    // (the first layer stores its skip rows: no zero fill of skip, no read of it)
+                    conv_sx(c, cd.wn[i].rs_sx, acts_pl, F, hx, rs_pl,
+                            SX_WN_RMW | EPI_ACC | EPI_MASK | (i == 0 ? SX_PLANAR_STORE2 : 0), nullptr, nullptr, 0, 1.f, 1.f, 1.f, 1.f, &w);
                     continue;
                 } else if (cd.wn[i].in.gate) {  // tanh * sigmoid in the conv's epilogue: acts directly
                     conv_sx(c, cd.wn[i].in, hx_pl, F, acts, nullptr, SX_GATE, nullptr, gc ? gc + (int64_t)i * 2 * Hf : nullptr,
@@ -1383,7 +1411,17 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
                  nullptr, 0, 0.1f, 1.f, 1.f, skip, 1.f, 0, 0, &ex);
         }
         // x1 = (x1 - post(skip)*mask) * mask
-        conv(c, cd.post, skip, sHF, F, x1, sCF, EPI_COUPLING, ylen);
+        if (pp) {
+            SxWn w;
+            w.len = ylen;
+            w.row_split = half;
+            w.planar_bstride = sCF;           // (x1's rows live inside z)
+            w.pl_rows = pp_next ? half : 0;   // ... and are the next coupling's x0: its operand planes
+            conv_sx(c, cd.post_sx, skip_pl, F, x1, pp_next ? x0_pl : nullptr, SX_WN_RMW | EPI_ACC | EPI_MASK | SX_PLANAR_COUPLING,
+                    nullptr, nullptr, 0, 1.f, 1.f, 1.f, 1.f, &w);
+            x0_planes_ready = pp_next;
+        } else
+            conv(c, cd.post, skip, sHF, F, x1, sCF, EPI_COUPLING, ylen);
     }
     c.note(hipGetLastError());
 
