@@ -238,7 +238,9 @@ typedef struct {
     double sx_bytes;        /* layer-granular bytes of the split-engine launches (as conv_bytes) */
 } vits_stats;
 
-/* Enable per-stage HIP-event timing (adds event records on the handle's stream). */
+/* Enable HIP-event timing on the handle's stream: 1 = stage marks plus events around every conv launch (vits_get_stats
+ * conv_ms / sx_ms, vits_launch_records; the event records serialise the launches a little), 2 = stage marks only
+ * (enc_ms .. total_ms), 0 = off. */
 int vits_set_timing(vits_handle *h, int enable);
 int vits_get_stats(vits_handle *h, vits_stats *out);
 

@@ -63,7 +63,7 @@ struct vits_handle {
     int64_t *d_ylen64 = nullptr;
     std::vector<int> h_ylen;
     // stats
-    bool timing = false;
+    int timing = 0;  // vits_set_timing: 0 off, 1 stage marks + events around every conv launch, 2 stage marks only
     vits_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_events;
     std::vector<char> conv_event_sx;  // 1: that launch went through the split-exact engine
@@ -248,7 +248,7 @@ void conv_account(Ctx &c, const ConvDesc &d, int T) {
 // with timing enabled: record the start event of the next conv launch (the caller records the end event)
 bool conv_event_begin(Ctx &c) {
     vits_handle *h = c.h;
-    if (!h->timing) return false;
+    if (h->timing != 1) return false;
     if (h->conv_events_used == h->conv_events.size()) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0);
@@ -1628,7 +1628,7 @@ void *vits_stream(vits_handle *h) { return h ? (void *)h->stream : nullptr; }
 
 int vits_set_timing(vits_handle *h, int enable) {
     if (!h) return VITS_E_ARG;
-    h->timing = enable != 0;
+    h->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return VITS_OK;
 }
 
@@ -1647,7 +1647,7 @@ static int run_device_locked(vits_handle *h, const int64_t *ids, const int64_t *
     if (h->model.gin && !sid) return fail(h, VITS_E_ARG, "Missing speaker id");
     std::memset(&h->stats, 0, sizeof h->stats);
     h->conv_events_used = 0;
-    g_launch_name_on = h->timing;
+    g_launch_name_on = h->timing == 1;
     h->B = B;
     h->T = T;
     h->range_failed = false;
@@ -1884,7 +1884,7 @@ static int vocoder_common(vits_handle *h, const float *z, int B, int F, const in
             return fail(h, VITS_E_ARG, "sid[%d]=%lld is out of range [0,%d)", b, (long long)sid[b], m.n_speakers);
     std::memset(&h->stats, 0, sizeof h->stats);
     h->conv_events_used = 0;
-    g_launch_name_on = h->timing;
+    g_launch_name_on = h->timing == 1;
     h->range_failed = false;
     const size_t nCF = (size_t)B * m.C * F;
     const int Fgen = sink && sink->chunk_frames + 2 * m.gen_rf_frames < F ? sink->chunk_frames + 2 * m.gen_rf_frames : F;

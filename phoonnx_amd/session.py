@@ -406,7 +406,8 @@ class MiSession:
         return v.value
 
     def set_timing(self, on=True):
-        self._lib.vits_set_timing(self._h, 1 if on else 0)
+        """True / 1: stage marks + events around every conv launch; 2: stage marks only; False / 0: off."""
+        self._lib.vits_set_timing(self._h, 2 if on == 2 else (1 if on else 0))
 
     def stats(self):
         s = _ffi.VitsStats()
