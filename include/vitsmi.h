@@ -101,6 +101,8 @@ int vits_meta(vits_handle *h, const char *key, char *buf, size_t n);
 /* Derived hyper-parameters: "hidden","inter","filter","n_heads","n_layers","n_vocab",
  * "n_speakers","gin","use_sdp","hop" (= product of upsample rates),"n_ups","resblock",
  * "gen_sx" (1: the generator runs on the split-operand matrix-core engine, 0: on the f32-MFMA engine),
+ * "enc_sx" (1: the text encoder's convs run on the split-operand engine too - f16x3 voices; VITSMI_ENC_ENGINE=f32 keeps
+ *   the f32-MFMA engine),
  * "gen_rf_frames" (one-sided receptive field of the generator in frames: the context chunked rendering adds),
  * "gen_nprod" (the generator's arithmetic, chosen by VITSMI_GEN_PRECISION in the environment at open time:
  *   2 = "f16x3", the default: fp32 operands as two fp16 planes, three MFMA products per fp32 product, fp32
