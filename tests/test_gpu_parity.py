@@ -627,6 +627,32 @@ def test_padded_batch_interior_equals_single(tmp_path):
     s.close()
 
 
+def test_timing_levels():
+    """vits_set_timing: 1 = stage marks + events around every conv launch (per-launch records), 2 = stage marks only,
+    0 = nothing recorded; the audio does not depend on it."""
+    s = _session("sx_rb2_ms")
+    rng = np.random.default_rng(21)
+    B, T = 2, 48
+    ids = rng.integers(1, 200, (B, T)).astype(np.int64)
+    lens = np.array([T, T - 9], np.int64)
+    sid = np.array([1, 3], np.int64)
+    sc = np.array([0, 1.5, 0], np.float32)
+    ref = s.synthesize_batch(ids, lens, sc, sid)["output"]
+    s.set_timing(True)
+    a = s.synthesize_batch(ids, lens, sc, sid)["output"]
+    st = s.stats()
+    recs = s.launch_records()
+    assert st["total_ms"] > 0 and st["conv_ms"] > 0 and len(recs) == st["conv_launches"] > 0
+    assert all(r["ms"] > 0 and r["flops"] > 0 for r in recs)
+    s.set_timing(2)
+    b = s.synthesize_batch(ids, lens, sc, sid)["output"]
+    st2 = s.stats()
+    assert st2["total_ms"] > 0 and st2["dec_ms"] > 0 and st2["conv_ms"] == 0 and s.launch_records() == []
+    s.set_timing(False)
+    assert np.array_equal(ref, a) and np.array_equal(ref, b)
+    s.close()
+
+
 def test_pipelined_session_equals_plain_session():
     # two handles / streams sharing one weight arena, each rendering half of the batch: same utterances, same audio
     # (equal-length rows, so every part pads to the same frame count; zero noise scales make it deterministic)
