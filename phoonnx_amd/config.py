@@ -100,87 +100,107 @@ class VoiceConfig:
     @staticmethod
     def from_dict(config: Dict[str, Any], phonemes_txt: Optional[str] = None, lang_code: Optional[str] = None,
                   phoneme_type_str: Optional[str] = None) -> "VoiceConfig":
-        """Build the configuration from a voice JSON (NOTE: like the reference, this writes the
-        special-token keys it derives back into `config`)."""
-        blank_between = BlankBetween.TOKENS_AND_WORDS
-        lang_code = lang_code or config.get("lang_code")
-        phoneme_type_str = phoneme_type_str or config.get("phoneme_type")
-        id_map = config.get("phoneme_id_map")
-        alphabet = config.get("alphabet")
+        """Build the configuration from a voice JSON (config.py:218-358).  NOTE: like the reference, this writes the
+        special-token keys it derives back into `config`.
 
-        if phonemes_txt:
-            if phonemes_txt.endswith(".txt"):
-                with open(phonemes_txt, "r", encoding="utf-8") as fh:
-                    id_map = load_phoneme_ids(fh)
-            elif phonemes_txt.endswith(".json"):
-                with open(phonemes_txt) as fh:
-                    id_map = json.load(fh)
-
-        if VoiceConfig.is_piper(config):
-            lang_code = lang_code or (config.get("language", {}).get("code") or config.get("espeak", {}).get("voice"))
-            phoneme_type_str = config.get("phoneme_type", PhonemeType.ESPEAK.value)
-            if phoneme_type_str == "text":
-                phoneme_type_str, alphabet = PhonemeType.UNICODE.value, Alphabet.UNICODE
-            else:
-                alphabet = Alphabet.IPA
-            # fixed in piper
-            config.update(pad=DEFAULT_PAD_TOKEN, blank=DEFAULT_BLANK_TOKEN, bos=DEFAULT_BOS_TOKEN, eos=DEFAULT_EOS_TOKEN)
-        elif VoiceConfig.is_mimic3(config):
-            if not phonemes_txt:
-                raise ValueError("mimic3 models require an external phonemes.txt file in addition to the config")
-            lang_code = config.get("text_language")
-            phoneme_type_str = config.get("phonemizer", PhonemeType.GRUUT.value)
-            ph = config.get("phonemes", {})
-            blank_between = BlankBetween(ph.get("blank_between", "tokens_and_words"))
-            config.update(ph)
-            if phoneme_type_str == "symbols":  # grapheme model, symbols come from phonemes.txt
-                phoneme_type_str, alphabet = PhonemeType.GRAPHEMES.value, Alphabet.UNICODE
-            else:
-                alphabet = Alphabet.IPA
-        elif VoiceConfig.is_coqui_vits(config):  # includes cotovia
-            if VoiceConfig.is_cotovia(config):
-                phoneme_type_str, alphabet = PhonemeType.COTOVIA.value, Alphabet.COTOVIA
-            else:
-                phoneme_type_str, alphabet = PhonemeType.GRAPHEMES.value, Alphabet.UNICODE
-            datasets = config.get("datasets", [])
-            if datasets and not lang_code:
-                lang_code = datasets[0].get("language")
-            chars = config.get("characters", {})
-            if config.get("add_blank", True):
-                blank_between = BlankBetween.TOKENS
-                chars["blank"] = chars.get("blank") or "<BLNK>"
-            config.update(chars)
-            if not config.get("enable_eos_bos_chars", True):
-                config["bos"] = config["eos"] = None
-            # vocabulary order: [pad] + punctuations + characters + [blank]
-            vocab = []
-            if chars.get("pad") is not None:
-                vocab.append(chars["pad"])
-            vocab.extend(chars.get("punctuations") or "")
-            vocab.extend(chars.get("characters") or "")
-            if chars.get("blank") is not None:
-                vocab.append(chars["blank"])
-            id_map = {sym: i for i, sym in enumerate(vocab)}
-
-        phoneme_type = PhonemeType(phoneme_type_str)
+        Structure: what the caller / the JSON say outright goes into a small resolution record; the dialect adapter that
+        recognises the JSON (Piper, Mimic 3, Coqui VITS incl. Cotovia; a phoonnx JSON needs none) overrides what its
+        format fixes; one constructor call at the end reads the record and the (possibly updated) JSON."""
+        external = _external_id_map(phonemes_txt)
+        res = _Resolved(lang_code=lang_code or config.get("lang_code"),
+                        phoneme_type=phoneme_type_str or config.get("phoneme_type"),
+                        id_map=config.get("phoneme_id_map") if external is None else external,
+                        alphabet=config.get("alphabet"), has_phonemes_txt=bool(phonemes_txt))
+        for recognises, adapt in ((VoiceConfig.is_piper, _adapt_piper), (VoiceConfig.is_mimic3, _adapt_mimic3),
+                                  (VoiceConfig.is_coqui_vits, _adapt_coqui)):
+            if recognises(config):
+                adapt(config, res)
+                break
+        phoneme_type = PhonemeType(res.phoneme_type)
         LOG.debug("phonemizer: %s", phoneme_type)
         inference = config.get("inference", {})
-        include_whitespace = " " in config.get("characters", "") or " " in config.get("phoneme_id_map", {})
+        scalar = config.get
         return VoiceConfig(
-            num_langs=config.get("num_langs", 1),
-            num_symbols=config.get("num_symbols", 256),
-            num_speakers=config.get("num_speakers", 1),
+            num_langs=scalar("num_langs", 1), num_symbols=scalar("num_symbols", 256), num_speakers=scalar("num_speakers", 1),
             sample_rate=config.get("audio", {}).get("sample_rate", 16000),
             noise_scale=inference.get("noise_scale", DEFAULT_NOISE_SCALE),
             length_scale=inference.get("length_scale", DEFAULT_LENGTH_SCALE),
             noise_w_scale=inference.get("noise_w", DEFAULT_NOISE_W_SCALE),
-            lang_code=lang_code, alphabet=alphabet, phonemizer_model=config.get("phonemizer_model"),
-            phoneme_id_map=id_map, phoneme_type=phoneme_type, speaker_id_map=config.get("speaker_id_map", {}),
-            blank_between=blank_between, include_whitespace=include_whitespace,
-            blank_at_start=config.get("blank_at_start", True), blank_at_end=config.get("blank_at_end", True),
-            pad_token=config.get("pad"), blank_token=config.get("blank"), bos_token=config.get("bos"),
-            eos_token=config.get("eos"),
-            word_sep_token=config.get("word_sep_token") or config.get("blank_word", " "))
+            lang_code=res.lang_code, alphabet=res.alphabet, phonemizer_model=scalar("phonemizer_model"),
+            phoneme_id_map=res.id_map, phoneme_type=phoneme_type, speaker_id_map=scalar("speaker_id_map", {}),
+            blank_between=res.blank_between,
+            include_whitespace=" " in scalar("characters", "") or " " in scalar("phoneme_id_map", {}),
+            blank_at_start=scalar("blank_at_start", True), blank_at_end=scalar("blank_at_end", True),
+            pad_token=scalar("pad"), blank_token=scalar("blank"), bos_token=scalar("bos"), eos_token=scalar("eos"),
+            word_sep_token=scalar("word_sep_token") or scalar("blank_word", " "))
+
+
+@dataclass
+class _Resolved:
+    """What VoiceConfig.from_dict has settled so far (caller arguments first, then the JSON, then the dialect adapter)."""
+    lang_code: Optional[str]
+    phoneme_type: Optional[str]
+    id_map: Optional[Dict[str, Any]]
+    alphabet: Any
+    has_phonemes_txt: bool = False
+    blank_between: BlankBetween = BlankBetween.TOKENS_AND_WORDS
+
+
+def _external_id_map(path: Optional[str]):
+    """phonemes.txt (Mimic 3 style) or a JSON id map next to the voice; None when absent or of another kind."""
+    if not path:
+        return None
+    if path.endswith(".txt"):
+        with open(path, "r", encoding="utf-8") as fh:
+            return load_phoneme_ids(fh)
+    if path.endswith(".json"):
+        with open(path) as fh:
+            return json.load(fh)
+    return None
+
+
+def _adapt_piper(config: Dict[str, Any], res: _Resolved) -> None:
+    """Piper voices (config.py:259-275): language from `language.code` / `espeak.voice`, "text" = unicode graphemes,
+    everything else IPA; the four special tokens are fixed by the format."""
+    res.lang_code = res.lang_code or (config.get("language", {}).get("code") or config.get("espeak", {}).get("voice"))
+    kind = config.get("phoneme_type", PhonemeType.ESPEAK.value)
+    res.phoneme_type, res.alphabet = ((PhonemeType.UNICODE.value, Alphabet.UNICODE) if kind == "text"
+                                      else (kind, Alphabet.IPA))
+    config.update(pad=DEFAULT_PAD_TOKEN, blank=DEFAULT_BLANK_TOKEN, bos=DEFAULT_BOS_TOKEN, eos=DEFAULT_EOS_TOKEN)
+
+
+def _adapt_mimic3(config: Dict[str, Any], res: _Resolved) -> None:
+    """Mimic 3 voices (config.py:277-297): the symbol table lives in phonemes.txt, the `phonemes` block carries the
+    special tokens and the blank policy; "symbols" = a grapheme model."""
+    if not res.has_phonemes_txt:
+        raise ValueError("mimic3 models require an external phonemes.txt file in addition to the config")
+    res.lang_code = config.get("text_language")
+    kind = config.get("phonemizer", PhonemeType.GRUUT.value)
+    block = config.get("phonemes", {})
+    res.blank_between = BlankBetween(block.get("blank_between", "tokens_and_words"))
+    config.update(block)
+    res.phoneme_type, res.alphabet = ((PhonemeType.GRAPHEMES.value, Alphabet.UNICODE) if kind == "symbols"
+                                      else (kind, Alphabet.IPA))
+
+
+def _adapt_coqui(config: Dict[str, Any], res: _Resolved) -> None:
+    """Coqui VITS voices, Cotovia included (config.py:299-338): graphemes (or Cotovia's alphabet), language from the
+    first dataset, vocabulary = [pad] + punctuations + characters + [blank]."""
+    res.phoneme_type, res.alphabet = ((PhonemeType.COTOVIA.value, Alphabet.COTOVIA) if VoiceConfig.is_cotovia(config)
+                                      else (PhonemeType.GRAPHEMES.value, Alphabet.UNICODE))
+    datasets = config.get("datasets", [])
+    if datasets and not res.lang_code:
+        res.lang_code = datasets[0].get("language")
+    chars = config.get("characters", {})
+    if config.get("add_blank", True):
+        res.blank_between = BlankBetween.TOKENS
+        chars["blank"] = chars.get("blank") or "<BLNK>"
+    config.update(chars)
+    if not config.get("enable_eos_bos_chars", True):
+        config["bos"] = config["eos"] = None
+    edge = lambda key: [chars[key]] if chars.get(key) is not None else []  # noqa: E731
+    vocab = edge("pad") + list(chars.get("punctuations") or "") + list(chars.get("characters") or "") + edge("blank")
+    res.id_map = {sym: i for i, sym in enumerate(vocab)}
 
 
 @dataclass
