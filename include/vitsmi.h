@@ -291,6 +291,16 @@ int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, in
  * bit 16: s_memtime ticks per pipeline step spent in {LDS wait, DMA wait, barrier, DMA issue, loads + MFMA}. */
 int vits_test_conv1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
                         int Cout, int K, int dil, int pad_l, int flags, float slope, float *out);
+/* The planar epilogue of the split-operand engine (f16x3 arithmetic, 16x16x32 loop; "same" padding), as the flow's
+ * res_skip / pre / post convs and the text encoder's convs use it: o = old + act(conv(x) + bias) * mask, rows
+ * [0, row_split) into a first planar tensor, the rest into a second.  flags: 1 ReLU, 2 mask (t < lens[b]), 4 residual
+ * (old [B][row_split][T] is added to the first tensor's rows), 8 accumulate (old [B][Cout][T] = the outputs' previous
+ * contents), 16 coupling update o = (old - value * mask) * mask (with 8), 32 the second tensor's rows are stored, not
+ * accumulated (with 8), 64 the operand planes are those of the second tensor's rows.  out: [B][Cout][T]; planes_out
+ * (nullable): [B][pl_rows][T] as read back from the fp16 operand planes the epilogue wrote. */
+int vits_test_conv1d_sx_planar(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
+                               int Cout, int K, int dil, int flags, const int64_t *lens, const float *old, int row_split,
+                               int pl_rows, float *out, float *planes_out);
 int vits_test_conv_transpose1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w,
                                   const float *bias, int Cout, int K, int stride, float *out);
 int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, int dil, int dbg, int iters,

@@ -2274,6 +2274,89 @@ int vits_test_conv1d_sx(int device_id, const float *x, int B, int Cin, int T, co
     return run_test_conv_sx(d, arena, x, B, T, flags, slope, out);
 }
 
+int vits_test_conv1d_sx_planar(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
+                               int Cout, int K, int dil, int flags, const int64_t *lens, const float *old, int row_split,
+                               int pl_rows, float *out, float *planes_out) {
+    // the planar epilogue of the split-operand engine (f16x3, 16x16x32 loop), as the flow and the text encoder use it:
+    // flags bit 0 ReLU, 1 mask (t < lens[b]), 2 residual (old: planar [B][row_split][T]), 3 accumulate (old: the
+    // outputs' previous contents, [B][Cout][T]), 4 coupling update, 5 the rows behind row_split are stored (not
+    // accumulated), 6 the planes are those of the rows behind row_split.  out = [B][Cout][T] (rows behind row_split from
+    // the second tensor); planes_out (nullable) = [B][pl_rows][T] read back from the operand planes.
+    if (int rc = test_dev(device_id)) return rc;
+    if (Cin % 32 || Cout % 32 || row_split % 32 || row_split > Cout || pl_rows % 32) return fail(nullptr, VITS_E_ARG, "bad planar test shape");
+    ConvDesc d;
+    std::vector<float> arena;
+    set_sx_f16(true);
+    std::string e = pack_test_conv(w, bias, Cin, Cout, K, dil, dil * (K - 1) / 2, 3, &d, &arena);
+    set_sx_f16(false);
+    if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
+    if (!d.s16) return fail(nullptr, VITS_E_ARG, "shape not taken by the 16x16x32 loop");
+    const int srows = Cout - row_split;
+    const size_t nx = (size_t)B * Cin * T, n1 = (size_t)B * (row_split ? row_split : 1) * T, n2 = (size_t)B * (srows ? srows : 1) * T;
+    float *dA = nullptr, *dx = nullptr, *d1 = nullptr, *d2 = nullptr, *dres = nullptr, *dpo = nullptr;
+    uint16_t *dxp = nullptr, *dpl = nullptr;
+    int *dlen = nullptr;
+    TCHECK(hipMalloc((void **)&dA, arena.size() * 4));
+    TCHECK(hipMalloc((void **)&dx, nx * 4 + 16));
+    TCHECK(hipMalloc((void **)&dxp, nx * 6 + 64));
+    TCHECK(hipMalloc((void **)&d1, n1 * 4 + 16));
+    TCHECK(hipMalloc((void **)&d2, n2 * 4 + 16));
+    TCHECK(hipMalloc((void **)&dres, n1 * 4 + 16));
+    TCHECK(hipMalloc((void **)&dpl, (size_t)B * 3 * (pl_rows ? pl_rows : 32) * T * 2 + 64));
+    TCHECK(hipMalloc((void **)&dpo, (size_t)B * (pl_rows ? pl_rows : 32) * T * 4 + 16));
+    TCHECK(hipMalloc((void **)&dlen, (size_t)B * 4));
+    std::vector<int> l32(B);
+    for (int b = 0; b < B; b++) l32[b] = lens ? (int)lens[b] : T;
+    TCHECK(hipMemcpy(dlen, l32.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dA, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemset(d1, 0, n1 * 4));
+    TCHECK(hipMemset(d2, 0, n2 * 4));
+    TCHECK(hipMemset(dres, 0, n1 * 4));
+    if (old) {
+        // [B][Cout][T] -> the two planar tensors (accumulate / coupling) or the residual (rows of the first tensor)
+        for (int b = 0; b < B; b++) {
+            if (row_split)
+                TCHECK(hipMemcpy(((flags & 4) ? dres : d1) + (size_t)b * row_split * T, old + (size_t)b * Cout * T, (size_t)row_split * T * 4,
+                                 hipMemcpyHostToDevice));
+            if (srows && !(flags & 4))
+                TCHECK(hipMemcpy(d2 + (size_t)b * srows * T, old + ((size_t)b * Cout + row_split) * T, (size_t)srows * T * 4,
+                                 hipMemcpyHostToDevice));
+        }
+    }
+    sx_split_planes_kernel<<<dim3((T + 255) / 256, Cin / 8, B), 256>>>(dx, (int64_t)Cin * T, T, nullptr, dxp, Cin, T, 1);
+    SxArgs a{};
+    fill_sx_args(a, d, dA, T);
+    a.wscale = d.wscale;
+    a.s16 = 1;
+    a.xp = reinterpret_cast<const u32x4 *>(dxp);
+    a.out_raw = row_split ? d1 : nullptr;
+    a.out_raw2 = srows ? d2 : nullptr;
+    a.row_split = row_split;
+    a.len = dlen;
+    a.res = (flags & 4) ? dres : nullptr;
+    a.out_pl = pl_rows ? dpl : nullptr;
+    a.pl_rows = pl_rows;
+    a.pl_of2 = (flags & 64) ? 1 : 0;
+    a.pl_bstride = (int64_t)3 * pl_rows * T;
+    a.flags = SX_WN_RMW | ((flags & 1) ? EPI_RELU : 0) | ((flags & 2) ? EPI_MASK : 0) | ((flags & 4) ? EPI_RES : 0) |
+              ((flags & 8) ? EPI_ACC : 0) | ((flags & 16) ? SX_PLANAR_COUPLING : 0) | ((flags & 32) ? SX_PLANAR_STORE2 : 0);
+    TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, false, 2));
+    if (pl_rows)
+        sx_unblock_kernel<<<dim3((T + 255) / 256, pl_rows / 8, B), 256>>>(nullptr, dpl, dpo, pl_rows, T, 1);
+    TCHECK(hipGetLastError());
+    TCHECK(hipDeviceSynchronize());
+    for (int b = 0; b < B; b++) {
+        if (row_split)
+            TCHECK(hipMemcpy(out + (size_t)b * Cout * T, d1 + (size_t)b * row_split * T, (size_t)row_split * T * 4, hipMemcpyDeviceToHost));
+        if (srows)
+            TCHECK(hipMemcpy(out + ((size_t)b * Cout + row_split) * T, d2 + (size_t)b * srows * T, (size_t)srows * T * 4, hipMemcpyDeviceToHost));
+    }
+    if (pl_rows && planes_out) TCHECK(hipMemcpy(planes_out, dpo, (size_t)B * pl_rows * T * 4, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dx); hipFree(dxp); hipFree(d1); hipFree(d2); hipFree(dres); hipFree(dpl); hipFree(dpo); hipFree(dlen);
+    return VITS_OK;
+}
+
 int vits_test_conv_transpose1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
                                   int Cout, int K, int stride, float *out) {
     if (int rc = test_dev(device_id)) return rc;

@@ -758,6 +758,31 @@ def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=
     return out
 
 
+def test_conv1d_sx_planar(x, w, bias=None, dil=1, lens=None, old=None, row_split=None, pl_rows=0, relu=False, mask=False,
+                          residual=False, accumulate=False, coupling=False, store2=False, planes_of2=False, device_id=0):
+    """The split-operand engine's planar epilogue (f16x3, "same" padding): o = old + act(conv(x) + bias) * mask, rows
+    [0, row_split) in a first tensor, the rest in a second (see include/vitsmi.h).  Returns (out [B, Cout, T],
+    planes [B, pl_rows, T] or None)."""
+    lib = _ffi.load()
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    B, Cin, T = x.shape
+    Cout, _, K = w.shape
+    b = None if bias is None else np.ascontiguousarray(bias, np.float32)
+    ln = None if lens is None else np.ascontiguousarray(lens, np.int64)
+    od = None if old is None else np.ascontiguousarray(old, np.float32)
+    out = np.empty((B, Cout, T), np.float32)
+    pl = np.empty((B, pl_rows, T), np.float32) if pl_rows else None
+    flags = (1 if relu else 0) | (2 if mask else 0) | (4 if residual else 0) | (8 if accumulate else 0) | \
+            (16 if coupling else 0) | (32 if store2 else 0) | (64 if planes_of2 else 0)
+    rc = lib.vits_test_conv1d_sx_planar(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, dil, flags,
+                                        _ffi.ptr(ln), _ffi.ptr(od), Cout if row_split is None else row_split, pl_rows,
+                                        _ffi.ptr(out), _ffi.ptr(pl))
+    if rc != 0:
+        raise SessionError(_ffi.last_error(None))
+    return out, pl
+
+
 def test_conv_pair_sx(x, w1, b1, w2, b2, dil1=1, dil2=1, chain=False, slope=0.1, device_id=0, timed=False):
     """Two dependent convs in ONE fused launch (raw-format stage of the generator; f16x3):
     chain=False (ResBlock1 step): out = c2(lrelu(c1(lrelu(x)))) + x

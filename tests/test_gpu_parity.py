@@ -483,6 +483,71 @@ def test_sx_generator_matches_reference_goldens(monkeypatch, preset, precision, 
     s.close()
 
 
+def _conv_same_f64(x, w, bias, dil):
+    B, Cin, T = x.shape
+    Cout, _, K = w.shape
+    pad = dil * (K - 1) // 2
+    xp = np.zeros((B, Cin, T + 2 * pad))
+    xp[:, :, pad:pad + T] = x
+    y = np.zeros((B, Cout, T))
+    for k in range(K):
+        y += np.einsum("oc,bct->bot", w[:, :, k].astype(np.float64), xp[:, :, k * dil:k * dil + T])
+    return y + (0 if bias is None else bias.astype(np.float64)[None, :, None])
+
+
+PLANAR_CASES = [
+    # (B, Cin, Cout, T, K, row_split, pl_rows, options)                      as used by
+    (2, 192, 576, 200, 1, None, 0, dict()),                                   # encoder q|k|v: planar out, nothing else
+    (2, 192, 192, 333, 1, None, 0, dict(residual=True)),                      # encoder o: x = x_in + o(att)
+    (3, 192, 768, 256, 3, None, 768, dict(relu=True, mask=True)),             # FFN conv_1: ReLU, mask, operand planes
+    (2, 768, 192, 131, 3, None, 0, dict(mask=True, accumulate=True)),         # FFN conv_2: x += y * mask
+    (2, 192, 384, 824, 1, 192, 192, dict(mask=True, accumulate=True)),        # flow res_skip: x / skip update, planes of x
+    (2, 192, 384, 300, 1, 192, 0, dict(mask=True, accumulate=True, store2=True)),   # ... first layer: skip stored
+    (2, 192, 192, 500, 1, 0, 192, dict(mask=True, accumulate=True, planes_of2=True)),  # ... last layer: planes of skip
+    (2, 192, 96, 700, 1, None, 96, dict(mask=True, accumulate=True, coupling=True)),   # coupling post: x1 update + planes
+    (1, 96, 192, 97, 1, None, 192, dict(mask=True)),                          # coupling pre (three 32-channel chunks)
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,T,K,row_split,pl_rows,opt", PLANAR_CASES)
+def test_conv_sx_planar_epilogue_matches_float64(B, Cin, Cout, T, K, row_split, pl_rows, opt):
+    """Kernel level: the planar epilogue of the split-operand engine (f16x3 products, 16x16x32 loop) against a float64
+    restatement of `old + act(conv(x) + bias) * mask` (modules.py:200-209, 447-466; attentions.py:66-75, 419-427)."""
+    from phoonnx_amd.session import test_conv1d_sx_planar
+    rng = np.random.default_rng(B * 1000 + Cin + Cout + T)
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    lens = np.array([T] + [int(v) for v in rng.integers(T // 3, T, B - 1)], np.int64)
+    rs = Cout if row_split is None else row_split
+    old = None
+    if opt.get("accumulate"):
+        old = rng.standard_normal((B, Cout, T)).astype(np.float32)
+    elif opt.get("residual"):
+        old = rng.standard_normal((B, Cout, T)).astype(np.float32)
+    got, planes = test_conv1d_sx_planar(x, w, bias, lens=lens, old=old, row_split=row_split, pl_rows=pl_rows, **opt)
+    v = _conv_same_f64(x, w, bias, 1)
+    if opt.get("relu"):
+        v = np.maximum(v, 0)
+    mk = (np.arange(T)[None, :] < lens[:, None]).astype(np.float64)[:, None, :] if opt.get("mask") else 1.0
+    o64 = np.zeros_like(v) if old is None else old.astype(np.float64)
+    if opt.get("residual"):
+        want = o64 + v * mk
+    elif opt.get("coupling"):
+        want = (o64 - v * mk) * mk
+    else:
+        want = o64 + v * mk
+        if opt.get("store2"):
+            want[:, rs:] = (v * mk)[:, rs:]
+    scale = float(np.abs(want).max())
+    assert scale > 1.0
+    np.testing.assert_allclose(got, want, atol=2e-5 * scale, rtol=0)
+    if pl_rows:
+        ref = want[:, rs:rs + pl_rows] if opt.get("planes_of2") else want[:, :pl_rows]
+        # (two fp16 planes carry ~22 bits of a value)
+        np.testing.assert_allclose(planes, ref, atol=2e-5 * scale, rtol=0)
+
+
 def test_fused_mrf_stage_is_bit_identical_to_separate_chains(monkeypatch):
     """The 32-channel ResBlock2 stage as ONE launch (conv_sx_pair_kernel<.., NCH>: every chain from one resident x tile,
     the multi-receptive-field sum in registers; opt-in, VITSMI_SX_MRF=1) against the default chain-per-launch form: same
