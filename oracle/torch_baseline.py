@@ -279,3 +279,35 @@ class TorchVits:
         return {"output": o.unsqueeze(1).numpy(), "y_lengths": y_len.numpy(), "w_ceil": w_ceil[:, 0].numpy(),
                 "z": z.numpy(), "z_p": z_p.numpy(), "logw": logw.numpy(), "x": x.numpy(), "m_p": m_p.numpy(),
                 "logs_p": logs_p.numpy()}
+
+
+def _worker(argv):
+    """`python torch_baseline.py --worker <voice.onnx> <tokens> <length_scale> <threads> <seconds> <start_epoch>`: one of P
+    processes that bench.py's cpu_baseline starts side by side (P x `threads` host threads): utterance after utterance at
+    B = 1 - the reference's own call shape (voice.py:350-351, sentences one by one) - from `start_epoch` for `seconds`;
+    prints "samples seconds"."""
+    import time
+    voice, tokens, ls, threads, seconds, start = argv[0], int(argv[1]), float(argv[2]), int(argv[3]), float(argv[4]), float(argv[5])
+    torch.set_num_threads(threads)
+    m = TorchVits(voice)
+    rng = np.random.default_rng(os.getpid())
+    scales = np.array([0.667, ls, 0.8], np.float32)
+    ids = rng.integers(0, 256, size=(1, tokens)).astype(np.int64)
+    lens = np.full((1,), tokens, np.int64)
+    ndp = rng.standard_normal((1, 2, tokens)).astype(np.float32)
+    nz = rng.standard_normal((1, m.C, tokens * 12)).astype(np.float32)
+    m.infer(ids[:, :64], np.full((1,), 64, np.int64), scales, None, ndp[:, :, :64], nz)  # warm-up
+    while time.time() < start:
+        time.sleep(0.01)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        r = m.infer(ids, lens, scales, None, ndp, nz)
+        n += int(np.asarray(r["y_lengths"]).sum()) * m.hop
+    print(n, time.perf_counter() - t0, flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+        _worker(sys.argv[2:])
+

@@ -74,9 +74,17 @@ def load():
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.exists(path):
+    if not os.environ.get("VITSMI_LIB"):
+        # the in-tree library must be the build of the in-tree sources: compared by content hash (_build_info.json, written
+        # by phoonnx_amd/build.py), rebuilt when it is not - or, without a compiler, refused: never a stale binary
         from . import build as _build
-        _build.build()
+        if _build.stale():
+            try:
+                _build.build()
+            except Exception as e:
+                raise RuntimeError(f"{path} is missing or was not built from the sources in this tree (source_sha "
+                                   f"{_build.source_sha()} vs recorded {_build.read_build_info().get('source_sha')}) "
+                                   f"and cannot be rebuilt here: {e}") from e
     lib = C.CDLL(path)
     vp, i64p, f32p = C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_float)
     lib.vits_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]

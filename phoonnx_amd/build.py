@@ -7,7 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvitsmi.so")
-SOURCES = ["vitsmi.hip", "g2p.hip", "model.cpp", "onnx_reader.cpp"]
+SOURCES = ["vitsmi.hip", "tu_conv_f32.hip", "tu_sx.hip", "tu_sx_s16.hip", "tu_sx_s32.hip", "tu_sx_bf16.hip", "tu_pair.hip", "g2p.hip",
+           "model.cpp", "onnx_reader.cpp"]
 HEADERS = ["kernels.hip.hpp", "conv_engine.hip.hpp", "conv_sx_engine.hip.hpp", "conv_sx_pair.hip.hpp", "sx_split.hip.hpp", "model.hpp",
            "g2p_model.hpp", "onnx_reader.hpp", "../../include/vitsmi.h", "../../include/g2pmi.h"]
 
@@ -19,45 +20,104 @@ def hipcc():
     raise RuntimeError("hipcc not found (ROCm toolchain required to build libvitsmi.so)")
 
 
+def source_sha():
+    """sha256 over every file the library is compiled from (and the extra compiler flags): what `libvitsmi.so` must match."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        h.update(f.encode() + b"\0")
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(os.environ.get("VITSMI_CXXFLAGS", "").encode())
+    return h.hexdigest()[:16]
+
+
+INFO = os.path.join(HERE, "_build_info.json")
+
+
+def read_build_info():
+    import json
+    try:
+        with open(INFO) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
 def stale():
+    """The library is missing, or was built from other sources than the ones in the tree.  Decided by CONTENT (the recorded
+    source hash), not by mtime: built `.so` files travel to the GPU box next to sources whose mtimes mean nothing there."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    rec = read_build_info().get("source_sha")
+    if rec is None:  # (a library without a record: fall back to mtimes)
+        t = os.path.getmtime(LIB)
+        return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return rec != source_sha()
 
 
-def write_build_info():
-    """phoonnx_amd/_build_info.json: the commit this tree was built from (the GPU box receives no .git)."""
+def write_build_info(compiled, sha):
+    """phoonnx_amd/_build_info.json: whether this call compiled, the hash of the sources the library was built from, and
+    the commit of the tree (the GPU box receives no .git)."""
     import json
     import time
     root = os.path.dirname(HERE)
+    info = dict(read_build_info())
+    info.update({"compiled": bool(compiled), "source_sha": sha})
+    if compiled:
+        info["time"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())
     try:
         head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5)
-        if head.returncode != 0 or not head.stdout.strip():
-            return
-        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], capture_output=True,
-                               text=True, timeout=10).stdout.strip() != ""
-        with open(os.path.join(HERE, "_build_info.json"), "w") as f:
-            json.dump({"commit": head.stdout.strip(), "dirty": dirty, "time": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}, f)
+        if head.returncode == 0 and head.stdout.strip() and compiled:
+            info["commit"] = head.stdout.strip()
+            info["dirty"] = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"],
+                                           capture_output=True, text=True, timeout=10).stdout.strip() != ""
     except Exception:
         pass
+    try:
+        with open(INFO, "w") as f:
+            json.dump(info, f)
+    except Exception:
+        pass
+    return info
 
 
 def build(force=False, verbose=False):
-    write_build_info()
+    sha = source_sha()
     if not force and not stale():
+        info = write_build_info(False, sha)
+        print(f"phoonnx_amd.build: reused libvitsmi.so (source_sha {sha} matches the record; built from "
+              f"{info.get('commit', '?')}{'+dirty' if info.get('dirty') else ''})", file=sys.stderr)
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-Wno-unused-result", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    cmd[1:1] = os.environ.get("VITSMI_CXXFLAGS", "").split()  # kernel experiments (-DSX_EXP_...)
+    # one hipcc process per translation unit, side by side, then one link (the HIP files dominate: minutes each)
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+    base[1:1] = os.environ.get("VITSMI_CXXFLAGS", "").split()  # kernel experiments (-DSX_EXP_...)
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    r = subprocess.run(cmd, capture_output=True, text=True)
+        base.insert(1, "-Rpass-analysis=kernel-resource-usage")
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        r = subprocess.run(base + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+        return src, obj, r
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    for src, _, r in results:
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError(f"hipcc failed compiling {src}")
+        if verbose:
+            sys.stderr.write(r.stderr)
+    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for _, o, _ in results],
+                       capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libvitsmi.so")
-    if verbose:
-        sys.stderr.write(r.stderr)
+        raise RuntimeError("hipcc failed linking libvitsmi.so")
+    write_build_info(True, sha)
+    print(f"phoonnx_amd.build: compiled libvitsmi.so (source_sha {sha})", file=sys.stderr)
     return LIB
 
 

@@ -598,14 +598,9 @@ inline int conv_stage_floats(int cfg) {
 
 template <int MW, int NW, int WM, int WN, int VEC, int ACT, int KS = 1>
 inline hipError_t launch_conv_k(const ConvArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;  // allow > 64 KiB of dynamic LDS, once per instantiation
+    static std::atomic<uint64_t> attr_done{0};  // allow > 64 KiB of dynamic LDS, once per (instantiation, device)
     auto kern = conv_engine_kernel<MW, NW, WM, WN, VEC, ACT, KS>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSxMaxDynLds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = sx_allow_big_lds(reinterpret_cast<const void *>(kern), attr_done); e != hipSuccess) return e;
     if (g_launch_name_on)
         snprintf(g_launch_name, sizeof g_launch_name, "conv_engine_kernel<%d, %d, %d, %d, %d, %d, %d>", MW, NW, WM, WN, VEC, ACT, KS);
     kern<<<grid, 256, lds, stream>>>(a);
@@ -619,7 +614,9 @@ inline hipError_t launch_conv_t(const ConvArgs &a, dim3 grid, bool vec4, bool ac
 }
 
 // Launch on `stream`; LW / padLa / xs_floats / magic are filled in here.
-inline hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
+hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream);
+#ifdef VITSMI_IMPL_CONV_F32  // (tu_conv_f32.hip: the f32 engine's instantiations are one translation unit)
+hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
     const int BN = conv_tile_n(cfg), BM = conv_tile_m(cfg);
     const int halo = (a.K - 1) * a.dil;
     // 16-byte DMA needs 16-byte aligned rows: T % 4 == 0, aligned base/batch stride, no ragged input mask
@@ -660,5 +657,6 @@ inline hipError_t launch_conv(ConvArgs a, int cfg, int B, hipStream_t stream) {
         default: return launch_conv_t<1, 1, 1, 4>(a, grid, vec4, act, lds, stream);
     }
 }
+#endif  // VITSMI_IMPL_CONV_F32
 
 }  // namespace vitsmi

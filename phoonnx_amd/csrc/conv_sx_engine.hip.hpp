@@ -1177,14 +1177,9 @@ inline int sx_tile_n(int cfg) { return cfg == 3 ? 128 : 256; }
 
 template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool RAWIN = false, int NP = 6, int SH = 32>
 inline hipError_t launch_conv_sx_k(const SxArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_done{0};
     auto kern = conv_sx_kernel<MW, NW, WM, WN, EPI, PROF, RAWIN, NP, SH>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kSxMaxDynLds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = sx_allow_big_lds(reinterpret_cast<const void *>(kern), attr_done); e != hipSuccess) return e;
     if (g_launch_name_on)
         snprintf(g_launch_name, sizeof g_launch_name, "conv_sx_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %d>", MW, NW, WM, WN, EPI,
                  PROF ? "true" : "false", RAWIN ? "true" : "false", NP, SH);
@@ -1262,8 +1257,12 @@ inline hipError_t launch_conv_sx_np(const SxArgs &a, int nprod, dim3 grid, size_
 // registers for it (cfg 1 / 2).  nprod: 6 (exact, default), 3 or 1 (declared reduced-precision modes).
 // pack_cfg: the tile config the weights were packed for, if not `cfg` (a taller one: 128-row packing read by the 64-
 // or 32-row kernel - same products in the same order, a shorter reduction per workgroup and 2-4x the workgroups).
-inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin = false, int nprod = 6,
-                                 int pack_cfg = -1) {
+hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin = false, int nprod = 6, int pack_cfg = -1);
+hipError_t launch_conv_sx_f16_s16(const SxArgs &a, int cfg, int epi, dim3 grid, size_t lds, hipStream_t stream);
+hipError_t launch_conv_sx_f16_s32(const SxArgs &a, int cfg, int epi, bool rawin, dim3 grid, size_t lds, hipStream_t stream);
+hipError_t launch_conv_sx_bf16(const SxArgs &a, int cfg, int epi, int nprod, bool rawin, dim3 grid, size_t lds, hipStream_t stream);
+#ifdef VITSMI_IMPL_SX
+hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin, int nprod, int pack_cfg) {
     const int BM = sx_tile_m(cfg), BN = sx_tile_n(cfg);
     a.wshift = 0;
     if (pack_cfg >= 0 && pack_cfg != cfg) {
@@ -1347,32 +1346,47 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
         a.flags = SX_WN_RMW | (a.flags & (EPI_ACC | EPI_RES | EPI_MASK | EPI_RELU | SX_PLANAR_STORE2 | SX_PLANAR_COUPLING));
     if (nprod == 2) {  // two fp16 planes, three products (fp32-grade): the same specialised epilogues
         if (a.wscale == 0.f) a.wscale = 1.f;
-        if (rawin)
-            return cfg == 1 ? launch_conv_sx_rawin<1, 4, 2, 2, 2>(a, epi, grid, lds, stream)
-                            : launch_conv_sx_rawin<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
-        if (s16) {
-            switch (cfg) {
-#if SX16_WIDE
-                case 0: return launch_conv_sx_epi<1, 8, 4, 1, 2, 16>(a, epi, grid, lds, stream);
-#else
-                case 0: return launch_conv_sx_epi<2, 4, 2, 2, 2, 16>(a, epi, grid, lds, stream);
-#endif
-                case 1: return launch_conv_sx_epi<1, 4, 2, 2, 2, 16>(a, epi, grid, lds, stream);
-                case 3: return launch_conv_sx_epi<1, 2, 2, 2, 2, 16>(a, epi, grid, lds, stream);
-                default: return launch_conv_sx_epi<1, 2, 1, 4, 2, 16>(a, epi, grid, lds, stream);
-            }
-        }
-        if (a.prof && cfg == 0) return launch_conv_sx_k<2, 4, 2, 2, -1, true, false, 2>(a, grid, lds, stream);
-        switch (cfg) {
-#if SX_CFG0_WIDE
-            case 0: return launch_conv_sx_epi<1, 8, 4, 1, 2>(a, epi, grid, lds, stream);
-#else
-            case 0: return launch_conv_sx_epi<2, 4, 2, 2, 2>(a, epi, grid, lds, stream);
-#endif
-            case 1: return launch_conv_sx_epi<1, 4, 2, 2, 2>(a, epi, grid, lds, stream);
-            default: return launch_conv_sx_epi<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
-        }
+        if (s16) return launch_conv_sx_f16_s16(a, cfg, epi, grid, lds, stream);
+        return launch_conv_sx_f16_s32(a, cfg, epi, rawin, grid, lds, stream);
     }
+    return launch_conv_sx_bf16(a, cfg, epi, nprod, rawin, grid, lds, stream);
+}
+#endif  // VITSMI_IMPL_SX
+
+// The instantiation families, one translation unit each (tu_sx_*.hip: they compile side by side):
+#ifdef VITSMI_IMPL_SX_S16
+hipError_t launch_conv_sx_f16_s16(const SxArgs &a, int cfg, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+    switch (cfg) {
+#if SX16_WIDE
+        case 0: return launch_conv_sx_epi<1, 8, 4, 1, 2, 16>(a, epi, grid, lds, stream);
+#else
+        case 0: return launch_conv_sx_epi<2, 4, 2, 2, 2, 16>(a, epi, grid, lds, stream);
+#endif
+        case 1: return launch_conv_sx_epi<1, 4, 2, 2, 2, 16>(a, epi, grid, lds, stream);
+        case 3: return launch_conv_sx_epi<1, 2, 2, 2, 2, 16>(a, epi, grid, lds, stream);
+        default: return launch_conv_sx_epi<1, 2, 1, 4, 2, 16>(a, epi, grid, lds, stream);
+    }
+}
+#endif
+#ifdef VITSMI_IMPL_SX_S32
+hipError_t launch_conv_sx_f16_s32(const SxArgs &a, int cfg, int epi, bool rawin, dim3 grid, size_t lds, hipStream_t stream) {
+    if (rawin)
+        return cfg == 1 ? launch_conv_sx_rawin<1, 4, 2, 2, 2>(a, epi, grid, lds, stream)
+                        : launch_conv_sx_rawin<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
+    if (a.prof && cfg == 0) return launch_conv_sx_k<2, 4, 2, 2, -1, true, false, 2>(a, grid, lds, stream);
+    switch (cfg) {
+#if SX_CFG0_WIDE
+        case 0: return launch_conv_sx_epi<1, 8, 4, 1, 2>(a, epi, grid, lds, stream);
+#else
+        case 0: return launch_conv_sx_epi<2, 4, 2, 2, 2>(a, epi, grid, lds, stream);
+#endif
+        case 1: return launch_conv_sx_epi<1, 4, 2, 2, 2>(a, epi, grid, lds, stream);
+        default: return launch_conv_sx_epi<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
+    }
+}
+#endif
+#ifdef VITSMI_IMPL_SX_BF16
+hipError_t launch_conv_sx_bf16(const SxArgs &a, int cfg, int epi, int nprod, bool rawin, dim3 grid, size_t lds, hipStream_t stream) {
     if (nprod != 6) {
         if (nprod != 3 && nprod != 1) return hipErrorInvalidValue;
         if (rawin)
@@ -1394,7 +1408,9 @@ inline hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, b
         default: return launch_conv_sx_epi<1, 2, 1, 4>(a, epi, grid, lds, stream);
     }
 }
+#endif
 
+#ifndef VITSMI_TU  // (plain kernels: compiled by vitsmi.hip only, not by the instantiation units tu_*.hip)
 // ---- layout conversion kernels ------------------------------------------------------------------------
 
 // planar fp32 x[b][c][t] (row pitch `pitch`, optionally masked by t < len[b]) -> planes [3][C/8][T][8]
@@ -1475,5 +1491,7 @@ __global__ __launch_bounds__(256) void sx_unblock_kernel(const float *raw, const
         out[(int64_t)b * C * T + (int64_t)(cg * 8 + e) * T + t] = v;
     }
 }
+
+#endif  // VITSMI_TU
 
 }  // namespace vitsmi

@@ -666,14 +666,9 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
 
 template <int MW, int NW, int WM, int WN, int EPI, bool CHAIN, int NCH = 1>
 inline hipError_t launch_conv_sx_pair_k(const SxPairArgs &a, dim3 grid, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
+    static std::atomic<uint64_t> attr_done{0};
     auto kern = conv_sx_pair_kernel<MW, NW, WM, WN, EPI, CHAIN, NCH>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kSxMaxDynLds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = sx_allow_big_lds(reinterpret_cast<const void *>(kern), attr_done); e != hipSuccess) return e;
     if (g_launch_name_on)
         snprintf(g_launch_name, sizeof g_launch_name, "conv_sx_pair_kernel<%d, %d, %d, %d, %d, %s, %d>", MW, NW, WM, WN, EPI,
                  CHAIN ? "true" : "false", NCH);
@@ -707,7 +702,10 @@ inline bool sx_pair_supported(int C, int cfg, int K1, int dil1, int K2, int dil2
 
 // flags: EPI_ACC (out += ...), EPI_DIV (then / div).  chain = false: out = c2(lrelu(c1(lrelu(x)))) + x;
 // chain = true: x1 = c1(lrelu(x)) + x, out = c2(lrelu(x1)) + x1.
-inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t stream, bool chain = false) {
+hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t stream, bool chain = false);
+hipError_t launch_conv_sx_mrf(SxPairArgs a, int B, hipStream_t stream);
+#ifdef VITSMI_IMPL_PAIR  // (tu_pair.hip)
+hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t stream, bool chain) {
     a.LW1 = 256 + (a.K1 - 1) * a.dil1;
     a.x_bytes = (unsigned)((size_t)4 * a.LW1 * 16);  // one 16-channel chunk: 2 planes x 2 halves x LW1 cells
     if (a.dil2 < 1) a.dil2 = 1;
@@ -761,6 +759,7 @@ inline hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t 
     SX_PAIR_CASES(1, 2, 1, 4, false)
 #undef SX_PAIR_CASES
 }
+#endif  // VITSMI_IMPL_PAIR
 
 // Fused multi-receptive-field stage (conv_sx_pair_kernel<.., NCH>): n = 2 or 3 two-step ResBlock2 chains of a 32-channel
 // stage, out = (sum of the chains) / div.  K1 / dil1 / K2 / dil2 per chain ("same" padding on both convs).
@@ -789,7 +788,8 @@ inline bool sx_mrf_geom(int C, int n, const int *K1, const int *dil1, const int 
 
 // a: xr, islope, mslope, T, out_raw, zeros, C, div, peak and ch[0 .. nchain) (wp / bias / wscale / K / dil; xoff, yoff are
 // filled in here)
-inline hipError_t launch_conv_sx_mrf(SxPairArgs a, int B, hipStream_t stream) {
+#ifdef VITSMI_IMPL_PAIR
+hipError_t launch_conv_sx_mrf(SxPairArgs a, int B, hipStream_t stream) {
     int K1[3], d1[3], K2[3], d2[3];
     if (a.nchain < 2 || a.nchain > 3) return hipErrorInvalidValue;
     for (int i = 0; i < a.nchain; i++) {
@@ -828,5 +828,6 @@ inline hipError_t launch_conv_sx_mrf(SxPairArgs a, int B, hipStream_t stream) {
     if (a.nchain == 2) return launch_conv_sx_pair_k<1, 2, 1, 4, EPI_DIV, true, 2>(a, grid, g.lds, stream);
     return launch_conv_sx_pair_k<1, 2, 1, 4, EPI_DIV, true, 3>(a, grid, g.lds, stream);
 }
+#endif  // VITSMI_IMPL_PAIR
 
 }  // namespace vitsmi

@@ -11,6 +11,7 @@
 #include <functional>
 #include <cctype>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -402,11 +403,20 @@ void resolve(const OnnxModel &om, Resolver &R) {
     if (use_struct && !serr.empty())
         throw std::runtime_error("the graph's nodes carry no module-path names and its structure is not that of a VITS export: " + serr);
     if (named && serr.empty()) {
+        // The structural walk is a heuristic (block boundaries from kernel / dilation changes, emb_g = the second 2-D Gather):
+        // where a graph carries the exporter's module paths those are the authority, and a disagreement is reported once, not
+        // fatal - a well-named third-party export must keep loading.  VITSMI_STRICT_NAMES=1 turns it into an error (tests,
+        // debugging a suspicious file).
+        static const bool strict = std::getenv("VITSMI_STRICT_NAMES") != nullptr;
         for (size_t i = 0; i < om.nodes.size(); i++) {
             const OnnxNode &n = om.nodes[i];
             if ((n.op != "Conv" && n.op != "ConvTranspose") || sp[i].empty()) continue;
-            if (sp[i] != n.name)
-                throw std::runtime_error("node '" + n.name + "' sits where the graph's structure expects '" + sp[i] + "'");
+            if (sp[i] != n.name) {
+                const std::string msg = "node '" + n.name + "' sits where the graph's structure expects '" + sp[i] + "'";
+                if (strict) throw std::runtime_error(msg);
+                fprintf(stderr, "vitsmi: warning: %s (names win; VITSMI_STRICT_NAMES=1 rejects such files)\n", msg.c_str());
+                break;
+            }
         }
     }
     for (size_t ni = 0; ni < om.nodes.size(); ni++) {

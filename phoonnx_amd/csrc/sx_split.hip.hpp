@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace vitsmi {
 
 typedef float sxf32x2 __attribute__((ext_vector_type(2)));
@@ -54,6 +56,18 @@ __device__ __forceinline__ void split2h_pair_pk(float x, float y, unsigned &w0, 
 constexpr int kSxPeakStride = 32;  // uints between slots: one 128-byte line each
 // (sx_publish_peak's four floats are static LDS: the dynamic part a kernel may ask for is the CU's 160 KiB less that)
 constexpr int kSxMaxDynLds = 160 * 1024 - 256;
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the (function, device) pair: a process that opens handles on several
+// GPUs must set it once per device, and the engine's launchers run on PipelinedSession's worker threads.  `done` is the
+// instantiation's own bit mask of devices (device id modulo 64; a collision only repeats the idempotent call).
+inline hipError_t sx_allow_big_lds(const void *kern, std::atomic<uint64_t> &done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipGetLastError();
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kSxMaxDynLds);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 // ... with the four floats in caller-provided LDS (a kernel whose dynamic LDS must be the whole of the CU's share: no
 // static allocation beside it).  `s_pk` may alias memory other waves are still reading: a barrier comes first.
 __device__ __forceinline__ void sx_publish_peak_at(unsigned *slots, int slot_idx, float pk, float *s_pk) {

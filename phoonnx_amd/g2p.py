@@ -84,6 +84,15 @@ def match_lang(target_lang: str, valid_langs: Sequence[str]) -> str:
         raise ValueError(f"unsupported language code: {target_lang}")
     if lang == "zh" and sub in ("CN", "SG", "MY"):
         sub = "Hans"
+    # A script mismatch is not "close": langcodes' tag_distance (what the reference asks, maximum 10) puts zh-Hant / zh-TW
+    # against a list that only has zh-CN, or sr-Cyrl against sr-Latn, far beyond that, and the reference raises.
+    def script_of(l, s):
+        if l == "zh":
+            return "Hant" if s in ("TW", "HK", "MO", "Hant") else "Hans"
+        return s if s is not None and len(s) == 4 and s.isalpha() else None
+    ws = script_of(lang, sub)
+    if ws is not None and not any(script_of(lang, s) in (ws, None) for _, s in cands):
+        raise ValueError(f"unsupported language code: {target_lang}")
     want = sub if sub is not None else _DEFAULT_REGION.get(lang)
     for v, s in cands:  # same region / script (the ByT5 list spells Chinese as zh-CN)
         if s == want or (lang == "zh" and {s, want} == {"CN", "Hans"}):

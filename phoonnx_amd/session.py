@@ -32,46 +32,70 @@ class RangeError(SessionError):
 class _PinnedPool:
     """Page-locked host blocks handed out as NumPy arrays (the DMA engine writes a result straight into the array the
     caller receives: no staging copy, no second copy into a fresh array).  A block goes back to the pool when the last
-    array viewing it has been garbage-collected; at most `keep_bytes` of idle blocks are retained."""
+    array viewing it has been garbage-collected; at most `keep_bytes` of idle blocks are retained.
+
+    The finalizer takes no lock: it may run inside ANY allocation of ANY thread (a cyclic-GC pass), including one made by
+    array() while it holds the pool's lock.  It only appends to a deque (atomic); array() sorts the returned blocks into
+    the free lists, under the lock, the next time it runs."""
 
     def __init__(self, keep_bytes=2 << 30):
+        import collections
         import threading
         self._free = {}
         self._idle = 0
         self._keep = keep_bytes
         self._mu = threading.Lock()
+        self._returned = collections.deque()   # (ptr, cap) of blocks whose arrays have died; drained by array()
+        self._types = {}                       # cap -> ctypes array type (ctypes caches every distinct type forever)
 
     @staticmethod
     def _cap(nbytes):
         return max(1 << 16, (int(nbytes) + (1 << 20) - 1) >> 20 << 20) if nbytes > (1 << 16) else 1 << 16
 
     def _give(self, ptr, cap):
-        with self._mu:
+        self._returned.append((ptr, cap))  # (lock-free: see the class docstring)
+
+    def _drain(self):
+        """(under self._mu) returned blocks -> free lists; what exceeds keep_bytes is released"""
+        release = []
+        while True:
+            try:
+                ptr, cap = self._returned.popleft()
+            except IndexError:
+                break
             if self._idle + cap <= self._keep:
                 self._free.setdefault(cap, []).append(ptr)
                 self._idle += cap
-                return
-        _ffi.load().vits_host_free(ptr)
+            else:
+                release.append(ptr)
+        return release
 
     def array(self, shape, dtype=np.float32):
         import weakref
-        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        count = int(np.prod(shape))
+        n = count * np.dtype(dtype).itemsize
         cap = self._cap(n)
         ptr = None
         with self._mu:
+            release = self._drain()
             # an idle block of this size class, or the smallest one up to twice as large
-            for c in sorted(k for k, v in self._free.items() if v and cap <= k <= 2 * cap):
+            for c in sorted([k for k, v in self._free.items() if v and cap <= k <= 2 * cap]):
                 ptr, cap = self._free[c].pop(), c
                 self._idle -= c
                 break
+            ctype = self._types.get(cap)
+            if ctype is None:
+                ctype = self._types[cap] = C.c_char * cap   # one type per size class, not per output length
+        for q in release:
+            _ffi.load().vits_host_free(q)
         if ptr is None:
             ptr = _ffi.load().vits_host_alloc(cap)
             if not ptr:
                 raise SessionError(f"cannot allocate {cap} bytes of pinned host memory")
-        buf = (C.c_char * max(n, 1)).from_address(ptr)
+        buf = ctype.from_address(ptr)
         fin = weakref.finalize(buf, self._give, ptr, cap)
         fin.atexit = False  # (at interpreter exit the driver reclaims it)
-        return np.frombuffer(buf, dtype, count=int(np.prod(shape))).reshape(shape)
+        return np.frombuffer(buf, dtype, count=count).reshape(shape)
 
 
 _POOL = _PinnedPool()
@@ -103,10 +127,21 @@ class ModelMeta:
 class MiSession:
     def __init__(self, path_or_bytes, sess_options=None, providers=None, provider_options=None, device_id: int = 0,
                  arena_device_ptr: Optional[int] = None, arena_bytes: int = 0, host_only: bool = False,
-                 gen_precision: Optional[str] = None, range_fallback: bool = True, layout_only: bool = False, **kwargs):
+                 gen_precision: Optional[str] = None, range_fallback: bool = True, layout_only: bool = False,
+                 pinned_results: bool = True, **kwargs):
         """gen_precision: arithmetic of the generator's convs - None (VITSMI_GEN_PRECISION or the default "f16x3"),
-        "f16x3", "bf16x6", "bf16x3", "bf16".  range_fallback: on a RangeError of the f16x3 arithmetic, reopen with
-        "bf16x6" and repeat the call (never silently clamped audio)."""
+        "f16x3", "bf16x6" (exact products), "f16" (the reduced-precision vocoder of BASELINE config 4: fp16 storage, one
+        fp16 product per fp32 product, fp32 accumulation).  range_fallback: on a RangeError of an fp16 arithmetic, reopen
+        with "bf16x6" and repeat the call (never silently clamped audio).
+        pinned_results: run() / synthesize_batch() return arrays that VIEW page-locked host memory (the DMA engine's
+        target; recycled when the array is garbage-collected).  An application that keeps many results alive thereby pins
+        that much host RAM: pass False to get ordinary pageable arrays (one extra host copy per call).
+        Thread safety: like onnxruntime's session.run, every entry point may be called from several threads; calls on one
+        session are serialised by a per-session lock (a run is three C calls - enqueue, frame counts, copy-out - on one
+        handle's workspace)."""
+        import threading
+        self._mu = threading.RLock()
+        self.pinned_results = bool(pinned_results)
         if not isinstance(path_or_bytes, (str, bytes)) or isinstance(path_or_bytes, bytes):
             if isinstance(path_or_bytes, bytes):
                 raise SessionError("MiSession loads a model from a file path, not from serialized bytes")
@@ -243,19 +278,20 @@ class MiSession:
                 raise SessionError(f"noise_z must be [B,inter,F], got {noise_z.shape}")
             noise.noise_z = noise_z.ctypes.data
             noise.noise_z_stride = noise_z.shape[2]
-        try:
-            self._begin(ids, lens, scales, sid, noise)
-            ylen = self.last_y_lengths()
-            S = int(ylen.max()) * self.hparam("hop")
-            audio = _POOL.array((B, 1, 1, S))
-            self._fetch(audio, 0, B)
-        except RangeError as exc:
-            self._fall_back_to_bf16x6(exc)
-            return self.synthesize_batch(ids, lens, scales, sid, noise_dp, noise_z, taps)
-        res = {"output": audio, "y_lengths": ylen}
-        for t in taps:
-            res[t] = self.tap(t)
-        return res
+        with self._mu:  # enqueue -> frame counts -> copy-out -> taps all use this handle's one workspace
+            try:
+                self._begin(ids, lens, scales, sid, noise)
+                ylen = self.last_y_lengths()
+                S = int(ylen.max()) * self.hparam("hop")
+                audio = _POOL.array((B, 1, 1, S)) if self.pinned_results else np.empty((B, 1, 1, S), np.float32)
+                self._fetch(audio, 0, B)
+            except RangeError as exc:
+                self._fall_back_to_bf16x6(exc)
+                return self.synthesize_batch(ids, lens, scales, sid, noise_dp, noise_z, taps)
+            res = {"output": audio, "y_lengths": ylen}
+            for t in taps:
+                res[t] = self.tap(t)
+            return res
 
     def _begin(self, ids, lens, scales, sid, noise):
         """vits_run_async: validated host arrays in, the whole path enqueued; frame counts are known on return."""
@@ -281,20 +317,21 @@ class MiSession:
             raise SessionError(f"z must have {self.hparam('inter')} channels")
         sid = None if sid is None else np.ascontiguousarray(sid, np.int64)
         out = _ffi.VitsOutput()
-        rc = self._lib.vits_run_vocoder(self._h, _ffi.ptr(z), B, F, _ffi.ptr(sid), C.byref(out))
-        if rc == _ffi.VITS_E_RANGE:
-            try:
+        with self._mu:
+            rc = self._lib.vits_run_vocoder(self._h, _ffi.ptr(z), B, F, _ffi.ptr(sid), C.byref(out))
+            if rc == _ffi.VITS_E_RANGE:
+                try:
+                    self._raise("vits_run_vocoder", rc)
+                except RangeError as exc:
+                    self._fall_back_to_bf16x6(exc)
+                return self.vocoder(z, sid)
+            if rc != 0:
                 self._raise("vits_run_vocoder", rc)
-            except RangeError as exc:
-                self._fall_back_to_bf16x6(exc)
-            return self.vocoder(z, sid)
-        if rc != 0:
-            self._raise("vits_run_vocoder", rc)
-        try:
-            dims = tuple(out.dims[i] for i in range(4))
-            return np.ctypeslib.as_array(out.data, shape=(int(np.prod(dims)),)).reshape(dims).copy()
-        finally:
-            self._lib.vits_free_output(self._h, C.byref(out))
+            try:
+                dims = tuple(out.dims[i] for i in range(4))
+                return np.ctypeslib.as_array(out.data, shape=(int(np.prod(dims)),)).reshape(dims).copy()
+            finally:
+                self._lib.vits_free_output(self._h, C.byref(out))
 
     # ------------------------------------------------------------------ chunked (streaming) rendering, SURVEY §8 f1
     def _stream(self, start):
@@ -493,13 +530,14 @@ class MiSession:
             sid = np.ascontiguousarray(sid, np.int64)
         noise = _ffi.VitsNoise()
         noise.seed = self._seed
-        rc = self._lib.vits_run(self._h, _ffi.ptr(ids), _ffi.ptr(lens), B, T, _ffi.ptr(scales), _ffi.ptr(sid),
-                                C.byref(noise), None)
-        if rc != 0:
-            raise SessionError(f"vits_run failed [{rc}]: {self._err()}")
-        ylen = self.last_y_lengths()
-        S = int(ylen.max()) * self.hparam("hop")
-        return self.last_pcm16(normalize, volume, shape=(B, S)), ylen
+        with self._mu:
+            rc = self._lib.vits_run(self._h, _ffi.ptr(ids), _ffi.ptr(lens), B, T, _ffi.ptr(scales), _ffi.ptr(sid),
+                                    C.byref(noise), None)
+            if rc != 0:
+                raise SessionError(f"vits_run failed [{rc}]: {self._err()}")
+            ylen = self.last_y_lengths()
+            S = int(ylen.max()) * self.hparam("hop")
+            return self.last_pcm16(normalize, volume, shape=(B, S)), ylen
 
     def sync(self):
         rc = self._lib.vits_sync(self._h)
@@ -522,7 +560,10 @@ class PipelinedSession:
         # `first` owns the weight arena the other handles borrow: it must never close and reopen itself under them
         # (MiSession's own fallback would free the arena while the borrowers run on it).  The fallback happens HERE,
         # for all handles together (_fall_back).
+        import threading
+        self._mu = threading.RLock()   # one batched call at a time per pipeline (its parts' locks are taken inside)
         self.range_fallback = first.range_fallback
+        self._first_had_fallback = first.range_fallback   # handed back by close()
         first.range_fallback = False
         self.range_fallbacks = 0
         self._n_parts = parts
@@ -659,14 +700,21 @@ class PipelinedSession:
             sid = np.ascontiguousarray(sid)
             if sid.dtype != np.int64 or sid.shape != (B,):
                 raise SessionError("Unexpected input: 'sid' must be int64 of shape [batch_size]")
+        with self._mu:
+            return self._synthesize_batch_locked(ids, lens, scales, sid, B)
+
+    def _synthesize_batch_locked(self, ids, lens, scales, sid, B):
+        import threading
         bnd = self.bounds(B)
         n = len(bnd) - 1
         hop = self.hparam("hop")
         ylen = np.zeros(B, np.int64)
         box = {}
+        pinned = self.parts[0].pinned_results
 
         def size_output():  # (barrier action: runs once, in one thread, when every part knows its frame counts)
-            box["out"] = _POOL.array((B, 1, 1, int(ylen.max()) * hop))
+            shape = (B, 1, 1, int(ylen.max()) * hop)
+            box["out"] = _POOL.array(shape) if pinned else np.empty(shape, np.float32)
 
         bar = threading.Barrier(n, action=size_output)
         errors = []
@@ -677,10 +725,11 @@ class PipelinedSession:
             try:
                 noise = _ffi.VitsNoise()
                 noise.seed = p._seed
-                p._begin(ids[b0:b1], lens[b0:b1], scales, None if sid is None else sid[b0:b1], noise)
-                ylen[b0:b1] = p.last_y_lengths()
-                bar.wait()
-                p._fetch(box["out"], b0, b1 - b0)
+                with p._mu:  # (a part may also be used on its own, e.g. bench.py's measure(): same per-session lock)
+                    p._begin(ids[b0:b1], lens[b0:b1], scales, None if sid is None else sid[b0:b1], noise)
+                    ylen[b0:b1] = p.last_y_lengths()
+                    bar.wait()
+                    p._fetch(box["out"], b0, b1 - b0)
             except threading.BrokenBarrierError:
                 pass  # another part failed; its error is reported
             except Exception as e:  # noqa: BLE001 - re-raised on the caller's thread
@@ -707,9 +756,16 @@ class PipelinedSession:
         for s in self.parts:
             s.sync()
 
-    def close(self):
-        for s in reversed(self.parts):  # the first handle owns the arena the others borrow
+    def close(self, close_first: bool = True):
+        """Closes the borrowed handles and (close_first) the arena owner.  close_first=False hands the first session back
+        to its caller as it was given: open, with its own range fallback restored."""
+        for s in reversed(self.parts[1:]):  # the first handle owns the arena the others borrow
             s.close()
+        first = self.parts[0]
+        del self.parts[1:]
+        first.range_fallback = self._first_had_fallback
+        if close_first:
+            first.close()
 
 
 # kernel-level hooks (tests)

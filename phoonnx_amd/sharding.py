@@ -134,7 +134,14 @@ class ShardedSynthesizer:
         self.hop = self.session.hparam("hop")
 
     def synthesize(self, utterances: Sequence[Sequence[int]], scales, sids: Optional[Sequence[int]] = None,
-                   gather: bool = False):
+                   gather=False, dst: int = 0):
+        """This rank's shard of the request, rendered.
+        gather=False: [(original index, waveform)] of this rank's utterances - results stay where they were made.
+        gather=True:  every rank returns every utterance's waveform in the original order.
+        gather="root": only rank `dst` does (the others return None) - what a front end that answers one client wants.
+        The gathers move tensors, not pickles: one small all_gather of the sample counts, then ONE collective over flat
+        fp32 buffers (every rank's valid samples back to back, padded to the longest rank) - on the device over RCCL/xGMI
+        when the backend is nccl, on the host with gloo."""
         shards, inv = partition([len(u) for u in utterances], self.world)
         mine = shards[self.rank]
         local = []
@@ -144,13 +151,45 @@ class ShardedSynthesizer:
             r = self.session.synthesize_batch(ids, lens, np.asarray(scales, np.float32), sid)
             for b in range(len(mine)):
                 n = int(r["y_lengths"][b]) * self.hop
-                local.append(r["output"][b, 0, 0, :n].copy())
+                local.append(r["output"][b, 0, 0, :n])
         if not gather or self.dist is None:
-            return [(int(i), w) for i, w in zip(mine, local)]
-        allw = [None] * self.world
-        self.dist.all_gather_object(allw, local)  # host-side gather of results; not on the compute path
-        flat = [w for part in allw for w in part]
-        return [flat[int(inv[i])] for i in range(len(utterances))]
+            return [(int(i), w.copy()) for i, w in zip(mine, local)]
+        import torch
+        dist = self.dist
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        # 1. sample counts of every utterance of every rank (shards differ by at most one utterance: pad with zeros)
+        rows = max(len(sh) for sh in shards)
+        cnt = torch.zeros(rows, dtype=torch.int64)
+        cnt[:len(local)] = torch.tensor([len(w) for w in local], dtype=torch.int64)
+        allcnt = torch.zeros(self.world * rows, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allcnt, cnt.to(dev))
+        allcnt = allcnt.cpu().view(self.world, rows)
+        width = int(allcnt.sum(1).max())
+        # 2. the waveforms: this rank's valid samples back to back in one flat buffer of the common width
+        flat = torch.zeros(max(width, 1), dtype=torch.float32)
+        if local:
+            flat[:int(cnt.sum())] = torch.from_numpy(np.concatenate(local))
+        flat = flat.to(dev)
+        root_only = gather == "root"
+        if root_only:
+            parts = [torch.empty_like(flat) for _ in range(self.world)] if self.rank == dst else None
+            dist.gather(flat, parts, dst=dst)
+            if self.rank != dst:
+                return None
+            everything = torch.stack(parts).cpu().numpy()
+        else:
+            out = torch.empty(self.world * flat.numel(), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(out, flat)
+            everything = out.cpu().numpy().reshape(self.world, flat.numel())
+        # 3. cut the rows apart and restore the request's order
+        res = [None] * len(utterances)
+        for rk, sh in enumerate(shards):
+            off = 0
+            for j, i in enumerate(sh):
+                n = int(allcnt[rk, j])
+                res[int(i)] = everything[rk, off:off + n].copy()
+                off += n
+        return res
 
     def close(self):
         self.session.close()
