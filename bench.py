@@ -35,7 +35,8 @@ HBM_PEAK_BPS = 8.0e12      # HBM3E peak (MI355X_MICROARCH.md)
 LENGTH_SCALE = {"high": 1.95, "medium": 1.95, "small": 1.95}
 DTYPE = {2: "f32 (f16x3 split: fp32 operands as two fp16 planes, three MFMA products, fp32 accumulate)",
          6: "f32 (bf16x6 split: fp32 operands as three bf16 planes, six exact MFMA products, fp32 accumulate)",
-         3: "f32 + bf16x3 vocoder (reduced precision)", 1: "f32 + bf16 vocoder (reduced precision)"}
+         1: "f32 up to z + f16 vocoder (reduced precision: one fp16 plane per operand, one MFMA product, fp32 accumulate, "
+            "fp16 activation storage)"}
 
 
 def git_head():
@@ -268,7 +269,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--speakers", type=int, default=1,
                     help="> 1: a multi-speaker voice (speaker-embedding path, gin 512) with sid uniform in [0, speakers) "
-                         "(BASELINE config 4: --preset medium --speakers 4 --batch 64 --mixed-lengths --gen-precision bf16)")
+                         "(BASELINE config 4: --preset medium --speakers 4 --batch 64 --mixed-lengths --gen-precision f16)")
     ap.add_argument("--mixed-lengths", action="store_true",
                     help="utterance lengths uniform in [tokens/4, tokens] (seed 1235), zero-padded, instead of all = tokens")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -276,12 +277,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements of the N=1 line (exact arithmetic, host-in/host-out, the medium "
                          "preset, per-step percentiles)")
-    ap.add_argument("--gen-precision", default="f16x3", choices=["f16x3", "bf16x6", "bf16x3", "bf16"],
+    ap.add_argument("--gen-precision", default="f16x3", choices=["f16x3", "bf16x6", "f16"],
                     help="arithmetic of the generator's convs (fp32 operands and results in every mode).  f16x3 (default): "
                          "two fp16 planes per operand, three MFMA products per fp32 product, error no larger than the "
                          "f32-MFMA engine's, range-guarded; bf16x6: three bf16 planes, six products, every product exact; "
-                         "bf16x3 / bf16: the declared reduced-precision vocoder modes of BASELINE config 4 (reported with "
-                         "their dtype, never as the headline number)")
+                         "f16: the declared reduced-precision vocoder of BASELINE config 4 - fp16 storage, one product - "
+                         "(reported with its dtype, never as the headline number)")
     ap.add_argument("--no-exact-check", action="store_true",
                     help="skip the second, shorter measurement of the same workload with the six-product exact arithmetic")
     ap.add_argument("--force-dist", action="store_true",
@@ -484,6 +485,8 @@ def main():
             kfl, kms, kn, kby = agg["sx_flops"], agg["sx_ms"], int(agg["sx_launches"]), agg["sx_bytes"]
             kname = ("conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 2 fp16 planes, 3 x v_mfma_f32_16x16x32_f16 per product)"
                      if nprod == 2 else
+                     "conv_sx_kernel (implicit-GEMM Conv1d, fp16 operands, one v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)"
+                     if nprod == 1 else
                      "conv_sx_kernel (implicit-GEMM Conv1d, fp32 operands as 3 bf16 planes, v_mfma_f32_32x32x16_bf16 plane products)")
             peak = MFMA16_PEAK_TFLOPS / (3 if nprod == 2 else nprod)
         else:

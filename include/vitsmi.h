@@ -72,7 +72,7 @@ int vits_open_layout(const char *onnx_path, vits_handle **out);
  * VITSMI_GEN_PRECISION in the environment. */
 typedef struct {
     int device_id;
-    const char *gen_precision;  /* NULL / "": environment or default ("f16x3"); "f16x3", "bf16x6", "bf16x3", "bf16" */
+    const char *gen_precision;  /* NULL / "": environment or default ("f16x3"); "f16x3", "bf16x6", "f16" */
     void *arena_dev;            /* as vits_open_with_arena, or NULL */
     size_t arena_bytes;
     int host_only;              /* as vits_open_host */
@@ -108,7 +108,9 @@ int vits_meta(vits_handle *h, const char *key, char *buf, size_t n);
  *   2 = "f16x3", the default: fp32 operands as two fp16 planes, three MFMA products per fp32 product, fp32
  *       accumulation; error no larger than the f32-MFMA engine's,
  *   6 = "bf16x6": three bf16 planes, six products, every fp32 product exact to 2^-24,
- *   3 / 1 = "bf16x3" / "bf16": BASELINE config 4's reduced-precision "bf16 vocoder"). */
+ *   1 = "f16": BASELINE config 4's reduced-precision vocoder - ONE fp16 plane per operand, one MFMA product per fp32
+ *       product, fp32 accumulation, generator activations STORED as fp16 (2 bytes per element instead of 8); everything
+ *       in front of z is the default arithmetic.  Range-guarded like f16x3 (VITS_E_RANGE, never clamped audio)). */
 int vits_hparam(vits_handle *h, const char *key, int64_t *out);
 
 /* ---- weight arena (multi-GPU: one rank reads + packs, RCCL broadcasts the bytes) ---- */
@@ -282,11 +284,13 @@ int vits_test_conv_transpose1d(int device_id, const float *x, int B, int Cin, in
  * are multiples of 32 (csrc/conv_sx_engine.hip.hpp); needs Cin % 16 == 0 and Cout % 32 == 0.
  * vits_test_conv1d_sx flags: bit0 -> out = leaky_relu(conv, slope) read back from the 16-bit output planes
  * (else the fp32 raw output), bit2 -> residual epilogue with res = x (Cin == Cout), bit3 -> leaky_relu(slope) on the
- * input (raw-input kernels, Cin <= 64), bits 4-5 -> arithmetic: 0 bf16x6 (six exact bf16 plane products), 1 bf16x3,
- * 2 bf16 (the declared reduced-precision vocoder modes), 3 f16x3 (two fp16 planes, three products: the generator's
- * default, VITSMI_GEN_PRECISION).  vits_test_conv_transpose1d_sx: a negative stride selects f16x3.
+ * input (raw-input kernels, Cin <= 64; with arithmetic 2: the input plane holds leaky_relu(x) and the residual is
+ * recovered from it), bits 4-5 -> arithmetic: 0 bf16x6 (six exact bf16 plane products), 2 f16 (one fp16 plane, one
+ * product: the reduced-precision vocoder), 3 f16x3 (two fp16 planes, three products: the generator's default,
+ * VITSMI_GEN_PRECISION), bit7 -> the planes are the only output (needs bit0).  vits_test_conv_transpose1d_sx: a negative
+ * stride selects f16x3.
  * vits_bench_conv1d_sx dbg bits: 1 no DMA after the first step, 2 no epilogue, 8 residual epilogue, 16 in-kernel
- * cycle breakdown (128-row tiles only), 32 / 64 bf16x3 / bf16, 128 f16x3, 256 the v_mfma_f32_32x32x16 main loop even where
+ * cycle breakdown (128-row tiles only), 64 f16 (single plane), 128 f16x3, 256 the v_mfma_f32_32x32x16 main loop even where
  * the 16x16x32 one applies.  ms_out holds 8 floats: [0] ms per launch, [1] tile config, [3..7] with
  * bit 16: s_memtime ticks per pipeline step spent in {LDS wait, DMA wait, barrier, DMA issue, loads + MFMA}. */
 int vits_test_conv1d_sx(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,

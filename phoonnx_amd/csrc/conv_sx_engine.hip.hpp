@@ -9,7 +9,10 @@
 //          of combined order <= 2, w0x0 + w0x1 + w1x0 + w0x2 + w1x1 + w2x0; the dropped terms are below
 //          3 * 2^-24 |w||x|.  Ceiling 2516.6 / 6 = 419 TFLOP/s (tools/mfma_bf16x6_probe.hip sustains 340-375 with
 //          both operands streaming from LDS).
-//   NP = 3 / 1: three / one bf16 product, the declared reduced-precision vocoder modes.
+//   f16    (NP = 1): ONE fp16 plane per operand and one product: the reduced-precision vocoder of BASELINE config 4
+//          ("bf16 vocoder": 16-bit storage, fp32 accumulation).  Activations are stored as the fp16 of the consumer's
+//          leaky-ReLU only (2 bytes per element instead of raw fp32 + two planes = 8); a residual is recovered from that
+//          plane by undoing the leaky-ReLU (exact); the multi-receptive-field sum stays fp32.  16x16x32 loop only.
 // Both full-precision modes carry the error bound of an fp32 FMA chain (what the reference's fp32 convolutions
 // and the f32 engine in conv_engine.hip.hpp compute); tests/test_gpu_parity.py checks them against float64.
 // Why: the f32 matrix pipe peaks at 157 TFLOP/s (measured 155), the f16 / bf16 pipe at 2.5 PFLOP/s.
@@ -98,6 +101,10 @@ struct SxArgs {
     uint16_t *out_pl;     // planes [3][Cr/8][T*ups][8] or nullptr; stores split(leaky_relu(value, oslope2))
     int64_t pl_bstride;   // bf16 elements between batch items
     const float *res;     // fp32 raw residual or nullptr
+    // f16 single-plane mode (NP = 1): the residual is read from the fp16 plane tensor that holds leaky_relu(residual,
+    // 1 / res_unslope) (plane layout and batch stride of out_pl); res then stays nullptr
+    const uint16_t *res_pl;
+    float res_unslope;
     const float *zeros;   // >= 1 KiB of zeros, 16-byte aligned
     int Cin, Cout, Cr;    // Cout = virtual rows (Cr * ups)
     int K, dil, padL, nchunks, ups;
@@ -233,9 +240,8 @@ constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL 
 // RAWIN: the input is the fp32 raw tensor itself; each x tile is loaded into registers, leaky-ReLU'd (islope) and
 // split into the three bf16 planes on its way into LDS.  Used where the layer is HBM-bound (<= 64 channels):
 // such tensors then exist only once, as 4-byte raw values, instead of raw + 6-byte planes.
-// NP = plane products per fp32 product: 6 = exact (default); 3 (w0x0 + w0x1 + w1x0, ~2^-16 relative) and
-// 1 (w0x0, plain bf16) are the declared reduced-precision vocoder modes (VITSMI_GEN_PRECISION, BASELINE config 4):
-// they read only the planes they use.
+// NP = arithmetic: 6 = six exact bf16 plane products; 2 = f16x3 (two fp16 planes, three products; the default); 1 = one
+// fp16 plane, one product (VITSMI_GEN_PRECISION=f16, BASELINE config 4; 16x16x32 loop only).
 // SH = MFMA shape of the main loop: 32 = v_mfma_f32_32x32x16 (one step = one tap of a 16-channel chunk), 16 =
 // v_mfma_f32_16x16x32 (one step = one tap of a 32-channel chunk; f16x3 arithmetic, plane input only).  Same products,
 // same accumulation order per output element up to the chunk grouping; the chip holds a higher clock on the 16x16x32
@@ -244,13 +250,15 @@ template <int MW, int NW, int WM, int WN, int EPI = -1, bool PROF = false, bool 
 __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2 && !RAWIN) ? 3 : 2)) void conv_sx_kernel(SxArgs a) {
     constexpr int BM = MW * WM * 32, BN = NW * WN * 32, MB = BM / 32;
     constexpr bool S16 = SH == 16;
-    static_assert(SH == 32 || (SH == 16 && NP == 2 && !RAWIN && !PROF), "16x16x32: f16x3 arithmetic on plane inputs");
-    static_assert(NP == 6 || NP == 3 || NP == 1 || NP == 2, "plane products");
-    constexpr bool F16 = NP == 2;                          // two fp16 planes, three products
-    constexpr int NPROD = F16 ? 3 : NP;
-    constexpr int NPL = NP == 6 ? 3 : (NP == 1 ? 1 : 2);  // x planes read
-    constexpr int NPLA = NPL;                              // weight planes read (f16: g0, g1; g0 * 2^-11 is made here)
-    constexpr int NPW = F16 ? 2 : 3;                       // weight planes packed per 32-row block
+    static_assert(SH == 32 || (SH == 16 && (NP == 2 || NP == 1) && !RAWIN && !PROF), "16x16x32: fp16 arithmetics on plane inputs");
+    static_assert(NP == 6 || NP == 1 || NP == 2, "arithmetic");
+    static_assert(NP != 1 || SH == 16, "the single-plane mode exists on the 16x16x32 loop only");
+    constexpr bool H1 = NP == 1;                           // one fp16 plane, one product
+    constexpr bool F16 = NP == 2 || H1;                    // fp16 planes (two: three products)
+    constexpr int NPROD = H1 ? 1 : (F16 ? 3 : NP);
+    constexpr int NPL = NP == 6 ? 3 : (H1 ? 1 : 2);        // x planes read
+    constexpr int NPLA = NPL;                              // weight planes read (f16x3: g0, g1; g0 * 2^-11 is made here)
+    constexpr int NPW = H1 ? 1 : (F16 ? 2 : 3);            // weight planes packed per 32-row block
     static_assert(WM * WN == 4, "four waves per workgroup");
     static_assert(MW <= 2, "load_a addresses two block rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_sx[];  // two x stages
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
     constexpr int HPS = MW;                 // half-steps per step
     constexpr int NQ = NW;                  // quarters per half-step
     struct AHalf {
-        u32x4 f[2][2];                      // [16-row sub-block][plane]
+        u32x4 f[2][NPL];                    // [16-row sub-block][plane]
     };
     f32x4 c16[MW][2][NW][2];                // [32-row block][sub-block a][32-column block][sub-block b]
 #pragma unroll
@@ -484,37 +492,56 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
         const uint64_t pa = reinterpret_cast<uint64_t>(wbase) + (uint64_t)((int64_t)st * STEPBYTES + m * BLKBYTES);
         const char *sb = reinterpret_cast<const char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) |
                                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)pa));
-        f.f[0][0] = global_read128<0>(voff0, sb);
-        f.f[0][1] = global_read128<1024>(voff0, sb);
-        f.f[1][0] = global_read128<2048>(voff0, sb);
-        f.f[1][1] = global_read128<3072>(voff0, sb);
+        if constexpr (H1) {
+            f.f[0][0] = global_read128<0>(voff0, sb);
+            f.f[1][0] = global_read128<1024>(voff0, sb);
+        } else {
+            f.f[0][0] = global_read128<0>(voff0, sb);
+            f.f[0][1] = global_read128<1024>(voff0, sb);
+            f.f[1][0] = global_read128<2048>(voff0, sb);
+            f.f[1][1] = global_read128<3072>(voff0, sb);
+        }
     };
+    constexpr int NAL = 2 * NPL;            // weight loads per half-step = B reads per quarter
     const uint32_t b_lane = lds0 + (uint32_t)((lane >> 4) * RS + wn * (NW * 32) + (lane & 15)) * 16u;
     const uint32_t plane_b = (uint32_t)(4 * RS) * 16u;
-    u32x4 bq[2][2][2];                      // [buffer][sub-block b][plane]
+    u32x4 bq[2][2][NPL];                    // [buffer][sub-block b][plane]
     auto load_bq = [&](auto BUF, auto Q, uint32_t bb0) __attribute__((always_inline)) {
         constexpr int bf = decltype(BUF)::value, q = decltype(Q)::value;
         if constexpr ((SX16_ABL & 2) != 0) return;
         bq[bf][0][0] = ds_read128<q * 512>(bb0);
-        bq[bf][0][1] = ds_read128<q * 512>(bb0 + plane_b);
+        if constexpr (!H1) bq[bf][0][1] = ds_read128<q * 512>(bb0 + plane_b);
         bq[bf][1][0] = ds_read128<q * 512 + 256>(bb0);
-        bq[bf][1][1] = ds_read128<q * 512 + 256>(bb0 + plane_b);
+        if constexpr (!H1) bq[bf][1][1] = ds_read128<q * 512 + 256>(bb0 + plane_b);
+    };
+    auto wait_bq = [&]() __attribute__((always_inline)) {  // the older of two quarters in flight has landed
+        if constexpr (H1) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
     };
     auto mma_q = [&](const AHalf &f, auto M, auto BUF, auto Q) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value, bf = decltype(BUF)::value, q = decltype(Q)::value;
         // products in the order of the 32x32x16 loop: g1*h0, g0'*h1', g0*h0; consecutive MFMAs hit different accumulators
         if constexpr ((SX16_ABL & 1) != 0) return;
         if constexpr (SX16_PRIO) __builtin_amdgcn_s_setprio(1);
+        if constexpr (H1) {
+#pragma unroll
+            for (int aa = 0; aa < 2; aa++)
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++)
+                    c16[m][aa][q][bb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, f.f[aa][0]),
+                                                                               __builtin_bit_cast(f16x8, bq[bf][bb][0]),
+                                                                               c16[m][aa][q][bb], 0, 0, 0);
+        } else
 #pragma unroll
         for (int c = 0; c < 3; c++)
 #pragma unroll
             for (int aa = 0; aa < 2; aa++)
 #pragma unroll
                 for (int bb = 0; bb < 2; bb++) {
-                    const f16x8 ga = c == 0 ? __builtin_bit_cast(f16x8, f.f[aa][1])
+                    const f16x8 ga = c == 0 ? __builtin_bit_cast(f16x8, f.f[aa][NPL - 1])
                                             : (c == 1 ? __builtin_bit_cast(f16x8, f.f[aa][0]) * (_Float16)0.00048828125f
                                                       : __builtin_bit_cast(f16x8, f.f[aa][0]));
-                    c16[m][aa][q][bb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga, __builtin_bit_cast(f16x8, bq[bf][bb][c == 1 ? 1 : 0]),
+                    c16[m][aa][q][bb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ga, __builtin_bit_cast(f16x8, bq[bf][bb][c == 1 ? NPL - 1 : 0]),
                                                                                c16[m][aa][q][bb], 0, 0, 0);
                 }
         if constexpr (SX16_PRIO) __builtin_amdgcn_s_setprio(0);
@@ -555,10 +582,10 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
     int iss[NA - 1], xct[NA - 1];
 #pragma unroll
     for (int j = 0; j < NA - 1; j++) {
-        iss[j] = 4;  // (the prologue's weight requests, youngest first; x(0) went out before all of them)
+        iss[j] = NAL;  // (the prologue's weight requests, youngest first; x(0) went out before all of them)
         xct[j] = 0;
     }
-    int a_since_x = 4 * (NA - 1);
+    int a_since_x = NAL * (NA - 1);
     auto half_step = [&](AHalf &fc, AHalf &fload, auto M, int hs) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value;
         // in flight behind A(hs) (requested by the previous half-step): the x DMAs if that half-step issued them
@@ -589,8 +616,8 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
         iss[0] = xct[0] = 0;
         if (hs + NA - 1 < H && !(SX_NOA && hs > 0)) {
             load_ah(fload, hs + NA - 1);
-            iss[0] = 4;
-            a_since_x += 4;
+            iss[0] = NAL;
+            a_since_x += NAL;
         }
         const bool do_x = chunk_start && more_x;
         if (do_x) {
@@ -612,11 +639,11 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (q + 1 < NQ) {
                 load_bq(std::integral_constant<int, (q + 1) & 1>{}, std::integral_constant<int, q + 1>{}, bb0);
-                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // quarter q has landed, q + 1 is in flight
+                wait_bq();  // quarter q has landed, q + 1 is in flight
             } else {
                 if (!last_of_chunk && hs + 1 < H) {
                     load_bq(std::integral_constant<int, NQ & 1>{}, I0, bnext);
-                    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    wait_bq();
                 } else
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -963,7 +990,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
         }
         return;
     }
-    if constexpr (EPI < 0) {
+    if constexpr (EPI < 0 && !H1) {
         if (a.flags & SX_WN_RMW) {
             // planar epilogue: o = old + act(acc * wscale + bias) * mask, stored as [B][rows][T] fp32 and / or as operand planes.
             //   old: the output itself (EPI_ACC), the planar tensor `res` (EPI_RES, x rows only), or nothing
@@ -1042,6 +1069,8 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
     float *rawb = a.out_raw + (int64_t)b * a.raw_bstride;     // (only dereferenced when the flags say so)
     uint16_t *plb = a.out_pl + (int64_t)b * a.pl_bstride;
     const float *resb = a.res + (int64_t)b * a.raw_bstride;
+    const uint16_t *resplb = a.res_pl + (int64_t)b * a.pl_bstride;  // (H1: the residual lives in a plane tensor)
+    const float unsl = a.res_unslope;
     // operands still to be loaded here: the residual (unless it was requested in the prologue) and / or the accumulate
     const bool res_epi = (flags & EPI_RES) && !PRE;
     const float *addp = res_epi ? resb : rawb;
@@ -1083,7 +1112,16 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int64_t c = cell_at(co0, r, tl, q);
-                if (has_add) adb[pp][j][q] = *reinterpret_cast<const f32x4 *>(addp + c);
+                if constexpr (H1) {
+                    // the residual from its fp16 plane (8 bytes per lane, leaky-ReLU undone); the running sum stays fp32 raw
+                    if (res_epi) {
+                        float o4[4];
+                        unact4h(*reinterpret_cast<const u32x2 *>(resplb + c), unsl, o4);
+                        adb[pp][j][q] = f32x4{o4[0], o4[1], o4[2], o4[3]};
+                    } else if (has_add)
+                        adb[pp][j][q] = *reinterpret_cast<const f32x4 *>(rawb + c);
+                } else if (has_add)
+                    adb[pp][j][q] = *reinterpret_cast<const f32x4 *>(addp + c);
                 if (two_adds) ad2[j][q] = *reinterpret_cast<const f32x4 *>(rawb + c);
             }
         }
@@ -1146,7 +1184,10 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
                         for (int e = 0; e < 4; e++) o[e] = fmaxf(v[e], v[e] * oslope2);
                     }
                     unsigned wa[3], wb[3];
-                    if constexpr (F16) {
+                    if constexpr (H1) {
+                        wa[0] = cvt1h_pair_pk(o[0], o[1], pk);
+                        wb[0] = cvt1h_pair_pk(o[2], o[3], pk);
+                    } else if constexpr (F16) {
                         split2h_pair_pk(o[0], o[1], wa[0], wa[1], pk);
                         split2h_pair_pk(o[2], o[3], wb[0], wb[1], pk);
                     } else {
@@ -1154,7 +1195,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
                         split3_pair(o[2], o[3], wb[0], wb[1], wb[2]);
                     }
 #pragma unroll
-                    for (int pl = 0; pl < (F16 ? 2 : 3); pl++)
+                    for (int pl = 0; pl < NPL; pl++)
                         *reinterpret_cast<u32x2 *>(plb + pl * plane_elems + cell) = u32x2{wa[pl], wb[pl]};
                 }
             }
@@ -1196,6 +1237,7 @@ constexpr int kSxEpiAccum = EPI_RES | EPI_ACC | SX_HAS_RAW;                     
 constexpr int kSxEpiRaw = SX_HAS_RAW;                                                // raw only (raw-format stages)
 constexpr int kSxEpiStageOut = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_PL | SX_PL_ACT;  // x = (xs + block) / n as planes
 constexpr int kSxEpiGate = SX_GATE | SX_HAS_RAW;                                     // WN in-layer + gate -> planar acts
+constexpr int kSxEpiInnerPl = EPI_RES | SX_HAS_PL | SX_PL_ACT;                       // (f16 single-plane mode) residual conv inside a block: the plane IS the stream
 
 template <int MW, int NW, int WM, int WN, int NP = 6, int SH = 32>
 inline hipError_t launch_conv_sx_epi(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
@@ -1246,21 +1288,15 @@ inline hipError_t launch_conv_sx_rawin(const SxArgs &a, int epi, dim3 grid, size
     }
 }
 
-// reduced-precision modes (NP = 3 or 1 plane products): generic epilogue only
-template <int MW, int NW, int WM, int WN, bool RAWIN>
-inline hipError_t launch_conv_sx_np(const SxArgs &a, int nprod, dim3 grid, size_t lds, hipStream_t stream) {
-    if (nprod == 3) return launch_conv_sx_k<MW, NW, WM, WN, -1, false, RAWIN, 3>(a, grid, lds, stream);
-    return launch_conv_sx_k<MW, NW, WM, WN, -1, false, RAWIN, 1>(a, grid, lds, stream);
-}
-
 // rawin: the input is a.xr (fp32 raw) instead of a.xp (planes); only the 64- and 32-row tiles have the
-// registers for it (cfg 1 / 2).  nprod: 6 (exact, default), 3 or 1 (declared reduced-precision modes).
+// registers for it (cfg 1 / 2).  nprod: 6 (bf16x6), 2 (f16x3), 1 (f16 single plane; s16 packings only).
 // pack_cfg: the tile config the weights were packed for, if not `cfg` (a taller one: 128-row packing read by the 64-
 // or 32-row kernel - same products in the same order, a shorter reduction per workgroup and 2-4x the workgroups).
 hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin = false, int nprod = 6, int pack_cfg = -1);
 hipError_t launch_conv_sx_f16_s16(const SxArgs &a, int cfg, int epi, dim3 grid, size_t lds, hipStream_t stream);
 hipError_t launch_conv_sx_f16_s32(const SxArgs &a, int cfg, int epi, bool rawin, dim3 grid, size_t lds, hipStream_t stream);
 hipError_t launch_conv_sx_bf16(const SxArgs &a, int cfg, int epi, int nprod, bool rawin, dim3 grid, size_t lds, hipStream_t stream);
+hipError_t launch_conv_sx_h1_s16(const SxArgs &a, int cfg, int epi, dim3 grid, size_t lds, hipStream_t stream);
 #ifdef VITSMI_IMPL_SX
 hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin, int nprod, int pack_cfg) {
     const int BM = sx_tile_m(cfg), BN = sx_tile_n(cfg);
@@ -1274,19 +1310,20 @@ hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool raw
     a.RS = a.LW;
     // an x stage is padded to whole DMA rounds (256 cells = 4 KiB), so that every wave issues the same count
     // (rows = 2 channel-group halves x the planes the mode reads: 3 bf16 planes, 2 in the fp16 / bf16x3 modes, 1 in bf16)
-    int xrows = nprod == 6 ? 6 : (nprod == 1 ? 2 : 4);
+    int xrows = nprod == 6 ? 6 : 4;
     const bool s16 = a.s16 != 0;
     if (cfg == 3 && !s16) return hipErrorInvalidValue;  // (64 x 128 tiles exist for the 16x16x32 loop only)
     if (s16) {
         // weights packed for the 16x16x32 main loop: chunks of 32 channels (4 channel groups x 2 planes = 8 rows per stage)
-        if (nprod != 2 || rawin || a.prof || (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) || a.Cin % 32) return hipErrorInvalidValue;
-        xrows = 8;
+        if ((nprod != 2 && nprod != 1) || rawin || a.prof || (a.flags & (DBG_NO_DMA | DBG_NO_EPI)) || a.Cin % 32) return hipErrorInvalidValue;
+        xrows = nprod == 1 ? 4 : 8;
         // rows 16 cells apart modulo 16: the ds_read_b128 of a B fragment (lanes 16 apart = the next channel group) is then
         // free of bank conflicts; where that does not fit two workgroups per CU the rows stay packed (mild conflicts)
         // (two workgroups per CU = 80 KiB each, all of it dynamic: the 16x16x32 kernels have no static LDS)
         const int rs16 = (a.LW + 15) / 16 * 16;
-        if (((size_t)8 * rs16 * 16 + 4095) / 4096 * 4096 + (size_t)8 * rs16 * 16 <= (size_t)80 * 1024) a.RS = rs16;
-    }
+        if (((size_t)xrows * rs16 * 16 + 4095) / 4096 * 4096 + (size_t)xrows * rs16 * 16 <= (size_t)80 * 1024) a.RS = rs16;
+    } else if (nprod == 1)
+        return hipErrorInvalidValue;  // (the single-plane mode exists on the 16x16x32 loop only)
     a.magic = (unsigned)((0x100000000ull + a.RS - 1) / a.RS);
     a.x_bytes = (unsigned)(((size_t)xrows * a.RS * 16 + 4095) / 4096 * 4096);
     if (s16 && (a.x_bytes > 10 * 4096 || ((long long)(2 * (a.Cin / 8) + 2) * a.T) * 16 >= (1ll << 32))) return hipErrorInvalidValue;
@@ -1339,11 +1376,17 @@ hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool raw
                           a.oslope == 1.f && (!(a.flags & EPI_DIV) || (a.flags & EPI_ACC));
     if (early_ok && epi != -2) epi |= SX_RES_EARLY;
     if (epi != -2) {
-        if ((epi & EPI_RES) && !a.res) return hipErrorInvalidValue;
+        if ((epi & EPI_RES) && !(nprod == 1 ? (const void *)a.res_pl : (const void *)a.res)) return hipErrorInvalidValue;
         if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
         a.flags = (a.flags & ~kSxEpiMask) | epi;
     } else
         a.flags = SX_WN_RMW | (a.flags & (EPI_ACC | EPI_RES | EPI_MASK | EPI_RELU | SX_PLANAR_STORE2 | SX_PLANAR_COUPLING));
+    if (nprod == 1) {  // one fp16 plane, one product (BASELINE config 4)
+        if (a.wscale == 0.f) a.wscale = 1.f;
+        if (a.res_unslope == 0.f) a.res_unslope = 1.f;
+        if ((a.flags & (SX_GATE | SX_WN_RMW)) || (a.res && !a.res_pl)) return hipErrorInvalidValue;
+        return launch_conv_sx_h1_s16(a, cfg, epi, grid, lds, stream);
+    }
     if (nprod == 2) {  // two fp16 planes, three products (fp32-grade): the same specialised epilogues
         if (a.wscale == 0.f) a.wscale = 1.f;
         if (s16) return launch_conv_sx_f16_s16(a, cfg, epi, grid, lds, stream);
@@ -1385,19 +1428,33 @@ hipError_t launch_conv_sx_f16_s32(const SxArgs &a, int cfg, int epi, bool rawin,
     }
 }
 #endif
+#ifdef VITSMI_IMPL_SX_H1
+// the single-plane mode's own epilogue set: planes (conv_pre, upsamplers, c1 of a ResBlock1 pair), residual conv inside a
+// block (plane -> plane), block output into the fp32 multi-receptive-field sum, stage output as a plane
+template <int MW, int NW, int WM, int WN>
+inline hipError_t launch_conv_sx_h1_epi(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+    switch (epi) {
+        case kSxEpiPlanes: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiPlanes, false, false, 1, 16>(a, grid, lds, stream);
+        case kSxEpiInnerPl: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiInnerPl, false, false, 1, 16>(a, grid, lds, stream);
+        case kSxEpiFirst: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst, false, false, 1, 16>(a, grid, lds, stream);
+        case kSxEpiAccum: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum, false, false, 1, 16>(a, grid, lds, stream);
+        case kSxEpiAccum | EPI_DIV: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum | EPI_DIV, false, false, 1, 16>(a, grid, lds, stream);
+        case kSxEpiStageOut: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiStageOut, false, false, 1, 16>(a, grid, lds, stream);
+        default: return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, 1, 16>(a, grid, lds, stream);
+    }
+}
+hipError_t launch_conv_sx_h1_s16(const SxArgs &a, int cfg, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_conv_sx_h1_epi<1, 8, 4, 1>(a, epi, grid, lds, stream);
+        case 1: return launch_conv_sx_h1_epi<1, 4, 2, 2>(a, epi, grid, lds, stream);
+        case 3: return launch_conv_sx_h1_epi<1, 2, 2, 2>(a, epi, grid, lds, stream);
+        default: return launch_conv_sx_h1_epi<1, 2, 1, 4>(a, epi, grid, lds, stream);
+    }
+}
+#endif
 #ifdef VITSMI_IMPL_SX_BF16
 hipError_t launch_conv_sx_bf16(const SxArgs &a, int cfg, int epi, int nprod, bool rawin, dim3 grid, size_t lds, hipStream_t stream) {
-    if (nprod != 6) {
-        if (nprod != 3 && nprod != 1) return hipErrorInvalidValue;
-        if (rawin)
-            return cfg == 1 ? launch_conv_sx_np<1, 4, 2, 2, true>(a, nprod, grid, lds, stream)
-                            : launch_conv_sx_np<1, 2, 1, 4, true>(a, nprod, grid, lds, stream);
-        switch (cfg) {
-            case 0: return launch_conv_sx_np<2, 4, 2, 2, false>(a, nprod, grid, lds, stream);
-            case 1: return launch_conv_sx_np<1, 4, 2, 2, false>(a, nprod, grid, lds, stream);
-            default: return launch_conv_sx_np<1, 2, 1, 4, false>(a, nprod, grid, lds, stream);
-        }
-    }
+    if (nprod != 6) return hipErrorInvalidValue;
     if (rawin)
         return cfg == 1 ? launch_conv_sx_rawin<1, 4, 2, 2>(a, epi, grid, lds, stream)
                         : launch_conv_sx_rawin<1, 2, 1, 4>(a, epi, grid, lds, stream);
@@ -1414,7 +1471,7 @@ hipError_t launch_conv_sx_bf16(const SxArgs &a, int cfg, int epi, int nprod, boo
 // ---- layout conversion kernels ------------------------------------------------------------------------
 
 // planar fp32 x[b][c][t] (row pitch `pitch`, optionally masked by t < len[b]) -> planes [3][C/8][T][8]
-// (f16 != 0: two fp16 planes in the same addressing, plane 2 untouched)
+// (f16 = 1: two fp16 planes in the same addressing, plane 2 untouched; f16 = 2: the single fp16 plane of the NP = 1 mode)
 // peak (f16 only, may be nullptr): 64 range-guard slots as in SxArgs::peak.  This is where tensors ENTER the split
 // engine (the generator's z, the flow's WN input), so non-finite values are caught here too: NaN counts as inf.
 __global__ __launch_bounds__(256) void sx_split_planes_kernel(const float *x, int64_t x_bstride, int pitch, const int *len,
@@ -1441,7 +1498,7 @@ __global__ __launch_bounds__(256) void sx_split_planes_kernel(const float *x, in
         const int CG = C >> 3;
         uint16_t *ob = out + (int64_t)b * 3 * CG * T * 8;
 #pragma unroll
-        for (int pl = 0; pl < (f16 ? 2 : 3); pl++) {
+        for (int pl = 0; pl < (f16 == 2 ? 1 : (f16 ? 2 : 3)); pl++) {
             u32x4 w;
             w.x = (unsigned)p[pl][0] | ((unsigned)p[pl][1] << 16);
             w.y = (unsigned)p[pl][2] | ((unsigned)p[pl][3] << 16);
@@ -1484,7 +1541,8 @@ __global__ __launch_bounds__(256) void sx_unblock_kernel(const float *raw, const
             const uint16_t *pb = planes + (int64_t)b * 3 * CG * T * 8;
             const int64_t o = ((int64_t)cg * T + t) * 8 + e, ps = (int64_t)CG * T * 8;
             // same order as the exact reconstruction: small terms first
-            if (f16) v = f16_bits_to_f32(pb[o + ps]) * (1.f / 2048.f) + f16_bits_to_f32(pb[o]);
+            if (f16 == 2) v = f16_bits_to_f32(pb[o]);
+            else if (f16) v = f16_bits_to_f32(pb[o + ps]) * (1.f / 2048.f) + f16_bits_to_f32(pb[o]);
             else v = (bf16_bits_to_f32(pb[o + 2 * ps]) + bf16_bits_to_f32(pb[o + ps])) + bf16_bits_to_f32(pb[o]);
         } else
             v = raw[(int64_t)b * C * T + ((int64_t)cg * T + t) * 8 + e];

@@ -572,6 +572,10 @@ void pick_tiling(int Cin, int Cout, int K, int dil, int padL, int hint, int &cfg
 
 thread_local int t_hint = 0;  // size class of the layers being packed (set by Model::build)
 thread_local bool t_sx_f16 = false;  // pack_conv_sx: two scaled fp16 planes instead of three bf16 planes
+thread_local bool t_sx_h1 = false;   // pack_conv_sx: ONE scaled fp16 plane in the 16x16x32 layout (VITSMI_GEN_PRECISION=f16)
+// the encoder / flow run f16x3 under the default arithmetic AND under the reduced-precision vocoder ("f16": everything in
+// front of z is unchanged); bf16x6 keeps them on their exact engines
+bool precision_is_fp16_family(const char *pe) { return !pe || !*pe || std::string(pe) == "f16x3" || std::string(pe) == "f16"; }
 thread_local int t_sx_min_cfg = 0;   // pack_conv_sx: smallest tile index allowed (1 = no 128-row tiles)
 thread_local bool t_sx_shape32 = false;  // pack_conv_sx: never the 16x16x32 packing (bench / ablation hooks)
 
@@ -709,8 +713,11 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
         const char *e = std::getenv("VITSMI_SX_SHAPE");  // "32": A/B timing against the v_mfma_f32_32x32x16 loop
         return e && std::string(e) == "32";
     }();
-    const bool want16 = t_sx_f16 && !sx_raw_format(Cin) && !shape32_only && !t_sx_shape32 && Cin % 32 == 0 &&
-                        (size_t)8 * (256 + (Kreal - 1) * dil) * 16 <= (size_t)10 * 4096;
+    const bool h1 = t_sx_h1;
+    if (h1 && (Cin % 32 || (size_t)4 * (256 + (Kreal - 1) * dil) * 16 > (size_t)10 * 4096))
+        throw std::runtime_error("the f16 single-plane arithmetic needs Cin % 32 == 0 and a halo of at most 384 columns");
+    const bool want16 = h1 || (t_sx_f16 && !sx_raw_format(Cin) && !shape32_only && !t_sx_shape32 && Cin % 32 == 0 &&
+                               (size_t)8 * (256 + (Kreal - 1) * dil) * 16 <= (size_t)10 * 4096);
     if (K < 3 && !want16) K = 3;
     auto wz = [&](int co, int ci, int tap) { return tap < Kreal ? w(co, ci, tap) : 0.f; };
     ConvDesc d;
@@ -722,12 +729,13 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     d.padL = padL;
     d.CK = 16;
     d.nchunks = Cin / 16;
-    d.rawin = sx_raw_format(Cin);
+    d.rawin = sx_raw_format(Cin) && !h1;  // (single-plane mode: every tensor is a plane tensor)
+    d.h1 = h1;
     d.cfg = sx_pick_cfg(Cout);
     if (d.rawin && d.cfg == 0) d.cfg = 1;  // the raw-input path exists for the 64- and 32-row tiles only
     d.mblocks = Cout / 32;
     const int MB = sx_tile_m(d.cfg) / 32;
-    const int npw = t_sx_f16 ? 2 : 3;                              // planes per 32-row block
+    const int npw = h1 ? 1 : (t_sx_f16 ? 2 : 3);                   // planes per 32-row block
     // 16x16x32 main loop (f16x3, plane input, 32-channel chunks): when the x stage of a 32-channel chunk (8 rows of
     // 256 + halo cells) fits ten DMA rounds, i.e. two workgroups per CU
     d.s16 = want16;
@@ -740,7 +748,7 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     if (bias_virtual) d.b_off = P.put(bias_virtual, Cout);
     d.macs_per_t = double(Cin) * Cout * Kreal;
     float wmul = 1.f;
-    if (t_sx_f16) {
+    if (t_sx_f16 || h1) {
         // per-tensor power of two that lifts the largest weight into [2^14, 2^15): both fp16 planes of every weight
         // within 2^-18 of the largest are then normal numbers; undone exactly on the accumulators
         float wmax = 0.f;
@@ -753,17 +761,18 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
         int e = 0;
         if (wmax > 0.f) std::frexp(wmax, &e);  // wmax = m * 2^e, m in [0.5, 1)
         wmul = std::ldexp(1.f, 15 - e);
-        d.f16 = true;
+        d.f16 = !h1;
         d.wscale = std::ldexp(1.f, e - 15);
     }
     if (P.dry) return d;
     uint16_t *dst = reinterpret_cast<uint16_t *>(P.arena.data() + d.w_off);
     if (d.s16) {
         // [m-tile][chunk of 32 ci][tap][32-row block][sub-block a][plane][lane][8]: 4 KiB per (32-row block, step)
+        // (single-plane mode: one plane, 2 KiB)
         for (int mb = 0; mb < d.mblocks; mb++)
             for (int chunk = 0; chunk < d.nchunks; chunk++)
                 for (int tap = 0; tap < K; tap++) {
-                    const int64_t base = ((((int64_t)(mb / MB) * d.nchunks + chunk) * K + tap) * MB + (mb % MB)) * 4;
+                    const int64_t base = ((((int64_t)(mb / MB) * d.nchunks + chunk) * K + tap) * MB + (mb % MB)) * 2 * npw;
                     for (int sub = 0; sub < 2; sub++)
                         for (int lane = 0; lane < 64; lane++) {
                             const int i16 = lane & 15, q = i16 >> 2;
@@ -771,7 +780,7 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
                             for (int i = 0; i < 8; i++) {
                                 uint16_t p[3];
                                 split2h_host(wz(mb * 32 + row32, chunk * 32 + 8 * (lane >> 4) + i, tap) * wmul, p);
-                                for (int pl = 0; pl < 2; pl++) dst[(base + sub * 2 + pl) * 512 + lane * 8 + i] = p[pl];
+                                for (int pl = 0; pl < npw; pl++) dst[(base + sub * npw + pl) * 512 + lane * 8 + i] = p[pl];
                             }
                         }
                 }
@@ -981,6 +990,7 @@ void split2h_host(float v, uint16_t p[3]) {
 }
 
 void set_sx_f16(bool on) { t_sx_f16 = on; }
+void set_sx_h1(bool on) { t_sx_h1 = on; }
 void set_sx_shape32(bool on) { t_sx_shape32 = on; }
 
 // Arithmetic of the split-operand convs for the opens that follow on this thread: an explicit choice
@@ -1054,6 +1064,7 @@ std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout
 
 std::string Model::build(const OnnxModel &om, bool layout_only) {
     t_sx_f16 = false;
+    t_sx_h1 = false;
     try {
         Resolver R;
         resolve(om, R);
@@ -1087,7 +1098,7 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
             const char *ge = std::getenv("VITSMI_GEN_ENGINE"), *ee = std::getenv("VITSMI_ENC_ENGINE");
             const char *pe = gen_precision_name();
             enc_want_sx = !(ge && std::string(ge) == "f32") && !(ee && std::string(ee) == "f32") &&
-                          (!pe || !*pe || std::string(pe) == "f16x3") && H % 32 == 0;
+                          precision_is_fp16_family(pe) && H % 32 == 0;
         }
         bool enc_all_sx = enc_want_sx;
         auto sx_twin = [&](const ConvDesc &f, const std::function<ConvDesc()> &mk) {
@@ -1255,7 +1266,7 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
                     const int ci = int(w->dims[1]), co = int(w->dims[0]);
                     if (!f32_only && !sx_raw_format(ci) && co % 64 == 0 && ci % 8 == 0 && sx_supported(ci, co, co, k, dil)) {
                         const char *pe = gen_precision_name();  // (same arithmetic as the generator)
-                        t_sx_f16 = !pe || !*pe || std::string(pe) == "f16x3";
+                        t_sx_f16 = precision_is_fp16_family(pe);
                         // frame-domain tensors are short (F ~ 3 T): 64-row tiles give the grid twice the workgroups
                         // (288 -> 576 at batch 32), measured 3.04 -> 2.87 ms for the flow
                         t_sx_min_cfg = 1;
@@ -1381,8 +1392,14 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
             // VITSMI_GEN_PRECISION=bf16x6 (exact products, six bf16 plane products), bf16x3 or bf16 pack bf16 planes
             const char *pe = gen_precision_name();
             gen_f16 = gen_sx && (!pe || !*pe || std::string(pe) == "f16x3");
+            // "f16": ONE fp16 plane per operand, one product, activations stored as fp16 (BASELINE config 4's reduced-
+            // precision vocoder); needs every generator conv on the 16x16x32 loop (pack_conv_sx throws where it cannot)
+            gen_h1 = gen_sx && pe && std::string(pe) == "f16";
+            if (pe && *pe && std::string(pe) != "f16x3" && std::string(pe) != "f16" && std::string(pe) != "bf16x6")
+                throw std::runtime_error(std::string("unknown generator precision '") + pe + "' (VITSMI_GEN_PRECISION: f16x3, bf16x6, f16)");
         }
         t_sx_f16 = gen_f16;
+        t_sx_h1 = gen_h1;
         auto gconv = [&](const std::string &name, int dil, int padL) {
             return gen_sx ? pack_named_sx(P, R, name, dil, padL) : pack_named(P, R, name, dil, padL);
         };
@@ -1431,6 +1448,7 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
             ups.push_back(st);
         }
         t_sx_f16 = false;
+        t_sx_h1 = false;
         const TRef &pw = R.need("dec.conv_post.weight", 3);
         if (pw.dims[0] != 1) throw std::runtime_error("conv_post must have one output channel");
         if (ups.empty() || pw.dims[1] != ups.back().C) throw std::runtime_error("conv_post: input width differs from the last stage");

@@ -41,6 +41,9 @@ struct ConvDesc {
     // of a sub-block permuted (row 4 q + r of sub-block a = row r + 8 (2 a + (q & 1)) + 4 (q >> 1) of the 32-row block)
     // so that the accumulators reach the epilogue's 32 x 32 layout with one half-row swap (conv_sx_engine.hip.hpp)
     bool s16 = false;
+    // sx only: ONE scaled fp16 plane (s16 layout, 2 KiB per 32-row block and step), one MFMA product per fp32 product; the
+    // conv's tensors are single fp16 planes holding the consumer's leaky-ReLU (VITSMI_GEN_PRECISION=f16, BASELINE config 4)
+    bool h1 = false;
     // sx only (flow WN in-layers): rows packed as [32 tanh | 32 sigmoid] per 64-row tile, the conv's epilogue applies
     // the gate and writes planar acts (conv_sx_engine.hip.hpp SX_GATE)
     bool gate = false;
@@ -141,6 +144,7 @@ struct Model {
     ConvDesc conv_pre;
     int C0 = 0;
     bool gen_f16 = false; // ... in its fp16 two-plane mode (VITSMI_GEN_PRECISION=f16x3)
+    bool gen_h1 = false;  // ... in its fp16 single-plane, single-product mode (VITSMI_GEN_PRECISION=f16; 16-bit activations)
     bool gen_sx = false;  // generator packed for the split-operand engine (all channel counts % 32 == 0)
     std::vector<UpStageDesc> ups;
     int64_t post_w = -1;  // [Cin, K] conv_post weight (Cout = 1, no bias)
@@ -176,6 +180,7 @@ void split3_host(float v, uint16_t p[3]);
 uint16_t f16_rne(float f);
 float f16_to_f32(uint16_t h);
 void split2h_host(float v, uint16_t p[3]);
+void set_sx_h1(bool on);   // ... one fp16 plane in the 16x16x32 layout (the NP = 1 mode)
 void set_sx_f16(bool on);  // pack_conv_sx format for the calls that follow on this thread (test hooks)
 void set_sx_shape32(bool on);  // ... never the 16x16x32 (s16) packing (bench hooks: ablation flags, A/B of the MFMA shapes)
 // generator arithmetic for the Model::build calls that follow on this thread: explicit name, or nullptr = take

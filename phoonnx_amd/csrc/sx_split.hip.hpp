@@ -49,6 +49,25 @@ __device__ __forceinline__ void split2h_pair_pk(float x, float y, unsigned &w0, 
     pk = __builtin_fmaxf(pk, __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y)));
     split2h_pair(x, y, w0, w1);
 }
+// ---- f16 single-plane storage (NP = 1, the reduced-precision vocoder of BASELINE config 4): an activation IS its fp16
+// rounding (clamped to +-65504, range-tracked like the two-plane split); one MFMA product per fp32 product.
+__device__ __forceinline__ unsigned cvt1h_pair_pk(float x, float y, float &pk) {
+    pk = __builtin_fmaxf(pk, __builtin_fmaxf(__builtin_fabsf(x), __builtin_fabsf(y)));
+    return cvt_pk_f16(__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f));
+}
+// four stored values (two packed words = the 8 bytes a lane owns of a cell) back to fp32, undoing the leaky-ReLU the
+// plane was stored with: x = p >= 0 ? p : p * unslope (unslope = 1 / slope; 1 = the plane holds x itself).  The map is
+// exact up to the fp32 multiply, so a tensor that is both a conv input (activated) and a residual (not) is stored once.
+__device__ __forceinline__ void unact4h(u32x2 w, float unslope, float (&o)[4]) {
+    // (hipcc 7.2: __builtin_bit_cast of a vector ELEMENT expression - bit_cast(f16x2, w.y) - folds to element 0; the
+    // elements go through scalars first)
+    const unsigned wx = w.x, wy = w.y;
+    const f16x2 a = __builtin_bit_cast(f16x2, wx), b = __builtin_bit_cast(f16x2, wy);
+    const float v[4] = {(float)a[0], (float)a[1], (float)b[0], (float)b[1]};
+#pragma unroll
+    for (int e = 0; e < 4; e++) o[e] = v[e] < 0.f ? v[e] * unslope : v[e];
+}
+
 // Publish a workgroup's peak (all 256 threads must call, uniformly): wave-wide max, the four wave maxima through LDS,
 // then ONE atomicMax on one of the launch's 64 slots - each slot on its own 128-byte line, and skipped when the slot
 // already holds as much (nearly always, after the first workgroups of a launch).  A first version with one atomic

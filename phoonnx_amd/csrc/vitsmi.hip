@@ -73,7 +73,7 @@ struct vits_handle {
     int cur_stage = 0;  // 0 enc, 1 dp, 2 flow, 3 dec
     uint64_t run_counter = 0;
     int gen_nprod = 2;  // generator arithmetic (VITSMI_GEN_PRECISION): 2 = two fp16 planes / three products (default), 6 = six
-                        // exact bf16 plane products, 3 / 1 = the reduced-precision bf16 modes
+                        // exact bf16 plane products, 1 = one fp16 plane / one product with fp16 activations (config 4)
     // f16 range guard: every launch that splits values into fp16 planes publishes the largest magnitude it saw into its
     // own 64 slots of d_range; range_reduce_kernel folds them at the end of a run into d_range_res = {max, min over
     // launches of the per-launch peak, launches tracked}, copied to the pinned h_range (read after the next sync).
@@ -229,7 +229,7 @@ struct Ctx {
 void conv_account(Ctx &c, const ConvDesc &d, int T) {
     vits_handle *h = c.h;
     double fl = 2.0 * d.macs_per_t * (double)T * c.B;
-    double by = 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T);
+    double by = (d.h1 ? 2.0 : 4.0) * c.B * ((double)d.Cin * T + (double)d.Cout * T);  // (stored dtype: SURVEY 8d)
     h->stats.conv_flops += fl;
     h->stats.conv_bytes += by;
     h->stats.conv_launches++;
@@ -352,7 +352,9 @@ struct SxWn {               // SX_WN_RMW arguments of conv_sx()
 
 void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, uint16_t *out_pl, int flags,
              const float *res = nullptr, const float *bias_b = nullptr, int bias_b_stride = 0, float div = 1.f,
-             float oslope = 1.f, float oslope2 = 1.f, float islope = 1.f, const SxWn *wn = nullptr) {
+             float oslope = 1.f, float oslope2 = 1.f, float islope = 1.f, const SxWn *wn = nullptr,
+             const uint16_t *res_pl = nullptr, float res_slope = 1.f) {
+    // res_pl (single-plane mode, d.h1): the residual is the plane tensor that holds leaky_relu(residual, res_slope)
     SxArgs a{};
     const int Cr = d.Cout / d.ups;
     const int64_t Tout = (int64_t)T * d.ups;
@@ -379,6 +381,8 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
         a.planar_bstride = wn->planar_bstride;
     }
     a.res = res;
+    a.res_pl = res_pl;
+    a.res_unslope = 1.f / res_slope;
     a.zeros = c.P(c.m.zeros_off);
     a.Cin = d.Cin;
     a.Cout = d.Cout;
@@ -395,7 +399,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.wscale = d.wscale;
     a.s16 = d.s16 ? 1 : 0;
     vits_handle *h = c.h;
-    a.peak = range_slots(h, d.f16 && (d.rawin || out_pl));  // launches that split values into fp16 planes
+    a.peak = range_slots(h, (d.f16 || d.h1) && (d.rawin || out_pl));  // launches that turn values into fp16 planes
     const bool ev = conv_event_begin(c);
     // Short grids (a single utterance, a streaming chunk): the 128-row packing is read by the 64- or 32-row kernel -
     // 2-4x the workgroups, each with half / a quarter of the reduction work per step.  Same arithmetic.
@@ -426,11 +430,14 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
             sx_tile_m(force % 10) <= sx_tile_m(d.cfg) && d.Cout % sx_tile_m(force % 10) == 0)
             run_cfg = force % 10;
     }
-    c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, d.f16 ? 2 : (h->cur_stage == 3 ? h->gen_nprod : 6), d.cfg));
-    if (ev) conv_event_end(c, true, 2.0 * d.macs_per_t * (double)T * c.B, 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T), d, T);
+    c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, d.h1 ? 1 : (d.f16 ? 2 : 6), d.cfg));
+    // layer-granular bytes in the STORED dtype ("bf16 storage halves these"): 2 bytes per element in the
+    // single-plane mode, 4 otherwise
+    const double ebytes = d.h1 ? 2.0 : 4.0;
+    if (ev) conv_event_end(c, true, 2.0 * d.macs_per_t * (double)T * c.B, ebytes * c.B * ((double)d.Cin * T + (double)d.Cout * T), d, T);
     conv_account(c, d, T);
     h->stats.sx_flops += 2.0 * d.macs_per_t * (double)T * c.B;
-    h->stats.sx_bytes += 4.0 * c.B * ((double)d.Cin * T + (double)d.Cout * T);
+    h->stats.sx_bytes += ebytes * c.B * ((double)d.Cin * T + (double)d.Cout * T);
     h->stats.sx_launches++;
 }
 
@@ -959,11 +966,102 @@ size_t gen_ws_bytes(const Model &m, int B, int F) {
     return (size_t)(m.gen_sx ? kGenRegionsSx : kGenRegions) * al(gen_region_floats(m, B, F));
 }
 
+// The generator in the single-plane arithmetic (VITSMI_GEN_PRECISION=f16, BASELINE config 4's reduced-precision vocoder):
+// ONE fp16 plane per operand, one MFMA product per fp32 product, fp32 accumulation.  Every tensor between two convs
+// exists once, as the fp16 of the consumer's leaky_relu ([C/8][T][8], 2 bytes per element): a conv reads it as its B
+// operand straight from LDS, and a residual add recovers x from it by undoing the leaky_relu (x = p >= 0 ? p : p / 0.1,
+// exact).  Only the multi-receptive-field sum xs (models.py:356-363; three read-modify-writes per stage) stays fp32.
+// Everything in front of z is the default arithmetic.  Same dataflow as run_generator_sx.
+int run_generator_h1(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B,
+                     int F, const float *dec_cond, Slab &s) {
+    const Model &m = h->model;
+    hipStream_t st = h->stream;
+    const size_t R = gen_region_floats(m, B, F);
+    const size_t RP = R + R / 2 + 64;  // (plane tensors keep the three-slot batch stride of the other modes)
+    auto planes = [&]() { return reinterpret_cast<uint16_t *>(slab_take<float>(s, RP)); };
+    uint16_t *stage_in[2] = {planes(), planes()}, *y_pl = planes(), *raa[2] = {planes(), planes()}, *tmp_pl = planes();
+    float *xs_raw = slab_take<float>(s, R);
+    h->cur_stage = 3;
+    stage_mark(h, 3);
+    const float S = 0.1f;  // Generator.LRELU_SLOPE / ResBlock LRELU_SLOPE
+    const int nst = (int)m.ups.size();
+    // z * y_mask (models.py:349) as conv_pre's operand plane (no activation in front of conv_pre)
+    sx_split_planes_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_pl, m.C, F, 2,
+                                                                              range_slots(h, true));
+    c.note(hipGetLastError());
+    h->stats.total_launches++;
+    // xa = leaky_relu(conv_pre(z) [+ cond(g)], 0.1) (models.py:349-354)
+    conv_sx(c, m.conv_pre, tmp_pl, F, nullptr, stage_in[0], 0, nullptr, dec_cond, m.C0, 1.f, 1.f, S);
+    const uint16_t *xa = stage_in[0];
+    int T = F;
+    for (int si = 0; si < nst; si++) {
+        const auto &stg = m.ups[si];
+        // y = up(xa), stored as leaky_relu(y, 0.1): the resblocks' first operand and, un-activated, their residual
+        conv_sx(c, stg.up, xa, T, nullptr, y_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
+        T *= stg.u;
+        uint16_t *xs_pl = stage_in[(si + 1) & 1];
+        const int nk = (int)stg.rbs.size();
+        const bool last_stage = si == nst - 1;
+        for (int j = 0; j < nk; j++) {
+            const auto &rbk = stg.rbs[j];
+            const uint16_t *cur = y_pl;
+            const bool final_rb = j == nk - 1;
+            for (int q = 0; q < rbk.n; q++) {
+                const bool last = q == rbk.n - 1;
+                int fl = EPI_RES;
+                float *dst = nullptr;          // fp32 destination: the running sum xs
+                uint16_t *dsta = raa[q & 1];   // plane destination: the block's stream
+                if (last) {
+                    // xs = rb0(x); xs += rb1(x); ...; x = xs / nk.  The stage output feeds the next upsampler as a plane
+                    // (leaky_relu 0.1); the last stage's feeds conv_post as fp32 (its kernel applies leaky_relu 0.01)
+                    fl |= (j == 0 ? 0 : EPI_ACC) | (final_rb && nk > 1 ? EPI_DIV : 0);
+                    dst = xs_raw;
+                    dsta = nullptr;
+                    if (final_rb && !last_stage) {
+                        dsta = xs_pl;
+                        if (nk > 1) fl |= SX_NO_RAW_STORE;
+                        else dst = nullptr;
+                    }
+                }
+                if (rbk.type1) {  // modules.py:301-314: x = c2(lrelu(c1(lrelu(x)))) + x
+                    conv_sx(c, rbk.c1[q], cur, T, nullptr, tmp_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
+                    conv_sx(c, rbk.c2[q], tmp_pl, T, dst, dsta, fl, nullptr, nullptr, 0, (float)nk, 1.f, S, 1.f, nullptr, cur, S);
+                } else  // modules.py:355-364: x = c(lrelu(x)) + x
+                    conv_sx(c, rbk.c1[q], cur, T, dst, dsta, fl, nullptr, nullptr, 0, (float)nk, 1.f, S, 1.f, nullptr, cur, S);
+                cur = dsta;
+            }
+        }
+        xa = xs_pl;
+    }
+    // leaky_relu(0.01), conv_post, tanh (models.py:364-366) from the fp32 stage output
+    h->S = T;
+    h->d_out = slab_take<float>(s, (size_t)B * T);
+    {
+        const size_t lds = (size_t)m.post_cin * (256 + m.post_k - 1) * sizeof(float);
+        if (m.post_k == 7)
+            post_conv_tanh_blocked_kernel<7><<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out,
+                                                                                        m.post_cin, m.post_k, T, 0.01f);
+        else
+            post_conv_tanh_blocked_kernel<0><<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out,
+                                                                                        m.post_cin, m.post_k, T, 0.01f);
+    }
+    c.note(hipGetLastError());
+    h->stats.total_launches++;
+    {
+        double fl = 2.0 * m.post_cin * m.post_k * (double)T * B, by = 4.0 * B * ((double)m.post_cin * T + T);
+        h->stats.dec_flops += fl;
+        h->stats.dec_bytes += by;
+    }
+    stage_mark(h, 4);
+    return 0;
+}
+
 // The generator on the split-operand engine.  Same dataflow as run_generator below; tensors that feed a conv
 // are stored as 16-bit planes (already leaky-ReLU'd by their producer), the residual stream as fp32 raw cells.
 int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B,
                      int F, const float *dec_cond, Slab &s) {
     const Model &m = h->model;
+    if (m.gen_h1) return run_generator_h1(h, c, z, z_bstride, z_cstride, ylen, B, F, dec_cond, s);
     hipStream_t st = h->stream;
     const size_t R = gen_region_floats(m, B, F);
     const size_t RP = R + R / 2 + 64;  // floats holding R elements as three 16-bit plane slots (the fp16 mode uses two)
@@ -1465,17 +1563,17 @@ static int open_common(const char *path, vits_handle **out, bool host_only, int 
         // Arithmetic of the generator's convs on the split-exact engine (fp32 operands and results in every mode):
         //   f16x3  (default) two fp16 planes per operand, three MFMA products: each product within ~3 * 2^-24
         //   bf16x6 three bf16 planes, six products: each product exact to 2^-24
-        //   bf16x3 / bf16: the declared reduced-precision vocoder modes (BASELINE config 4, "bf16 vocoder")
-        // gen_nprod: 2 = f16x3 (Model::build packed the weights for it), else the number of bf16 plane products.
+        //   f16    the reduced-precision vocoder of BASELINE config 4: ONE fp16 plane per operand, one product, fp32
+        //          accumulation, generator activations stored as fp16 (everything in front of z unchanged)
+        // gen_nprod: 2 = f16x3, 1 = f16 (Model::build packed the weights for either), 6 = the six bf16 plane products.
         const char *pe = gen_precision_name();
         const std::string ps = pe ? pe : "";
         if (ps.empty() || ps == "f16x3") h->gen_nprod = 2;
         else if (ps == "bf16x6") h->gen_nprod = 6;
-        else if (ps == "bf16x3") h->gen_nprod = 3;
-        else if (ps == "bf16") h->gen_nprod = 1;
+        else if (ps == "f16") h->gen_nprod = 1;
         else {
             delete h;
-            return fail(nullptr, VITS_E_ARG, "VITSMI_GEN_PRECISION must be f16x3, bf16x6, bf16x3 or bf16 (got '%s')", pe);
+            return fail(nullptr, VITS_E_ARG, "VITSMI_GEN_PRECISION must be f16x3, bf16x6 or f16 (got '%s')", pe);
         }
         if (!h->model.gen_sx) h->gen_nprod = 6;
     }
@@ -2232,8 +2330,15 @@ static int run_test_conv_sx(const ConvDesc &d, const std::vector<float> &arena, 
     TCHECK(hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice));
     TCHECK(hipMemset(draw, 0, no * 4));
     TCHECK(hipMemset(dop, 0, no * 6));
+    if (d.h1 && (flags & 8)) {
+        // single-plane mode with an input slope: the plane holds leaky_relu(x, slope) - what the conv consumes - and the
+        // residual x is recovered from it (out = conv(lrelu(x)) + x): activate on the host, then store
+        std::vector<float> xa(nx);
+        for (size_t i = 0; i < nx; i++) xa[i] = x[i] >= 0.f ? x[i] : x[i] * slope;
+        TCHECK(hipMemcpy(dx, xa.data(), nx * 4, hipMemcpyHostToDevice));
+    }
     sx_split_planes_kernel<<<dim3((T + 255) / 256, d.Cin / 8, B), 256>>>(dx, (int64_t)d.Cin * T, T, nullptr, dxp, d.Cin, T,
-                                                                         d.f16 ? 1 : 0);
+                                                                         d.h1 ? 2 : (d.f16 ? 1 : 0));
     TCHECK(hipMalloc((void **)&dres, nx * 4 + 16));  // x in the raw layout: raw-input operand and residual
     sx_block_kernel<<<dim3((T + 255) / 256, d.Cin / 8, B), 256>>>(dx, (int64_t)d.Cin * T, T, nullptr, dres, d.Cin, T);
     SxArgs a{};
@@ -2241,19 +2346,24 @@ static int run_test_conv_sx(const ConvDesc &d, const std::vector<float> &arena, 
     a.xp = reinterpret_cast<const u32x4 *>(dxp);
     a.xr = dres;
     a.islope = (flags & 8) ? slope : 1.f;  // (raw-input convs only)
-    a.out_raw = draw;
+    a.out_raw = (flags & 128) ? nullptr : draw;  // (bit 7: planes are the only output - the specialised plane epilogues)
     a.out_pl = dop;
     a.oslope = 1.f;
     a.oslope2 = (flags & 1) ? slope : 1.f;
     if (flags & 4) {  // residual: res = x (same shape only)
         if (d.Cin != d.Cout || d.ups != 1) return fail(nullptr, VITS_E_ARG, "residual test needs Cin == Cout");
-        a.res = dres;
+        if (d.h1) {
+            a.res_pl = dxp;  // the residual is the input plane itself, un-activated on the way in
+            a.res_unslope = (flags & 8) ? 1.f / slope : 1.f;
+        } else
+            a.res = dres;
         a.flags |= EPI_RES;
     }
-    const int nprod = d.f16 ? 2 : (((flags >> 4) & 3) == 1 ? 3 : (((flags >> 4) & 3) == 2 ? 1 : 6));
+    const int nprod = d.h1 ? 1 : (d.f16 ? 2 : 6);
     a.wscale = d.wscale;
     TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, nprod));
-    sx_unblock_kernel<<<dim3((To + 255) / 256, Cr / 8, B), 256>>>(draw, (flags & 1) ? dop : nullptr, dout, Cr, To, d.f16 ? 1 : 0);
+    sx_unblock_kernel<<<dim3((To + 255) / 256, Cr / 8, B), 256>>>(draw, (flags & 1) ? dop : nullptr, dout, Cr, To,
+                                                                  d.h1 ? 2 : (d.f16 ? 1 : 0));
     TCHECK(hipGetLastError());
     TCHECK(hipDeviceSynchronize());
     TCHECK(hipMemcpy(out, dout, no * 4, hipMemcpyDeviceToHost));
@@ -2267,9 +2377,14 @@ int vits_test_conv1d_sx(int device_id, const float *x, int B, int Cin, int T, co
     if (int rc = test_dev(device_id)) return rc;
     ConvDesc d;
     std::vector<float> arena;
-    set_sx_f16(((flags >> 4) & 3) == 3);  // precision code 3: two fp16 planes
+    const int prec = (flags >> 4) & 3;  // 0: bf16x6, 3: f16x3 (two fp16 planes), 2: f16 (one fp16 plane, one product)
+    if (prec == 1) return fail(nullptr, VITS_E_ARG, "precision code 1 (bf16x3) was retired");
+    if ((flags & 128) && !(flags & 1)) return fail(nullptr, VITS_E_ARG, "planes-only output is read back from the planes (bit 0)");
+    set_sx_f16(prec == 3);
+    set_sx_h1(prec == 2);
     std::string e = pack_test_conv(w, bias, Cin, Cout, K, dil, pad_l, 3, &d, &arena);
     set_sx_f16(false);
+    set_sx_h1(false);
     if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
     return run_test_conv_sx(d, arena, x, B, T, flags, slope, out);
 }
@@ -2451,9 +2566,11 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
     ConvDesc d;
     std::vector<float> arena;
     set_sx_f16((dbg & 128) != 0);
+    set_sx_h1((dbg & 64) != 0);  // one fp16 plane, one product (VITSMI_GEN_PRECISION=f16)
     set_sx_shape32((dbg & (1 | 2 | 16 | 256)) != 0);  // ablation / cycle-breakdown builds exist for the 32x32x16 loop only
     std::string e = pack_test_conv(w.data(), nullptr, Cin, Cout, K, dil, dil * (K - 1) / 2, 3, &d, &arena);
     set_sx_f16(false);
+    set_sx_h1(false);
     set_sx_shape32(false);
     if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
     float *dA = nullptr, *dx = nullptr, *draw = nullptr, *dres = nullptr;
@@ -2468,7 +2585,8 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
     TCHECK(hipMemcpy(dA, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
     TCHECK(hipMemcpy(dx, x.data(), nx * 4, hipMemcpyHostToDevice));
     TCHECK(hipMemset(dres, 0, no * 4));
-    sx_split_planes_kernel<<<dim3((T + 255) / 256, Cin / 8, B), 256>>>(dx, (int64_t)Cin * T, T, nullptr, dxp, Cin, T, d.f16 ? 1 : 0);
+    sx_split_planes_kernel<<<dim3((T + 255) / 256, Cin / 8, B), 256>>>(dx, (int64_t)Cin * T, T, nullptr, dxp, Cin, T,
+                                                                       d.h1 ? 2 : (d.f16 ? 1 : 0));
     SxArgs a{};
     fill_sx_args(a, d, dA, T);
     a.wscale = d.wscale;
@@ -2478,8 +2596,13 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
     a.flags = ((dbg & 1) ? DBG_NO_DMA : 0) | ((dbg & 2) ? DBG_NO_EPI : 0);
     if (dbg & 8) {  // residual epilogue with raw + planes outputs (ResBlock tail)
         a.flags |= EPI_RES;
-        a.res = dres;
-        a.out_raw = draw;
+        if (d.h1) {  // (single-plane mode: plane in, residual from a plane, plane out - the ResBlock tail of that mode)
+            a.res_pl = reinterpret_cast<const uint16_t *>(dres);
+            a.res_unslope = 10.f;
+        } else {
+            a.res = dres;
+            a.out_raw = draw;
+        }
     }
     if (d.rawin) {  // <= 64 input channels: as the generator runs such layers: fp32 raw in (lrelu on load), raw out
         a.xr = dx;
@@ -2496,11 +2619,11 @@ int vits_bench_conv1d_sx(int device_id, int B, int Cin, int Cout, int T, int K, 
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, d.f16 ? 2 : ((dbg & 32) ? 3 : ((dbg & 64) ? 1 : 6))));
+    for (int i = 0; i < 2; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, d.h1 ? 1 : (d.f16 ? 2 : 6)));
     TCHECK(hipDeviceSynchronize());
     if (dprof) TCHECK(hipMemset(dprof, 0, 64));
     hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, d.f16 ? 2 : ((dbg & 32) ? 3 : ((dbg & 64) ? 1 : 6))));
+    for (int i = 0; i < iters; i++) TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, d.h1 ? 1 : (d.f16 ? 2 : 6)));
     hipEventRecord(e1, nullptr);
     TCHECK(hipEventSynchronize(e1));
     float ms = 0.f;

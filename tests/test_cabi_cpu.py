@@ -143,7 +143,7 @@ def test_layout_only_open_equals_full_pack(preset, precision):
 
 def test_gen_precision_option_and_fixture_runs_on_sx():
     path = os.path.join(GOLDEN, "sx_rb1.onnx")
-    for name, nprod in (("f16x3", 2), ("bf16x6", 6), ("bf16x3", 3), ("bf16", 1), (None, 2)):
+    for name, nprod in (("f16x3", 2), ("bf16x6", 6), ("f16", 1), (None, 2)):
         s = MiSession(path, host_only=True, gen_precision=name)
         assert s.hparam("gen_sx") == 1 and s.hparam("gen_nprod") == nprod
         s.close()

@@ -150,18 +150,21 @@ def test_generator_f16_mode_agrees_with_exact_mode(monkeypatch, preset, B, T):
     assert err < 2e-5, err
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-3), ("bf16", 8e-2)])
-def test_config4_multispeaker_mixed_lengths_reduced_precision_vocoder(monkeypatch, mode, tol):
-    """BASELINE config 4: multi-speaker voice, mixed-length padded batch, reduced-precision vocoder
-    (VITSMI_GEN_PRECISION).  Everything up to z is computed exactly as always; the generator then uses three
-    (bf16x3) or one (bf16) bf16 plane product per fp32 product.  Declared waveform tolerances: bf16x3 stays inside
-    north_star's 1e-3; plain bf16 is a quality/speed trade-off, 8e-2 max-abs on a unit-scale waveform."""
+def _snr_db(ref, got):
+    ref, got = ref.astype(np.float64), got.astype(np.float64)
+    return 10 * np.log10((ref ** 2).sum() / max(((got - ref) ** 2).sum(), 1e-30))
+
+
+def test_config4_multispeaker_mixed_lengths_reduced_precision_vocoder():
+    """BASELINE config 4: multi-speaker voice, mixed-length padded batch, reduced-precision vocoder (gen_precision "f16":
+    one fp16 plane per operand, one MFMA product per fp32 product, fp32 accumulation, generator activations stored as fp16).
+    Everything up to z is computed exactly as always.  Declared bar: waveform within 1e-2
+    max-abs AND >= 35 dB SNR of the fp32 oracle, per utterance."""
     from phoonnx_amd import MiSession
     from vits_oracle import VitsOracle
     path = _voice("medium", n_speakers=4)
-    monkeypatch.setenv("VITSMI_GEN_PRECISION", mode)
-    s, o = MiSession(path), VitsOracle(path)
-    assert s.hparam("gen_nprod") == {"bf16x3": 3, "bf16": 1}[mode]
+    s, o = MiSession(path, gen_precision="f16"), VitsOracle(path)
+    assert s.hparam("gen_nprod") == 1 and s.hparam("gen_sx") == 1
     rng = np.random.default_rng(4)
     B, T = 8, 72
     lens = np.array([T] + [int(v) for v in rng.integers(T // 4, T, B - 1)], np.int64)
@@ -177,9 +180,90 @@ def test_config4_multispeaker_mixed_lengths_reduced_precision_vocoder(monkeypatc
     assert np.array_equal(got["y_lengths"], ref["y_lengths"])
     np.testing.assert_allclose(got["z"], ref["z"], atol=5e-4, rtol=0)      # exact part of the pipeline
     hop = s.hparam("hop")
-    err = max(float(np.abs(got["output"][b, 0, 0, :int(ref["y_lengths"][b]) * hop] -
-                           ref["output"][b, 0, 0, :int(ref["y_lengths"][b]) * hop]).max()) for b in range(B))
-    assert err < tol, (mode, err)
+    errs, snrs = [], []
+    for b in range(B):
+        n = int(ref["y_lengths"][b]) * hop
+        errs.append(float(np.abs(got["output"][b, 0, 0, :n] - ref["output"][b, 0, 0, :n]).max()))
+        snrs.append(_snr_db(ref["output"][b, 0, 0, :n], got["output"][b, 0, 0, :n]))
+    print(f"config 4 (B=8, 4 speakers, mixed lengths), f16 vocoder vs fp32 oracle: max-abs {max(errs):.3g}, worst SNR {min(snrs):.1f} dB")
+    assert max(errs) < 1e-2 and min(snrs) > 35.0, (errs, snrs)
+    st = s.stats()
+    assert st["f16_saturated"] == 0 and 0 < st["f16_peak_max"] < 65504.0   # range-guarded like f16x3
+    s.close()
+
+
+@pytest.mark.parametrize("preset", ["high", "medium"])
+def test_f16_vocoder_against_the_oracle_single_speaker(preset):
+    """The same bar on the two bench voices (ResBlock1 with 128-row MFMA-bound stages / ResBlock2), B = 3."""
+    from phoonnx_amd import MiSession
+    from vits_oracle import VitsOracle
+    path = _voice(preset)
+    s, o = MiSession(path, gen_precision="f16"), VitsOracle(path)
+    assert s.hparam("gen_nprod") == 1
+    rng = np.random.default_rng(8)
+    B, T = 3, 80
+    lens = np.array([T, T - 11, T // 2], np.int64)
+    ids = np.zeros((B, T), np.int64)
+    for b in range(B):
+        ids[b, :lens[b]] = rng.integers(0, 256, lens[b])
+    sc = np.array([0.667, 1.4, 0.8], np.float32)
+    ndp = rng.standard_normal((B, 2, T)).astype(np.float32)
+    nz = rng.standard_normal((B, 192, T * 8)).astype(np.float32)
+    ref = o.infer(ids, lens, sc, None, ndp, nz)
+    got = s.synthesize_batch(ids, lens, sc, None, ndp, nz)
+    assert np.array_equal(got["y_lengths"], ref["y_lengths"])
+    hop = s.hparam("hop")
+    errs, snrs = [], []
+    for b in range(B):
+        n = int(ref["y_lengths"][b]) * hop
+        errs.append(float(np.abs(got["output"][b, 0, 0, :n] - ref["output"][b, 0, 0, :n]).max()))
+        snrs.append(_snr_db(ref["output"][b, 0, 0, :n], got["output"][b, 0, 0, :n]))
+    print(f"{preset}, f16 vocoder vs fp32 oracle: max-abs {max(errs):.3g}, worst SNR {min(snrs):.1f} dB")
+    assert max(errs) < 1e-2 and min(snrs) > 35.0, (errs, snrs)
+    s.close()
+
+
+@pytest.mark.parametrize("preset", ["high", "medium"])
+def test_baseline_config3_exact_shape_against_the_oracle(preset):
+    """BASELINE config 3 exactly - B = 32 x 256 phoneme ids, full pipeline, the bench's scales, injected noise - rendered as
+    ONE batch on the GPU and compared with the C oracle (OpenMP build) on eight utterances of that batch (the whole batch is
+    ~50 s of host time per voice; the eight are spread over it and include the longest and the shortest rendering).  An
+    utterance's samples do not depend on its batch neighbours except inside the generator's receptive field at its END (a
+    shorter batch ends the tensor there, the longer one continues with masked frames: SURVEY section 8c), so the comparison
+    stops gen_rf frames short of each utterance's end.  Durations exact, waveform within north_star's 1e-3."""
+    from phoonnx_amd import MiSession
+    from vits_oracle import VitsOracle
+    path = _voice(preset)
+    s = MiSession(path)
+    try:
+        o = VitsOracle(path, native=True)
+    except Exception:  # noqa: BLE001 - no -march=native build on this host
+        o = VitsOracle(path)
+    rng = np.random.default_rng(1234)
+    B, T = 32, 256
+    ids = rng.integers(0, 256, (B, T)).astype(np.int64)
+    lens = np.full(B, T, np.int64)
+    sc = np.array([0.667, 1.95, 0.8], np.float32)     # bench.py LENGTH_SCALE: ~3 frames per id
+    ndp = rng.standard_normal((B, 2, T)).astype(np.float32)
+    nz = rng.standard_normal((B, s.hparam("inter"), T * 6)).astype(np.float32)
+    got = s.synthesize_batch(ids, lens, sc, None, ndp, nz, taps=("w_ceil",))
+    hop = s.hparam("hop")
+    ylen = got["y_lengths"]
+    assert got["output"].shape == (B, 1, 1, hop * int(ylen.max())) and int(ylen.max()) <= T * 6
+    order = np.argsort(ylen)
+    pick = sorted({int(order[0]), int(order[-1]), 0, 5, 13, 18, 24, 31})
+    ref = o.infer(ids[pick], lens[pick], sc, None, ndp[pick], nz[pick])
+    assert np.array_equal(ref["y_lengths"], ylen[pick])                     # frame counts: exact
+    assert np.array_equal(ref["w_ceil"], got["w_ceil"][pick])               # every token's duration: exact
+    rf = 64                                                                 # >= the generator's one-sided receptive field in frames
+    worst = 0.0
+    for j, b in enumerate(pick):
+        n = (int(ylen[b]) - rf) * hop
+        assert n > 100 * hop
+        worst = max(worst, float(np.abs(got["output"][b, 0, 0, :n] - ref["output"][j, 0, 0, :n]).max()))
+    print(f"config 3 ({preset}, B=32 x 256, {int(ylen.sum()) * hop} samples): max-abs vs oracle on {len(pick)} utterances {worst:.3g}")
+    assert 0.02 < np.abs(ref["output"]).max() < 0.999
+    assert worst < 1e-3, worst
     s.close()
 
 
@@ -369,11 +453,12 @@ def test_config2_vocoder_only_fullsize_matches_oracle(preset, B, F):
     s.close()
 
 
-def test_config4_batch64_properties_bf16_vocoder(monkeypatch):
-    """BASELINE config 4 at its stated size: 4-speaker voice, B=64 mixed lengths with padding mask, bf16 vocoder.
-    The oracle cannot render 64 utterances inside a test; properties: durations independent of the batch composition
-    and of the vocoder arithmetic, shape law, finiteness, and each utterance's interior equal to its own B=1 rendering
-    within the mode's declared tolerance, with its SNR reported against the f16x3 rendering."""
+def test_config4_batch64_properties_f16_vocoder():
+    """BASELINE config 4 at its stated size: 4-speaker voice, B=64 mixed lengths with padding mask, reduced-precision
+    ("f16") vocoder.  The oracle cannot render 64 utterances inside a test; properties: durations independent of the batch
+    composition and of the vocoder arithmetic, shape law, finiteness, every utterance within the mode's declared bar
+    (1e-2 max-abs, 35 dB SNR) of the default fp32-grade (f16x3) rendering, and an utterance's interior equal to its own B=1
+    rendering."""
     from phoonnx_amd import MiSession
     path = _voice("medium", n_speakers=4)
     rng = np.random.default_rng(64)
@@ -387,7 +472,7 @@ def test_config4_batch64_properties_bf16_vocoder(monkeypatch):
     full = MiSession(path)
     ref = full.synthesize_batch(ids, lens, sc, sid)
     full.close()
-    s = MiSession(path, gen_precision="bf16")
+    s = MiSession(path, gen_precision="f16")
     assert s.hparam("gen_nprod") == 1
     r = s.synthesize_batch(ids, lens, sc, sid, taps=("w_ceil",))
     hop = s.hparam("hop")
@@ -397,14 +482,10 @@ def test_config4_batch64_properties_bf16_vocoder(monkeypatch):
     worst, snr_min = 0.0, 1e9
     for b in range(B):
         n = int(r["y_lengths"][b]) * hop
-        a, f = r["output"][b, 0, 0, :n].astype(np.float64), ref["output"][b, 0, 0, :n].astype(np.float64)
-        worst = max(worst, float(np.abs(a - f).max()))
-        snr_min = min(snr_min, 10 * np.log10((f ** 2).sum() / max(((a - f) ** 2).sum(), 1e-30)))
-    print(f"config 4, B=64: bf16 vocoder vs f16x3: max-abs {worst:.3g}, worst per-utterance SNR {snr_min:.1f} dB")
-    # SURVEY §7 suggests 1e-2 max-abs + 35 dB for a bf16 vocoder; a single bf16 product per fp32 product (8-bit
-    # mantissas on BOTH operands through ~40 conv layers) measures ~1e-2..6e-2 on these unit-scale synthetic voices:
-    # declared tolerance 8e-2 and 20 dB, bf16x3 (the mode that meets 1e-3) is the recommended reduced mode.
-    assert worst < 8e-2 and snr_min > 20.0
+        worst = max(worst, float(np.abs(r["output"][b, 0, 0, :n] - ref["output"][b, 0, 0, :n]).max()))
+        snr_min = min(snr_min, _snr_db(ref["output"][b, 0, 0, :n], r["output"][b, 0, 0, :n]))
+    print(f"config 4, B=64: f16 vocoder vs f16x3: max-abs {worst:.3g}, worst per-utterance SNR {snr_min:.1f} dB")
+    assert worst < 1e-2 and snr_min > 35.0
     for b in (0, 17):
         one = s.synthesize_batch(ids[b:b + 1, :lens[b]].copy(), lens[b:b + 1], sc, sid[b:b + 1])
         assert one["y_lengths"][0] == r["y_lengths"][b]
