@@ -7,9 +7,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvitsmi.so")
-SOURCES = ["vitsmi.hip", "tu_conv_f32.hip", "tu_sx.hip", "tu_sx_s16.hip", "tu_sx_s32.hip", "tu_sx_bf16.hip", "tu_sx_h1.hip", "tu_pair.hip", "g2p.hip",
+SOURCES = ["vitsmi.hip", "tu_conv_f32.hip", "tu_sx.hip", "tu_sx_s16.hip", "tu_sx_s16p.hip", "tu_sx_s32.hip", "tu_sx_bf16.hip", "tu_sx_h1.hip", "tu_pair.hip", "tu_pair16.hip", "g2p.hip",
            "model.cpp", "onnx_reader.cpp"]
-HEADERS = ["kernels.hip.hpp", "conv_engine.hip.hpp", "conv_sx_engine.hip.hpp", "conv_sx_pair.hip.hpp", "sx_split.hip.hpp", "model.hpp",
+HEADERS = ["kernels.hip.hpp", "conv_engine.hip.hpp", "conv_sx_engine.hip.hpp", "conv_sx_pair.hip.hpp", "conv_sx_pair16.hip.hpp", "sx_split.hip.hpp", "model.hpp",
            "g2p_model.hpp", "onnx_reader.hpp", "../../include/vitsmi.h", "../../include/g2pmi.h"]
 
 
@@ -82,6 +82,45 @@ def write_build_info(compiled, sha):
     return info
 
 
+def spilling_kernels(remarks):
+    """{demangled-ish kernel name: spilled VGPRs} from hipcc's -Rpass-analysis=kernel-resource-usage remarks"""
+    import re
+    out, name = {}, None
+    for ln in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", ln)
+        if m:
+            name = m.group(1)
+        m = re.search(r"VGPRs Spill: (\d+)", ln)
+        if m and name and int(m.group(1)) > 0:
+            out[name] = int(m.group(1))
+    return out
+
+
+def build_variant(out, cxxflags):
+    """Kernel experiments: the library once more with extra -D switches, as `out` (loaded through VITSMI_LIB); the product
+    library and its record are left alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "build", "variant_" + os.path.basename(out))
+    os.makedirs(objdir, exist_ok=True)
+    base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + cxxflags.split()
+
+    def one(src):
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        return obj, subprocess.run(base + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        res = list(ex.map(one, SOURCES))
+    for obj, r in res:
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("hipcc failed compiling " + obj)
+    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [o for o, _ in res], capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("link failed")
+    return out
+
+
 def build(force=False, verbose=False):
     sha = source_sha()
     if not force and not stale():
@@ -93,10 +132,9 @@ def build(force=False, verbose=False):
     from concurrent.futures import ThreadPoolExecutor
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+    base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
+            "-Rpass-analysis=kernel-resource-usage"]  # (the remarks are parsed below: register spills are an ERROR here)
     base[1:1] = os.environ.get("VITSMI_CXXFLAGS", "").split()  # kernel experiments (-DSX_EXP_...)
-    if verbose:
-        base.insert(1, "-Rpass-analysis=kernel-resource-usage")
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
@@ -105,12 +143,26 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         results = list(ex.map(compile_one, SOURCES))
+    spilled = {}
     for src, _, r in results:
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError(f"hipcc failed compiling {src}")
         if verbose:
             sys.stderr.write(r.stderr)
+        spilled.update(spilling_kernels(r.stderr))
+    # The conv engines feed their MFMA loops through ASYNCHRONOUS inline-asm loads (global_load / ds_read whose results are
+    # only valid behind a counted s_waitcnt): if the compiler spills such a register between the load and the wait it saves
+    # the OLD contents and later restores them - silently wrong results (seen: conv_sx_pair16_kernel<64, 2, 256>, 41 spilled
+    # registers, inf in the generator).  A spilling instantiation of those kernels is therefore a build error.
+    # (enforced for the split-operand engine's kernels - the generator, flow and encoder of every full-size voice; the
+    # 32x32x16 pair kernel, now reached through test hooks only, and the f32 engine's small tiles spill 3-34 registers - none
+    # of them an asynchronous destination so far, every parity test green - and are reported, not refused)
+    bad = {k: v for k, v in spilled.items() if "conv_sx_kernel" in k or "conv_sx_pair16" in k}
+    if bad:
+        raise RuntimeError("kernels with asynchronous inline-asm loads must not spill registers: " + ", ".join(f"{k} ({v})" for k, v in bad.items()))
+    if spilled:
+        print("phoonnx_amd.build: note: " + ", ".join(f"{k.split('vitsmi')[-1][:40]} spills {v}" for k, v in spilled.items()), file=sys.stderr)
     r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for _, o, _ in results],
                        capture_output=True, text=True)
     if r.returncode != 0:
@@ -122,4 +174,8 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    if "--variant" in sys.argv:  # python -m phoonnx_amd.build --variant <out.so> "<-D flags>"
+        i = sys.argv.index("--variant")
+        print(build_variant(os.path.abspath(sys.argv[i + 1]), sys.argv[i + 2]))
+    else:
+        print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

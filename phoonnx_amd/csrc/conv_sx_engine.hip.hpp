@@ -231,10 +231,15 @@ enum : int {
     // neighbours (attention, LayerNorm) work on planar tensors.
     SX_WN_RMW = 1 << 19,  // (bits 16-18: DBG_NO_DMA, DBG_NO_EPI, EPI_NO_PADFILL of conv_engine.hip.hpp)
     SX_PLANAR_STORE2 = 1 << 20,  // planar epilogue with EPI_ACC: rows of out_raw2 are stored, not accumulated
-    SX_PLANAR_COUPLING = 1 << 21  // planar epilogue with EPI_ACC: o = (old - value * mask) * mask (modules.py:464, mean_only)
+    SX_PLANAR_COUPLING = 1 << 21,  // planar epilogue with EPI_ACC: o = (old - value * mask) * mask (modules.py:464, mean_only)
+    // The residual (EPI_RES) is read from the PLANE tensor res_pl, which holds leaky_relu(residual, 1 / res_unslope) - one
+    // fp16 plane (NP = 1: always) or the two planes h0, h1' of the f16x3 arithmetic (NP = 2: 22 bits, |x' - x| <= 2^-22 |x|) -
+    // with the leaky-ReLU undone on the way in: a tensor that is both a conv input and a residual is then stored ONCE, as
+    // operand planes, and no fp32 copy of the residual stream exists.
+    SX_RES_PL = 1 << 22
 };
 constexpr int kSxEpiMask = EPI_RES | EPI_ACC | EPI_DIV | SX_HAS_RAW | SX_HAS_PL | SX_RAW_ACT | SX_PL_ACT | SX_HAS_BIASB | SX_RES_EARLY |
-                           SX_GATE;
+                           SX_GATE | SX_RES_PL;
 
 // One 256-thread workgroup = 4 waves arranged WM x WN, each owning MW x NW 32x32 accumulator blocks.
 // RAWIN: the input is the fp32 raw tensor itself; each x tile is loaded into registers, leaky-ReLU'd (islope) and
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
     // scalar.  So the per-lane byte offsets and the validity masks are computed once per tile (the general path spends
     // ~25 VALU operations, eight of them quarter-rate multiplies, in front of every DMA, next to a saturated matrix
     // pipe); lanes whose cell is padding are masked off and their LDS cells are zeroed once, below.
-    constexpr int MAXIT = S16 ? 10 : 6;
+    constexpr int MAXIT = S16 ? 12 : 6;
     // (16x16x32: launch_conv_sx admits only what the fast path covers)
     const bool fastx = S16 || (F16 && !RAWIN && nit <= MAXIT && !(a.flags & DBG_NO_DMA) &&
                                (2 * pstride + 2 * (int64_t)T) * 16 < (1ll << 32));  // 32-bit byte offsets inside an utterance
@@ -558,7 +563,9 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
             case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
             case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
             case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;  // (nx_issued <= MAXIT = 10)
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;  // (nx_issued <= MAXIT = 12)
         }
     };
     const std::integral_constant<int, 0> I0{};
@@ -1069,8 +1076,10 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
     float *rawb = a.out_raw + (int64_t)b * a.raw_bstride;     // (only dereferenced when the flags say so)
     uint16_t *plb = a.out_pl + (int64_t)b * a.pl_bstride;
     const float *resb = a.res + (int64_t)b * a.raw_bstride;
-    const uint16_t *resplb = a.res_pl + (int64_t)b * a.pl_bstride;  // (H1: the residual lives in a plane tensor)
+    const uint16_t *resplb = a.res_pl + (int64_t)b * a.pl_bstride;  // (SX_RES_PL: the residual lives in a plane tensor)
     const float unsl = a.res_unslope;
+    // (compile-time in the specialised instantiations, a uniform run-time test in the generic one)
+    const bool respl = H1 || (EPI >= 0 ? (EPI & SX_RES_PL) != 0 : a.res_pl != nullptr);
     // operands still to be loaded here: the residual (unless it was requested in the prologue) and / or the accumulate
     const bool res_epi = (flags & EPI_RES) && !PRE;
     const float *addp = res_epi ? resb : rawb;
@@ -1112,11 +1121,23 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int64_t c = cell_at(co0, r, tl, q);
-                if constexpr (H1) {
-                    // the residual from its fp16 plane (8 bytes per lane, leaky-ReLU undone); the running sum stays fp32 raw
+                if (respl) {
+                    // the residual from its operand plane(s) (8 bytes per lane and plane, leaky-ReLU undone); the running sum
+                    // stays fp32 raw
                     if (res_epi) {
                         float o4[4];
-                        unact4h(*reinterpret_cast<const u32x2 *>(resplb + c), unsl, o4);
+                        if constexpr (H1) {
+                            unact4h(*reinterpret_cast<const u32x2 *>(resplb + c), unsl, o4);
+                        } else {
+                            float h0[4], h1[4];
+                            unact4h(*reinterpret_cast<const u32x2 *>(resplb + c), 1.f, h0);
+                            unact4h(*reinterpret_cast<const u32x2 *>(resplb + plane_elems + c), 1.f, h1);
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float v = __builtin_fmaf(h1[e], 1.f / 2048.f, h0[e]);
+                                o4[e] = v < 0.f ? v * unsl : v;
+                            }
+                        }
                         adb[pp][j][q] = f32x4{o4[0], o4[1], o4[2], o4[3]};
                     } else if (has_add)
                         adb[pp][j][q] = *reinterpret_cast<const f32x4 *>(rawb + c);
@@ -1297,6 +1318,7 @@ hipError_t launch_conv_sx_f16_s16(const SxArgs &a, int cfg, int epi, dim3 grid, 
 hipError_t launch_conv_sx_f16_s32(const SxArgs &a, int cfg, int epi, bool rawin, dim3 grid, size_t lds, hipStream_t stream);
 hipError_t launch_conv_sx_bf16(const SxArgs &a, int cfg, int epi, int nprod, bool rawin, dim3 grid, size_t lds, hipStream_t stream);
 hipError_t launch_conv_sx_h1_s16(const SxArgs &a, int cfg, int epi, dim3 grid, size_t lds, hipStream_t stream);
+hipError_t launch_conv_sx_f16_s16p(const SxArgs &a, int cfg, int epi, dim3 grid, size_t lds, hipStream_t stream);
 #ifdef VITSMI_IMPL_SX
 hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool rawin, int nprod, int pack_cfg) {
     const int BM = sx_tile_m(cfg), BN = sx_tile_n(cfg);
@@ -1326,7 +1348,7 @@ hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool raw
         return hipErrorInvalidValue;  // (the single-plane mode exists on the 16x16x32 loop only)
     a.magic = (unsigned)((0x100000000ull + a.RS - 1) / a.RS);
     a.x_bytes = (unsigned)(((size_t)xrows * a.RS * 16 + 4095) / 4096 * 4096);
-    if (s16 && (a.x_bytes > 10 * 4096 || ((long long)(2 * (a.Cin / 8) + 2) * a.T) * 16 >= (1ll << 32))) return hipErrorInvalidValue;
+    if (s16 && (a.x_bytes > 12 * 4096 || ((long long)(2 * (a.Cin / 8) + 2) * a.T) * 16 >= (1ll << 32))) return hipErrorInvalidValue;
     // two x stages; the weights never touch LDS.  (16x16x32: the second stage ends with its last row - the DMA rounds are
     // whole 4 KiB but lanes past the last row are masked off - which keeps the 50-cell halo of a k = 11, dilation 5 conv
     // inside 80 KiB)
@@ -1352,6 +1374,11 @@ hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool raw
     if (a.out_raw && !(a.flags & SX_NO_RAW_STORE)) epi |= SX_HAS_RAW | (a.oslope != 1.f ? SX_RAW_ACT : 0);
     if (a.out_pl && !(a.flags & SX_GATE)) epi |= SX_HAS_PL | (a.oslope2 != 1.f ? SX_PL_ACT : 0);
     if (a.bias_b) epi |= SX_HAS_BIASB;
+    if (a.res_pl && nprod == 2 && (a.flags & EPI_RES)) {
+        if (a.res || rawin || (a.flags & (SX_WN_RMW | SX_GATE))) return hipErrorInvalidValue;
+        epi |= SX_RES_PL;
+        if (a.res_unslope == 0.f) a.res_unslope = 1.f;
+    }
     if (a.flags & SX_WN_RMW) {
         // (its own epilogue block in the generic instantiation: force that one)
         const bool p_acc = (a.flags & EPI_ACC) != 0;
@@ -1376,7 +1403,7 @@ hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool raw
                           a.oslope == 1.f && (!(a.flags & EPI_DIV) || (a.flags & EPI_ACC));
     if (early_ok && epi != -2) epi |= SX_RES_EARLY;
     if (epi != -2) {
-        if ((epi & EPI_RES) && !(nprod == 1 ? (const void *)a.res_pl : (const void *)a.res)) return hipErrorInvalidValue;
+        if ((epi & EPI_RES) && !((nprod == 1 || (epi & SX_RES_PL)) ? (const void *)a.res_pl : (const void *)a.res)) return hipErrorInvalidValue;
         if ((epi & EPI_ACC) && !a.out_raw) return hipErrorInvalidValue;
         a.flags = (a.flags & ~kSxEpiMask) | epi;
     } else
@@ -1389,6 +1416,7 @@ hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool raw
     }
     if (nprod == 2) {  // two fp16 planes, three products (fp32-grade): the same specialised epilogues
         if (a.wscale == 0.f) a.wscale = 1.f;
+        if (s16 && (epi & SX_RES_PL)) return launch_conv_sx_f16_s16p(a, cfg, epi, grid, lds, stream);
         if (s16) return launch_conv_sx_f16_s16(a, cfg, epi, grid, lds, stream);
         return launch_conv_sx_f16_s32(a, cfg, epi, rawin, grid, lds, stream);
     }
@@ -1425,6 +1453,27 @@ hipError_t launch_conv_sx_f16_s32(const SxArgs &a, int cfg, int epi, bool rawin,
 #endif
         case 1: return launch_conv_sx_epi<1, 4, 2, 2, 2>(a, epi, grid, lds, stream);
         default: return launch_conv_sx_epi<1, 2, 1, 4, 2>(a, epi, grid, lds, stream);
+    }
+}
+#endif
+#ifdef VITSMI_IMPL_SX_S16P
+// f16x3 with the residual stream kept as operand planes (SX_RES_PL): the epilogues of the plane-stream generator
+template <int MW, int NW, int WM, int WN>
+inline hipError_t launch_conv_sx_s16p_epi(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+    switch (epi) {
+        case kSxEpiInnerPl | SX_RES_PL: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiInnerPl | SX_RES_PL, false, false, 2, 16>(a, grid, lds, stream);
+        case kSxEpiFirst | SX_RES_PL: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiFirst | SX_RES_PL, false, false, 2, 16>(a, grid, lds, stream);
+        case kSxEpiAccum | SX_RES_PL: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiAccum | SX_RES_PL, false, false, 2, 16>(a, grid, lds, stream);
+        case kSxEpiStageOut | SX_RES_PL: return launch_conv_sx_k<MW, NW, WM, WN, kSxEpiStageOut | SX_RES_PL, false, false, 2, 16>(a, grid, lds, stream);
+        default: return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, 2, 16>(a, grid, lds, stream);
+    }
+}
+hipError_t launch_conv_sx_f16_s16p(const SxArgs &a, int cfg, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+    switch (cfg) {
+        case 0: return launch_conv_sx_s16p_epi<1, 8, 4, 1>(a, epi, grid, lds, stream);
+        case 1: return launch_conv_sx_s16p_epi<1, 4, 2, 2>(a, epi, grid, lds, stream);
+        case 3: return launch_conv_sx_s16p_epi<1, 2, 2, 2>(a, epi, grid, lds, stream);
+        default: return launch_conv_sx_s16p_epi<1, 2, 1, 4>(a, epi, grid, lds, stream);
     }
 }
 #endif

@@ -572,6 +572,7 @@ void pick_tiling(int Cin, int Cout, int K, int dil, int padL, int hint, int &cfg
 
 thread_local int t_hint = 0;  // size class of the layers being packed (set by Model::build)
 thread_local bool t_sx_f16 = false;  // pack_conv_sx: two scaled fp16 planes instead of three bf16 planes
+thread_local bool t_sx_force16 = false;  // pack_conv_sx: the 16x16x32 layout whatever the channel count (conv_sx_pair16's weights)
 thread_local bool t_sx_h1 = false;   // pack_conv_sx: ONE scaled fp16 plane in the 16x16x32 layout (VITSMI_GEN_PRECISION=f16)
 // the encoder / flow run f16x3 under the default arithmetic AND under the reduced-precision vocoder ("f16": everything in
 // front of z is unchanged); bf16x6 keeps them on their exact engines
@@ -716,8 +717,12 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     const bool h1 = t_sx_h1;
     if (h1 && (Cin % 32 || (size_t)4 * (256 + (Kreal - 1) * dil) * 16 > (size_t)10 * 4096))
         throw std::runtime_error("the f16 single-plane arithmetic needs Cin % 32 == 0 and a halo of at most 384 columns");
-    const bool want16 = h1 || (t_sx_f16 && !sx_raw_format(Cin) && !shape32_only && !t_sx_shape32 && Cin % 32 == 0 &&
-                               (size_t)8 * (256 + (Kreal - 1) * dil) * 16 <= (size_t)10 * 4096);
+    // (force16: the 32- / 64-channel convs of a plane-stream generator - the fused pair kernel's weights; their own x stage
+    // of up to twelve DMA rounds serves the unfused fallback)
+    const bool want16 = h1 || (t_sx_f16 && t_sx_force16 && sx_raw_format(Cin) && Cin % 32 == 0 &&
+                               (size_t)8 * (256 + (Kreal - 1) * dil) * 16 <= (size_t)12 * 4096) ||
+                        (t_sx_f16 && !sx_raw_format(Cin) && !shape32_only && !t_sx_shape32 && Cin % 32 == 0 &&
+                         (size_t)8 * (256 + (Kreal - 1) * dil) * 16 <= (size_t)10 * 4096);
     if (K < 3 && !want16) K = 3;
     auto wz = [&](int co, int ci, int tap) { return tap < Kreal ? w(co, ci, tap) : 0.f; };
     ConvDesc d;
@@ -729,7 +734,7 @@ ConvDesc pack_conv_sx(Packer &P, int Cin, int Cout, int K, int dil, int padL, WF
     d.padL = padL;
     d.CK = 16;
     d.nchunks = Cin / 16;
-    d.rawin = sx_raw_format(Cin) && !h1;  // (single-plane mode: every tensor is a plane tensor)
+    d.rawin = sx_raw_format(Cin) && !h1 && !(t_sx_f16 && t_sx_force16);  // (plane-stream generators: every tensor is a plane tensor)
     d.h1 = h1;
     d.cfg = sx_pick_cfg(Cout);
     if (d.rawin && d.cfg == 0) d.cfg = 1;  // the raw-input path exists for the 64- and 32-row tiles only
@@ -991,6 +996,7 @@ void split2h_host(float v, uint16_t p[3]) {
 
 void set_sx_f16(bool on) { t_sx_f16 = on; }
 void set_sx_h1(bool on) { t_sx_h1 = on; }
+void set_sx_force16(bool on) { t_sx_force16 = on; }
 void set_sx_shape32(bool on) { t_sx_shape32 = on; }
 
 // Arithmetic of the split-operand convs for the opens that follow on this thread: an explicit choice
@@ -1065,6 +1071,7 @@ std::string pack_test_convT(const float *w, const float *bias, int Cin, int Cout
 std::string Model::build(const OnnxModel &om, bool layout_only) {
     t_sx_f16 = false;
     t_sx_h1 = false;
+    t_sx_force16 = false;
     try {
         Resolver R;
         resolve(om, R);
@@ -1400,6 +1407,11 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
         }
         t_sx_f16 = gen_f16;
         t_sx_h1 = gen_h1;
+        // Both fp16 arithmetics run the PLANE-STREAM generator (vitsmi.hip run_generator_planes): every tensor between two
+        // convs is stored once, as the operand planes of its consumer - also on the 32- / 64-channel stages, whose convs are
+        // therefore packed for plane input on the 16x16x32 loop like everyone else (no raw-input kernels)
+        gen_planes = gen_f16 || gen_h1;
+        t_sx_force16 = gen_f16;
         auto gconv = [&](const std::string &name, int dil, int padL) {
             return gen_sx ? pack_named_sx(P, R, name, dil, padL) : pack_named(P, R, name, dil, padL);
         };
@@ -1449,6 +1461,7 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
         }
         t_sx_f16 = false;
         t_sx_h1 = false;
+        t_sx_force16 = false;
         const TRef &pw = R.need("dec.conv_post.weight", 3);
         if (pw.dims[0] != 1) throw std::runtime_error("conv_post must have one output channel");
         if (ups.empty() || pw.dims[1] != ups.back().C) throw std::runtime_error("conv_post: input width differs from the last stage");

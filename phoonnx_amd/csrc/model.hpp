@@ -144,6 +144,7 @@ struct Model {
     ConvDesc conv_pre;
     int C0 = 0;
     bool gen_f16 = false; // ... in its fp16 two-plane mode (VITSMI_GEN_PRECISION=f16x3)
+    bool gen_planes = false;  // gen_f16 || gen_h1: the plane-stream generator (every inter-conv tensor stored once, as operand planes)
     bool gen_h1 = false;  // ... in its fp16 single-plane, single-product mode (VITSMI_GEN_PRECISION=f16; 16-bit activations)
     bool gen_sx = false;  // generator packed for the split-operand engine (all channel counts % 32 == 0)
     std::vector<UpStageDesc> ups;
@@ -180,6 +181,7 @@ void split3_host(float v, uint16_t p[3]);
 uint16_t f16_rne(float f);
 float f16_to_f32(uint16_t h);
 void split2h_host(float v, uint16_t p[3]);
+void set_sx_force16(bool on);  // ... the 16x16x32 layout also for <= 64 input channels (the fused pair kernel's operand)
 void set_sx_h1(bool on);   // ... one fp16 plane in the 16x16x32 layout (the NP = 1 mode)
 void set_sx_f16(bool on);  // pack_conv_sx format for the calls that follow on this thread (test hooks)
 void set_sx_shape32(bool on);  // ... never the 16x16x32 (s16) packing (bench hooks: ablation flags, A/B of the MFMA shapes)

@@ -18,6 +18,7 @@
 #include "../../include/vitsmi.h"
 #include "conv_sx_engine.hip.hpp"
 #include "conv_sx_pair.hip.hpp"
+#include "conv_sx_pair16.hip.hpp"
 #include "kernels.hip.hpp"
 #include "model.hpp"
 
@@ -558,6 +559,66 @@ void conv_sx_pair(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const float *x
     h->stats.sx_launches++;
 }
 
+// Two dependent convs of a ResBlock on the 16x16x32 loop (conv_sx_pair16.hip.hpp): f16x3 (fp32 raw tensors; the convs'
+// second weight copy, ConvDesc::w16_off) or the single-plane arithmetic (fp16 plane tensors).  VITSMI_PAIR16=0: off (A/B).
+bool sx_pair16_ok(const vits_handle *h, const ConvDesc &c1, const ConvDesc &c2) {
+    static const bool off = [] {
+        const char *e = std::getenv("VITSMI_PAIR16");
+        return (e && e[0] == '0') || std::getenv("VITSMI_SX_NO_PAIR") != nullptr;
+    }();
+    if (off || c1.Cin != c1.Cout || c2.Cin != c2.Cout || c1.Cin != c2.Cin || c1.ups != 1 || c2.ups != 1) return false;
+    if (c1.padL * 2 != (c1.K - 1) * c1.dil || c2.padL * 2 != (c2.K - 1) * c2.dil) return false;
+    const bool h1 = c1.h1 && c2.h1, f3 = c1.f16 && c2.f16 && c1.s16 && c2.s16 && !c1.rawin && !c2.rawin;
+    if (!h1 && !f3) return false;
+    if (c1.cfg != c2.cfg || c1.cfg != (c1.Cin == 64 ? 1 : 2)) return false;  // (weights packed for a tile of all C rows)
+    (void)h;
+    return sx_pair16_plan(c1.Cin, h1 ? 1 : 2, c1.K, c1.dil, c2.K, c2.dil, nullptr) != 0;
+}
+
+// x: the operand-plane tensor holding leaky_relu(x, slope) (two fp16 planes: f16x3; one: the single-plane arithmetic).
+// out_raw: fp32 raw destination (flags & P16_HAS_RAW) and / or EPI_ACC operand; out_pl (flags & P16_HAS_PL): operand planes of
+// leaky_relu(result, slope).
+void conv_sx_pair16(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const uint16_t *x, int T, float *out_raw, uint16_t *out_pl, int flags,
+                    float div, float slope, bool chain) {
+    SxPair16Args a{};
+    const bool h1 = c1.h1;
+    const int C = c1.Cin;
+    a.xpl = x;
+    a.x_bstride = (int64_t)3 * C * T;
+    a.islope = a.mslope = a.oslope = slope;
+    a.T = T;
+    a.wp1 = reinterpret_cast<const u32x4 *>(c.P(c1.w_off));
+    a.wp2 = reinterpret_cast<const u32x4 *>(c.P(c2.w_off));
+    a.bias1 = c.P(c1.b_off);
+    a.bias2 = c.P(c2.b_off);
+    a.wscale1 = c1.wscale;
+    a.wscale2 = c2.wscale;
+    a.out_raw = out_raw;
+    a.raw_bstride = (int64_t)C * T;
+    a.out_pl = out_pl;
+    a.pl_bstride = (int64_t)3 * C * T;
+    a.zeros = c.P(c.m.zeros_off);
+    a.K1 = c1.K; a.dil1 = c1.dil; a.pad1 = c1.padL;
+    a.K2 = c2.K; a.dil2 = c2.dil; a.pad2 = c2.padL;
+    a.flags = flags;
+    a.div = div;
+    vits_handle *h = c.h;
+    a.peak = range_slots(h, true);
+    const double ebytes = h1 ? 2.0 : 4.0;
+    const bool ev = conv_event_begin(c);
+    c.note(launch_conv_sx_pair16(a, C, h1 ? 1 : 2, c.B, c.st, chain));
+    const double fl = 2.0 * (c1.macs_per_t + c2.macs_per_t) * (double)T * c.B;
+    const double by = ebytes * c.B * ((double)(c1.Cin + c1.Cout) * T + (double)(c2.Cin + c2.Cout) * T);
+    if (ev) conv_event_end(c, true, fl, by, c1, T);
+    conv_account(c, c1, T);
+    conv_account(c, c2, T);
+    h->stats.conv_launches--;  // (two convs, one launch)
+    h->stats.total_launches--;
+    h->stats.sx_flops += fl;
+    h->stats.sx_bytes += by;
+    h->stats.sx_launches++;
+}
+
 // The multi-receptive-field sum of a 32-channel ResBlock2 stage, xs = (rb_0(x) + .. + rb_{n-1}(x)) / n with every rb a
 // two-step chain (models.py:356-363, modules.py:355-364), as ONE launch (conv_sx_pair_kernel<.., NCH = n>): can it?
 bool sx_mrf_ok(const vits_handle *h, const UpStageDesc &stg) {
@@ -966,13 +1027,15 @@ size_t gen_ws_bytes(const Model &m, int B, int F) {
     return (size_t)(m.gen_sx ? kGenRegionsSx : kGenRegions) * al(gen_region_floats(m, B, F));
 }
 
-// The generator in the single-plane arithmetic (VITSMI_GEN_PRECISION=f16, BASELINE config 4's reduced-precision vocoder):
-// ONE fp16 plane per operand, one MFMA product per fp32 product, fp32 accumulation.  Every tensor between two convs
-// exists once, as the fp16 of the consumer's leaky_relu ([C/8][T][8], 2 bytes per element): a conv reads it as its B
-// operand straight from LDS, and a residual add recovers x from it by undoing the leaky_relu (x = p >= 0 ? p : p / 0.1,
-// exact).  Only the multi-receptive-field sum xs (models.py:356-363; three read-modify-writes per stage) stays fp32.
-// Everything in front of z is the default arithmetic.  Same dataflow as run_generator_sx.
-int run_generator_h1(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B,
+// The PLANE-STREAM generator of the two fp16 arithmetics: f16x3 (the default: two fp16 planes per operand, three MFMA
+// products per fp32 product) and f16 (VITSMI_GEN_PRECISION=f16, BASELINE config 4's reduced-precision vocoder: one plane, one
+// product).  Every tensor between two convs exists ONCE, as the operand planes of the consumer's leaky_relu
+// ([planes][C/8][T][8]: 4 / 2 bytes per element): a conv reads them as its B operand straight from LDS (by LDS-DMA), and
+// a residual add recovers x from them by undoing the leaky_relu (x = p >= 0 ? p : p / 0.1; exact up to the planes' own
+// resolution - 22 bits in f16x3).  No fp32 copy of the residual stream is written or read; only the multi-receptive-field
+// sum xs (models.py:356-363; three read-modify-writes per stage) is fp32.  Everything in front of z is unchanged.  Same
+// dataflow as run_generator_sx (which now serves the exact bf16x6 arithmetic only).
+int run_generator_planes(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B,
                      int F, const float *dec_cond, Slab &s) {
     const Model &m = h->model;
     hipStream_t st = h->stream;
@@ -986,8 +1049,8 @@ int run_generator_h1(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
     const float S = 0.1f;  // Generator.LRELU_SLOPE / ResBlock LRELU_SLOPE
     const int nst = (int)m.ups.size();
     // z * y_mask (models.py:349) as conv_pre's operand plane (no activation in front of conv_pre)
-    sx_split_planes_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_pl, m.C, F, 2,
-                                                                              range_slots(h, true));
+    sx_split_planes_kernel<<<dim3((F + 255) / 256, m.C / 8, B), 256, 0, st>>>(z, z_bstride, z_cstride, ylen, tmp_pl, m.C, F,
+                                                                              m.gen_h1 ? 2 : 1, range_slots(h, true));
     c.note(hipGetLastError());
     h->stats.total_launches++;
     // xa = leaky_relu(conv_pre(z) [+ cond(g)], 0.1) (models.py:349-354)
@@ -1023,9 +1086,36 @@ int run_generator_h1(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
                         else dst = nullptr;
                     }
                 }
+                // flags of a fused launch: the multi-receptive-field arithmetic + which of the two destinations it writes
+                auto p16_flags = [&](int f, float *d_raw, uint16_t *d_pl) {
+                    return (f & (EPI_ACC | EPI_DIV)) | (d_raw && !(f & SX_NO_RAW_STORE) ? P16_HAS_RAW : 0) | (d_pl ? P16_HAS_PL : 0);
+                };
                 if (rbk.type1) {  // modules.py:301-314: x = c2(lrelu(c1(lrelu(x)))) + x
-                    conv_sx(c, rbk.c1[q], cur, T, nullptr, tmp_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
-                    conv_sx(c, rbk.c2[q], tmp_pl, T, dst, dsta, fl, nullptr, nullptr, 0, (float)nk, 1.f, S, 1.f, nullptr, cur, S);
+                    if (sx_pair16_ok(h, rbk.c1[q], rbk.c2[q]))
+                        conv_sx_pair16(c, rbk.c1[q], rbk.c2[q], cur, T, dst, dsta, p16_flags(fl, dst, dsta), (float)nk, S, false);
+                    else {
+                        conv_sx(c, rbk.c1[q], cur, T, nullptr, tmp_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
+                        conv_sx(c, rbk.c2[q], tmp_pl, T, dst, dsta, fl, nullptr, nullptr, 0, (float)nk, 1.f, S, 1.f, nullptr, cur, S);
+                    }
+                } else if (q + 1 < rbk.n && sx_pair16_ok(h, rbk.c1[q], rbk.c1[q + 1])) {
+                    // modules.py:355-364, two steps in one launch: x1 = c(lrelu(x)) + x ; x = c'(lrelu(x1)) + x1
+                    q++;
+                    const bool last2 = q == rbk.n - 1;
+                    int fl2 = EPI_RES;
+                    float *dst2 = nullptr;
+                    uint16_t *dsta2 = raa[q & 1];
+                    if (last2) {
+                        fl2 |= (j == 0 ? 0 : EPI_ACC) | (final_rb && nk > 1 ? EPI_DIV : 0);
+                        dst2 = xs_raw;
+                        dsta2 = nullptr;
+                        if (final_rb && !last_stage) {
+                            dsta2 = xs_pl;
+                            if (nk > 1) fl2 |= SX_NO_RAW_STORE;
+                            else dst2 = nullptr;
+                        }
+                    }
+                    conv_sx_pair16(c, rbk.c1[q - 1], rbk.c1[q], cur, T, dst2, dsta2, p16_flags(fl2, dst2, dsta2), (float)nk, S, true);
+                    dsta = dsta2;
                 } else  // modules.py:355-364: x = c(lrelu(x)) + x
                     conv_sx(c, rbk.c1[q], cur, T, dst, dsta, fl, nullptr, nullptr, 0, (float)nk, 1.f, S, 1.f, nullptr, cur, S);
                 cur = dsta;
@@ -1061,7 +1151,7 @@ int run_generator_h1(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
 int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B,
                      int F, const float *dec_cond, Slab &s) {
     const Model &m = h->model;
-    if (m.gen_h1) return run_generator_h1(h, c, z, z_bstride, z_cstride, ylen, B, F, dec_cond, s);
+    if (m.gen_planes) return run_generator_planes(h, c, z, z_bstride, z_cstride, ylen, B, F, dec_cond, s);
     hipStream_t st = h->stream;
     const size_t R = gen_region_floats(m, B, F);
     const size_t RP = R + R / 2 + 64;  // floats holding R elements as three 16-bit plane slots (the fp16 mode uses two)
@@ -2492,6 +2582,118 @@ int vits_test_conv_pair_sx(int device_id, const float *x, int B, int C, int T, c
                            const float *w2, const float *b2, int K, int dil1, int dil2, int chain, float slope, float *out,
                            float *ms_out) {
     if (int rc = test_dev(device_id)) return rc;
+    // chain: bit 0 = CHAIN (two ResBlock2 steps), bits 1-2 = kernel: 0 conv_sx_pair_kernel (32x32x16 form, f16x3, fp32 raw
+    // tensors), 1 conv_sx_pair16_kernel in f16x3, 2 the same in the single-plane arithmetic (both: operand planes of
+    // leaky_relu(x) in); bit 3 (pair16 only): the result is read back from the output PLANES (leaky_relu(out, slope)) instead
+    // of the fp32 output
+    const int kern = (chain >> 1) & 3;
+    const bool from_plane = (chain & 8) != 0;
+    chain &= 1;
+    if (kern) {
+        const bool h1 = kern == 2;
+        ConvDesc d1, d2;
+        std::vector<float> arena;
+        set_sx_f16(!h1);
+        set_sx_force16(!h1);
+        set_sx_h1(h1);
+        std::string e = pack_test_conv(w1, b1, C, C, K, dil1, dil1 * (K - 1) / 2, 3, &d1, &arena);
+        if (e.empty()) e = pack_test_conv(w2, b2, C, C, K, dil2, dil2 * (K - 1) / 2, 3, &d2, &arena);
+        set_sx_f16(false);
+        set_sx_force16(false);
+        set_sx_h1(false);
+        if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
+        if (!d1.s16 || !d2.s16 || d1.rawin || !sx_pair16_plan(C, h1 ? 1 : 2, d1.K, d1.dil, d2.K, d2.dil, nullptr))
+            return fail(nullptr, VITS_E_ARG, "this conv pair cannot run fused on the 16x16x32 loop (C %d, kernel %d, dilation %d)", C, K, dil1);
+        const size_t n = (size_t)B * C * T;
+        float *dA = nullptr, *dx = nullptr, *dxr = nullptr, *draw = nullptr, *dout = nullptr;
+        uint16_t *dxp = nullptr, *dop = nullptr;
+        TCHECK(hipMalloc((void **)&dA, arena.size() * 4));
+        TCHECK(hipMalloc((void **)&dx, n * 4 + 16));
+        TCHECK(hipMalloc((void **)&dxr, n * 4 + 16));
+        TCHECK(hipMalloc((void **)&dxp, n * 6 + 16));
+        TCHECK(hipMalloc((void **)&dop, n * 6 + 16));
+        TCHECK(hipMalloc((void **)&draw, n * 4 + 16));
+        TCHECK(hipMalloc((void **)&dout, n * 4 + 16));
+        TCHECK(hipMemcpy(dA, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+        TCHECK(hipMemset(draw, 0, n * 4));
+        TCHECK(hipMemset(dop, 0, n * 6));
+        {  // the input planes hold leaky_relu(x, slope)
+            std::vector<float> xa(n);
+            for (size_t i = 0; i < n; i++) xa[i] = x[i] >= 0.f ? x[i] : x[i] * slope;
+            TCHECK(hipMemcpy(dx, xa.data(), n * 4, hipMemcpyHostToDevice));
+            sx_split_planes_kernel<<<dim3((T + 255) / 256, C / 8, B), 256>>>(dx, (int64_t)C * T, T, nullptr, dxp, C, T, h1 ? 2 : 1);
+        }
+        SxPair16Args a{};
+        a.xpl = dxp;
+        a.x_bstride = (int64_t)3 * C * T;
+        a.islope = a.mslope = a.oslope = slope;
+        a.T = T;
+        a.wp1 = reinterpret_cast<const u32x4 *>(dA + d1.w_off);
+        a.wp2 = reinterpret_cast<const u32x4 *>(dA + d2.w_off);
+        a.bias1 = d1.b_off >= 0 ? dA + d1.b_off : nullptr;
+        a.bias2 = d2.b_off >= 0 ? dA + d2.b_off : nullptr;
+        a.wscale1 = d1.wscale;
+        a.wscale2 = d2.wscale;
+        a.out_raw = draw;
+        a.raw_bstride = (int64_t)C * T;
+        a.out_pl = dop;
+        a.pl_bstride = (int64_t)3 * C * T;
+        a.zeros = dA;
+        a.K1 = d1.K; a.dil1 = d1.dil; a.pad1 = d1.padL;
+        a.K2 = d2.K; a.dil2 = d2.dil; a.pad2 = d2.padL;
+        a.flags = from_plane ? P16_HAS_PL : P16_HAS_RAW;
+        a.div = 1.f;
+        TCHECK(launch_conv_sx_pair16(a, C, h1 ? 1 : 2, B, nullptr, chain != 0));
+        TCHECK(hipDeviceSynchronize());
+#if P16_PROF
+        {
+            unsigned long long *dprof = nullptr;
+            const size_t nwg = 1 << 17;  // (>= the launch's workgroups)
+            TCHECK(hipMalloc((void **)&dprof, nwg * 64));
+            TCHECK(hipMemset(dprof, 0, nwg * 64));
+            a.prof = dprof;
+            TCHECK(launch_conv_sx_pair16(a, C, h1 ? 1 : 2, B, nullptr, chain != 0));
+            TCHECK(hipDeviceSynchronize());
+            std::vector<unsigned long long> hp(nwg * 8);
+            TCHECK(hipMemcpy(hp.data(), dprof, nwg * 64, hipMemcpyDeviceToHost));
+            double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+            unsigned long long n = 0, tmin = ~0ull, tmax = 0;
+            for (size_t w = 0; w < nwg; w++)
+                if (hp[w * 8 + 7]) {
+                    n++;
+                    double life = 0;
+                    for (int i = 0; i < 7; i++) { sum[i] += (double)hp[w * 8 + i]; life += (double)hp[w * 8 + i]; }
+                    tmin = hp[w * 8 + 7] < tmin ? hp[w * 8 + 7] : tmin;
+                    const unsigned long long te = hp[w * 8 + 7] + (unsigned long long)life;
+                    tmax = te > tmax ? te : tmax;
+                }
+            fprintf(stderr, "p16prof C %d npl %d K %d wgs %llu span %.0f kcyc | x landed %.0f  convert+barrier %.0f  phase1 %.0f  hand-over %.0f  phase2 %.0f  epilogue %.0f  drain %.0f (cycles per workgroup)\n",
+                    C, h1 ? 1 : 2, K, n, (double)(tmax - tmin) / 1e3, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n);
+            a.prof = nullptr;
+            hipFree(dprof);
+        }
+#endif
+        if (ms_out) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0);
+            hipEventCreate(&e1);
+            hipEventRecord(e0, nullptr);
+            for (int i = 0; i < 10; i++) TCHECK(launch_conv_sx_pair16(a, C, h1 ? 1 : 2, B, nullptr, chain != 0));
+            hipEventRecord(e1, nullptr);
+            TCHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            *ms_out = ms / 10;
+            hipEventDestroy(e0);
+            hipEventDestroy(e1);
+        }
+        sx_unblock_kernel<<<dim3((T + 255) / 256, C / 8, B), 256>>>(draw, from_plane ? dop : nullptr, dout, C, T, h1 ? 2 : 1);
+        TCHECK(hipGetLastError());
+        TCHECK(hipDeviceSynchronize());
+        TCHECK(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+        hipFree(dA); hipFree(dx); hipFree(dxr); hipFree(dxp); hipFree(dop); hipFree(draw); hipFree(dout);
+        return VITS_OK;
+    }
     ConvDesc d1, d2;
     std::vector<float> arena;
     set_sx_f16(true);

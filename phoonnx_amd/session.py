@@ -842,10 +842,14 @@ def test_conv1d_sx_planar(x, w, bias=None, dil=1, lens=None, old=None, row_split
     return out, pl
 
 
-def test_conv_pair_sx(x, w1, b1, w2, b2, dil1=1, dil2=1, chain=False, slope=0.1, device_id=0, timed=False):
-    """Two dependent convs in ONE fused launch (raw-format stage of the generator; f16x3):
+def test_conv_pair_sx(x, w1, b1, w2, b2, dil1=1, dil2=1, chain=False, slope=0.1, device_id=0, timed=False, kernel="pair",
+                      from_plane=False):
+    """Two dependent convs in ONE fused launch (32- / 64-channel stage of the generator):
     chain=False (ResBlock1 step): out = c2(lrelu(c1(lrelu(x)))) + x
-    chain=True (two ResBlock2 steps): x1 = c1(lrelu(x)) + x; out = c2(lrelu(x1)) + x1.    timed=True -> (out, ms)."""
+    chain=True (two ResBlock2 steps): x1 = c1(lrelu(x)) + x; out = c2(lrelu(x1)) + x1.    timed=True -> (out, ms).
+    kernel: "pair" = conv_sx_pair_kernel (32x32x16 loop, f16x3), "pair16" = conv_sx_pair16_kernel (16x16x32 loop) in f16x3,
+    "pair16_f16" = the same in the single-plane arithmetic (fp16 plane in; from_plane: the result read back from the output
+    plane, leaky_relu(out, slope) as fp16)."""
     lib = _ffi.load()
     x = np.ascontiguousarray(x, np.float32)
     w1 = np.ascontiguousarray(w1, np.float32)
@@ -859,7 +863,9 @@ def test_conv_pair_sx(x, w1, b1, w2, b2, dil1=1, dil2=1, chain=False, slope=0.1,
     out = np.empty_like(x)
     ms = C.c_float(0.0)
     rc = lib.vits_test_conv_pair_sx(device_id, _ffi.ptr(x), B, Cc, T, _ffi.ptr(w1), _ffi.ptr(b1), _ffi.ptr(w2),
-                                    _ffi.ptr(b2), K, dil1, dil2, 1 if chain else 0, float(slope), _ffi.ptr(out),
+                                    _ffi.ptr(b2), K, dil1, dil2,
+                                    (1 if chain else 0) | ({"pair": 0, "pair16": 1, "pair16_f16": 2}[kernel] << 1) | (8 if from_plane else 0),
+                                    float(slope), _ffi.ptr(out),
                                     C.byref(ms) if timed else None)
     if rc != 0:
         raise SessionError(_ffi.last_error(None))

@@ -371,6 +371,95 @@ def test_conv_chain_sx_equals_two_launches_and_oracle(B, C, T, K, d1, d2):
     np.testing.assert_allclose(got, ref, atol=5e-5, rtol=1e-5)
 
 
+def _pair_ref(x, w1, b1, w2, b2, K, d1, d2, chain):
+    from vits_oracle import conv1d
+    lr = lambda v: np.where(v > 0, v, v * np.float32(0.1)).astype(np.float32)
+    p1, p2 = d1 * (K - 1) // 2, d2 * (K - 1) // 2
+    if chain:
+        r1 = conv1d(lr(x), w1, b1, dil=d1, pad_l=p1, pad_r=p1) + x
+        return conv1d(lr(r1), w2, b2, dil=d2, pad_l=p2, pad_r=p2) + r1
+    return conv1d(lr(conv1d(lr(x), w1, b1, dil=d1, pad_l=p1, pad_r=p1)), w2, b2, dil=d2, pad_l=p2, pad_r=p2) + x
+
+
+PAIR16_CASES = [(B, C, T, K, d, 1, False) for (B, C, T, K, d) in PAIR_CASES] + [c + (True,) for c in CHAIN_CASES] + [
+    (1, 32, 390, 3, 1, 1, False),     # three tiles of 126 kept columns, the last one ragged
+    (2, 64, 129, 5, 1, 1, True),
+]
+
+
+@pytest.mark.parametrize("B,C,T,K,d1,d2,chain", PAIR16_CASES)
+def test_conv_pair16_f16x3_matches_two_launches_and_oracle(B, C, T, K, d1, d2, chain):
+    """conv_sx_pair16_kernel (the fused ResBlock step on the 16x16x32 loop) in the default arithmetic: same products in the
+    same order as two conv_sx_kernel launches; the input arrives as the two operand planes of leaky_relu(x) (by LDS-DMA), the
+    residual is x reconstructed from them in LDS (22 bits),
+    so the result is within ~2^-22 |x| of the two-launch form (no longer bit-identical) - and within the engine's tolerance
+    of the oracle's fp32 convolutions."""
+    from phoonnx_amd.session import test_conv1d_sx, test_conv_pair_sx
+    rng = np.random.default_rng(C * 1000 + T + K + d1 + 7)
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    w1 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    w2 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K) * 2).astype(np.float32)
+    b1 = rng.standard_normal(C).astype(np.float32)
+    b2 = rng.standard_normal(C).astype(np.float32)
+    got = test_conv_pair_sx(x, w1, b1, w2, b2, dil1=d1, dil2=d2, chain=chain, slope=0.1, kernel="pair16")
+    p1, p2 = d1 * (K - 1) // 2, d2 * (K - 1) // 2
+    if chain:
+        x1 = test_conv1d_sx(x, w1, b1, dil=d1, pad_l=p1, in_slope=0.1, residual=True, precision="f16x3")
+        two = test_conv1d_sx(x1, w2, b2, dil=d2, pad_l=p2, in_slope=0.1, residual=True, precision="f16x3")
+    else:
+        mid = test_conv1d_sx(x, w1, b1, dil=d1, pad_l=p1, in_slope=0.1, precision="f16x3")
+        two = test_conv1d_sx(mid, w2, b2, dil=d2, pad_l=p2, in_slope=0.1, precision="f16x3") + x
+    assert float(np.abs(got - two).max()) < 6e-6, float(np.abs(got - two).max())
+    ref = _pair_ref(x, w1, b1, w2, b2, K, d1, d2, chain)
+    np.testing.assert_allclose(got, ref, atol=5e-5, rtol=1e-5)
+    # ... and written as the operand planes of leaky_relu(out): 22 bits
+    pl = test_conv_pair_sx(x, w1, b1, w2, b2, dil1=d1, dil2=d2, chain=chain, slope=0.1, kernel="pair16", from_plane=True)
+    np.testing.assert_allclose(pl, np.where(ref > 0, ref, ref * np.float32(0.1)), atol=5e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,T,K,d1,d2,chain", PAIR16_CASES)
+def test_conv_pair16_single_plane_mode(B, C, T, K, d1, d2, chain):
+    """The same kernel in the reduced-precision arithmetic (gen_precision "f16"): fp16 plane in (the consumer's leaky_relu
+    already applied), one product, the intermediate as one fp16 plane in LDS, residual = the stored plane with the leaky_relu
+    undone, fp32 or fp16-plane out.  Against the float64 evaluation of exactly those roundings (differences: fp32
+    accumulation, and the rare intermediate that rounds the other way), and against the unrounded fp32 reference at the
+    mode's own resolution."""
+    from phoonnx_amd.session import test_conv_pair_sx
+    rng = np.random.default_rng(C * 1000 + T + K + d1 + 9)
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    w1 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    w2 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K) * 2).astype(np.float32)
+    b1 = rng.standard_normal(C).astype(np.float32)
+    b2 = rng.standard_normal(C).astype(np.float32)
+    sl = np.float32(0.1)
+    lr = lambda v: np.where(v > 0, v, v * float(sl))
+    h = lambda v: np.asarray(v, np.float32).astype(np.float16).astype(np.float64)
+
+    def conv64(xq, wq, bb, d):
+        p = d * (K - 1) // 2
+        xp = np.pad(xq, ((0, 0), (0, 0), (p, p)))
+        return sum(np.einsum("oc,bct->bot", wq[:, :, k], xp[:, :, k * d:k * d + T]) for k in range(K)) + bb[None, :, None].astype(np.float64)
+
+    xa = h(lr(x).astype(np.float32))                                  # the stored input plane
+    _, w1q = _f16_operands(x, w1)
+    _, w2q = _f16_operands(x, w2)
+    xres = np.where(xa >= 0, xa, xa * float(np.float32(1.0) / sl))      # the residual the kernel recovers
+    c1 = conv64(xa, w1q, b1, d1)
+    if chain:
+        x1 = c1 + xres
+        want = conv64(h(lr(x1)), w2q, b2, d2) + x1
+    else:
+        want = conv64(h(lr(c1)), w2q, b2, d2) + xres
+    got = test_conv_pair_sx(x, w1, b1, w2, b2, dil1=d1, dil2=d2, chain=chain, slope=0.1, kernel="pair16_f16")
+    np.testing.assert_allclose(got, want, atol=3e-3, rtol=0)
+    assert float(np.sqrt(((got - want) ** 2).mean())) < 1e-4             # ... and nearly everywhere to fp32-accumulation error
+    ref = _pair_ref(x, w1, b1, w2, b2, K, d1, d2, chain)
+    rms = float(np.sqrt((ref.astype(np.float64) ** 2).mean()))
+    assert float(np.sqrt(((got - ref) ** 2).mean())) < 2e-3 * rms        # fp16 operands: ~2^-11 per rounding
+    pl = test_conv_pair_sx(x, w1, b1, w2, b2, dil1=d1, dil2=d2, chain=chain, slope=0.1, kernel="pair16_f16", from_plane=True)
+    np.testing.assert_allclose(pl, lr(want), atol=3e-3, rtol=2.0 ** -10)
+
+
 def test_conv_pair_sx_refuses_what_it_cannot_fuse():
     """The fused launch is refused - never silently computed some other way - where the second conv's reach leaves too
     little of a 256-column tile (64 channels keep >= 200 columns: a k = 7, dilation 12 second conv keeps 184), and for
@@ -386,7 +475,8 @@ def test_conv_pair_sx_refuses_what_it_cannot_fuse():
 
 def test_conv_pair_sx_is_used_by_the_generator_and_can_be_switched_off(monkeypatch):
     """A ResBlock1 voice with 64- and 32-channel raw-format stages: fused and unfused generators give the same
-    waveform bit for bit, and the fused one issues fewer launches."""
+    waveform (to ~2^-22 of the residual stream: the fused kernel on the 16x16x32 loop reconstructs the residual from its
+    operand planes), and the fused one issues fewer launches."""
     from phoonnx_amd import MiSession
     path = os.path.join(GOLDEN, "sx_rb1.onnx")
     g = np.load(os.path.join(GOLDEN, "sx_rb1.npz"))
@@ -409,7 +499,7 @@ def test_conv_pair_sx_is_used_by_the_generator_and_can_be_switched_off(monkeypat
     assert r.returncode == 0, r.stderr[-800:]
     nb = int(r.stdout.split("LAUNCHES")[1].split()[0])
     assert na < nb, (na, nb)                     # 64- and 32-channel ResBlock1 steps: one launch instead of two
-    assert np.array_equal(np.load(out), a["output"])
+    np.testing.assert_allclose(np.load(out), a["output"], atol=5e-6, rtol=0)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,T,K,u", [(2, 32, 32, 50, 16, 8), (2, 128, 64, 129, 4, 2)])
