@@ -685,6 +685,12 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
             constexpr int i = decltype(I)::value;
             half_step(ab[i % NA], ab[(i + NA - 1) % NA], std::integral_constant<int, i % HPS>{}, hs + i);
         });
+    // hipcc sinks kernel-argument loads (s_load) that only the epilogue uses to THIS point, the block between the unrolled
+    // loop and its tail.  A scalar load in flight counts in lgkmcnt and returns out of order, so the tail steps' counted
+    // `s_waitcnt lgkmcnt(n)` could pass with a ds_read still outstanding: drain the counter once here (per tile, not per step).
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     // (no exit from the middle of the unrolled body: see the 32x32x16 loop)
     static_for<U - 1>([&](auto I) {
         constexpr int i = decltype(I)::value;
@@ -894,6 +900,12 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
         step(f0, f1, s);
         step(f1, f0, s + 1);
     }
+    // hipcc sinks kernel-argument loads (s_load) that only the epilogue uses to THIS point, the block between the unrolled
+    // loop and its tail.  A scalar load in flight counts in lgkmcnt and returns out of order, so the tail steps' counted
+    // `s_waitcnt lgkmcnt(n)` could pass with a ds_read still outstanding: drain the counter once here (per tile, not per step).
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     if (S & 1) step(f0, f1, S - 1);
     if constexpr (PROF) {
         stamp(4);

@@ -357,6 +357,12 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
                 constexpr int i = decltype(I)::value;
                 step(fs[i], fs[(i + DEPTH) % NS], s + i);
             });
+        // hipcc sinks kernel-argument loads (s_load) that only the epilogue uses to THIS point, the block between the unrolled
+        // loop and its tail.  A scalar load in flight counts in lgkmcnt and returns out of order, so the tail steps' counted
+        // `s_waitcnt lgkmcnt(n)` could pass with a ds_read still outstanding: drain the counter once here (per tile, not per step).
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         static_for<NS - 1>([&](auto I) {
             constexpr int i = decltype(I)::value;
             if (s + i < S) step(fs[i], fs[(i + DEPTH) % NS], s + i);

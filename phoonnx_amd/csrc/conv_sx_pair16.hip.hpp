@@ -53,6 +53,7 @@ struct SxPair16Args {
     int LW1, RS1, RS2;        // x tile width (cells), row strides of the x tile / of Y (cells, multiples of 16)
     unsigned magic1;          // ceil(2^32 / RS1)
     unsigned y_off;           // byte offset of Y in LDS (0: Y overlays the x tile)
+    unsigned b_off;           // byte offset of the two bias vectors in LDS (2 x C floats)
     int BNo, NT, B;
     int flags;                // EPI_ACC | EPI_DIV | P16_HAS_RAW | P16_HAS_PL
     float div;
@@ -92,6 +93,21 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
     const char *wbase1 = reinterpret_cast<const char *>(a.wp1) + wm * BLKBYTES;
     const char *wbase2 = reinterpret_cast<const char *>(a.wp2) + wm * BLKBYTES;
     float pk = 0.f;
+    // Every kernel argument the later phases use is read NOW and pinned in scalar registers: hipcc sinks a kernarg load
+    // (s_load) to the block of its first use - e.g. in front of the tail steps of a phase - and a scalar load in flight counts in
+    // lgkmcnt and returns out of order: the counted `s_waitcnt lgkmcnt(n)` of the operand pipeline would then let an MFMA
+    // read a register its ds_read has not written yet (seen: every parity case failing after one more late-read argument).
+    const int k_flags = a.flags, k_pad2 = a.pad2, k_BNo = a.BNo, k_K2 = a.K2, k_dil2 = a.dil2;
+    const unsigned k_b_off = a.b_off;
+    float *const k_out_raw = a.out_raw;
+    uint16_t *const k_out_pl = a.out_pl;
+    const int64_t k_raw_bs = a.raw_bstride, k_pl_bs = a.pl_bstride;
+    const float k_ws1 = a.wscale1, k_ws2 = a.wscale2, k_msl = a.mslope, k_osl = a.oslope, k_div = a.div, k_unisl = a.un_islope;
+    unsigned *const k_peak = a.peak;
+    asm volatile("" ::"s"(k_flags), "s"(k_pad2), "s"(k_BNo), "s"(k_K2), "s"(k_dil2), "s"(k_b_off), "s"(k_out_raw), "s"(k_out_pl));
+    asm volatile("" ::"s"(k_raw_bs), "s"(k_pl_bs), "s"(__float_as_uint(k_ws1)), "s"(__float_as_uint(k_ws2)), "s"(__float_as_uint(k_msl)),
+                 "s"(__float_as_uint(k_osl)), "s"(__float_as_uint(k_div)), "s"(__float_as_uint(k_unisl)), "s"(k_peak), "s"(wbase2));
+    asm volatile("" ::"s"(a.y_off), "s"(a.pad1), "s"(a.K1), "s"(a.dil1), "s"(a.bias1), "s"(a.bias2), "s"(a.zeros));
 
     struct ASet {
         u32x4 f[2][NPL];
@@ -135,7 +151,7 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
 #endif
     // =================================================================== prologue: the whole x tile -> LDS
     // x tile column 0 = time t1 - pad1; cells outside the tensor are zero (the convs' zero padding)
-    const int S1 = NCH * a.K1, S2 = NCH * a.K2;
+    const int S1 = NCH * a.K1, S2 = NCH * k_K2;
     {
         // LDS-DMA, 16 bytes per lane: the flattened [plane][row][RS1] cell space in rounds of 256 cells; a lane whose cell is
         // padding (column past LW1, row past the tile, time outside the tensor) reads the zero page.  (Plane p, group g of
@@ -153,6 +169,14 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
                                  : static_cast<const void *>(reinterpret_cast<const char *>(a.zeros) + lane * 16);
             // (lanes past the tile's last cell are masked off: nothing is written behind the allocation)
             if (i < ncell) lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + (size_t)base * 16));
+        }
+        // both bias vectors ride along (one DMA of wave 0): read from LDS in the hand-over / the epilogue - as dependent global
+        // loads at those points each cost an exposed L2 round trip per tile (r04f stamps: ~1.5 k cycles, twice)
+        if (wave == 0) {
+            const int k = lane - (lane >= C / 4 ? C / 4 : 0);
+            const float *bp = lane < C / 4 ? a.bias1 : a.bias2;
+            const void *src = (bp && lane < C / 2) ? static_cast<const void *>(bp + 4 * k) : static_cast<const void *>(a.zeros + 4 * (lane & 31));
+            lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + a.b_off));  // (all 64 lanes: the slot is 1 KiB)
         }
         prefetch_a(wbase1, S1);
         // (vector-memory operations retire in order: when only the weight requests are in flight the tile has landed)
@@ -273,6 +297,12 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
                 constexpr int i = decltype(I)::value;
                 step(fs[i], fs[(i + D) % NS], s + i);
             });
+        // hipcc sinks kernel-argument loads (s_load) that only the epilogue uses to THIS point, the block between the unrolled
+        // loop and its tail.  A scalar load in flight counts in lgkmcnt and returns out of order, so the tail steps' counted
+        // `s_waitcnt lgkmcnt(n)` could pass with a ds_read still outstanding: drain the counter once here (per tile, not per step).
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         static_for<NS - 1>([&](auto I) {
             constexpr int i = decltype(I)::value;
             if (s + i < S) step(fs[i], fs[(i + D) % NS], s + i);
@@ -298,7 +328,7 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
 #define ACC(n, r) c16[(r) >> 3][2 * (n) + (((r) >> 2) & 1)][(r) & 3]
     // x at tile column j, channels 32 wm + 8 q + 4 hi .. + 3 (q = 0..3: the lane's rows of a 32 x 32 block), from the resident
     // operand planes with the leaky-ReLU undone; the 4 (8) reads travel together
-    const float un_isl = a.un_islope;
+    const float un_isl = k_unisl;
     auto read_x16 = [&](int j, f32x4 (&o)[4]) __attribute__((always_inline)) {
         const uint32_t ad = lds0 + (uint32_t)((4 * wm) * RS1 + j + a.pad1) * 16u + 8u * hi;
         const uint32_t rb = (uint32_t)RS1 * 16u;
@@ -309,6 +339,7 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
             if constexpr (!H1) asm volatile("ds_read_b64 %0, %1" : "=v"(w1[q]) : "v"(ad + (uint32_t)q * rb + XPB) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);  // (see the bias reads: nothing else ties the conversions below to the wait)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             float v[4];
@@ -349,12 +380,20 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
         __builtin_amdgcn_sched_barrier(0);
     }
     {
-        const float wsc = a.wscale1, msl = a.mslope;
-        const float *biasp = a.bias1 ? a.bias1 : a.zeros;
-        const int b_on = a.bias1 ? 1 : 0;
+        const float wsc = k_ws1, msl = k_msl;
         f32x4 bq4[4];
+        {
+            u32x4 t4[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) bq4[q] = *reinterpret_cast<const f32x4 *>(biasp + (wm * 32 + 8 * q + 4 * hi) * b_on);
+            for (int q = 0; q < 4; q++)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(t4[q]) : "v"(lds0 + k_b_off + (uint32_t)(wm * 32 + 8 * q + 4 * hi) * 4u) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (the consumers of t4 have no data dependence on the wait statement: without this fence the scheduler may hoist
+            // them above it and read registers the ds_reads have not written yet)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq4[q] = __builtin_bit_cast(f32x4, t4[q]);
+        }
 #pragma unroll
         for (int n = 0; n < NQ; n++) {
             const int j = wn * BNW + n * 32 + l31;
@@ -372,7 +411,7 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
                     }
                     o[e] = live ? fmaxf(v, v * msl) : 0.f;
                 }
-                const uint32_t cell = ylds + (uint32_t)((4 * wm + q) * RS2 + j + a.pad2) * 16u + 8u * hi;
+                const uint32_t cell = ylds + (uint32_t)((4 * wm + q) * RS2 + j + k_pad2) * 16u + 8u * hi;
                 if constexpr (H1) {
                     const unsigned wa = cvt1h_pair_pk(o[0], o[1], pk), wb = cvt1h_pair_pk(o[2], o[3], pk);
                     asm volatile("ds_write_b64 %0, %1" ::"v"(cell), "v"(u32x2{wa, wb}) : "memory");
@@ -393,26 +432,34 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
     P16_STAMP(4);
 
     // =================================================================== phase 2: c2 over Y (stored pad2 columns to the right)
-    run_conv(wbase2, a.K2, a.dil2, ylds + (uint32_t)((lane >> 4) * RS2 + wn * BNW + (lane & 15)) * 16u, (uint32_t)RS2 * 16u, YPB);
+    run_conv(wbase2, k_K2, k_dil2, ylds + (uint32_t)((lane >> 4) * RS2 + wn * BNW + (lane & 15)) * 16u, (uint32_t)RS2 * 16u, YPB);
     P16_STAMP(5);
     gather_acc();
 
     // =================================================================== epilogue: bias2 + residual [+ xs] [/ n] -> raw / plane
     {
-        const int flags = a.flags;
-        float *rawb = a.out_raw + (int64_t)b * a.raw_bstride;
-        uint16_t *plb = a.out_pl + (int64_t)b * a.pl_bstride;
-        const float wsc = a.wscale2, rdiv = a.div, osl = a.oslope;
-        const float *biasp = a.bias2 ? a.bias2 : a.zeros;
-        const int b_on = a.bias2 ? 1 : 0;
+        const int flags = k_flags;
+        float *rawb = k_out_raw + (int64_t)b * k_raw_bs;
+        uint16_t *plb = k_out_pl + (int64_t)b * k_pl_bs;
+        const float wsc = k_ws2, rdiv = k_div, osl = k_osl;
         f32x4 bq4[4];
+        {
+            u32x4 t4[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) bq4[q] = *reinterpret_cast<const f32x4 *>(biasp + (wm * 32 + 8 * q + 4 * hi) * b_on);
+            for (int q = 0; q < 4; q++)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(t4[q]) : "v"(lds0 + k_b_off + (uint32_t)(C + wm * 32 + 8 * q + 4 * hi) * 4u) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (the consumers of t4 have no data dependence on the wait statement: without this fence the scheduler may hoist
+            // them above it and read registers the ds_reads have not written yet)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq4[q] = __builtin_bit_cast(f32x4, t4[q]);
+        }
 #pragma unroll
         for (int n = 0; n < NQ; n++) {
             const int j = wn * BNW + n * 32 + l31;
             const int t = t1 + j;
-            const bool kept = j >= a.pad2 && j < a.pad2 + a.BNo && t < T;  // overlap columns belong to the neighbours
+            const bool kept = j >= k_pad2 && j < k_pad2 + k_BNo && t < T;  // overlap columns belong to the neighbours
             const int tl = t < 0 ? 0 : (t < T ? t : T - 1);
             f32x4 adl[4], xres[4];
             if constexpr (!KEEP) read_x16(j, xres);
@@ -462,13 +509,13 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
         a.prof[(size_t)blockIdx.x * 8 + 7] = tp[0];
     }
 #endif
-    if (a.peak) sx_publish_peak(a.peak, (int)blockIdx.x, pk);  // (uniform branch; every thread arrives)
+    if (k_peak) sx_publish_peak(k_peak, (int)blockIdx.x, pk);  // (uniform branch; every thread arrives)
 }
 
 // Geometry of a fused pair at tile width BN; false when it does not fit
 struct SxPair16Geom {
     int LW1, RS1, RS2, BNo;
-    unsigned y_off;
+    unsigned y_off, b_off;
     size_t lds;
 };
 inline bool sx_pair16_geom(int C, int npl, int BN, bool ovl, int K1, int dil1, int K2, int dil2, SxPair16Geom *g) {
@@ -487,7 +534,8 @@ inline bool sx_pair16_geom(int C, int npl, int BN, bool ovl, int K1, int dil1, i
         g->RS2 = RS2;
         g->BNo = BN - halo2;
         g->y_off = ovl ? 0u : (unsigned)xb;
-        g->lds = ovl ? (xb > yb ? xb : yb) : xb + yb;
+        g->b_off = (unsigned)(ovl ? (xb > yb ? xb : yb) : xb + yb);
+        g->lds = (size_t)g->b_off + 1024;  // (the two bias vectors: one 1 KiB DMA slot)
     }
     return BN - halo2 >= BN / 2 + BN / 8;  // (more than 37 % of a tile recomputed: not worth it)
 }
@@ -517,7 +565,10 @@ int sx_pair16_plan(int C, int npl, int K1, int dil1, int K2, int dil2, bool *ovl
         return e ? std::atoi(e) : 0;
     }();
     if (!((C == 32 || C == 64) && (npl == 1 || npl == 2))) return 0;
-    const bool o = npl == 2 && C == 64;  // f16x3 at 64 channels: x + Y side by side would leave two workgroups per CU
+    // f16x3 at 64 channels: x + Y side by side would leave one workgroup per CU; Y overlays the x tile and the residual waits
+    // in registers.  (At 32 channels the overlay would pay only with a third workgroup per CU, i.e. <= 168 registers: the
+    // 256-column variant then spills 34 - refused, see the build's spill rule.)
+    const bool o = npl == 2 && C == 64;
     if (ovl) *ovl = o;
     // (measured r04e: the wider tile wins in every shape: less halo, fewer fixed costs per column.  At 64 channels only the
     // 128-column tile exists: the 256-column one needs more than 256 registers, and a kernel whose operands arrive through
@@ -546,6 +597,7 @@ hipError_t launch_conv_sx_pair16(SxPair16Args a, int C, int npl, int B, hipStrea
     a.RS2 = g.RS2;
     a.BNo = g.BNo;
     a.y_off = g.y_off;
+    a.b_off = g.b_off;
     a.magic1 = (unsigned)((0x100000000ull + a.RS1 - 1) / a.RS1);
     a.NT = (a.T + a.BNo - 1) / a.BNo;
     a.B = B;

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Static check of the conv engines' ISA for the scalar-load hazard: every kernel of the split-operand
+engine feeds its MFMA loop through inline-asm ds_reads behind COUNTED `s_waitcnt lgkmcnt(n)`.  hipcc sinks kernel-argument
+loads (s_load_dword*) that only the epilogue needs into the block between the unrolled main loop and its tail steps; a
+scalar load in flight counts in lgkmcnt and returns out of order, so a counted wait could pass with a ds_read outstanding.
+The engines drain the counter once at that boundary; this script compiles each instantiation unit to assembly and verifies
+that EVERY s_load between a kernel's first and last MFMA is followed by `s_waitcnt lgkmcnt(0)` before any counted wait.
+
+    python tools/check_isa_hazards.py        (needs hipcc; ~1 min per unit; exit code 1 on a finding)
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "phoonnx_amd", "csrc")
+UNITS = ["tu_sx_h1", "tu_sx_s16p", "tu_sx_s16", "tu_sx_s32", "tu_sx_bf16", "tu_pair16", "tu_pair"]
+
+
+def check(unit):
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, unit + ".s")
+        r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", "-x", "hip",
+                            "--cuda-device-only", "-S", os.path.join(CSRC, unit + ".hip"), "-o", out], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise SystemExit(f"hipcc failed on {unit}")
+        txt = open(out).read()
+    parts = re.split(r"\n(_ZN6vitsmi[0-9]+conv_sx[^:\n]*):", txt)
+    bad, n = [], 0
+    for i in range(1, len(parts), 2):
+        name, lines = parts[i], parts[i + 1].split("s_endpgm")[0].split("\n")
+        n += 1
+        mf = [k for k, l in enumerate(lines) if "v_mfma" in l]
+        if not mf:
+            continue
+        for k, l in enumerate(lines):
+            if "s_load_dword" in l and mf[0] < k < mf[-1]:
+                nxt = next((m for m in lines[k + 1:] if "lgkmcnt" in m), "")
+                if "lgkmcnt(0)" not in nxt:
+                    bad.append((name, k, nxt.strip()))
+                    break
+    return n, bad
+
+
+def main():
+    total = 0
+    for u in UNITS:
+        n, bad = check(u)
+        print(f"{u}: {n} kernels, unsafe: {len(bad)}")
+        for name, k, nxt in bad:
+            print(f"   {name}: s_load at line {k} followed by '{nxt}'")
+        total += len(bad)
+    sys.exit(1 if total else 0)
+
+
+if __name__ == "__main__":
+    main()
