@@ -1410,8 +1410,12 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
         // Both fp16 arithmetics run the PLANE-STREAM generator (vitsmi.hip run_generator_planes): every tensor between two
         // convs is stored once, as the operand planes of its consumer - also on the 32- / 64-channel stages, whose convs are
         // therefore packed for plane input on the 16x16x32 loop like everyone else (no raw-input kernels)
-        gen_planes = gen_f16 || gen_h1;
-        t_sx_force16 = gen_f16;
+        // (measured r04l: in f16x3 the plane-stream form is 3-5 % SLOWER end to end - its fused pair kernel on the 16x16x32 loop
+        // takes 1.35 / 0.85 ms per 64- / 32-channel ResBlock1 step against 1.14 / 0.72 for the 32x32x16 one on fp32 raw
+        // tensors - so f16x3 keeps the raw-stream generator; VITSMI_F16X3_STREAM=planes selects the other for A/B runs)
+        const char *se = std::getenv("VITSMI_F16X3_STREAM");
+        gen_planes = gen_h1 || (gen_f16 && se && std::string(se) == "planes");
+        t_sx_force16 = gen_f16 && gen_planes;
         auto gconv = [&](const std::string &name, int dil, int padL) {
             return gen_sx ? pack_named_sx(P, R, name, dil, padL) : pack_named(P, R, name, dil, padL);
         };

@@ -626,6 +626,36 @@ def test_sx_generator_matches_reference_goldens(monkeypatch, preset, precision, 
     s.close()
 
 
+@pytest.mark.parametrize("precision,tol", [("f16x3", 5e-5), ("f16", 1e-2)])
+@pytest.mark.parametrize("preset", SX_PRESETS)
+def test_plane_stream_generator_matches_reference_goldens(monkeypatch, preset, precision, tol):
+    """The PLANE-STREAM generator (vitsmi.hip run_generator_planes: every inter-conv tensor stored once, as the operand
+    planes of its consumer's leaky_relu; residuals recovered from them; fused ResBlock steps on conv_sx_pair16_kernel)
+    against the reference fixtures - in the single-plane arithmetic, whose only generator it is (declared tolerance 1e-2 /
+    35 dB, measured ~1e-3), and in f16x3, where it is selectable (VITSMI_F16X3_STREAM=planes; the default there is the
+    raw-stream generator, which measures 3-5 % faster) and must be as accurate as the default."""
+    monkeypatch.setenv("VITSMI_GEN_PRECISION", precision)
+    monkeypatch.setenv("VITSMI_F16X3_STREAM", "planes")
+    s = _session(preset)
+    assert s.hparam("gen_sx") == 1 and s.hparam("gen_nprod") == (2 if precision == "f16x3" else 1)
+    g = np.load(os.path.join(GOLDEN, preset + ".npz"))
+    worst, snr = 0.0, 1e9
+    for c in golden_cases(g):
+        r = s.synthesize_batch(case_get(g, c, "ids"), case_get(g, c, "lens"), case_get(g, c, "scales"),
+                               case_get(g, c, "sid"), case_get(g, c, "noise_dp"), case_get(g, c, "noise_z"), taps=("z",))
+        assert np.array_equal(r["y_lengths"], case_get(g, c, "out_y_lengths")), (preset, c)
+        np.testing.assert_allclose(r["z"], case_get(g, c, "out_z"), atol=STAGE_TOL, rtol=0)
+        ref = case_get(g, c, "out_output")
+        worst = max(worst, float(np.abs(r["output"] - ref).max()))
+        d = (r["output"] - ref).astype(np.float64)
+        snr = min(snr, 10 * np.log10((ref.astype(np.float64) ** 2).sum() / max((d ** 2).sum(), 1e-30)))
+    print(f"{preset} {precision} plane stream: worst waveform error vs the reference fixture {worst:.3g}, SNR {snr:.1f} dB")
+    assert worst < tol and snr > 35.0
+    recs = s.stats()
+    assert recs["sx_launches"] > 0
+    s.close()
+
+
 def _conv_same_f64(x, w, bias, dil):
     B, Cin, T = x.shape
     Cout, _, K = w.shape
