@@ -411,13 +411,18 @@ def main():
         g = torch.Generator(device="cpu").manual_seed(77 + seed)
         return torch.randint(0, int(first.hparam("n_speakers")), (Bn,), generator=g, dtype=torch.int64)
 
-    def measure(first, preset, steps, warmup, parts, lockstep, seed):
-        """K timed passes of the whole path on `parts` handles sharing `first`'s arena -> (dt, samples, pipe)."""
+    def measure(first, preset, steps, warmup, parts, lockstep, seed, inputs_h=None):
+        """K timed passes of the whole path on `parts` handles sharing `first`'s arena -> (dt, samples, pipe).
+        inputs_h: (ids, lens, sid) host tensors of another workload than the command line's (the config-4 block)."""
         pipe = PipelinedSession(first, max(1, parts))
         pipe.set_seed(1234 + rank * 16)
         scales = np.array([0.667, LENGTH_SCALE[preset], 0.8], np.float32)
-        ids_h, lens_h = make_inputs(seed)
-        sid_h = make_sid(seed, first)
+        if inputs_h is not None:
+            ids_h, lens_h, sid_h = inputs_h
+        else:
+            ids_h, lens_h = make_inputs(seed)
+            sid_h = make_sid(seed, first)
+        B, T = int(ids_h.shape[0]), int(ids_h.shape[1])
         ids, lens = ids_h.cuda(), lens_h.cuda()
         sid = None if sid_h is None else sid_h.cuda()
         sid_ptr = None if sid is None else sid.data_ptr()
@@ -650,6 +655,44 @@ def main():
         except Exception as e:  # noqa: BLE001
             exact = {"gen_precision": "bf16x6", "value": None, "note": f"failed: {e}"}
 
+
+    # ---------------------------------------------------------------- the reference's own call shape: ONE utterance per call
+    # (voice.py:350-351; sentences one after the other, :265-269) - wall clock per session.run-shaped call (host ids in, host
+    # waveform out), and the time to the first chunk of the streaming form
+    def b1_of(s_one, preset):
+        g = torch.Generator(device="cpu").manual_seed(4321)
+        ids1 = torch.randint(0, 256, (1, a.tokens), generator=g, dtype=torch.int64).numpy()
+        lens1 = np.full((1,), a.tokens, np.int64)
+        sc = np.array([0.667, LENGTH_SCALE[preset], 0.8], np.float32)
+        for _ in range(3):
+            s_one.synthesize_batch(ids1, lens1, sc)
+        per, n_s = [], 0
+        for _ in range(20):
+            t0 = time.perf_counter()
+            r1 = s_one.synthesize_batch(ids1, lens1, sc)
+            per.append((time.perf_counter() - t0) * 1e3)
+            n_s = int(r1["y_lengths"].sum()) * hop_of(s_one)
+        launches = int(s_one.stats()["total_launches"])  # (of the last call: the counters restart with every run)
+        first = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            it = s_one.synthesize_stream(ids1, lens1, sc, chunk_frames=64)
+            next(it)
+            first.append((time.perf_counter() - t0) * 1e3)
+            for _c in it:
+                pass
+        return {"preset": preset, "ms_per_call": pctl(per), "samples": n_s, "rtf": float(np.median(per)) * 1e-3 / (n_s / 22050.0),
+                "first_chunk_ms": pctl(first), "chunk_frames": 64, "launches_per_call": launches,
+                "note": "MiSession.synthesize_batch on one 256-id utterance: wall clock of the whole call, host arrays in and out; "
+                        "first_chunk_ms = synthesize_stream until its first 64-frame chunk is in host memory"}
+
+    b1 = None
+    if extras and a.batch == 32 and not a.total_batch and a.speakers <= 1:
+        try:
+            b1 = {a.preset: b1_of(sess, a.preset)}
+        except Exception as e:  # noqa: BLE001
+            b1 = {"error": f"{type(e).__name__}: {e}"}
+
     # The headline voice's handles are done: free their ~60 GB of workspace before another voice is measured (with them
     # open, the second voice's freshly allocated workspace measured 25-30 % slower on its HBM-bound kernels - 404 vs 523 M
     # samples/s, tools/exp_order.py - and recovered the moment they were closed)
@@ -670,9 +713,54 @@ def main():
                     "frames_per_id": nm / km / hop_of(mfirst) / (B * T), "roofline": mroof, "stages": mstage,
                     "f16_range": mrange,
                     "note": "measured in the same process after the headline voice's handles were closed"}
-            mp_.close()
+            mp_.close(close_first=False)
+            if b1 is not None and "error" not in b1:
+                try:
+                    b1["medium"] = b1_of(mfirst, "medium")
+                except Exception as e:  # noqa: BLE001
+                    b1["medium"] = {"error": f"{type(e).__name__}: {e}"}
+            mfirst.close()
         except Exception as e:  # noqa: BLE001
             also = {"preset": "medium", "value": None, "note": f"failed: {type(e).__name__}: {e}"}
+
+    # ---------------------------------------------------------------- BASELINE config 4: multi-speaker voice (speaker-embedding
+    # path), batch 64 of mixed lengths with the padding mask in play, reduced-precision ("f16") vocoder - next to the same
+    # batch in the default fp32-grade arithmetic
+    config4 = None
+    if extras and a.batch == 32 and not a.total_batch and a.speakers <= 1:
+        try:
+            c4 = {}
+            g4 = torch.Generator(device="cpu").manual_seed(1234)
+            B4 = 64
+            ids4 = torch.randint(0, 256, (B4, a.tokens), generator=g4, dtype=torch.int64)
+            lens4 = torch.randint(max(1, a.tokens // 4), a.tokens + 1, (B4,), generator=torch.Generator(device="cpu").manual_seed(2469),
+                                  dtype=torch.int64)
+            lens4[0] = a.tokens
+            ids4 = ids4 * (torch.arange(a.tokens)[None, :] < lens4[:, None])
+            sid4 = torch.randint(0, 4, (B4,), generator=torch.Generator(device="cpu").manual_seed(77), dtype=torch.int64)
+            for prec in ("f16", "f16x3"):
+                f4 = MiSession(voice_path("medium", 4), device_id=local_rank, gen_precision=prec)
+                k4 = max(5, a.steps)
+                dt4, n4, p4, _ = measure(f4, "medium", k4, max(2, a.warmup), a.also_parts, a.lockstep, 1234, (ids4, lens4, sid4))
+                c4[prec] = {"value": n4 / dt4, "unit": "samples/s", "ms_per_step": dt4 / k4 * 1e3, "steps": k4,
+                            "gen_nprod": int(f4.hparam("gen_nprod")), "pipeline_parts": len(p4.parts)}
+                p4.close()
+            config4 = {"workload": f"VITS full pipeline, preset=medium, 4 speakers (sid per utterance), batch=64 x {a.tokens} phoneme ids "
+                                   f"(lengths uniform in [T/4, T], zero-padded, padding mask), scales=[0.667,{LENGTH_SCALE['medium']:.2f},0.8]",
+                       "dtype": DTYPE[1], "value": c4["f16"]["value"], "unit": "samples/s", "ms_per_step": c4["f16"]["ms_per_step"],
+                       "f16x3_same_batch": c4["f16x3"], "speedup_over_f16x3": c4["f16"]["value"] / c4["f16x3"]["value"],
+                       "accuracy": "waveform within 1e-2 max-abs and >= 35 dB SNR of the fp32 oracle (tests/test_gpu_fullsize.py: "
+                                   "measured 7.8e-4 / 62.6 dB on this voice)",
+                       "high_f16": None}
+            fh = MiSession(voice, device_id=local_rank, gen_precision="f16")
+            kh = max(5, a.steps)
+            dth, nh, ph, _ = measure(fh, a.preset, kh, max(2, a.warmup), a.parts, a.lockstep, 1234 + rank)
+            config4["high_f16"] = {"preset": a.preset, "value": nh / dth, "unit": "samples/s", "ms_per_step": dth / kh * 1e3,
+                                   "speedup_over_headline": (nh / dth) / (samples / dt),
+                                   "note": "the headline batch (single speaker, fixed lengths) with the f16 vocoder"}
+            ph.close()
+        except Exception as e:  # noqa: BLE001
+            config4 = {"error": f"{type(e).__name__}: {e}"}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.speakers <= 1:  # (N = 1 only: the other ranks would sit in the final barrier)
@@ -706,6 +794,10 @@ def main():
                        "weights": weights, "commit": git_head()},
             "roofline": roofline, "cpu_baseline": cpu, "step_ms": step_pct, "host_io": host_io, "one_handle": one_handle,
             "exact_arithmetic": exact, "also": also, "stages": stage, "f16_range": f16_range,
+            "b1": b1, "config4": config4,
+            "value_is": "device-resident ids in, waveform left on the device (the contract's HBM-resident timed region); the "
+                        "figure shaped like the reference's session.run (host ids in, one host fp32 [B,1,1,S] array out) is "
+                        "host_io.value",
         }
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = value / world / cpu["value"]
