@@ -65,6 +65,7 @@ struct SxPairArgs {
     } ch[3];
     int nchain;
     unsigned a_ring;          // (32-channel variant) byte offset of the shared weight ring in LDS: 3 groups x 2 steps x 2 KiB
+    unsigned bias_off;        // (one chain) byte offset of the two bias vectors in LDS (one 1 KiB DMA slot behind the tile)
     unsigned long long *prof;  // (SX_PAIR_PROF builds) 8 counters of this launch: six phase sums in shader cycles, -, workgroups
 };
 
@@ -191,6 +192,28 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
                 lds_dma<16>(wbase1 + (int64_t)(2 * g + sub) * STEPBYTES + pl * 1024 + lane * 16,
                             reinterpret_cast<float *>(lds_sx + a.a_ring + (unsigned)((g * 2 + sub) * 2048 + pl * 1024)));
             }
+    // (round 4) both bias vectors -> LDS by one DMA of wave 0, ahead of the x tile: as dependent global loads at the hand-over
+    // and in the epilogue each exposed an L2 round trip per tile (conv_sx_pair16's stamps: ~1.5 k cycles, twice, of ~29 k)
+    constexpr bool BIAS_LDS = NCH == 1;
+    if constexpr (BIAS_LDS) {
+        if (wave == 0) {
+            constexpr int CC = WM * 32;
+            const int k = lane - (lane >= CC / 4 ? CC / 4 : 0);
+            const float *bp = lane < CC / 4 ? a.bias1 : a.bias2;
+            const void *src = (bp && lane < CC / 2) ? static_cast<const void *>(bp + 4 * k) : static_cast<const void *>(a.zeros + 4 * (lane & 31));
+            lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + a.bias_off));
+        }
+    }
+    auto bias_from_lds = [&](int conv, f32x4 (&bq)[4]) __attribute__((always_inline)) {
+        u32x4 t4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(t4[q]) : "v"(lds0 + a.bias_off + (uint32_t)(conv * (WM * 32) + wm * 32 + 8 * q + 4 * hi) * 4u) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);  // (nothing else ties the consumers to the wait)
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[q] = __builtin_bit_cast(f32x4, t4[q]);
+    };
     constexpr int NXC = 3;
     {
         u32x4 xst[MAXCH][NXC][2];
@@ -547,8 +570,11 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
         const uint32_t YC = a.y_chunk_bytes, LW2 = (uint32_t)a.LW2;
         const int row0 = wm * 32;
         f32x4 bq[4];
+        if constexpr (BIAS_LDS) bias_from_lds(0, bq);
+        else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
+            for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
+        }
 #pragma unroll
         for (int n = 0; n < NW; n++) {
             const int col = (wn * NW + n) * 32 + l31;
@@ -609,8 +635,11 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
         const int b_on = cp.bias2 ? 1 : 0;
         const int row0 = wm * 32;
         f32x4 bq[4];
+        if constexpr (BIAS_LDS) bias_from_lds(1, bq);
+        else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
+            for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4 *>(biasp + (row0 + 8 * q + 4 * hi) * b_on);
+        }
         static_for<NW / 2>([&](auto R) {
             constexpr int rr = decltype(R)::value;
             f32x4 adl[2][4];
@@ -740,6 +769,8 @@ hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t stream,
         a.a_ring = (unsigned)((lds + 1023) / 1024 * 1024);
         lds = a.a_ring + 3 * 4096;
     }
+    a.bias_off = (unsigned)((lds + 15) / 16 * 16);  // the two bias vectors: one 1 KiB DMA slot
+    lds = a.bias_off + 1024;
     const long long nb = (long long)a.NT * B;
     if (nb == 0) return hipSuccess;
     const long long wgs = (nb + 7) / 8 * 8;
