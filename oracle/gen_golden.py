@@ -143,7 +143,7 @@ def build_model(torch, models, name, seed=1234):
     return m, kw
 
 
-def export_onnx(torch, m, kw, path, name=""):
+def export_onnx(torch, m, kw, path, name="", opset=15, constant_folding=True, keep_initializers=False):
     """Mirror of export_onnx.py:250-327 (this container has no `onnx` package;
     the legacy exporter's only use of it is a post-step that is a no-op here)."""
     from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
@@ -172,8 +172,9 @@ def export_onnx(torch, m, kw, path, name=""):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         torch.onnx.export(model=m, args=(seqs, lens, scales, sid), f=path, verbose=False,
-                          opset_version=15, input_names=names, output_names=["output"],
-                          dynamic_axes=dyn, dynamo=False)
+                          opset_version=opset, input_names=names, output_names=["output"],
+                          dynamic_axes=dyn, dynamo=False, do_constant_folding=constant_folding,
+                          keep_initializers_as_inputs=keep_initializers)
     m.forward = old_forward
     # metadata_props (export_onnx.py:335-350): ModelProto field 14, appended
     meta = {"model_type": "vits", "n_speakers": kw["n_speakers"], "n_vocab": kw["n_vocab"],
@@ -313,12 +314,29 @@ def main():
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
     ap.add_argument("--preset", nargs="*", default=["tiny_rb1", "tiny_rb2_ms", "tiny_dp"])
     ap.add_argument("--big", default=None, help="directory for medium/high/medium_ms (not committed)")
+    # exporter variants: the same seeded model written the ways third-party exports differ from
+    # export_onnx.py:318-327 - other opsets, no constant folding, initializers listed as graph inputs.  `--variants DIR`
+    # writes <preset>.<variant>.onnx for every --preset (no goldens: the weights, hence the packed arena, are the base file's)
+    ap.add_argument("--variants", default=None)
     a = ap.parse_args()
     torch, models = _import_reference()
     torch.set_num_threads(8)
     out = a.big or a.out
     presets = ["medium", "high", "medium_ms"] if a.big and a.preset == ["tiny_rb1", "tiny_rb2_ms", "tiny_dp"] else a.preset
     os.makedirs(out, exist_ok=True)
+    if a.variants:
+        os.makedirs(a.variants, exist_ok=True)
+        for name in a.preset:
+            m, kw = build_model(torch, models, name)
+            for tag, opt in (("opset11", dict(opset=11)), ("opset13", dict(opset=13)), ("opset17", dict(opset=17)),
+                             ("nofold", dict(constant_folding=False)), ("initinputs", dict(keep_initializers=True))):
+                path = os.path.join(a.variants, f"{name}.{tag}.onnx")
+                try:
+                    export_onnx(torch, m, kw, path, name, **opt)
+                    print("   wrote", path, os.path.getsize(path), "bytes")
+                except Exception as e:  # noqa: BLE001 - an opset the exporter refuses for this graph is a finding, not a failure
+                    print("   export failed", tag, type(e).__name__, str(e)[:200])
+        return
     for name in presets:
         print("preset", name)
         m, kw = build_model(torch, models, name)

@@ -426,6 +426,11 @@ void resolve(const OnnxModel &om, Resolver &R) {
         std::string mod, leaf;
         split_path(nm, mod, leaf);
         if (n.op == "Conv" || n.op == "ConvTranspose") {
+            if (n.inputs.size() > 1 && !init(n.inputs[1]))
+                // (the reference exports with constant folding, export_onnx.py:318-327, which turns the weight-norm chains
+                // g * v / |v| of the flow's convs into plain initializers; this reader does not evaluate graph arithmetic)
+                throw std::runtime_error("the weight of node '" + n.name + "' is computed inside the graph (weight-norm chain left in: "
+                                         "exported with do_constant_folding=False?); re-export with constant folding");
             if (n.inputs.size() > 1) R.put(mod + ".weight", init(n.inputs[1]));
             if (n.inputs.size() > 2 && !n.inputs[2].empty()) R.put(mod + ".bias", init(n.inputs[2]));
             auto a = n.ints.find("dilations");
@@ -439,6 +444,16 @@ void resolve(const OnnxModel &om, Resolver &R) {
         } else if (n.op == "Gather" && !n.inputs.empty()) {
             const OnnxTensor *t = init(n.inputs[0]);
             if (t && t->dtype == 1 && t->dims.size() == 2) R.put(mod + ".weight", t);
+        } else if (n.op == "LayerNormalization" && n.inputs.size() >= 3) {
+            // opset >= 17: modules.py:14-26 (F.layer_norm over the channel axis) is exported as ONE node (X, Scale, B) instead of
+            // the ReduceMean / Sub / Pow / .. / Mul / Add chain of opset <= 16
+            const OnnxTensor *g = init(n.inputs[1]), *bt = init(n.inputs[2]);
+            if (g && g->dtype == 1 && g->dims.size() == 1) R.put(mod + ".gamma", g);
+            if (bt && bt->dtype == 1 && bt->dims.size() == 1) R.put(mod + ".beta", bt);
+            auto ep = n.floats.find("epsilon");
+            if (ep != n.floats.end() && std::fabs(ep->second - 1e-5f) > 1e-7f)
+                throw std::runtime_error("LayerNormalization node '" + n.name + "' has epsilon " + std::to_string(ep->second) +
+                                         "; this engine implements the reference's 1e-5 (modules.py:17)");
         } else if ((n.op == "Mul" || n.op == "Add") && mod.find("norm") != std::string::npos) {
             for (const auto &i : n.inputs) {
                 const OnnxTensor *t = init(i);

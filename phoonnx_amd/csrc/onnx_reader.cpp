@@ -142,13 +142,19 @@ OnnxNode node(Span s) {
                 Field g;
                 std::string an;
                 std::vector<int64_t> iv;
-                bool has = false;
+                bool has = false, hasf = false;
+                float fv = 0.f;
                 while (next(a, g)) {
                     if (g.num == 1) an = str(ld(g, "AttributeProto.name"));
-                    else if (g.num == 3) { iv.push_back(int64_t(scalar(g, "AttributeProto.i"))); has = true; }
+                    else if (g.num == 2 && g.wire == 5) {  // AttributeProto.f (fixed32)
+                        const uint32_t bits = uint32_t(g.val);
+                        std::memcpy(&fv, &bits, 4);
+                        hasf = true;
+                    } else if (g.num == 3) { iv.push_back(int64_t(scalar(g, "AttributeProto.i"))); has = true; }
                     else if (g.num == 8) { ints_of(g, iv); has = true; }
                 }
                 if (has) n.ints[an] = iv;
+                if (hasf) n.floats[an] = fv;
                 break;
             }
             default: break;

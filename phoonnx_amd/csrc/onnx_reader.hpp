@@ -43,6 +43,7 @@ struct OnnxNode {
     std::string name, op;
     std::vector<std::string> inputs, outputs;
     std::map<std::string, std::vector<int64_t>> ints;  // attribute ints / single i
+    std::map<std::string, float> floats;               // attribute f (LayerNormalization epsilon)
 };
 
 struct OnnxModel {

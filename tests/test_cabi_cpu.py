@@ -322,3 +322,29 @@ def test_structure_that_is_not_a_vits_export_is_rejected_with_a_reason(tmp_path)
     bad.write_bytes(rn.rename(bytes(out)))
     with pytest.raises(SessionError, match="structure|conv_post|not found"):
         MiSession(str(bad), host_only=True)
+
+
+@pytest.mark.parametrize("variant", ["opset11", "opset13", "opset17", "initinputs", "nofold"])
+def test_exporter_variants_resolve_or_are_refused_with_a_reason(variant):
+    """VERDICT r3 item 6c.  The reference exports one way (opset 15, constant folding on, initializers not listed as inputs:
+    phoonnx_train/export_onnx.py:318-327); third-party voices differ.  tests/golden/variants/ holds the `tiny_rb2_ms` model
+    of the fixtures written by the SAME exporter call with one knob changed (oracle/gen_golden.py --variants).  The reader
+    must produce the identical packed arena and hyper-parameters - opset 11 / 13 (other shape-plumbing nodes), opset 17
+    (LayerNorm as ONE LayerNormalization node instead of a ReduceMean .. Mul Add chain), initializers listed as graph inputs
+    (not to be mistaken for feeds) - or refuse with the reason: without constant folding the flow's weight-norm chains stay in
+    the graph as arithmetic this reader does not evaluate."""
+    base = MiSession(os.path.join(GOLDEN, "tiny_rb2_ms.onnx"), host_only=True)
+    path = os.path.join(GOLDEN, "variants", f"tiny_rb2_ms.{variant}.onnx")
+    if variant == "nofold":
+        with pytest.raises(SessionError, match="computed inside the graph.*constant folding"):
+            MiSession(path, host_only=True)
+        base.close()
+        return
+    s = MiSession(path, host_only=True)
+    assert [i.name for i in s.get_inputs()] == ["input", "input_lengths", "scales", "sid"]
+    for k in ("hidden", "inter", "filter", "n_heads", "n_layers", "n_speakers", "gin", "use_sdp", "hop", "n_ups", "resblock"):
+        assert s.hparam(k) == base.hparam(k), k
+    assert np.array_equal(np.asarray(s.arena_host()), np.asarray(base.arena_host()))
+    s.close()
+    base.close()
+
