@@ -287,6 +287,10 @@ def make_cases(torch, m, kw, rng, big=False, long_case=False):
         add("b3_noise", ids, lens, [0.667, 1.3, 0.8], sids(3), True)
         ids, lens = padded([64])
         add("b1_zero", ids, lens, [0.0, 1.5, 0.0], sids(1), False)
+        # a batch at the bench's length scale: ~400-600 frames per utterance, mixed lengths (every generator stage is many
+        # tiles wide, the padding mask is in play) - the real exporter graph at full size
+        ids, lens = padded([200, 137, 96, 180])
+        add("b4_long_noise", ids, lens, [0.667, 1.95, 0.8], sids(4), True)
         return cases
 
     ids, lens = padded([40, 33, 17])
