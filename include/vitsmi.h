@@ -321,6 +321,11 @@ int vits_test_conv_pair_sx(int device_id, const float *x, int B, int C, int T, c
  * [B,C,T] host, emb_rel_k/v [2w+1, dk], lens int64[B]; out [B,C,T]. */
 int vits_test_attention(int device_id, const float *qkv, int B, int C, int T, int n_heads, const float *rel_k,
                         const float *rel_v, int window, const int64_t *lens, float *out);
+/* ... the f16x3 16x16x32 kernel (kernel = 1; head width 32 / 64 / 96) or the fp32-MFMA one (kernel = 0): out_planes (may be
+ * NULL) receives the output's fp16 operand planes [B][3][C/8][T][8]; reps > 0 times reps launches into ms_out[0] (ms each). */
+int vits_test_attention16(int device_id, const float *qkv, int B, int C, int T, int n_heads, const float *rel_k,
+                          const float *rel_v, int window, const int64_t *lens, float *out, uint16_t *out_planes, int kernel,
+                          int reps, float *ms_out);
 
 #ifdef __cplusplus
 }

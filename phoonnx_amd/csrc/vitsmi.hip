@@ -19,6 +19,7 @@
 #include "conv_sx_engine.hip.hpp"
 #include "conv_sx_pair.hip.hpp"
 #include "conv_sx_pair16.hip.hpp"
+#include "attention16.hip.hpp"
 #include "kernels.hip.hpp"
 #include "model.hpp"
 
@@ -464,6 +465,51 @@ void launch_attention(hipStream_t st, int B, int T, int n_heads, int dk, int win
 #undef VITSMI_ATT
 }
 
+// ... on the 16-bit matrix pipe as f16x3 products (attention16.hip.hpp): head widths of 32 / 64 / 96, q | k | v given as
+// operand planes too (the q|k|v conv's planar epilogue writes them).  VITSMI_ATT16=0 keeps the fp32-MFMA kernel (A/B timing).
+bool attention16_ok(int dk, int window) {
+    static const bool off = [] { const char *e = std::getenv("VITSMI_ATT16"); return e && e[0] == '0'; }();
+    return !off && dk % 32 == 0 && dk <= 96 && window <= 4;
+}
+template <int DKS, int NS, int QT>
+hipError_t launch_attention16_t(hipStream_t st, const Att16Args &a) {
+    constexpr int lds = NS * 4 * (DKS * 2) * 1024 + 9 * DKS * 32 * 4 + 16 + 64 * QT * kAtt16RelPitch * 4;
+    static std::atomic<uint64_t> done{0};
+    if (lds > 64 * 1024)
+        if (hipError_t e = sx_allow_big_lds(reinterpret_cast<const void *>(&attention_relpos16_kernel<DKS, NS, QT>), done)) return e;
+    const int ntile = (a.T + 64 * QT - 1) / (64 * QT), npair = a.nh * a.B;
+    attention_relpos16_kernel<DKS, NS, QT><<<dim3(((npair + 7) / 8) * 8 * ntile), 256, lds, st>>>(a);
+    return hipSuccess;
+}
+// stages / query tiles per wave: two stages, 64 queries per workgroup; VITSMI_ATT16_NS / VITSMI_ATT16_QT override (A/B timing)
+hipError_t launch_attention16(hipStream_t st, int B, int T, int n_heads, int dk, int window, const uint16_t *qkv_pl, float *att,
+                              uint16_t *att_pl, const float *rel_k, const float *rel_v, const int *len, int H, unsigned *peak,
+                              unsigned long long *prof = nullptr) {
+    static const int env_ns = [] { const char *e = std::getenv("VITSMI_ATT16_NS"); return e ? std::atoi(e) : 0; }();
+    static const int env_qt = [] { const char *e = std::getenv("VITSMI_ATT16_QT"); return e ? std::atoi(e) : 0; }();
+    Att16Args a{};
+    a.qkv_pl = qkv_pl;
+    a.out = att;
+    a.out_pl = att_pl;
+    a.relk = rel_k;
+    a.relv = rel_v;
+    a.len = len;
+    a.Hc = H;
+    a.T = T;
+    a.dk = dk;
+    a.win = window;
+    a.nh = n_heads;
+    a.B = B;
+    a.peak = att_pl ? peak : nullptr;
+    a.prof = prof;
+    int ns = env_ns ? env_ns : 2, qt = env_qt ? env_qt : 1;  // (measured: 2, 3 and 4 stages time alike)
+    if (dk == 32) return launch_attention16_t<1, 3, 1>(st, a);
+    if (dk == 64) return launch_attention16_t<2, 3, 1>(st, a);
+    if (qt == 2) return ns >= 3 ? launch_attention16_t<3, 3, 2>(st, a) : launch_attention16_t<3, 2, 2>(st, a);
+    if (ns >= 4) return launch_attention16_t<3, 4, 1>(st, a);
+    return ns == 3 ? launch_attention16_t<3, 3, 1>(st, a) : launch_attention16_t<3, 2, 1>(st, a);
+}
+
 // A token- / frame-domain conv on the split-operand engine with the planar epilogue (SX_WN_RMW): x_pl = fp16 operand planes
 // of the input; out (may be nullptr when out_pl is given) = planar fp32 [B][Cout][T]; out_pl = operand planes of the output
 // for the next conv; flags = EPI_RELU | EPI_MASK | EPI_ACC | EPI_RES (res: planar, the shape of out).
@@ -821,6 +867,7 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     need += al((size_t)B * 3 * H * T);                     // qkv
     need += al((size_t)B * m.FF * T);                      // ffn hidden
     if (m.enc_sx) need += 2 * al(nHT * 3 / 2 + 64) + al((size_t)B * m.FF * T * 3 / 2 + 64);  // operand planes: x, attn out, ffn hidden
+    if (m.enc_sx && attention16_ok(m.dk, m.window)) need += al(nHT * 9 / 2 + 64);  // operand planes: q | k | v
     need += al((size_t)B * 2 * C * T) + 2 * al((size_t)B * C * T);  // stats, m_p, logs_p
     need += al((size_t)B * Cdp * T) * 5;                   // dp buffers
     int pr_rows = 32;  // spline parameters per position: 3 * bins - 1 (29 for the reference's 10 bins, up to 47)
@@ -862,20 +909,26 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     const float *xin = xe;  // layer input: the embedding for layer 0, x afterwards
     // split-operand engine (Model::enc_sx): every conv reads fp16 operand planes and writes planar fp32 (what attention,
     // LayerNorm and the duration predictor read) or planes for the next conv
-    uint16_t *x_pl = nullptr, *att_pl = nullptr, *ff_pl = nullptr;
+    uint16_t *x_pl = nullptr, *att_pl = nullptr, *ff_pl = nullptr, *qkv_pl = nullptr;
     if (m.enc_sx) {
         x_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, nHT * 3 / 2 + 64));
         att_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, nHT * 3 / 2 + 64));
         ff_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, (size_t)B * m.FF * T * 3 / 2 + 64));
+        if (attention16_ok(m.dk, m.window)) qkv_pl = reinterpret_cast<uint16_t *>(slab_take<float>(s, nHT * 9 / 2 + 64));
         split_planes(c, xe, x_pl, H, T, len);
     }
     for (auto &L : m.enc) {
         if (m.enc_sx) {
-            conv_sx_planar(c, L.qkv_sx, x_pl, T, qkv, nullptr, 0);
+            const bool a16 = attention16_ok(m.dk, m.window);
+            conv_sx_planar(c, L.qkv_sx, x_pl, T, a16 ? nullptr : qkv, a16 ? qkv_pl : nullptr, 0);  // (a16 reads the planes only)
             // (the attention kernel writes its output as conv_o's operand planes too when head widths are whole cells)
             uint16_t *apl = m.dk % 8 == 0 ? att_pl : nullptr;
-            launch_attention(st, B, T, m.n_heads, m.dk, m.window, qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, apl,
-                             apl ? range_slots(h, true) : nullptr);
+            if (a16)
+                c.note(launch_attention16(st, B, T, m.n_heads, m.dk, m.window, qkv_pl, nullptr, apl, c.P(L.rel_k), c.P(L.rel_v), len,
+                                          H, range_slots(h, true)));
+            else
+                launch_attention(st, B, T, m.n_heads, m.dk, m.window, qkv, att, c.P(L.rel_k), c.P(L.rel_v), len, H, apl,
+                                 apl ? range_slots(h, true) : nullptr);
             c.note(hipGetLastError());
             h->stats.total_launches++;
             h->stats.enc_flops += 2.0 * B * m.n_heads * (2.0 * m.dk * T * (double)T);
@@ -2872,6 +2925,89 @@ int vits_test_attention(int device_id, const float *qkv, int B, int C, int T, in
     TCHECK(hipDeviceSynchronize());
     TCHECK(hipMemcpy(out, dout, no * 4, hipMemcpyDeviceToHost));
     hipFree(dq); hipFree(dout); hipFree(drk); hipFree(drv); hipFree(dlen);
+    return VITS_OK;
+}
+
+// ... the 16x16x32 f16x3 kernel (kernel = 1) or the fp32-MFMA one (0) with timing: the q | k | v tensor is split into
+// operand planes on the device first (what the q|k|v conv's epilogue does in the pipeline); out_planes (optional) receives the
+// output's operand planes [B][3][C/8][T][8]; reps > 0: ms_out[0] = mean launch duration over reps launches (HIP events).
+int vits_test_attention16(int device_id, const float *qkv, int B, int C, int T, int n_heads, const float *rel_k,
+                          const float *rel_v, int window, const int64_t *lens, float *out, uint16_t *out_planes, int kernel,
+                          int reps, float *ms_out) {
+    if (int rc = test_dev(device_id)) return rc;
+    if (window > 4 || C % n_heads || C % 8) return fail(nullptr, VITS_E_ARG, "bad attention test arguments");
+    int dk = C / n_heads;
+    if (kernel == 1 && !(dk % 32 == 0 && dk <= 96)) return fail(nullptr, VITS_E_ARG, "attention16 needs a head width of 32, 64 or 96");
+    float *dq = nullptr, *dout = nullptr, *drk = nullptr, *drv = nullptr;
+    uint16_t *dqp = nullptr, *dop = nullptr;
+    unsigned *dpk = nullptr;
+    int *dlen = nullptr;
+    size_t nq = (size_t)B * 3 * C * T, no = (size_t)B * C * T, nr = (size_t)(2 * window + 1) * dk;
+    std::vector<int> l32(B);
+    for (int b = 0; b < B; b++) l32[b] = (int)lens[b];
+    TCHECK(hipMalloc((void **)&dq, nq * 4));
+    TCHECK(hipMalloc((void **)&dqp, nq * 3 * 2));
+    TCHECK(hipMalloc((void **)&dop, no * 3 * 2));
+    TCHECK(hipMalloc((void **)&dpk, kSxPeakSlots * kSxPeakStride * 4));
+    TCHECK(hipMalloc((void **)&dout, no * 4));
+    TCHECK(hipMalloc((void **)&drk, nr * 4));
+    TCHECK(hipMalloc((void **)&drv, nr * 4));
+    TCHECK(hipMalloc((void **)&dlen, B * 4));
+    TCHECK(hipMemset(dpk, 0, kSxPeakSlots * kSxPeakStride * 4));
+    TCHECK(hipMemset(dop, 0xff, no * 3 * 2));
+    TCHECK(hipMemset(dout, 0xff, no * 4));
+    TCHECK(hipMemcpy(dq, qkv, nq * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(drk, rel_k, nr * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(drv, rel_v, nr * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dlen, l32.data(), B * 4, hipMemcpyHostToDevice));
+    sx_split_planes_kernel<<<dim3((T + 255) / 256, 3 * C / 8, B), 256>>>(dq, (int64_t)3 * C * T, T, nullptr, dqp, 3 * C, T, 1, dpk);
+    unsigned long long *dprof = nullptr;
+    const int prof_wgs = ((n_heads * B + 7) / 8) * 8 * ((T + 63) / 64);
+#if ATT16_PROF
+    TCHECK(hipMalloc((void **)&dprof, (size_t)prof_wgs * 4 * 8));
+    TCHECK(hipMemset(dprof, 0, (size_t)prof_wgs * 4 * 8));
+#endif
+    auto go = [&] {
+        if (kernel == 1) (void)launch_attention16(nullptr, B, T, n_heads, dk, window, dqp, dout, dop, drk, drv, dlen, C, dpk, dprof);
+        else launch_attention(nullptr, B, T, n_heads, dk, window, dq, dout, drk, drv, dlen, C, dk % 8 == 0 ? dop : nullptr, dpk);
+    };
+    go();
+    TCHECK(hipGetLastError());
+    TCHECK(hipDeviceSynchronize());
+    if (reps > 0 && ms_out) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        hipEventRecord(e0, nullptr);
+        for (int r = 0; r < reps; r++) go();
+        hipEventRecord(e1, nullptr);
+        TCHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        ms_out[0] = ms / reps;
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+    }
+    if (dprof && kernel == 1) {  // ATT16_PROF builds: where a workgroup's time goes (shader-clock cycles, means over the launch)
+        std::vector<unsigned long long> hp((size_t)prof_wgs * 4);
+        TCHECK(hipMemcpy(hp.data(), dprof, hp.size() * 8, hipMemcpyDeviceToHost));
+        double d[3] = {0, 0, 0};
+        unsigned long long t0 = ~0ull, t1 = 0;
+        int n = 0;
+        for (int w = 0; w < prof_wgs; w++) {
+            if (!hp[w * 4 + 3]) continue;
+            for (int k = 0; k < 3; k++) d[k] += (double)(hp[w * 4 + k + 1] - hp[w * 4 + k]);
+            t0 = hp[w * 4] < t0 ? hp[w * 4] : t0;
+            t1 = hp[w * 4 + 3] > t1 ? hp[w * 4 + 3] : t1;
+            n++;
+        }
+        if (n) std::fprintf(stderr, "att16 stamps B=%d T=%d: %d workgroups; cycles prologue %.0f loop %.0f epilogue %.0f; first start -> last end %llu\n",
+                            B, T, n, d[0] / n, d[1] / n, d[2] / n, t1 - t0);
+        hipFree(dprof);
+    }
+    TCHECK(hipMemcpy(out, dout, no * 4, hipMemcpyDeviceToHost));
+    if (out_planes) TCHECK(hipMemcpy(out_planes, dop, no * 3 * 2, hipMemcpyDeviceToHost));
+    hipFree(dq); hipFree(dqp); hipFree(dop); hipFree(dpk); hipFree(dout); hipFree(drk); hipFree(drv); hipFree(dlen);
     return VITS_OK;
 }
 

@@ -902,6 +902,32 @@ def test_conv_transpose1d(x, w, bias, stride, device_id=0, sx=False):
     return out
 
 
+def test_attention16(qkv, n_heads, rel_k, rel_v, lens, device_id=0, kernel=1, planes=False, reps=0):
+    """attention16.hip.hpp (kernel=1) or the fp32-MFMA kernel (0) on q|k|v planar fp32 [B, 3C, T]; returns out [B, C, T],
+    plus the output's operand planes (uint16 [B, 3, C/8, T, 8]) when planes=True, plus ms per launch when reps > 0."""
+    lib = _ffi.load()
+    qkv = np.ascontiguousarray(qkv, np.float32)
+    B, C3, T = qkv.shape
+    Cc = C3 // 3
+    rel_k = np.ascontiguousarray(rel_k, np.float32)
+    rel_v = np.ascontiguousarray(rel_v, np.float32)
+    window = (rel_k.shape[0] - 1) // 2
+    lens = np.ascontiguousarray(lens, np.int64)
+    out = np.empty((B, Cc, T), np.float32)
+    opl = np.empty((B, 3, Cc // 8, T, 8), np.uint16) if planes else None
+    ms = (C.c_float * 1)()
+    rc = lib.vits_test_attention16(device_id, _ffi.ptr(qkv), B, Cc, T, n_heads, _ffi.ptr(rel_k), _ffi.ptr(rel_v), window,
+                                   _ffi.ptr(lens), _ffi.ptr(out), _ffi.ptr(opl) if planes else None, int(kernel), int(reps), ms)
+    if rc != 0:
+        raise SessionError(_ffi.last_error(None))
+    res = (out,)
+    if planes:
+        res += (opl,)
+    if reps > 0:
+        res += (float(ms[0]),)
+    return res[0] if len(res) == 1 else res
+
+
 def test_attention(qkv, n_heads, rel_k, rel_v, lens, device_id=0):
     lib = _ffi.load()
     qkv = np.ascontiguousarray(qkv, np.float32)

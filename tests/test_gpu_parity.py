@@ -567,6 +567,57 @@ def test_attention_sharp_softmax():
     np.testing.assert_allclose(got, ref, atol=1e-4, rtol=1e-4)
 
 
+def _planes_value(pl):
+    """fp16 operand planes [B, 3, C/8, T, 8] (f16x3 format: h0, h1 * 2^11) -> the fp32 values they stand for [B, C, T]"""
+    h = pl.view(np.float16).astype(np.float64)
+    v = h[:, 0] + h[:, 1] / 2048.0
+    B, CG, T, _ = v.shape
+    return v.transpose(0, 1, 3, 2).reshape(B, CG * 8, T)
+
+
+ATT16_CASES = [(1, 2, 96, 256, [256]), (2, 2, 96, 70, [33, 70]), (1, 1, 64, 3, [3]), (2, 2, 32, 129, [129, 64]),
+               (3, 2, 96, 500, [500, 1, 257]), (2, 4, 32, 65, [64, 65]), (1, 2, 96, 33, [32])]
+
+
+@pytest.mark.parametrize("B,heads,dk,T,lens", ATT16_CASES)
+def test_attention16_matches_oracle(B, heads, dk, T, lens):
+    """the f16x3 16x16x32 attention kernel (attention16.hip.hpp) against the oracle's attention core at the fp32 kernel's
+    tolerance, and its second output (conv_o's operand planes) against its first"""
+    from phoonnx_amd.session import test_attention16
+    from vits_oracle import attention_core
+    rng = np.random.default_rng(T * 7 + dk)
+    C = heads * dk
+    qkv = rng.standard_normal((B, 3 * C, T)).astype(np.float32)
+    rk = (rng.standard_normal((9, dk)) * dk ** -0.5).astype(np.float32)
+    rv = (rng.standard_normal((9, dk)) * dk ** -0.5).astype(np.float32)
+    lens = np.asarray(lens, np.int64)
+    got, pl = test_attention16(qkv, heads, rk, rv, lens, planes=True)
+    ref = attention_core(qkv, heads, rk, rv, lens)
+    val = _planes_value(pl)
+    for b in range(B):
+        np.testing.assert_allclose(got[b, :, :lens[b]], ref[b, :, :lens[b]], atol=2e-5, rtol=1e-4)
+        assert np.all(got[b, :, lens[b]:] == 0)
+        np.testing.assert_allclose(val[b], got[b].astype(np.float64), atol=1e-9, rtol=3e-7)
+
+
+def test_attention16_window_2_and_sharp_softmax():
+    from phoonnx_amd.session import test_attention16
+    from vits_oracle import attention_core
+    rng = np.random.default_rng(5)
+    B, heads, dk, T = 1, 2, 32, 200
+    C = heads * dk
+    qkv = rng.standard_normal((B, 3 * C, T)).astype(np.float32)
+    qkv[:, :C] *= 6.0
+    qkv[:, C:2 * C, 150:] *= 5.0   # the maximum jumps late in the key sweep
+    lens = np.asarray([T], np.int64)
+    for nrel in (9, 5):
+        rk = rng.standard_normal((nrel, dk)).astype(np.float32)
+        rv = rng.standard_normal((nrel, dk)).astype(np.float32)
+        got = test_attention16(qkv, heads, rk, rv, lens)
+        ref = attention_core(qkv, heads, rk, rv, lens)
+        np.testing.assert_allclose(got, ref, atol=1e-4, rtol=1e-4)
+
+
 # ------------------------------------------------------------------ whole path vs reference fixtures
 
 TAPS = ("x", "m_p", "logs_p", "logw", "w_ceil", "z_p", "z")

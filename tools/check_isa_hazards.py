@@ -16,7 +16,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "phoonnx_amd", "csrc")
-UNITS = ["tu_sx_h1", "tu_sx_s16p", "tu_sx_s16", "tu_sx_s32", "tu_sx_bf16", "tu_pair16", "tu_pair"]
+UNITS = ["tu_sx_h1", "tu_sx_s16p", "tu_sx_s16", "tu_sx_s32", "tu_sx_bf16", "tu_pair16", "tu_pair", "vitsmi"]
+# kernels with counted lgkmcnt waits: the conv engines, and the 16x16x32 attention kernel (attention16.hip.hpp, in vitsmi.hip)
+KERNELS = r"_ZN6vitsmi[0-9]+(?:conv_sx|attention_relpos16)\w*"
 
 
 def check(unit):
@@ -28,10 +30,10 @@ def check(unit):
             sys.stderr.write(r.stderr)
             raise SystemExit(f"hipcc failed on {unit}")
         txt = open(out).read()
-    parts = re.split(r"\n(_ZN6vitsmi[0-9]+conv_sx[^:\n]*):", txt)
     bad, n = [], 0
-    for i in range(1, len(parts), 2):
-        name, lines = parts[i], parts[i + 1].split("s_endpgm")[0].split("\n")
+    for name in re.findall(r"\n(" + KERNELS + r"):", txt):
+        i = txt.index("\n" + name + ":")
+        lines = txt[i:txt.index(".Lfunc_end", i)].split("\n")  # (a kernel with an early exit has several s_endpgm)
         n += 1
         mf = [k for k, l in enumerate(lines) if "v_mfma" in l]
         if not mf:
