@@ -9,8 +9,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvitsmi.so")
 SOURCES = ["vitsmi.hip", "tu_conv_f32.hip", "tu_sx.hip", "tu_sx_s16.hip", "tu_sx_s16p.hip", "tu_sx_s32.hip", "tu_sx_bf16.hip", "tu_sx_h1.hip", "tu_pair.hip", "tu_pair16.hip", "g2p.hip",
            "model.cpp", "onnx_reader.cpp"]
-HEADERS = ["kernels.hip.hpp", "conv_engine.hip.hpp", "conv_sx_engine.hip.hpp", "conv_sx_pair.hip.hpp", "conv_sx_pair16.hip.hpp", "sx_split.hip.hpp", "model.hpp",
-           "g2p_model.hpp", "onnx_reader.hpp", "../../include/vitsmi.h", "../../include/g2pmi.h"]
+# every header under csrc/ (a header missing from a hand-kept list once left the library unrebuilt after an edit), and the C ABI
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + ["../../include/vitsmi.h", "../../include/g2pmi.h"]
 
 
 def hipcc():

@@ -20,6 +20,7 @@
 #include "conv_sx_pair.hip.hpp"
 #include "conv_sx_pair16.hip.hpp"
 #include "attention16.hip.hpp"
+#include "conv_sx_small.hip.hpp"
 #include "kernels.hip.hpp"
 #include "model.hpp"
 
@@ -432,7 +433,14 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
             sx_tile_m(force % 10) <= sx_tile_m(d.cfg) && d.Cout % sx_tile_m(force % 10) == 0)
             run_cfg = force % 10;
     }
-    c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, d.h1 ? 1 : (d.f16 ? 2 : 6), d.cfg));
+    // Short launches of the token / frame domain (one utterance, a streaming chunk): the reduction-splitting kernel of
+    // conv_sx_small.hip.hpp.  VITSMI_SX_SMALL_MAX = largest launch in workgroups that takes it (0: never; A/B timing).
+    static const long long small_max = [] { const char *e = std::getenv("VITSMI_SX_SMALL_MAX"); return e ? std::atoll(e) : 768ll; }();
+    const int nprod = d.h1 ? 1 : (d.f16 ? 2 : 6);
+    if (small_max > 0 && conv_sx_small_ok(a, d.rawin, nprod) && conv_sx_small_wgs(a, c.B) <= small_max)
+        c.note(launch_conv_sx_small(a, c.B, d.cfg, c.st));
+    else
+        c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, nprod, d.cfg));
     // layer-granular bytes in the STORED dtype ("bf16 storage halves these"): 2 bytes per element in the
     // single-plane mode, 4 otherwise
     const double ebytes = d.h1 ? 2.0 : 4.0;
@@ -2538,7 +2546,7 @@ int vits_test_conv1d_sx_planar(int device_id, const float *x, int B, int Cin, in
     // the planar epilogue of the split-operand engine (f16x3, 16x16x32 loop), as the flow and the text encoder use it:
     // flags bit 0 ReLU, 1 mask (t < lens[b]), 2 residual (old: planar [B][row_split][T]), 3 accumulate (old: the
     // outputs' previous contents, [B][Cout][T]), 4 coupling update, 5 the rows behind row_split are stored (not
-    // accumulated), 6 the planes are those of the rows behind row_split.  out = [B][Cout][T] (rows behind row_split from
+    // accumulated), 6 the planes are those of the rows behind row_split, 7 run the short-launch kernel.  out = [B][Cout][T] (rows behind row_split from
     // the second tensor); planes_out (nullable) = [B][pl_rows][T] read back from the operand planes.
     if (int rc = test_dev(device_id)) return rc;
     if (Cin % 32 || Cout % 32 || row_split % 32 || row_split > Cout || pl_rows % 32) return fail(nullptr, VITS_E_ARG, "bad planar test shape");
@@ -2599,7 +2607,11 @@ int vits_test_conv1d_sx_planar(int device_id, const float *x, int B, int Cin, in
     a.pl_bstride = (int64_t)3 * pl_rows * T;
     a.flags = SX_WN_RMW | ((flags & 1) ? EPI_RELU : 0) | ((flags & 2) ? EPI_MASK : 0) | ((flags & 4) ? EPI_RES : 0) |
               ((flags & 8) ? EPI_ACC : 0) | ((flags & 16) ? SX_PLANAR_COUPLING : 0) | ((flags & 32) ? SX_PLANAR_STORE2 : 0);
-    TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, false, 2));
+    if (flags & 128) {  // the short-launch kernel (conv_sx_small.hip.hpp) instead of the engine's
+        if (!conv_sx_small_ok(a, false, 2)) return fail(nullptr, VITS_E_ARG, "arguments not taken by the short-launch kernel");
+        TCHECK(launch_conv_sx_small(a, B, d.cfg, nullptr));
+    } else
+        TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, false, 2));
     if (pl_rows)
         sx_unblock_kernel<<<dim3((T + 255) / 256, pl_rows / 8, B), 256>>>(nullptr, dpl, dpo, pl_rows, T, 1);
     TCHECK(hipGetLastError());

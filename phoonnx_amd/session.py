@@ -818,10 +818,11 @@ def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=
 
 
 def test_conv1d_sx_planar(x, w, bias=None, dil=1, lens=None, old=None, row_split=None, pl_rows=0, relu=False, mask=False,
-                          residual=False, accumulate=False, coupling=False, store2=False, planes_of2=False, device_id=0):
+                          residual=False, accumulate=False, coupling=False, store2=False, planes_of2=False, device_id=0,
+                          small=False):
     """The split-operand engine's planar epilogue (f16x3, "same" padding): o = old + act(conv(x) + bias) * mask, rows
-    [0, row_split) in a first tensor, the rest in a second (see include/vitsmi.h).  Returns (out [B, Cout, T],
-    planes [B, pl_rows, T] or None)."""
+    [0, row_split) in a first tensor, the rest in a second (see include/vitsmi.h).  small=True: through the short-launch
+    kernel (conv_sx_small.hip.hpp) instead of the engine's.  Returns (out [B, Cout, T], planes [B, pl_rows, T] or None)."""
     lib = _ffi.load()
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
@@ -833,7 +834,7 @@ def test_conv1d_sx_planar(x, w, bias=None, dil=1, lens=None, old=None, row_split
     out = np.empty((B, Cout, T), np.float32)
     pl = np.empty((B, pl_rows, T), np.float32) if pl_rows else None
     flags = (1 if relu else 0) | (2 if mask else 0) | (4 if residual else 0) | (8 if accumulate else 0) | \
-            (16 if coupling else 0) | (32 if store2 else 0) | (64 if planes_of2 else 0)
+            (16 if coupling else 0) | (32 if store2 else 0) | (64 if planes_of2 else 0) | (128 if small else 0)
     rc = lib.vits_test_conv1d_sx_planar(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(w), _ffi.ptr(b), Cout, K, dil, flags,
                                         _ffi.ptr(ln), _ffi.ptr(od), Cout if row_split is None else row_split, pl_rows,
                                         _ffi.ptr(out), _ffi.ptr(pl))

@@ -490,7 +490,12 @@ def test_config4_batch64_properties_f16_vocoder():
         one = s.synthesize_batch(ids[b:b + 1, :lens[b]].copy(), lens[b:b + 1], sc, sid[b:b + 1])
         assert one["y_lengths"][0] == r["y_lengths"][b]
         n = (int(one["y_lengths"][0]) - s.hparam("gen_rf_frames")) * hop
-        np.testing.assert_allclose(r["output"][b, 0, 0, :n], one["output"][0, 0, 0, :n], atol=1e-4)
+        # (a single utterance runs its token / frame domain on the short-launch kernel, whose fp32 sums are ordered
+        # differently from the engine's: z differs in its last bits, and the fp16 activation storage of this vocoder turns
+        # that into differences of its own rounding size - far inside the mode's bar, checked here at a fifth of it)
+        d = float(np.abs(r["output"][b, 0, 0, :n] - one["output"][0, 0, 0, :n]).max())
+        print(f"  utterance {b}: batch-64 vs batch-1 rendering max-abs {d:.3g}, SNR {_snr_db(one['output'][0, 0, 0, :n], r['output'][b, 0, 0, :n]):.1f} dB")
+        assert d < 2e-3 and _snr_db(one["output"][0, 0, 0, :n], r["output"][b, 0, 0, :n]) > 45.0
     s.close()
 
 

@@ -733,10 +733,13 @@ PLANAR_CASES = [
 ]
 
 
+@pytest.mark.parametrize("small", [False, True], ids=["engine", "short-launch"])
 @pytest.mark.parametrize("B,Cin,Cout,T,K,row_split,pl_rows,opt", PLANAR_CASES)
-def test_conv_sx_planar_epilogue_matches_float64(B, Cin, Cout, T, K, row_split, pl_rows, opt):
-    """Kernel level: the planar epilogue of the split-operand engine (f16x3 products, 16x16x32 loop) against a float64
-    restatement of `old + act(conv(x) + bias) * mask` (modules.py:200-209, 447-466; attentions.py:66-75, 419-427)."""
+def test_conv_sx_planar_epilogue_matches_float64(B, Cin, Cout, T, K, row_split, pl_rows, opt, small):
+    """Kernel level: the planar epilogue of the split-operand engine (f16x3 products, 16x16x32 loop) - and of the
+    short-launch kernel that takes its place on small grids (conv_sx_small.hip.hpp: reduction split over the waves) -
+    against a float64 restatement of `old + act(conv(x) + bias) * mask` (modules.py:200-209, 447-466;
+    attentions.py:66-75, 419-427)."""
     from phoonnx_amd.session import test_conv1d_sx_planar
     rng = np.random.default_rng(B * 1000 + Cin + Cout + T)
     x = rng.standard_normal((B, Cin, T)).astype(np.float32)
@@ -749,7 +752,7 @@ def test_conv_sx_planar_epilogue_matches_float64(B, Cin, Cout, T, K, row_split, 
         old = rng.standard_normal((B, Cout, T)).astype(np.float32)
     elif opt.get("residual"):
         old = rng.standard_normal((B, Cout, T)).astype(np.float32)
-    got, planes = test_conv1d_sx_planar(x, w, bias, lens=lens, old=old, row_split=row_split, pl_rows=pl_rows, **opt)
+    got, planes = test_conv1d_sx_planar(x, w, bias, lens=lens, old=old, row_split=row_split, pl_rows=pl_rows, small=small, **opt)
     v = _conv_same_f64(x, w, bias, 1)
     if opt.get("relu"):
         v = np.maximum(v, 0)

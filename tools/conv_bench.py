@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--prof", action="store_true", help="with --sx: per-step cycle breakdown of the 128x128 kernel")
     ap.add_argument("--sx", action="store_true", help="benchmark the split-operand engine instead (f16x3 arithmetic)")
     ap.add_argument("--bf16x6", action="store_true", help="with --sx: the six-product exact arithmetic")
+    ap.add_argument("--all-shapes", action="store_true", help="with --sx: the token- and frame-domain shapes too")
     ap.add_argument("--shapes", action="store_true",
                     help="with --sx: A/B of the two MFMA shapes of the main loop (16x16x32 where it applies vs 32x32x16), "
                          "interleaved rounds in one process")
@@ -80,7 +81,7 @@ def main():
                       f"{best(0, 8):7.3f} vs {best(256, 8):7.3f} ms x{best(256, 8) / best(0, 8):.3f}", flush=True)
             return
         for name, Cin, Cout, T, K, dil, hint in shapes:
-            if hint != 0:
+            if hint != 0 and not a.all_shapes:
                 continue
             line = f"{name:24s} T={T:7d}"
             for tag, dbg in (("planes", 0), ("res+raw+planes", 8), ("noDMA", 1), ("noEPI", 2), ("none", 3)):
