@@ -212,6 +212,9 @@ __global__ __launch_bounds__(256) void attention_relpos16_kernel(Att16Args a) {
     const uint32_t k_lane = (uint32_t)((g >> 1) * ROW + c * 32 + (g & 1) * 16);
     const uint32_t v_lane = (uint32_t)(KB + (4 * g + ((lane >> 2) & 3)) * 32 + (lane & 3) * 8);
     int st = 0;
+    // (hazard 2 of DESIGN 5.1g: a kernel-argument s_load still in flight would let the loop's counted lgkmcnt waits pass early)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     ATT16_STAMP(1);
     for (int kb = 0; kb < nkb; kb++) {
         const int j0 = kb * 32;
