@@ -53,7 +53,7 @@ EXPORTS = [
     "vits_run", "vits_free_output", "vits_run_device", "vits_sync", "vits_last_y_lengths", "vits_last_pcm16", "vits_run_vocoder",
     "vits_tap",
     "vits_set_timing", "vits_get_stats", "vits_stream", "vits_test_conv1d", "vits_test_conv_transpose1d",
-    "vits_test_attention", "vits_test_attention16", "vits_bench_conv1d", "vits_test_conv1d_sx", "vits_test_conv1d_sx_planar",
+    "vits_test_attention", "vits_test_attention16", "vits_bench_conv1d", "vits_test_conv1d_sx", "vits_test_conv1d_sx_planar", "vits_test_conv1d_sx_gate", "vits_test_set_sx_small_max",
     "vits_test_conv_transpose1d_sx",
     "vits_bench_conv1d_sx", "vits_test_conv_pair_sx", "vits_fetch_output", "vits_run_async", "vits_host_alloc", "vits_host_free",
     "vits_launch_records",
@@ -142,6 +142,9 @@ def load():
     lib.vits_test_conv_transpose1d_sx.argtypes = lib.vits_test_conv_transpose1d.argtypes
     lib.vits_test_conv1d_sx_planar.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                                vp, vp, C.c_int, C.c_int, vp, vp]
+    lib.vits_test_set_sx_small_max.argtypes = [C.c_longlong]
+    lib.vits_test_set_sx_small_max.restype = C.c_longlong
+    lib.vits_test_conv1d_sx_gate.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.vits_bench_conv1d_sx.argtypes = [C.c_int] * 9 + [f32p]
     lib.vits_test_conv_pair_sx.argtypes = [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_float, vp, f32p]

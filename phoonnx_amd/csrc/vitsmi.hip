@@ -353,6 +353,13 @@ struct SxWn {               // SX_WN_RMW arguments of conv_sx()
     int64_t planar_bstride = 0;   // batch stride of out_raw / res (0: row_split * T)
 };
 
+// largest launch (in workgroups of the short-launch kernel) that conv_sx() hands to conv_sx_small_kernel; process-wide,
+// VITSMI_SX_SMALL_MAX at start-up, vits_test_set_sx_small_max() for A/B tests
+std::atomic<long long> &sx_small_max() {
+    static std::atomic<long long> v{[] { const char *e = std::getenv("VITSMI_SX_SMALL_MAX"); return e ? std::atoll(e) : 768ll; }()};
+    return v;
+}
+
 void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, uint16_t *out_pl, int flags,
              const float *res = nullptr, const float *bias_b = nullptr, int bias_b_stride = 0, float div = 1.f,
              float oslope = 1.f, float oslope2 = 1.f, float islope = 1.f, const SxWn *wn = nullptr,
@@ -435,7 +442,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     }
     // Short launches of the token / frame domain (one utterance, a streaming chunk): the reduction-splitting kernel of
     // conv_sx_small.hip.hpp.  VITSMI_SX_SMALL_MAX = largest launch in workgroups that takes it (0: never; A/B timing).
-    static const long long small_max = [] { const char *e = std::getenv("VITSMI_SX_SMALL_MAX"); return e ? std::atoll(e) : 768ll; }();
+    const long long small_max = sx_small_max().load(std::memory_order_relaxed);
     const int nprod = d.h1 ? 1 : (d.f16 ? 2 : 6);
     if (small_max > 0 && conv_sx_small_ok(a, d.rawin, nprod) && conv_sx_small_wgs(a, c.B) <= small_max)
         c.note(launch_conv_sx_small(a, c.B, d.cfg, c.st));
@@ -2624,6 +2631,65 @@ int vits_test_conv1d_sx_planar(int device_id, const float *x, int B, int Cin, in
     }
     if (pl_rows && planes_out) TCHECK(hipMemcpy(planes_out, dpo, (size_t)B * pl_rows * T * 4, hipMemcpyDeviceToHost));
     hipFree(dA); hipFree(dx); hipFree(dxp); hipFree(d1); hipFree(d2); hipFree(dres); hipFree(dpl); hipFree(dpo); hipFree(dlen);
+    return VITS_OK;
+}
+
+// A/B hook: the short-launch kernel's launch-size limit (0 = every launch on the engine); returns the previous value
+long long vits_test_set_sx_small_max(long long wgs) { return sx_small_max().exchange(wgs); }
+
+// The WN in-layer with its gate epilogue (SX_GATE; f16x3, 16x16x32 loop): acts = tanh(a + g_a) * sigmoid(b + g_b), a / b = the
+// conv's rows.  w / bias arrive in the PACKED row order (32 tanh rows, their 32 sigmoid partners, the next 32 tanh rows, ..: what
+// model.cpp's out_perm produces), bias_b [B][Cout] (the per-utterance conditioning) in the module's order (tanh half, sigmoid
+// half).  flags bit 0: the short-launch kernel (conv_sx_small.hip.hpp) instead of the engine's; bit 1: acts through the fp16
+// operand planes instead of the planar fp32 output.  out = [B][Cout / 2][T].
+int vits_test_conv1d_sx_gate(int device_id, const float *x, int B, int Cin, int T, const float *w, const float *bias,
+                             const float *bias_b, int Cout, int K, int dil, int flags, float *out) {
+    if (int rc = test_dev(device_id)) return rc;
+    if (Cin % 32 || Cout % 64) return fail(nullptr, VITS_E_ARG, "bad gate test shape");
+    ConvDesc d;
+    std::vector<float> arena;
+    set_sx_f16(true);
+    std::string e = pack_test_conv(w, bias, Cin, Cout, K, dil, dil * (K - 1) / 2, 3, &d, &arena);
+    set_sx_f16(false);
+    if (!e.empty()) return fail(nullptr, VITS_E_ARG, "%s", e.c_str());
+    if (!d.s16) return fail(nullptr, VITS_E_ARG, "shape not taken by the 16x16x32 loop");
+    const int H = Cout / 2;
+    const size_t nx = (size_t)B * Cin * T, no = (size_t)B * H * T;
+    float *dA = nullptr, *dx = nullptr, *dact = nullptr, *dbb = nullptr;
+    uint16_t *dxp = nullptr, *dpl = nullptr;
+    TCHECK(hipMalloc((void **)&dA, arena.size() * 4));
+    TCHECK(hipMalloc((void **)&dx, nx * 4 + 16));
+    TCHECK(hipMalloc((void **)&dxp, nx * 6 + 64));
+    TCHECK(hipMalloc((void **)&dact, no * 4 + 16));
+    TCHECK(hipMalloc((void **)&dpl, no * 6 + 64));
+    TCHECK(hipMalloc((void **)&dbb, (size_t)B * Cout * 4));
+    TCHECK(hipMemcpy(dA, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dx, x, nx * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemcpy(dbb, bias_b, (size_t)B * Cout * 4, hipMemcpyHostToDevice));
+    TCHECK(hipMemset(dact, 0xff, no * 4));
+    sx_split_planes_kernel<<<dim3((T + 255) / 256, Cin / 8, B), 256>>>(dx, (int64_t)Cin * T, T, nullptr, dxp, Cin, T, 1);
+    SxArgs a{};
+    fill_sx_args(a, d, dA, T);
+    a.wscale = d.wscale;
+    a.s16 = 1;
+    a.xp = reinterpret_cast<const u32x4 *>(dxp);
+    a.bias_b = dbb;
+    a.bias_b_stride = Cout;
+    a.flags = SX_GATE;
+    a.raw_bstride = (int64_t)H * T;
+    a.pl_bstride = (int64_t)3 * H * T;
+    if (flags & 2) a.out_pl = dpl;
+    else a.out_raw = dact;
+    if (flags & 1) {
+        if (!conv_sx_small_ok(a, false, 2)) return fail(nullptr, VITS_E_ARG, "arguments not taken by the short-launch kernel");
+        TCHECK(launch_conv_sx_small(a, B, d.cfg, nullptr));
+    } else
+        TCHECK(launch_conv_sx(a, d.cfg == 0 ? 3 : d.cfg, B, nullptr, false, 2, d.cfg));
+    if (flags & 2) sx_unblock_kernel<<<dim3((T + 255) / 256, H / 8, B), 256>>>(nullptr, dpl, dact, H, T, 1);
+    TCHECK(hipGetLastError());
+    TCHECK(hipDeviceSynchronize());
+    TCHECK(hipMemcpy(out, dact, no * 4, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dx); hipFree(dxp); hipFree(dact); hipFree(dpl); hipFree(dbb);
     return VITS_OK;
 }
 

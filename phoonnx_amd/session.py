@@ -843,6 +843,28 @@ def test_conv1d_sx_planar(x, w, bias=None, dil=1, lens=None, old=None, row_split
     return out, pl
 
 
+def test_conv1d_sx_gate(x, w, bias, g, dil=1, small=False, planes=False, device_id=0):
+    """The flow's WN in-layer with its gate epilogue: acts = tanh(a + g_a) * sigmoid(b + g_b) where (a | b) = conv(x) + bias
+    ("same" padding), w [2H, Cin, K], bias [2H], g [B, 2H] in the module's channel order (modules.py:195-203,
+    commons.py:99-106).  The hook wants the rows pair-interleaved the way the packer lays them out; that permutation is
+    applied here.  small: the short-launch kernel; planes: the result through the fp16 operand planes.  -> [B, H, T]"""
+    lib = _ffi.load()
+    x = np.ascontiguousarray(x, np.float32)
+    B, Cin, T = x.shape
+    C2, _, K = w.shape
+    H = C2 // 2
+    perm = np.concatenate([np.concatenate([np.arange(p, p + 32), H + np.arange(p, p + 32)]) for p in range(0, H, 32)])
+    wp = np.ascontiguousarray(np.asarray(w, np.float32)[perm])
+    bp = np.ascontiguousarray(np.asarray(bias, np.float32)[perm])
+    gg = np.ascontiguousarray(g, np.float32)
+    out = np.empty((B, H, T), np.float32)
+    rc = lib.vits_test_conv1d_sx_gate(device_id, _ffi.ptr(x), B, Cin, T, _ffi.ptr(wp), _ffi.ptr(bp), _ffi.ptr(gg), C2, K, dil,
+                                      (1 if small else 0) | (2 if planes else 0), _ffi.ptr(out))
+    if rc != 0:
+        raise SessionError(_ffi.last_error(None))
+    return out
+
+
 def test_conv_pair_sx(x, w1, b1, w2, b2, dil1=1, dil2=1, chain=False, slope=0.1, device_id=0, timed=False, kernel="pair",
                       from_plane=False):
     """Two dependent convs in ONE fused launch (32- / 64-channel stage of the generator):

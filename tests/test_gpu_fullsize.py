@@ -499,6 +499,35 @@ def test_config4_batch64_properties_f16_vocoder():
     s.close()
 
 
+@pytest.mark.parametrize("preset", ["medium", "high"])
+def test_single_utterance_short_launch_kernels_match_the_engine(preset):
+    """The reference's real call (one utterance, voice.py:350-351) runs its token- / frame-domain convs on the short-launch
+    kernel (conv_sx_small.hip.hpp) and, with it switched off, on the throughput engine: same durations, same frame count,
+    taps and waveform within fp32 summation-order distance."""
+    from phoonnx_amd import MiSession, _ffi
+    lib = _ffi.load()
+    s = MiSession(_voice(preset))
+    rng = np.random.default_rng(11)
+    ids = rng.integers(0, 256, (1, 200)).astype(np.int64)
+    lens = np.array([200], np.int64)
+    sc = np.array([0.0, 1.2, 0.0], np.float32)   # (no noise: both renderings are functions of the ids alone)
+    a = s.synthesize_batch(ids, lens, sc, taps=("w_ceil", "z_p", "z"))
+    assert s.stats()["sx_launches"] > 0
+    prev = lib.vits_test_set_sx_small_max(0)
+    try:
+        b = s.synthesize_batch(ids, lens, sc, taps=("w_ceil", "z_p", "z"))
+    finally:
+        lib.vits_test_set_sx_small_max(prev)
+    assert prev > 0
+    assert np.array_equal(a["w_ceil"], b["w_ceil"]) and np.array_equal(a["y_lengths"], b["y_lengths"])
+    for k in ("z_p", "z"):
+        np.testing.assert_allclose(a[k], b[k], atol=2e-5, rtol=0, err_msg=k)
+    d = float(np.abs(a["output"] - b["output"]).max())
+    print(f"{preset}: one utterance, short-launch kernels vs engine: waveform max-abs {d:.3g}")
+    assert d < 2e-5
+    s.close()
+
+
 def test_langid_voice_runs_and_ignores_the_language_id(tmp_path):
     """A third-party style graph that declares `langid` (voice.py:369): the feed built by TTSVoice passes through."""
     from phoonnx_amd import MiSession, SessionError

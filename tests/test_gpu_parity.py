@@ -775,6 +775,24 @@ def test_conv_sx_planar_epilogue_matches_float64(B, Cin, Cout, T, K, row_split, 
         np.testing.assert_allclose(planes, ref, atol=2e-5 * scale, rtol=0)
 
 
+@pytest.mark.parametrize("small", [False, True], ids=["engine", "short-launch"])
+@pytest.mark.parametrize("planes", [False, True], ids=["planar", "planes"])
+@pytest.mark.parametrize("B,Cin,H,T,K", [(2, 192, 192, 300, 5), (1, 192, 192, 97, 5), (3, 96, 64, 50, 3)])
+def test_conv_sx_gate_epilogue_matches_float64(B, Cin, H, T, K, planes, small):
+    """Kernel level: the WN in-layer + gate (fused_add_tanh_sigmoid_multiply, commons.py:99-106 on modules.py:195-203) on the
+    split-operand engine and on the short-launch kernel, against float64: acts = tanh(a + g_a) * sigmoid(b + g_b)."""
+    from phoonnx_amd.session import test_conv1d_sx_gate
+    rng = np.random.default_rng(B * 100 + T + K)
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((2 * H, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    bias = rng.standard_normal(2 * H).astype(np.float32)
+    g = rng.standard_normal((B, 2 * H)).astype(np.float32)
+    got = test_conv1d_sx_gate(x, w, bias, g, small=small, planes=planes)
+    v = _conv_same_f64(x, w, bias, 1) + g.astype(np.float64)[:, :, None]
+    want = np.tanh(v[:, :H]) / (1.0 + np.exp(-v[:, H:]))
+    np.testing.assert_allclose(got, want, atol=3e-6, rtol=0)
+
+
 def test_fused_mrf_stage_is_bit_identical_to_separate_chains(monkeypatch):
     """The 32-channel ResBlock2 stage as ONE launch (conv_sx_pair_kernel<.., NCH>: every chain from one resident x tile,
     the multi-receptive-field sum in registers; opt-in, VITSMI_SX_MRF=1) against the default chain-per-launch form: same
