@@ -306,7 +306,7 @@ int vits_test_conv1d_sx_planar(int device_id, const float *x, int B, int Cin, in
                                int Cout, int K, int dil, int flags, const int64_t *lens, const float *old, int row_split,
                                int pl_rows, float *out, float *planes_out);
 /* A/B hook: largest conv launch (workgroups of csrc/conv_sx_small.hip.hpp's kernel) that takes the short-launch kernel;
- * 0 = never (process-wide; default 768 or VITSMI_SX_SMALL_MAX).  Returns the previous value. */
+ * 0 = never (process-wide; default 1536 or VITSMI_SX_SMALL_MAX).  Returns the previous value. */
 long long vits_test_set_sx_small_max(long long wgs);
 /* The WN in-layer conv with the gate epilogue (tanh(a + g_a) * sigmoid(b + g_b)): w / bias in the packed row order (32 tanh
  * rows, their 32 sigmoid partners, ...), bias_b [B][Cout] in the module's order; flags bit 0: the short-launch kernel, bit 1:

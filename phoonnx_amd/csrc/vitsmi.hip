@@ -356,7 +356,7 @@ struct SxWn {               // SX_WN_RMW arguments of conv_sx()
 // largest launch (in workgroups of the short-launch kernel) that conv_sx() hands to conv_sx_small_kernel; process-wide,
 // VITSMI_SX_SMALL_MAX at start-up, vits_test_set_sx_small_max() for A/B tests
 std::atomic<long long> &sx_small_max() {
-    static std::atomic<long long> v{[] { const char *e = std::getenv("VITSMI_SX_SMALL_MAX"); return e ? std::atoll(e) : 768ll; }()};
+    static std::atomic<long long> v{[] { const char *e = std::getenv("VITSMI_SX_SMALL_MAX"); return e ? std::atoll(e) : 1536ll; }()};
     return v;
 }
 
