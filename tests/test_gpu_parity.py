@@ -730,6 +730,8 @@ PLANAR_CASES = [
     (2, 192, 192, 500, 1, 0, 192, dict(mask=True, accumulate=True, planes_of2=True)),  # ... last layer: planes of skip
     (2, 192, 96, 700, 1, None, 96, dict(mask=True, accumulate=True, coupling=True)),   # coupling post: x1 update + planes
     (1, 96, 192, 97, 1, None, 192, dict(mask=True)),                          # coupling pre (three 32-channel chunks)
+    (2, 768, 192, 300, 3, None, 192, dict(mask=True, accumulate=True)),       # FFN conv_2 with planes
+    (2, 256, 128, 200, 3, None, 0, dict(relu=True, mask=True)),               # eight chunks, ReLU, no old operand
 ]
 
 
