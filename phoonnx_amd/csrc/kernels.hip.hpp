@@ -491,6 +491,200 @@ __global__ __launch_bounds__(256) void dds_layer_kernel(DdsLayerArgs a) {
     }
 }
 
+// ---- a6, 16 columns per workgroup (round 4).  dds_layer_kernel above takes 32 time steps per workgroup because its matrix
+// instruction (32x32x2) has 32 columns: a 256-token utterance is 8 workgroups, each with a chain of 192 dependent 64-cycle MFMAs
+// on its busiest waves (6 row blocks over 4 waves: 2, 2, 1, 1) behind a stage 1 of 72 loads and 24 GELUs per thread - 35 k cycles
+// per layer, 12 layers per utterance.  Here: v_mfma_f32_16x16x4_f32 (the same exact fp32 FMA chains, 16 columns), twice the
+// workgroups, C / 16 row tiles dealt evenly (192 channels: 3 per wave, 144 dependent 32-cycle MFMAs), half the stage-1 work per
+// thread.  Weights: DDSDesc::L::pw16 (model.cpp: lane (row & 15, k & 3) reads float4 = four consecutive k-steps of its row).
+struct DdsLayer16Args {
+    const float *in;
+    float *out;
+    const int *len;
+    const float *dw_w, *dw_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const float *pw16, *pw_bias;
+    int T, dil, mask_out;
+};
+
+template <int NBLK>  // C / 32
+__global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
+    constexpr int C = NBLK * 32, NRT = C / 16, NS = C / 4, NS4 = NS / 4;  // row tiles, k-steps, float4 groups of steps per row
+    constexpr int MAXR = (NRT + 3) / 4;                                     // row tiles per wave
+    constexpr int CPT = C / 16;                                            // stage 1: channels per thread
+    __shared__ float y1[C * 16];   // [ci][tl]: B operand of the 1x1 conv
+    __shared__ float red[16][16];
+    __shared__ float stat[2][16];
+    __shared__ float prm[9][C];    // dw_b, dw_w tap 0..2, ln1_g, ln1_b, pw_bias, ln2_g, ln2_b
+    const int tid = threadIdx.x, tl = tid & 15, cg = tid >> 4;
+    const int lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    const int t0 = blockIdx.x * 16, t = t0 + tl, b = blockIdx.y;
+    const int T = a.T;
+    const int L = a.len ? a.len[b] : T;
+    const bool tv = t < T;
+    const float *p = a.in + (int64_t)b * C * T;
+    float *o = a.out + (int64_t)b * C * T;
+    for (int e = tid; e < C; e += 256) {
+        prm[0][e] = a.dw_b[e];
+        prm[1][e] = a.dw_w[e * 3];
+        prm[2][e] = a.dw_w[e * 3 + 1];
+        prm[3][e] = a.dw_w[e * 3 + 2];
+        prm[4][e] = a.ln1_g[e];
+        prm[5][e] = a.ln1_b[e];
+        prm[6][e] = a.pw_bias[e];
+        prm[7][e] = a.ln2_g[e];
+        prm[8][e] = a.ln2_b[e];
+    }
+    // ---- stage 1: depthwise conv (k = 3) of x * mask, LayerNorm over channels, GELU -> y1 (thread: channels cg + 16 i)
+    {
+        float v[CPT];
+        const int pad = a.dil;
+        float s = 0.f;
+        bool ok[3];
+        int tt[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            tt[k] = t + k * a.dil - pad;
+            ok[k] = tv && tt[k] >= 0 && tt[k] < T && tt[k] < L;
+            tt[k] = ok[k] ? tt[k] : 0;
+        }
+        float xr[CPT][3];
+#pragma unroll
+        for (int i = 0; i < CPT; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) xr[i][k] = p[(int64_t)(cg + 16 * i) * T + tt[k]];
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();  // prm is in LDS
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = cg + 16 * i;
+            float x = prm[0][c];
+#pragma unroll
+            for (int k = 0; k < 3; k++) x += prm[1 + k][c] * (ok[k] ? xr[i][k] : 0.f);
+            v[i] = tv ? x : 0.f;
+            s += v[i];
+        }
+        red[cg][tl] = s;
+        __syncthreads();
+        float mean = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; g++) mean += red[g][tl];
+        mean /= (float)C;
+        __syncthreads();
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const float d = v[i] - mean;
+            q += d * d;
+        }
+        red[cg][tl] = q;
+        __syncthreads();
+        float var = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; g++) var += red[g][tl];
+        var /= (float)C;
+        const float rs = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int c = cg + 16 * i;
+            y1[c * 16 + tl] = tv ? gelu_erf((v[i] - mean) * rs * prm[4][c] + prm[5][c]) : 0.f;
+        }
+    }
+    // this wave's first row tile of weights travels under the barrier; the residual operands of all its tiles too
+    const float4 *wp = reinterpret_cast<const float4 *>(a.pw16);
+    float4 wa[2][NS4];
+    auto load_w = [&](int set, int rt) {
+#pragma unroll
+        for (int i = 0; i < NS4; i++) wa[set][i] = wp[((int64_t)(rt * 4 + kq) * 16 + col) * NS4 + i];
+    };
+    if (wave < NRT) load_w(0, wave);
+    const int tc = t0 + col;
+    const bool tcv = tc < T;
+    float resv[MAXR][4];
+#pragma unroll
+    for (int j = 0; j < MAXR; j++) {
+        const int rt = wave + 4 * j;
+        if (rt < NRT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) resv[j][r] = p[(int64_t)(rt * 16 + 4 * kq + r) * T + (tcv ? tc : 0)];
+        }
+    }
+    __syncthreads();
+    // ---- stage 2: 1x1 conv.  A lane (row & 15 = col id of A, k & 3 = kq) x B lane (column col, k & 3 = kq); C/D: column col,
+    // rows 4 kq + r of the tile.  The next tile's weights are requested before this tile's chain starts.
+    f32x4 acc[MAXR];
+    const float *yb = y1 + kq * 16 + col;
+#pragma unroll
+    for (int j = 0; j < MAXR; j++) {
+        const int rt = wave + 4 * j;
+        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rt < NRT) {  // (uniform per wave)
+            if (j + 1 < MAXR && rt + 4 < NRT) load_w((j + 1) & 1, rt + 4);
+#pragma unroll
+            for (int i = 0; i < NS4; i++) {
+                const float4 w = wa[j & 1][i];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, yb[(16 * i + 0) * 16], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, yb[(16 * i + 4) * 16], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, yb[(16 * i + 8) * 16], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, yb[(16 * i + 12) * 16], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- stage 3: + bias, LayerNorm over channels (this lane: column col, rows 4 kq + r of its tiles), GELU, residual, mask
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXR; j++) {
+        const int rt = wave + 4 * j;
+        if (rt < NRT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[j][r] += prm[6][rt * 16 + 4 * kq + r];
+                s += acc[j][r];
+            }
+        }
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    __syncthreads();  // (red is free again)
+    if (kq == 0) red[wave][col] = s;
+    __syncthreads();
+    if (tid < 16) stat[0][tid] = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) / (float)C;
+    __syncthreads();
+    const float mean = stat[0][col];
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXR; j++) {
+        const int rt = wave + 4 * j;
+        if (rt < NRT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float d = acc[j][r] - mean;
+                q += d * d;
+            }
+        }
+    }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    if (kq == 0) red[4 + wave][col] = q;
+    __syncthreads();
+    if (tid < 16) stat[1][tid] = 1.0f / sqrtf((red[4][tid] + red[5][tid] + red[6][tid] + red[7][tid]) / (float)C + 1e-5f);
+    __syncthreads();
+    const float rs = stat[1][col];
+    if (!tcv) return;
+    const float mk = (!a.mask_out || tc < L) ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXR; j++) {
+        const int rt = wave + 4 * j;
+        if (rt < NRT) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int c = rt * 16 + 4 * kq + r;
+                const float y = gelu_erf((acc[j][r] - mean) * rs * prm[7][c] + prm[8][c]);
+                o[(int64_t)c * T + tc] = (resv[j][r] + y) * mk;
+            }
+        }
+    }
+}
+
 // ---- a7: ConvFlow pre (1 -> C) + conditioning add: h = w*z[ch] + b + cond (modules.py:498-499,119)
 // grid (T / 256, C, B): one element per thread (a per-thread loop over the channels is a chain of C dependent
 // load -> store round trips on a handful of waves)

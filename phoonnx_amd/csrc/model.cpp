@@ -931,6 +931,19 @@ DDSDesc pack_dds(Packer &P, const Resolver &R, const std::string &pfx) {
         L.ln2_b = P.put(R.need(pfx + ".norms_2." + std::to_string(l) + ".beta", 1, Cd));
         L.pw = pack_named(P, R, pfx + ".convs_1x1." + std::to_string(l), 1, 0);
         if (L.pw.Cin != Cd || L.pw.Cout != Cd) throw std::runtime_error(pfx + ": 1x1 conv does not match the depthwise width");
+        if (Cd % 16 == 0) {
+            // the 16-column kernel's A fragments: lane (row & 15, k & 3) reads its row's weights of k = 4 step + (k & 3), four
+            // consecutive steps per float4: Wp[((row tile * 4 + k & 3) * 16 + row & 15) * (C / 4) + step]
+            const TRef &w1 = R.need(pfx + ".convs_1x1." + std::to_string(l) + ".weight", 3);
+            const int C = int(Cd), NS = C / 4;
+            L.pw16 = P.alloc(int64_t(C) * C);
+            if (!P.dry) {
+                float *dst = P.arena.data() + L.pw16;
+                for (int o = 0; o < C; o++)
+                    for (int i = 0; i < C; i++)
+                        dst[(int64_t((o / 16) * 4 + (i & 3)) * 16 + (o & 15)) * NS + (i >> 2)] = w1.p[int64_t(o) * C + i];
+            }
+        }
     }
     if (!d.n_layers) throw std::runtime_error("no DDSConv layers under " + pfx);
     return d;

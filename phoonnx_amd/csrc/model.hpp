@@ -58,6 +58,7 @@ struct DDSDesc {  // modules.py:81-129
         int dil = 1;
         int64_t ln1_g = -1, ln1_b = -1, ln2_g = -1, ln2_b = -1;
         ConvDesc pw;  // 1x1
+        int64_t pw16 = -1;  // the same weights as the A operand of v_mfma_f32_16x16x4_f32 (dds_layer16_kernel): [C/16][4][16][C/4]
     } l[4];
 };
 

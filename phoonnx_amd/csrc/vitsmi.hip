@@ -805,6 +805,42 @@ void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const i
             if (nxt == cur) {                             // ... unless it would read it too (n_layers == 1): detour
                 nxt = 1;
             }
+            // 16 columns per workgroup on v_mfma_f32_16x16x4_f32 (kernels.hip.hpp dds_layer16_kernel; VITSMI_DDS16=0: the
+            // 32-column kernel, A/B timing)
+            static const bool dds16_off = [] { const char *e = std::getenv("VITSMI_DDS16"); return e && e[0] == '0'; }();
+            if (!dds16_off && L.pw16 >= 0 && (nblk == 2 || nblk == 4 || nblk == 6 || nblk == 8)) {
+                DdsLayer16Args q{};
+                q.in = bufs[cur];
+                q.out = bufs[nxt];
+                q.len = len;
+                q.dw_w = c.P(L.dw_w);
+                q.dw_b = c.P(L.dw_b);
+                q.ln1_g = c.P(L.ln1_g);
+                q.ln1_b = c.P(L.ln1_b);
+                q.ln2_g = c.P(L.ln2_g);
+                q.ln2_b = c.P(L.ln2_b);
+                q.pw16 = c.P(L.pw16);
+                q.pw_bias = L.pw.b_off >= 0 ? c.P(L.pw.b_off) : c.P(c.m.zeros_off);
+                q.T = T;
+                q.dil = L.dil;
+                q.mask_out = l == d.n_layers - 1;
+                const dim3 dg16((T + 15) / 16, c.B);
+                switch (nblk) {
+                    case 2: dds_layer16_kernel<2><<<dg16, 256, 0, c.st>>>(q); break;
+                    case 4: dds_layer16_kernel<4><<<dg16, 256, 0, c.st>>>(q); break;
+                    case 6: dds_layer16_kernel<6><<<dg16, 256, 0, c.st>>>(q); break;
+                    default: dds_layer16_kernel<8><<<dg16, 256, 0, c.st>>>(q); break;
+                }
+                c.note(hipGetLastError());
+                c.h->stats.total_launches++;
+                {
+                    const double fl = 2.0 * L.pw.macs_per_t * (double)T * c.B;
+                    c.h->stats.conv_flops += fl;
+                    (c.h->cur_stage == 1 ? c.h->stats.dp_flops : c.h->stats.enc_flops) += fl;
+                }
+                cur = nxt;
+                continue;
+            }
             DdsLayerArgs a{};
             a.in = bufs[cur];
             a.out = bufs[nxt];
