@@ -576,7 +576,9 @@ def _planes_value(pl):
 
 
 ATT16_CASES = [(1, 2, 96, 256, [256]), (2, 2, 96, 70, [33, 70]), (1, 1, 64, 3, [3]), (2, 2, 32, 129, [129, 64]),
-               (3, 2, 96, 500, [500, 1, 257]), (2, 4, 32, 65, [64, 65]), (1, 2, 96, 33, [32])]
+               (3, 2, 96, 500, [500, 1, 257]), (2, 4, 32, 65, [64, 65]), (1, 2, 96, 33, [32]),
+               # (a launch of more than one workgroup per CU, ragged)
+               (40, 2, 96, 300, [300 - 7 * i for i in range(40)])]
 
 
 @pytest.mark.parametrize("B,heads,dk,T,lens", ATT16_CASES)

@@ -9,7 +9,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from phoonnx_amd.session import test_attention16
 rng = np.random.default_rng(0)
-for B, T in ((32, 500), (1, 500), (32, 128), (64, 300)):
+for B, T in ((32, 500), (1, 500), (32, 128), (64, 300), (32, 256), (1, 256)):
     heads, dk = 2, 96
     C = heads * dk
     qkv = rng.standard_normal((B, 3 * C, T)).astype(np.float32)
