@@ -504,6 +504,12 @@ struct DdsLayer16Args {
     const float *dw_w, *dw_b, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     const float *pw16, *pw_bias;
     int T, dil, mask_out;
+    // optional tail (the LAST layer of a stack): the 1 x 1 conv that follows the stack - C -> tail_rows, weights in the pw16
+    // layout with the rows padded to 16 - applied to the layer's result while it is in LDS: tail_out[b][row][t] = (W out + bias)
+    // [* (t < len)]; `out` itself is then not stored.  (models.py:69, modules.py:500: proj(h) * x_mask)
+    const float *tail_w16, *tail_b;
+    float *tail_out;
+    int tail_rows, tail_mask;
 };
 
 template <int NBLK>  // C / 32
@@ -669,8 +675,9 @@ __global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
     if (tid < 16) stat[1][tid] = 1.0f / sqrtf((red[4][tid] + red[5][tid] + red[6][tid] + red[7][tid]) / (float)C + 1e-5f);
     __syncthreads();
     const float rs = stat[1][col];
-    if (!tcv) return;
     const float mk = (!a.mask_out || tc < L) ? 1.f : 0.f;
+    const bool tail = a.tail_w16 != nullptr;  // (uniform)
+    if (!tail && !tcv) return;
 #pragma unroll
     for (int j = 0; j < MAXR; j++) {
         const int rt = wave + 4 * j;
@@ -679,7 +686,36 @@ __global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
             for (int r = 0; r < 4; r++) {
                 const int c = rt * 16 + 4 * kq + r;
                 const float y = gelu_erf((acc[j][r] - mean) * rs * prm[7][c] + prm[8][c]);
-                o[(int64_t)c * T + tc] = (resv[j][r] + y) * mk;
+                const float v = (resv[j][r] + y) * mk;
+                if (tail) y1[c * 16 + col] = tcv ? v : 0.f;  // (y1 is free: every wave passed a barrier after its MFMA chain)
+                else o[(int64_t)c * T + tc] = v;
+            }
+        }
+    }
+    if (!tail) return;
+    __syncthreads();
+    // ---- tail: tail_rows x C times the [C][16] result, row tiles of 16 dealt to the waves
+    const float4 *tw = reinterpret_cast<const float4 *>(a.tail_w16);
+    const int nrt2 = (a.tail_rows + 15) >> 4;
+    float *to = a.tail_out + (int64_t)b * a.tail_rows * T;
+    const float tmk = (!a.tail_mask || tc < L) ? 1.f : 0.f;
+    for (int rt = wave; rt < nrt2; rt += 4) {
+        float4 w[NS4];
+#pragma unroll
+        for (int i = 0; i < NS4; i++) w[i] = tw[((int64_t)(rt * 4 + kq) * 16 + col) * NS4 + i];
+        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NS4; i++) {
+            t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, yb[(16 * i + 0) * 16], t4, 0, 0, 0);
+            t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, yb[(16 * i + 4) * 16], t4, 0, 0, 0);
+            t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, yb[(16 * i + 8) * 16], t4, 0, 0, 0);
+            t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, yb[(16 * i + 12) * 16], t4, 0, 0, 0);
+        }
+        if (tcv) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rt * 16 + 4 * kq + r;
+                if (row < a.tail_rows) to[(int64_t)row * T + tc] = (t4[r] + (a.tail_b ? a.tail_b[row] : 0.f)) * tmk;
             }
         }
     }

@@ -949,6 +949,23 @@ DDSDesc pack_dds(Packer &P, const Resolver &R, const std::string &pfx) {
     return d;
 }
 
+// A 1 x 1 conv [Cout, Cin, 1] in the A-operand layout of dds_layer16_kernel (see pack_dds: pw16), rows zero-padded to a
+// multiple of 16: the conv that follows a DDSConv stack runs as the tail of its last layer.  -1 where the shape does not fit.
+int64_t pack_pw16(Packer &P, const Resolver &R, const std::string &name, int Cin) {
+    const TRef *w = R.get(name + ".weight");
+    if (!w || w->dims.size() != 3 || w->dims[2] != 1 || w->dims[1] != Cin || Cin % 16 || R.geti(name + ".group", 1) != 1) return -1;
+    const int Cout = int(w->dims[0]), Cp = (Cout + 15) / 16 * 16, NS = Cin / 4;
+    const int64_t off = P.alloc(int64_t(Cp) * Cin);
+    if (!P.dry) {
+        float *dst = P.arena.data() + off;
+        for (int64_t i = 0; i < int64_t(Cp) * Cin; i++) dst[i] = 0.f;
+        for (int o = 0; o < Cout; o++)
+            for (int i = 0; i < Cin; i++)
+                dst[(int64_t((o / 16) * 4 + (i & 3)) * 16 + (o & 15)) * NS + (i >> 2)] = w->p[int64_t(o) * Cin + i];
+    }
+    return off;
+}
+
 }  // namespace
 
 uint16_t bf16_rne(float f) {
@@ -1220,6 +1237,7 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
         if (use_sdp) {
             dp_pre = pack_named(P, R, "dp.pre", 1, 0);
             dp_proj = pack_named(P, R, "dp.proj", 1, 0);
+            dp_proj16 = pack_pw16(P, R, "dp.proj", dp_proj.Cin);
             dp_convs = pack_dds(P, R, "dp.convs");
             int order[3] = {7, 5, 3};  // models.py:109-110
             for (int i = 0; i < 3; i++) {
@@ -1229,6 +1247,7 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
                 cf[i].pre_b = P.put(R.need(s + ".pre.bias", 1, Cd));
                 cf[i].convs = pack_dds(P, R, s + ".convs");
                 cf[i].proj = pack_named(P, R, s + ".proj", 1, 0);
+                cf[i].proj16 = pack_pw16(P, R, s + ".proj", cf[i].proj.Cin);
                 if (cf[i].proj.Cin != Cd || cf[i].convs.l[0].pw.Cin != Cd || (cf[i].proj.Cout + 1) % 3)
                     throw std::runtime_error(s + ": unexpected ConvFlow shape");
                 cf[i].nb = (cf[i].proj.Cout + 1) / 3;

@@ -66,6 +66,7 @@ struct ConvFlowDesc {  // modules.py:469-527
     int64_t pre_w = -1, pre_b = -1;  // [C], [C]
     DDSDesc convs;
     ConvDesc proj;  // C -> 3*nb-1
+    int64_t proj16 = -1;  // ... once more in dds_layer16_kernel's A-operand layout (rows padded to 16): the layer's fused tail
     int nb = 10;
 };
 
@@ -129,6 +130,7 @@ struct Model {
 
     // ---- stochastic duration predictor (reverse)
     ConvDesc dp_pre, dp_proj;
+    int64_t dp_proj16 = -1;  // dp_proj in dds_layer16_kernel's A-operand layout (the fused tail of the last DDSConv layer)
     DDSDesc dp_convs;
     ConvFlowDesc cf[3];  // execution order: flows.7, flows.5, flows.3
     float ea_m0 = 0.f, ea_logs0 = 0.f;

@@ -790,8 +790,14 @@ void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const 
 }
 
 // DDSConv (modules.py:117-129) in place on h [B,C,T]; y,y2 are scratch of the same size.
-void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const int *len, int C, int T) {
+// tail (optional): the masked 1 x 1 conv `tail` (weights once more at tail16 in the 16-column kernel's layout) applied to the
+// stack's result inside the last layer's launch, written to tail_out [B][tail->Cout][T]; hbuf does then NOT receive the stack's
+// result.  Returns whether the tail was taken (false: the caller runs the conv itself).
+bool ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const int *len, int C, int T,
+             const ConvDesc *tail = nullptr, int64_t tail16 = -1, float *tail_out = nullptr) {
     static const bool unfused = std::getenv("VITSMI_DDS_UNFUSED") != nullptr;  // A/B timing only
+    static const bool tail_off = [] { const char *e = std::getenv("VITSMI_DDS_TAIL"); return e && e[0] == '0'; }();  // A/B timing only
+    bool tail_done = false;
     const int nblk = C / 32;
     if (!unfused && C <= 256 && C % 32 == 0 && nblk != 5 && nblk != 7 && d.K == 3 && d.n_layers > 0) {
         // one launch per layer (dds_layer_kernel), ping-ponging between the three buffers so that the result of the
@@ -824,6 +830,17 @@ void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const i
                 q.T = T;
                 q.dil = L.dil;
                 q.mask_out = l == d.n_layers - 1;
+                if (left == 0 && tail && tail16 >= 0 && tail_out && !tail_off && tail->Cin == C && tail->K == 1 && tail->Cout <= C) {
+                    q.tail_w16 = c.P(tail16);
+                    q.tail_b = tail->b_off >= 0 ? c.P(tail->b_off) : nullptr;
+                    q.tail_out = tail_out;
+                    q.tail_rows = tail->Cout;
+                    q.tail_mask = 1;
+                    tail_done = true;
+                    const double tfl = 2.0 * tail->macs_per_t * (double)T * c.B;  // (accounted as conv() would)
+                    c.h->stats.conv_flops += tfl;
+                    (c.h->cur_stage == 1 ? c.h->stats.dp_flops : c.h->stats.enc_flops) += tfl;
+                }
                 const dim3 dg16((T + 15) / 16, c.B);
                 switch (nblk) {
                     case 2: dds_layer16_kernel<2><<<dg16, 256, 0, c.st>>>(q); break;
@@ -878,8 +895,8 @@ void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const i
             }
             cur = nxt;
         }
-        if (cur != 0) c.note(hipMemcpyAsync(hbuf, bufs[cur], (size_t)c.B * C * T * 4, hipMemcpyDeviceToDevice, c.st));
-        return;
+        if (cur != 0 && !tail_done) c.note(hipMemcpyAsync(hbuf, bufs[cur], (size_t)c.B * C * T * 4, hipMemcpyDeviceToDevice, c.st));
+        return tail_done;
     }
     for (int l = 0; l < d.n_layers; l++) {
         const auto &L = d.l[l];
@@ -899,6 +916,7 @@ void ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const i
         int fl = LN_GELU | LN_ACCUM | (l == d.n_layers - 1 ? LN_MASK : 0);
         layernorm(c, y2, hbuf, L.ln2_g, L.ln2_b, len, C, T, fl);
     }
+    return false;
 }
 
 void stage_mark(vits_handle *h, int idx) {
@@ -1042,8 +1060,8 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
         float *z = slab_take<float>(s, (size_t)B * 2 * T);
         // h = pre(x) [+ cond(g)] ; DDSConv ; cond = proj(h)*mask (models.py:65-70)
         conv(c, m.dp_pre, x, sHT, T, hb, sC, 0, nullptr, nullptr, 0, dp_cond, m.dp_cond_rows);
-        ddsconv(c, m.dp_convs, hb, y, y2, len, Cd, T);
-        conv(c, m.dp_proj, hb, sC, T, cond, sC, EPI_MASK, len);
+        if (!ddsconv(c, m.dp_convs, hb, y, y2, len, Cd, T, &m.dp_proj, m.dp_proj16, cond))
+            conv(c, m.dp_proj, hb, sC, T, cond, sC, EPI_MASK, len);
         // z = randn * noise_scale_w (models.py:111)
         int64_t nz = (int64_t)B * 2 * T;
         if (noise_w == 0.f) {
@@ -1062,8 +1080,8 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
             int ch0 = swapped, ch1 = swapped ^ 1;
             cf_pre_kernel<<<dim3((T + 255) / 256, Cd, B), 256, 0, st>>>(z, ch0, c.P(cf.pre_w), c.P(cf.pre_b), cond, h2, Cd, T);
             h->stats.total_launches++;
-            ddsconv(c, cf.convs, h2, y, y2, len, Cd, T);
-            conv(c, cf.proj, h2, sC, T, pr, (int64_t)cf.proj.Cout * T, EPI_MASK, len);
+            if (!ddsconv(c, cf.convs, h2, y, y2, len, Cd, T, &cf.proj, cf.proj16, pr))
+                conv(c, cf.proj, h2, sC, T, pr, (int64_t)cf.proj.Cout * T, EPI_MASK, len);
             float sqc = std::sqrt((float)Cd);
             if (cf.nb <= 10)
                 rqs_inverse_kernel<10><<<dim3((T + 63) / 64, B), 64, 0, st>>>(pr, z, len, ch0, ch1, cf.nb, T, sqc);
