@@ -510,6 +510,12 @@ struct DdsLayer16Args {
     const float *tail_w16, *tail_b;
     float *tail_out;
     int tail_rows, tail_mask;
+    // optional head (the FIRST layer of a ConvFlow's stack): the layer's input is h = head_w[c] * z[b][t] + head_b[c] + in[b][c][t]
+    // (ConvFlow.pre, a 1 -> C conv of one channel of z, plus the conditioning tensor `in`: modules.py:498-499) formed while
+    // loading instead of read from a tensor a kernel of its own wrote.  head_z = that channel's row of utterance 0, rows of the
+    // utterances head_zstride apart.
+    const float *head_z, *head_w, *head_b;
+    int64_t head_zstride;
 };
 
 template <int NBLK>  // C / 32
@@ -520,9 +526,10 @@ __global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
     __shared__ float y1[C * 16];   // [ci][tl]: B operand of the 1x1 conv
     __shared__ float red[16][16];
     __shared__ float stat[2][16];
-    __shared__ float prm[9][C];    // dw_b, dw_w tap 0..2, ln1_g, ln1_b, pw_bias, ln2_g, ln2_b
+    __shared__ float prm[11][C];   // dw_b, dw_w tap 0..2, ln1_g, ln1_b, pw_bias, ln2_g, ln2_b, head_w, head_b
     const int tid = threadIdx.x, tl = tid & 15, cg = tid >> 4;
     const int lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+    const bool head = a.head_z != nullptr;  // (uniform)
     const int t0 = blockIdx.x * 16, t = t0 + tl, b = blockIdx.y;
     const int T = a.T;
     const int L = a.len ? a.len[b] : T;
@@ -539,6 +546,8 @@ __global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
         prm[6][e] = a.pw_bias[e];
         prm[7][e] = a.ln2_g[e];
         prm[8][e] = a.ln2_b[e];
+        prm[9][e] = head ? a.head_w[e] : 0.f;
+        prm[10][e] = head ? a.head_b[e] : 0.f;
     }
     // ---- stage 1: depthwise conv (k = 3) of x * mask, LayerNorm over channels, GELU -> y1 (thread: channels cg + 16 i)
     {
@@ -553,11 +562,15 @@ __global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
             ok[k] = tv && tt[k] >= 0 && tt[k] < T && tt[k] < L;
             tt[k] = ok[k] ? tt[k] : 0;
         }
-        float xr[CPT][3];
+        float xr[CPT][3], zt[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < CPT; i++)
 #pragma unroll
             for (int k = 0; k < 3; k++) xr[i][k] = p[(int64_t)(cg + 16 * i) * T + tt[k]];
+        if (head) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) zt[k] = a.head_z[(int64_t)b * a.head_zstride + tt[k]];
+        }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();  // prm is in LDS
 #pragma unroll
@@ -565,7 +578,7 @@ __global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
             const int c = cg + 16 * i;
             float x = prm[0][c];
 #pragma unroll
-            for (int k = 0; k < 3; k++) x += prm[1 + k][c] * (ok[k] ? xr[i][k] : 0.f);
+            for (int k = 0; k < 3; k++) x += prm[1 + k][c] * (ok[k] ? xr[i][k] + (prm[9][c] * zt[k] + prm[10][c]) : 0.f);
             v[i] = tv ? x : 0.f;
             s += v[i];
         }
@@ -614,7 +627,21 @@ __global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
             for (int r = 0; r < 4; r++) resv[j][r] = p[(int64_t)(rt * 16 + 4 * kq + r) * T + (tcv ? tc : 0)];
         }
     }
+    const float zres = head ? a.head_z[(int64_t)b * a.head_zstride + (tcv ? tc : 0)] : 0.f;
     __syncthreads();
+    if (head) {  // (prm is visible since stage 1's first barrier)
+#pragma unroll
+        for (int j = 0; j < MAXR; j++) {
+            const int rt = wave + 4 * j;
+            if (rt < NRT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int c = rt * 16 + 4 * kq + r;
+                    resv[j][r] += prm[9][c] * zres + prm[10][c];
+                }
+            }
+        }
+    }
     // ---- stage 2: 1x1 conv.  A lane (row & 15 = col id of A, k & 3 = kq) x B lane (column col, k & 3 = kq); C/D: column col,
     // rows 4 kq + r of the tile.  The next tile's weights are requested before this tile's chain starts.
     f32x4 acc[MAXR];

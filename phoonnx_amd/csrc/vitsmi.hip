@@ -793,8 +793,22 @@ void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const 
 // tail (optional): the masked 1 x 1 conv `tail` (weights once more at tail16 in the 16-column kernel's layout) applied to the
 // stack's result inside the last layer's launch, written to tail_out [B][tail->Cout][T]; hbuf does then NOT receive the stack's
 // result.  Returns whether the tail was taken (false: the caller runs the conv itself).
+// head (optional, ConvFlow stacks): the stack's input is head->w[c] * z + head->b[c] + head->in (ConvFlow.pre + conditioning),
+// formed by the first layer while it loads; hbuf is then never read.  *head_done tells whether that happened (false: the caller
+// must have filled hbuf, e.g. by cf_pre_kernel).
+struct DdsHead {
+    const float *in, *z, *w, *b;  // conditioning tensor [B][C][T], z channel row of utterance 0 (rows 2 T apart), pre weights
+};
+bool dds16_head_ok(const DDSDesc &d, int C) {
+    static const bool off = [] { const char *e = std::getenv("VITSMI_DDS16"); return e && e[0] == '0'; }();
+    static const bool head_off = [] { const char *e = std::getenv("VITSMI_DDS_HEAD"); return e && e[0] == '0'; }();  // A/B timing only
+    static const bool unfused = std::getenv("VITSMI_DDS_UNFUSED") != nullptr;
+    const int nblk = C / 32;
+    return !off && !head_off && !unfused && C <= 256 && C % 32 == 0 && d.K == 3 && d.n_layers > 1 && d.l[0].pw16 >= 0 &&
+           (nblk == 2 || nblk == 4 || nblk == 6 || nblk == 8);
+}
 bool ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const int *len, int C, int T,
-             const ConvDesc *tail = nullptr, int64_t tail16 = -1, float *tail_out = nullptr) {
+             const ConvDesc *tail = nullptr, int64_t tail16 = -1, float *tail_out = nullptr, const DdsHead *head = nullptr) {
     static const bool unfused = std::getenv("VITSMI_DDS_UNFUSED") != nullptr;  // A/B timing only
     static const bool tail_off = [] { const char *e = std::getenv("VITSMI_DDS_TAIL"); return e && e[0] == '0'; }();  // A/B timing only
     bool tail_done = false;
@@ -818,6 +832,13 @@ bool ddsconv(Ctx &c, const DDSDesc &d, float *hbuf, float *y, float *y2, const i
                 DdsLayer16Args q{};
                 q.in = bufs[cur];
                 q.out = bufs[nxt];
+                if (l == 0 && head) {  // (dds16_head_ok: the caller checked that this path is taken)
+                    q.in = head->in;
+                    q.head_z = head->z;
+                    q.head_w = head->w;
+                    q.head_b = head->b;
+                    q.head_zstride = (int64_t)2 * T;
+                }
                 q.len = len;
                 q.dw_w = c.P(L.dw_w);
                 q.dw_b = c.P(L.dw_b);
@@ -1078,9 +1099,13 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
             swapped ^= 1;  // Flip (modules.py:384-391)
             const auto &cf = m.cf[f];
             int ch0 = swapped, ch1 = swapped ^ 1;
-            cf_pre_kernel<<<dim3((T + 255) / 256, Cd, B), 256, 0, st>>>(z, ch0, c.P(cf.pre_w), c.P(cf.pre_b), cond, h2, Cd, T);
-            h->stats.total_launches++;
-            if (!ddsconv(c, cf.convs, h2, y, y2, len, Cd, T, &cf.proj, cf.proj16, pr))
+            DdsHead hd{cond, z + (int64_t)ch0 * T, c.P(cf.pre_w), c.P(cf.pre_b)};
+            const bool use_head = dds16_head_ok(cf.convs, Cd);
+            if (!use_head) {
+                cf_pre_kernel<<<dim3((T + 255) / 256, Cd, B), 256, 0, st>>>(z, ch0, c.P(cf.pre_w), c.P(cf.pre_b), cond, h2, Cd, T);
+                h->stats.total_launches++;
+            }
+            if (!ddsconv(c, cf.convs, h2, y, y2, len, Cd, T, &cf.proj, cf.proj16, pr, use_head ? &hd : nullptr))
                 conv(c, cf.proj, h2, sC, T, pr, (int64_t)cf.proj.Cout * T, EPI_MASK, len);
             float sqc = std::sqrt((float)Cd);
             if (cf.nb <= 10)
