@@ -12,8 +12,8 @@
 //     barrier in the loop;
 //   * three MFMAs per fp32 product as in the engine, here as two accumulators (g0 h0 + g1 h0, and g0 h1' which carries 2^-11).
 // Epilogues: the planar one of the token / frame domain (SX_WN_RMW: o = old + act(acc + bias) * mask into one or two planar
-// fp32 tensors and / or operand planes; the coupling variant) and the WN gate (SX_GATE: tanh(a) * sigmoid(b) of a packed row
-// pair, per-utterance conditioning bias).  Same argument block (SxArgs) and semantics as conv_sx_kernel; conv_sx() in
+// fp32 tensors and / or operand planes; the coupling variant), the WN gate (SX_GATE: tanh(a) * sigmoid(b) of a packed row
+// pair, per-utterance conditioning bias) and the generator's (raw cells and / or planes, residual, running sum; ups == 1).  Same argument block (SxArgs) and semantics as conv_sx_kernel; conv_sx() in
 // vitsmi.hip picks this kernel when the launch would be at most a few workgroups per CU.
 #pragma once
 #include "conv_sx_engine.hip.hpp"
@@ -166,6 +166,50 @@ __global__ __launch_bounds__(256) void conv_sx_small_kernel(SxArgs a, int MBP) {
         f32x4 val = red[0][wave][lane];
 #pragma unroll
         for (int w = 1; w < 4; w++) val += red[w][wave][lane];
+        if (!(a.flags & SX_WN_RMW)) {
+            // the generator's epilogue (conv_sx_kernel's, ups == 1): bias [+ per-utterance bias] [+ residual] [+ running sum] [/ n],
+            // then fp32 raw cells [Cr/8][T][8] with leaky_relu(oslope) and / or operand planes with leaky_relu(oslope2)
+            const int row0 = mt * 32 + 8 * (2 * sub + (g & 1)) + 4 * (g >> 1);
+            const int t = t0 + n * 16 + c;
+            if (t < T) {
+                const int64_t cell = ((int64_t)(row0 >> 3) * T + t) * 8 + (row0 & 4);
+                float *rawb = a.out_raw ? a.out_raw + (int64_t)b * a.raw_bstride : nullptr;
+                f32x4 v;
+                const f32x4 bq = *reinterpret_cast<const f32x4 *>(biasp + row0 * b_on);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = __builtin_fmaf(val[e], wsc, bq[e]);
+                if (a.bias_b) v += *reinterpret_cast<const f32x4 *>(a.bias_b + (int64_t)b * a.bias_b_stride + row0);
+                if (a.flags & EPI_RES) v += *reinterpret_cast<const f32x4 *>(a.res + (int64_t)b * a.raw_bstride + cell);
+                if (a.flags & EPI_ACC) v += *reinterpret_cast<const f32x4 *>(rawb + cell);
+                if (a.flags & EPI_DIV) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = v[e] / a.div;
+                }
+                if (rawb && !(a.flags & SX_NO_RAW_STORE)) {
+                    f32x4 o = v;
+                    if (a.oslope != 1.f) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o[e] = fmaxf(v[e], v[e] * a.oslope);
+                    }
+                    *reinterpret_cast<f32x4 *>(rawb + cell) = o;
+                }
+                if (a.out_pl) {
+                    f32x4 o = v;
+                    if (a.oslope2 != 1.f) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o[e] = fmaxf(v[e], v[e] * a.oslope2);
+                    }
+                    unsigned wa[2], wb2[2];
+                    split2h_pair_pk(o[0], o[1], wa[0], wa[1], pk);
+                    split2h_pair_pk(o[2], o[3], wb2[0], wb2[1], pk);
+                    uint16_t *plb = a.out_pl + (int64_t)b * a.pl_bstride;
+                    *reinterpret_cast<u32x2 *>(plb + cell) = u32x2{wa[0], wb2[0]};
+                    *reinterpret_cast<u32x2 *>(plb + (int64_t)a.Cr * T + cell) = u32x2{wa[1], wb2[1]};
+                }
+            }
+            if (a.peak) sx_publish_peak_at(a.peak, (int)blockIdx.x, pk, s_pk);  // (all threads arrive)
+            return;
+        }
         const bool p_acc = (a.flags & EPI_ACC) != 0, p_res = (a.flags & EPI_RES) != 0, p_relu = (a.flags & EPI_RELU) != 0;
         const bool coupling = (a.flags & SX_PLANAR_COUPLING) != 0;
         const int Lb = ((a.flags & EPI_MASK) && a.len) ? a.len[b] : T;
@@ -212,7 +256,9 @@ __global__ __launch_bounds__(256) void conv_sx_small_kernel(SxArgs a, int MBP) {
 inline bool conv_sx_small_ok(const SxArgs &a, bool rawin, int nprod) {
     if (rawin || nprod != 2 || !a.s16 || a.ups != 1 || a.Cin % 32 || a.Cout % 32 || a.res_pl || a.prof) return false;
     if (a.flags & SX_GATE) return !(a.flags & SX_WN_RMW) && a.Cr % 64 == 0 && (a.out_raw || a.out_pl);
-    if (!(a.flags & SX_WN_RMW)) return false;
+    if (!(a.flags & SX_WN_RMW))  // the generator's epilogue (plane-input convs of the > 64-channel stages, conv_pre)
+        return a.Cr == a.Cout && (a.out_raw || a.out_pl) && !((a.flags & EPI_RES) && !a.res) && !((a.flags & EPI_ACC) && !a.out_raw) &&
+               !((a.flags & EPI_DIV) && a.div == 0.f) && !(a.flags & (DBG_NO_DMA | DBG_NO_EPI));
     const bool p_acc = (a.flags & EPI_ACC) != 0;
     return !((a.row_split < a.Cout && !a.out_raw2) || (a.row_split && !a.out_raw && (p_acc || !a.out_pl)) || a.row_split % 32 ||
              a.row_split > a.Cout || a.pl_rows % 32 || a.pl_rows > (a.pl_of2 ? a.Cout - a.row_split : a.row_split) ||
@@ -226,6 +272,8 @@ inline long long conv_sx_small_wgs(const SxArgs &a, int B) {
 inline hipError_t launch_conv_sx_small(SxArgs a, int B, int pack_cfg, hipStream_t stream) {
     const bool gate = (a.flags & SX_GATE) != 0;
     if (a.wscale == 0.f) a.wscale = 1.f;
+    if (a.oslope == 0.f) a.oslope = 1.f;
+    if (a.oslope2 == 0.f) a.oslope2 = 1.f;
     a.MT = a.Cout / (gate ? 64 : 32);
     a.NT = (a.T + (gate ? 15 : 31)) / (gate ? 16 : 32);
     a.B = B;

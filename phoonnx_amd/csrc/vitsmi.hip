@@ -2598,7 +2598,12 @@ static int run_test_conv_sx(const ConvDesc &d, const std::vector<float> &arena, 
     }
     const int nprod = d.h1 ? 1 : (d.f16 ? 2 : 6);
     a.wscale = d.wscale;
-    TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, nprod));
+    if (flags & 256) {  // the short-launch kernel (conv_sx_small.hip.hpp) with the generator's epilogue
+        a.s16 = d.s16 ? 1 : 0;
+        if (!conv_sx_small_ok(a, d.rawin, nprod)) return fail(nullptr, VITS_E_ARG, "arguments not taken by the short-launch kernel");
+        TCHECK(launch_conv_sx_small(a, B, d.cfg, nullptr));
+    } else
+        TCHECK(launch_conv_sx(a, d.cfg, B, nullptr, d.rawin, nprod));
     sx_unblock_kernel<<<dim3((To + 255) / 256, Cr / 8, B), 256>>>(draw, (flags & 1) ? dop : nullptr, dout, Cr, To,
                                                                   d.h1 ? 2 : (d.f16 ? 1 : 0));
     TCHECK(hipGetLastError());

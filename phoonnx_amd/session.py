@@ -787,14 +787,15 @@ def test_conv1d(x, w, bias=None, dil=1, pad_l=0, lrelu_slope=None, relu=False, d
 
 
 def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=False, in_slope=None, device_id=0,
-                   precision="f32", planes_only=False):
+                   precision="f32", planes_only=False, small=False):
     """The split-operand engine (Cin % 16 == 0, Cout % 32 == 0).  planes_slope: read the result back from
     the 16-bit output planes, which carry leaky_relu(conv, planes_slope); residual: out = conv(x) + x;
     in_slope: out = conv(leaky_relu(x, in_slope)) [+ x] - Cin <= 64 (the raw-input kernels), or precision "f16", whose
     input plane then holds leaky_relu(x) and whose residual is recovered from that plane.
     precision: "f32" = six exact bf16 plane products; "f16x3" = two fp16 planes, three products (fp32-grade); "f16" = one
     fp16 plane, one product, fp16 storage (the reduced-precision vocoder of BASELINE config 4).
-    planes_only: the planes are the launch's only output (the specialised plane epilogues); needs planes_slope."""
+    planes_only: the planes are the launch's only output (the specialised plane epilogues); needs planes_slope.
+    small: the short-launch kernel (conv_sx_small.hip.hpp, f16x3 on plane inputs, Cin % 32 == 0) with the same epilogue."""
     lib = _ffi.load()
     x = np.ascontiguousarray(x, np.float32)
     w = np.ascontiguousarray(w, np.float32)
@@ -805,6 +806,7 @@ def test_conv1d_sx(x, w, bias=None, dil=1, pad_l=0, planes_slope=None, residual=
     flags = (1 if planes_slope is not None else 0) | (4 if residual else 0) | (8 if in_slope is not None else 0)
     flags |= {"f32": 0, "f16": 2, "f16x3": 3}[precision] << 4
     flags |= 128 if planes_only else 0
+    flags |= 256 if small else 0
     if in_slope is not None and planes_slope is not None and in_slope != planes_slope:
         raise ValueError("the hook takes one slope value")
     if in_slope is not None and Cin > 64 and precision != "f16":

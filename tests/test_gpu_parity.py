@@ -567,6 +567,40 @@ def test_attention_sharp_softmax():
     np.testing.assert_allclose(got, ref, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,T,K,dil", [(2, 128, 128, 700, 3, 1), (1, 128, 128, 333, 7, 3), (2, 192, 256, 97, 7, 1),
+                                                 (1, 256, 256, 130, 11, 5), (3, 128, 128, 64, 5, 2)])
+@pytest.mark.parametrize("mode", ["raw", "planes", "planes_only", "residual"])
+def test_short_launch_kernel_generator_epilogue_matches_the_engine(B, Cin, Cout, T, K, dil, mode):
+    """The generator's epilogue (raw cells, operand planes with the consumer's leaky_relu, residual) on the short-launch kernel
+    (conv_sx_small.hip.hpp: plane-input convs of the > 64-channel stages at batch 1) against the engine's launch of the same
+    conv and against float64."""
+    from phoonnx_amd.session import test_conv1d_sx
+    if mode == "residual" and Cin != Cout:
+        pytest.skip("residual needs Cin == Cout")
+    rng = np.random.default_rng(Cin + T + K)
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    pad = dil * (K - 1) // 2
+    kw = dict(dil=dil, pad_l=pad, precision="f16x3")
+    if mode == "planes":
+        kw["planes_slope"] = 0.1
+    elif mode == "planes_only":
+        kw.update(planes_slope=0.1, planes_only=True)
+    elif mode == "residual":
+        kw["residual"] = True
+    a = test_conv1d_sx(x, w, bias, small=True, **kw)
+    e = test_conv1d_sx(x, w, bias, **kw)
+    want = _conv_same_f64(x, w, bias, dil)
+    if mode == "residual":
+        want = want + x
+    if mode in ("planes", "planes_only"):
+        want = np.where(want > 0, want, 0.1 * want)
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(a, want, atol=3e-6 * scale, rtol=0)
+    np.testing.assert_allclose(a, e, atol=3e-6 * scale, rtol=0)
+
+
 def _planes_value(pl):
     """fp16 operand planes [B, 3, C/8, T, 8] (f16x3 format: h0, h1 * 2^11) -> the fp32 values they stand for [B, C, T]"""
     h = pl.view(np.float16).astype(np.float64)
