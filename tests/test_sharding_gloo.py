@@ -203,11 +203,16 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     run without an MI355X) and exit non-zero; under a launcher whose WORLD_SIZE disagrees with --gpus it must refuse."""
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode != 0
+    # (the elastic agent terminates the surviving rank as soon as the first one has failed: on a loaded box the second rank can
+    # be killed before it reaches its own device check, so the observation is retried - it only has to be made once)
+    for attempt in range(4):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode != 0
+        assert '"metric"' not in r.stdout
+        if r.stderr.count("bench.py needs an MI355X") >= 2:
+            break
     assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-1500:]      # both ranks got as far as the device check
-    assert '"metric"' not in r.stdout
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
                        timeout=120, env=env2)
