@@ -444,7 +444,12 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     // conv_sx_small.hip.hpp.  VITSMI_SX_SMALL_MAX = largest launch in workgroups that takes it (0: never; A/B timing).
     const long long small_max = sx_small_max().load(std::memory_order_relaxed);
     const int nprod = d.h1 ? 1 : (d.f16 ? 2 : 6);
-    if (small_max > 0 && conv_sx_small_ok(a, d.rawin, nprod) && conv_sx_small_wgs(a, c.B) <= small_max)
+    // (generator convs - neither planar nor gated - stay on the engine whatever the launch size: a chunked rendering
+    // (vits_run_chunked) must equal the unchunked one bit for bit, so a conv's kernel must not depend on how many frames a launch
+    // covers.  VITSMI_SX_SMALL_GEN=1 lifts that for single-shot latency: 1.31 -> 1.27 ms on `medium`, 3.34 -> 3.24 on `high`.)
+    static const bool small_gen = [] { const char *e = std::getenv("VITSMI_SX_SMALL_GEN"); return e && e[0] == '1'; }();
+    const bool small_kind = (a.flags & (SX_WN_RMW | SX_GATE)) != 0 || small_gen;
+    if (small_max > 0 && small_kind && conv_sx_small_ok(a, d.rawin, nprod) && conv_sx_small_wgs(a, c.B) <= small_max)
         c.note(launch_conv_sx_small(a, c.B, d.cfg, c.st));
     else
         c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, nprod, d.cfg));
