@@ -138,20 +138,24 @@ __global__ void dds_dw_ln_gelu_kernel(const float *x, float *y, const float *w, 
 // PL: the result is written once more as the two fp16 operand planes of the split-operand conv engine ([C/8][T][8] cells
 // per plane, batch stride 3 planes; conv_sx_engine.hip.hpp), transposed through LDS so that every cell leaves as one
 // 16-byte store; `peak` = that engine's range-guard slots (C % 8 == 0).
-template <int DW, bool PL = false>
+// TS: time steps per workgroup (32, or 16: twice the workgroups with half the loads per thread - the plain LayerNorms of the
+// encoder at batch 32 x 256 tokens are 256 workgroups of pure latency at TS = 32: 11.4 -> see DESIGN 5.3)
+template <int DW, bool PL = false, int TS = 32>
 __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *out, const float *gamma,
                                                       const float *beta, const int *len, int C, int T, int flags,
                                                       const float *dw_w, const float *dw_b, int K, int dil,
                                                       uint16_t *planes = nullptr, unsigned *peak = nullptr) {
-    __shared__ float red[8][32];
-    __shared__ __attribute__((aligned(16))) uint16_t cells[PL ? 2 : 1][PL ? 32 * 32 * 8 : 8];  // [plane][channel group][t][8]
-    const int tid = threadIdx.x, tl = tid & 31, cg = tid >> 5;
-    const int t = blockIdx.x * 32 + tl, b = blockIdx.y;
+    static_assert(TS == 32 || TS == 16, "time steps per workgroup");
+    constexpr int NG = 256 / TS;  // channel groups: thread (tl, cg) owns channels cg, cg + NG, ..
+    __shared__ float red[NG][TS];
+    __shared__ __attribute__((aligned(16))) uint16_t cells[PL ? 2 : 1][PL ? 32 * TS * 8 : 8];  // [plane][channel group of 8][t][8]
+    const int tid = threadIdx.x, tl = tid & (TS - 1), cg = tid / TS;
+    const int t = blockIdx.x * TS + tl, b = blockIdx.y;
     const int L = len ? len[b] : T;
     const bool tv = t < T;
     const float *p = in + (int64_t)b * C * T;
     float *o = out + (int64_t)b * C * T;
-    constexpr int CPT = 32;  // channels per thread, C <= 256
+    constexpr int CPT = 256 / NG;  // channels per thread, C <= 256
     float v[CPT];
     const int pad = (K * dil - dil) / 2;
     float s = 0.f;
@@ -162,14 +166,14 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
     const int tcl = tv ? t : T - 1;
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
-        const int c = cg + 8 * i, cc = c < C ? c : cg;
+        const int c = cg + NG * i, cc = c < C ? c : cg;
         gv[i] = gamma[cc];
         bv[i] = beta[cc];
         if (DW == 0) v[i] = p[(int64_t)cc * T + tcl];
     }
     if (flags & LN_ACCUM) {  // (uniform; `in` and `out` may be the same tensor: read before anything is stored)
 #pragma unroll
-        for (int i = 0; i < CPT; i++) av[i] = o[(int64_t)(cg + 8 * i < C ? cg + 8 * i : cg) * T + tcl];
+        for (int i = 0; i < CPT; i++) av[i] = o[(int64_t)(cg + NG * i < C ? cg + NG * i : cg) * T + tcl];
     } else {
 #pragma unroll
         for (int i = 0; i < CPT; i++) av[i] = 0.f;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
     const float relu_floor = (flags & LN_RELU_IN) ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
-        const int c = cg + 8 * i;
+        const int c = cg + NG * i;
         float x = 0.f;
         if (DW == 0) {
             x = (c < C && tv) ? fmaxf(v[i], relu_floor) : 0.f;
@@ -208,13 +212,13 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; g++) mean += red[g][tl];
+    for (int g = 0; g < NG; g++) mean += red[g][tl];
     mean /= (float)C;
     __syncthreads();
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
-        const int c = cg + 8 * i;
+        const int c = cg + NG * i;
         const float d = (c < C) ? v[i] - mean : 0.f;
         q += d * d;
     }
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
     __syncthreads();
     float var = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; g++) var += red[g][tl];
+    for (int g = 0; g < NG; g++) var += red[g][tl];
     var /= (float)C;
     const float rs = 1.0f / sqrtf(var + 1e-5f);
     const float mk = (!(flags & LN_MASK) || t < L) ? 1.f : 0.f;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
     }
 #pragma unroll
     for (int i = 0; i < CPT; i++) {
-        const int c = cg + 8 * i;
+        const int c = cg + NG * i;
         if (c < C && tv) {
             const float y = yv[i];
             o[(int64_t)c * T + t] = y;
@@ -246,8 +250,8 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
                 pk = !(__builtin_fabsf(y) <= kF16Max) ? __builtin_inff() : __builtin_fmaxf(pk, __builtin_fabsf(y));
                 const float yc = __builtin_amdgcn_fmed3f(y, -65504.f, 65504.f);
                 const _Float16 h0 = (_Float16)yc, h1 = (_Float16)((yc - (float)h0) * 2048.f);
-                cells[0][(i * 32 + tl) * 8 + cg] = __builtin_bit_cast(unsigned short, h0);
-                cells[1][(i * 32 + tl) * 8 + cg] = __builtin_bit_cast(unsigned short, h1);
+                cells[0][((c >> 3) * TS + tl) * 8 + (c & 7)] = __builtin_bit_cast(unsigned short, h0);
+                cells[1][((c >> 3) * TS + tl) * 8 + (c & 7)] = __builtin_bit_cast(unsigned short, h1);
             }
         }
     }
@@ -255,9 +259,9 @@ __global__ __launch_bounds__(256) void ln_tile_kernel(const float *in, float *ou
         __syncthreads();
         const int CG = C >> 3;
         uint16_t *pb = planes + (int64_t)b * 3 * CG * T * 8;
-        const int tb = blockIdx.x * 32;
-        for (int cell = tid; cell < CG * 32; cell += 256) {
-            const int g = cell >> 5, tt = tb + (cell & 31);
+        const int tb = blockIdx.x * TS;
+        for (int cell = tid; cell < CG * TS; cell += 256) {
+            const int g = cell / TS, tt = tb + (cell & (TS - 1));
             if (tt < T) {
 #pragma unroll
                 for (int pl = 0; pl < 2; pl++)

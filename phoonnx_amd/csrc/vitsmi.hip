@@ -781,9 +781,17 @@ void pinned_put(vits_handle *h, void *q) {
 // planes (optional): the result once more as fp16 operand planes of the split-operand engine (see split_planes)
 void layernorm(Ctx &c, const float *in, float *out, int64_t g, int64_t b, const int *len, int C, int T, int flags,
                uint16_t *planes = nullptr) {
-    if (C <= 256 && planes && C % 8 == 0)
+    // (16 time steps per workgroup: VITSMI_LN_TS=32 keeps the 32-step form, A/B timing)
+    static const bool ts32 = [] { const char *e = std::getenv("VITSMI_LN_TS"); return e && std::atoi(e) == 32; }();
+    if (C <= 256 && planes && C % 8 == 0 && !ts32)
+        ln_tile_kernel<0, true, 16><<<dim3((T + 15) / 16, c.B), 256, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags, nullptr,
+                                                                                nullptr, 1, 1, planes, range_slots(c.h, true));
+    else if (C <= 256 && planes && C % 8 == 0)
         ln_tile_kernel<0, true><<<dim3((T + 31) / 32, c.B), 256, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags, nullptr,
                                                                             nullptr, 1, 1, planes, range_slots(c.h, true));
+    else if (C <= 256 && !ts32)
+        ln_tile_kernel<0, false, 16><<<dim3((T + 15) / 16, c.B), 256, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags, nullptr,
+                                                                                 nullptr, 1, 1);
     else if (C <= 256)
         ln_tile_kernel<0><<<dim3((T + 31) / 32, c.B), 256, 0, c.st>>>(in, out, c.P(g), c.P(b), len, C, T, flags, nullptr,
                                                                       nullptr, 1, 1);
