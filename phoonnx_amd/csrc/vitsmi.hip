@@ -65,6 +65,8 @@ struct vits_handle {
     int *d_len = nullptr, *d_ylen = nullptr, *d_cum = nullptr;
     int64_t *d_ylen64 = nullptr;
     std::vector<int> h_ylen;
+    int *h_ylen_pin = nullptr;     // pinned landing buffer of the one mid-run readback (a pageable destination makes the copy a
+    int h_ylen_pin_n = 0;          // staged, synchronous one: the stream then waits for the host twice)
     // stats
     int timing = 0;  // vits_set_timing: 0 off, 1 stage marks + events around every conv launch, 2 stage marks only
     vits_stats stats{};
@@ -1153,8 +1155,17 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     c.note(hipGetLastError());
     if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
     h->h_ylen.resize(B);
-    HIPCHECK(h, hipMemcpyAsync(h->h_ylen.data(), h->d_ylen, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    if (h->h_ylen_pin_n < B) {
+        if (h->h_ylen_pin) hipHostFree(h->h_ylen_pin);
+        h->h_ylen_pin = nullptr;
+        h->h_ylen_pin_n = 0;
+        const int cap = B < 64 ? 64 : B;
+        if (hipHostMalloc((void **)&h->h_ylen_pin, sizeof(int) * cap) == hipSuccess) h->h_ylen_pin_n = cap;
+    }
+    int *ydst = h->h_ylen_pin_n >= B ? h->h_ylen_pin : h->h_ylen.data();
+    HIPCHECK(h, hipMemcpyAsync(ydst, h->d_ylen, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     HIPCHECK(h, hipStreamSynchronize(st));  // the one data-dependent readback: output length
+    if (ydst != h->h_ylen.data()) std::memcpy(h->h_ylen.data(), ydst, sizeof(int) * B);
     if (h->range_pending) {  // an earlier asynchronous run whose range verdict nobody has looked at
         const vits_stats keep = h->stats;
         const int rr = range_check(h);
@@ -1898,6 +1909,7 @@ void vits_close(vits_handle *h) {
         hipSetDevice(h->device);
         if (h->stream) hipStreamSynchronize(h->stream);
         if (h->arena_owned && h->arena_dev) hipFree(h->arena_dev);
+        if (h->h_ylen_pin) hipHostFree(h->h_ylen_pin);
         if (h->tok.base) hipFree(h->tok.base);
         if (h->frm.base) hipFree(h->frm.base);
         if (h->io.base) hipFree(h->io.base);
