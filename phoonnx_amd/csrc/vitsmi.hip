@@ -65,6 +65,8 @@ struct vits_handle {
     int *d_len = nullptr, *d_ylen = nullptr, *d_cum = nullptr;
     int64_t *d_ylen64 = nullptr;
     std::vector<int> h_ylen;
+    char *h_in_pin = nullptr;      // pinned staging of a call's ids | lens | sid: one host-to-device copy instead of three
+    size_t h_in_pin_bytes = 0;     // staged pageable ones
     int *h_ylen_pin = nullptr;     // pinned landing buffer of the one mid-run readback (a pageable destination makes the copy a
     int h_ylen_pin_n = 0;          // staged, synchronous one: the stream then waits for the host twice)
     // stats
@@ -1910,6 +1912,7 @@ void vits_close(vits_handle *h) {
         if (h->stream) hipStreamSynchronize(h->stream);
         if (h->arena_owned && h->arena_dev) hipFree(h->arena_dev);
         if (h->h_ylen_pin) hipHostFree(h->h_ylen_pin);
+        if (h->h_in_pin) hipHostFree(h->h_in_pin);
         if (h->tok.base) hipFree(h->tok.base);
         if (h->frm.base) hipFree(h->frm.base);
         if (h->io.base) hipFree(h->io.base);
@@ -2098,11 +2101,28 @@ static int stage_inputs(vits_handle *h, const int64_t *ids, const int64_t *lens,
         if (rc == VITS_OK && hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st) != hipSuccess)
             rc = fail(h, VITS_E_DEVICE, "host-to-device copy failed");
     };
-    cp(sg.d_ids, ids, (size_t)B * T * 8);
-    cp(sg.d_lens, lens, (size_t)B * 8);
-    if (sid) {
-        cp(d_sid, sid, (size_t)B * 8);
-        sg.d_sid = d_sid;
+    {
+        // ids | lens | sid are contiguous on the device: gather them in pinned memory and send them as one copy
+        const size_t n_ids = (size_t)B * T * 8, n_b = (size_t)B * 8, n_all = n_ids + n_b + (sid ? n_b : 0);
+        if (h->h_in_pin_bytes < n_all) {
+            if (h->h_in_pin) hipHostFree(h->h_in_pin);
+            h->h_in_pin = nullptr;
+            h->h_in_pin_bytes = 0;
+            const size_t cap = n_all < 65536 ? 65536 : n_all;
+            if (hipHostMalloc((void **)&h->h_in_pin, cap) == hipSuccess) h->h_in_pin_bytes = cap;
+        }
+        if (h->h_in_pin_bytes >= n_all) {
+            // (the previous call's copy out of this buffer has completed: every call ends its input phase with a stream sync)
+            std::memcpy(h->h_in_pin, ids, n_ids);
+            std::memcpy(h->h_in_pin + n_ids, lens, n_b);
+            if (sid) std::memcpy(h->h_in_pin + n_ids + n_b, sid, n_b);
+            cp(sg.d_ids, h->h_in_pin, n_all);
+        } else {
+            cp(sg.d_ids, ids, n_ids);
+            cp(sg.d_lens, lens, n_b);
+            if (sid) cp(d_sid, sid, n_b);
+        }
+        if (sid) sg.d_sid = d_sid;
     }
     if (noise) {
         sg.has_noise = true;
