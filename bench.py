@@ -40,17 +40,30 @@ DTYPE = {2: "f32 (f16x3 split: fp32 operands as two fp16 planes, three MFMA prod
 
 
 def git_head():
-    """Commit of this tree: from git where there is one, else from the build stamp (the GPU box receives no .git)."""
+    """Commit of this tree: from git where there is one (with "+dirty" if tracked files differ from it), else the commit the
+    library's build record names (the GPU box receives no .git; "+" = the tree had uncommitted changes when it was built:
+    config.source_sha, a hash over the sources themselves, is what identifies the code that ran)."""
     try:
         h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
                            timeout=5).stdout.strip()
         if h:
-            return h
+            d = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True,
+                               timeout=10).stdout.strip()
+            return h + ("+dirty" if d else "")
     except Exception:
         pass
     try:
         info = json.load(open(os.path.join(ROOT, "phoonnx_amd", "_build_info.json")))
-        return info["commit"] + ("+dirty" if info.get("dirty") else "")
+        return info["commit"] + ("+" if info.get("dirty") else "")
+    except Exception:
+        return None
+
+
+def source_sha():
+    """phoonnx_amd.build.source_sha(): sha256 over every file libvitsmi.so is compiled from (recomputable from a checkout)"""
+    try:
+        from phoonnx_amd import build
+        return build.source_sha()
     except Exception:
         return None
 
@@ -227,9 +240,12 @@ def cpu_baseline(voice_path, preset, tokens, scales, seed, hop, budget_s=60.0):
 
 
 # ------------------------------------------------------------------------------------------------ launcher
-def launch_ranks(a, argv):
+def launch_ranks(a, argv, timeout_s=None):
     """`--gpus N` without a torchrun environment: start the N ranks as fresh child processes (nothing in this process
-    has touched the GPU) and relay rank 0's JSON line."""
+    has touched the GPU) and relay rank 0's JSON line.  The children get `timeout_s` (BENCH_LAUNCH_TIMEOUT_S, default 1800 s)
+    to finish; on a timeout, a non-zero exit or a missing result line ONE machine-readable line says what happened:
+    {"error": ..., "rank": ..., "stderr_tail": ...} - the first such line a rank printed itself (phoonnx_amd.sharding.
+    report_rank_failure), else one made here from the launcher's view."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -239,16 +255,37 @@ def launch_ranks(a, argv):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for ln in r.stdout.splitlines():
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("BENCH_LAUNCH_TIMEOUT_S", "1800"))
+    # (own process group: on a timeout every rank goes, not just the elastic agent)
+    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    timed_out = False
+    try:
+        out, err = pr.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        import signal
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)
+        except Exception:  # noqa: BLE001
+            pr.kill()
+        out, err = pr.communicate()
+    sys.stderr.write(err or "")
+    line = rank_err = None
+    for ln in (out or "").splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
-    if line:
+        elif ln.startswith("{") and '"error"' in ln and rank_err is None:
+            rank_err = ln
+    if line and not timed_out and pr.returncode == 0:
         print(line, flush=True)
-    elif r.stdout:
-        sys.stderr.write(r.stdout[-2000:])
-    return r.returncode if line or r.returncode else 1
+        return 0
+    if rank_err is None:
+        rank_err = json.dumps({"error": f"timed out after {timeout_s:.0f} s" if timed_out else
+                               (f"the ranks exited with code {pr.returncode}" if pr.returncode else "no result line from rank 0"),
+                               "rank": None, "n_gpus": a.gpus, "stderr_tail": (err or "")[-1500:]})
+    print(rank_err, flush=True)
+    return pr.returncode if pr.returncode else 1
 
 
 def pctl(xs):
@@ -411,10 +448,12 @@ def main():
         g = torch.Generator(device="cpu").manual_seed(77 + seed)
         return torch.randint(0, int(first.hparam("n_speakers")), (Bn,), generator=g, dtype=torch.int64)
 
-    def measure(first, preset, steps, warmup, parts, lockstep, seed, inputs_h=None):
+    def measure(first, preset, steps, warmup, parts, lockstep, seed, inputs_h=None, pipe=None):
         """K timed passes of the whole path on `parts` handles sharing `first`'s arena -> (dt, samples, pipe).
-        inputs_h: (ids, lens, sid) host tensors of another workload than the command line's (the config-4 block)."""
-        pipe = PipelinedSession(first, max(1, parts))
+        inputs_h: (ids, lens, sid) host tensors of another workload than the command line's (the config-4 block).
+        pipe: an existing pipeline of `first` to run on instead of a new one."""
+        if pipe is None:
+            pipe = PipelinedSession(first, max(1, parts))
         pipe.set_seed(1234 + rank * 16)
         scales = np.array([0.667, LENGTH_SCALE[preset], 0.8], np.float32)
         if inputs_h is not None:
@@ -584,8 +623,12 @@ def main():
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt_max, samples_all = float(mx[0]), float(sm[1])
         # every rank's own numbers, for rank 0's line (outside the timed region; a few hundred bytes over the host path)
-        mine_rec = {"rank": rank, "device": local_rank, "rows": B, "padded_tokens": T, "ms_per_step": dt / a.steps * 1e3,
-                    "samples_per_step": samples / a.steps, "load_s": t_load, "broadcast_s": open_stats.get("bcast_s"),
+        props = torch.cuda.get_device_properties(local_rank)
+        bus = ":".join(f"{getattr(props, k):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(props, k)) or None
+        mine_rec = {"rank": rank, "device": local_rank, "pci_bus": bus, "device_uuid": str(getattr(props, "uuid", "")) or None,
+                    "rows": B, "padded_tokens": T, "ms_per_step": dt / a.steps * 1e3,
+                    "samples_per_step": samples / a.steps, "samples_per_s": samples / dt if dt > 0 else None,
+                    "load_s": t_load, "broadcast_s": open_stats.get("bcast_s"),
                     "layout_open_s": open_stats.get("open_s"), "arena_checksum": weights.get("checksum")}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine_rec)
@@ -639,6 +682,26 @@ def main():
         _p1.close(close_first=False)
         one_handle = {"value": n1 / dt1, "unit": "samples/s", "steps": k1, "ms_per_step": dt1 / k1 * 1e3,
                       "note": "the same batch on ONE engine handle / stream: the schedule of the `roofline` and `stages` blocks"}
+
+    # The same batch as the exported graph itself renders it (tails="reference"): its generator is not masked, so every
+    # utterance is rendered to the longest one's length.  `value` does not render those tails (the default: each generator
+    # launch ends an utterance's tensors gen_rf_frames behind its end; every valid sample is bit-identical, tests/
+    # test_gpu_fullsize.py::test_ragged_rendering_equals_the_padded_rendering_on_every_valid_sample); both count VALID
+    # samples only.
+    padded = None
+    if extras and B > 1:
+        try:
+            pipe.set_tails("reference")
+            kp = max(3, a.steps // 2)
+            dtp, npd, _pp, _ = measure(sess, a.preset, kp, 2, a.parts, a.lockstep, 1234 + rank, pipe=pipe)
+            padded = {"value": npd / dtp, "unit": "samples/s", "steps": kp, "ms_per_step": dtp / kp * 1e3,
+                      "over_value": (npd / dtp) / (samples / dt) if samples else None,
+                      "note": "tails=\"reference\": the graph's own padded rendering of the same batch (every utterance rendered to the "
+                              "longest one's length, as onnxruntime would); same valid samples bit for bit, same count of them"}
+        except Exception as e:  # noqa: BLE001
+            padded = {"value": None, "note": f"failed: {type(e).__name__}: {e}"}
+        finally:
+            pipe.set_tails("zero")
 
     # the same workload once more with every fp32 product exact (bf16x6), after (outside) the headline's timed region
     exact = None
@@ -791,9 +854,18 @@ def main():
                        "frames_per_id": samples_all / a.steps / hop /
                                         (float(lens_all.sum()) if a.total_batch else float(lens_h.sum()) * world),
                        "sharding": shard_info, "ranks": per_rank,
-                       "weights": weights, "commit": git_head()},
+                       "ranks_summary": None if not per_rank else {
+                           "nccl_world": world, "nccl_world_equals_n_gpus": world == a.gpus,
+                           "samples_per_s_min": min(r["samples_per_s"] for r in per_rank),
+                           "samples_per_s_max": max(r["samples_per_s"] for r in per_rank),
+                           "samples_per_s_sum": sum(r["samples_per_s"] for r in per_rank),
+                           "distinct_devices": len({r["pci_bus"] or r["device"] for r in per_rank}),
+                           "broadcast_s_max": max((r["broadcast_s"] or 0.0) for r in per_rank)},
+                       "tails": "zero: samples behind an utterance's end are not rendered (MiSession tails=\"zero\", the default); "
+                                "padded_rendering = the graph's own padded form of the same batch",
+                       "weights": weights, "commit": git_head(), "source_sha": source_sha()},
             "roofline": roofline, "cpu_baseline": cpu, "step_ms": step_pct, "host_io": host_io, "one_handle": one_handle,
-            "exact_arithmetic": exact, "also": also, "stages": stage, "f16_range": f16_range,
+            "exact_arithmetic": exact, "padded_rendering": padded, "also": also, "stages": stage, "f16_range": f16_range,
             "b1": b1, "config4": config4,
             "value_is": "device-resident ids in, waveform left on the device (the contract's HBM-resident timed region); the "
                         "figure shaped like the reference's session.run (host ids in, one host fp32 [B,1,1,S] array out) is "
@@ -801,6 +873,29 @@ def main():
         }
         if cpu and cpu.get("value"):
             line["gpu_over_cpu"] = value / world / cpu["value"]
+
+        # every reported figure once more, short, as the LAST key of the line (the tail of a long line is what survives a
+        # bounded stdout capture)
+        def g(d, *ks):
+            for k in ks:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        line["summary"] = {
+            "value": value, "ms_per_step": line["ms_per_step"], "n_gpus": world, "preset": a.preset, "dtype": a.gen_precision,
+            "padded_rendering.value": g(padded, "value"), "one_handle.value": g(one_handle, "value"), "host_io.value": g(host_io, "value"),
+            "exact_arithmetic.value": g(exact, "value"), "also.preset": g(also, "preset"), "also.value": g(also, "value"),
+            "also.ms_per_step": g(also, "ms_per_step"), "also.roofline.bound": g(also, "roofline", "bound"),
+            "also.roofline.frac": g(also, "roofline", "frac"), "also.dec_hbm_frac_marks": g(also, "stages", "stage_marks_only", "dec_hbm_frac"),
+            "roofline.bound": g(roofline, "bound"), "roofline.frac": g(roofline, "frac"), "roofline.achieved": g(roofline, "achieved"),
+            "roofline.peak": g(roofline, "peak"), "roofline.unit": g(roofline, "unit"), "roofline.traffic": g(roofline, "traffic"),
+            "stages_marks_ms": {k: g(stage, "stage_marks_only", k) for k in ("enc_ms", "dp_ms", "flow_ms", "dec_ms", "total_ms")},
+            "also.stages_marks_ms": {k: g(also, "stages", "stage_marks_only", k) for k in ("enc_ms", "dp_ms", "flow_ms", "dec_ms", "total_ms")},
+            "b1_ms": {k: g(b1, k, "ms_per_call", "median") for k in ("high", "medium")},
+            "b1_first_chunk_ms": {k: g(b1, k, "first_chunk_ms", "median") for k in ("high", "medium")},
+            "config4.value": g(config4, "value"), "config4.f16x3_same_batch": g(config4, "f16x3_same_batch", "value"),
+            "config4.high_f16": g(config4, "high_f16", "value"),
+            "cpu_baseline.value": g(cpu, "value"), "cpu_baseline.cores": g(cpu, "cores"), "cpu_baseline.kind": g(cpu, "kind"),
+            "gpu_over_cpu": line.get("gpu_over_cpu"), "commit": line["config"]["commit"], "source_sha": line["config"].get("source_sha")}
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -818,5 +913,18 @@ def hop_of(s):
     return s.hparam("hop")
 
 
+def guarded_main():
+    """main(), with a rank's failure turned into one {"error", "rank", "stderr_tail"} line on stdout and a non-zero exit (a
+    peer that died inside a collective, a device error): the launcher relays it instead of a result."""
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001
+        from phoonnx_amd.sharding import report_rank_failure
+        report_rank_failure(e, int(os.environ.get("RANK", "0")), "bench.py")
+        os._exit(1)   # (no destructors: a process group whose peer is gone can block in its own teardown)
+
+
 if __name__ == "__main__":
-    main()
+    guarded_main()

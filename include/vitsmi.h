@@ -95,7 +95,9 @@ int vits_num_inputs(vits_handle *h);                 /* 3, or 4 with "sid" */
 const char *vits_input_name(vits_handle *h, int i);
 
 /* metadata_props written by export_onnx.py:335-350 (sample_rate, n_speakers, ...).
- * Returns the value length, or VITS_E_ARG if the key is absent. */
+ * Returns the value length, or VITS_E_ARG if the key is absent.
+ * One key is the loader's own: "vitsmi.name_warnings" - present only when node names and graph structure disagree about
+ * which module a Conv belongs to (the names win, the file loads): every such node, one per line. */
 int vits_meta(vits_handle *h, const char *key, char *buf, size_t n);
 
 /* Derived hyper-parameters: "hidden","inter","filter","n_heads","n_layers","n_vocab",
@@ -246,6 +248,17 @@ typedef struct {
  * conv_ms / sx_ms, vits_launch_records; the event records serialise the launches a little), 2 = stage marks only
  * (enc_ms .. total_ms), 0 = off. */
 int vits_set_timing(vits_handle *h, int enable);
+
+/* Padded batches (B > 1 with unequal frame counts; the reference itself only ever runs B = 1, voice.py:350-351).  The
+ * exported graph does not mask its generator (models.py:348-368, 720): it renders every utterance to the longest one's
+ * length, and the samples behind utterance b's end (y_lengths[b] * hop) are the generator's response to zeros.
+ *   reference = 0 (default): those samples are NOT rendered.  Every generator launch ends utterance b's tensors
+ *       "gen_rf_frames" behind y_lengths[b], so each VALID sample is bit-identical to the padded rendering, and the
+ *       output holds 0.0 from y_lengths[b] * hop on.
+ *   reference = 1 (or VITSMI_TAILS=reference in the environment at open time): the graph's padded rendering, tails
+ *       included - what onnxruntime returns for the same padded feed.
+ * Applies to the following runs of this handle (whole and chunked). */
+int vits_set_tails(vits_handle *h, int reference);
 int vits_get_stats(vits_handle *h, vits_stats *out);
 
 /* One record per conv-engine launch of the last run made with timing enabled, in launch order (call after

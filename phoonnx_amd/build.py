@@ -96,6 +96,110 @@ def spilling_kernels(remarks):
     return out
 
 
+def _regs(tok):
+    """'v[116:119]' -> {116..119}, 'v174' -> {174}; anything else (SGPRs, AGPRs, literals) -> empty"""
+    import re
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def spill_hazards(asm_text, kernel_filter=None):
+    """The hazard behind the no-spill rule, checked on the ISA itself (DESIGN 5.1g hazard 1): the conv engines issue
+    ASYNCHRONOUS inline-asm loads (global_load / ds_read inside ';;#ASMSTART' blocks) whose destination registers only
+    become valid behind a counted s_waitcnt the compiler knows nothing about.  If the register allocator spills such a
+    register between the load and its first use it saves the OLD contents (and restores them later): silently wrong
+    numbers.  For every kernel of `asm_text` (hipcc -S output) this walks the instructions - loop bodies twice, so a load at
+    the bottom of an iteration meets a spill at the top of the next - with the set of VGPRs that are destinations of asm
+    loads not yet READ by any instruction and not yet behind a full drain (s_waitcnt vmcnt(0) / lgkmcnt(0)); a
+    scratch_store (spill) of a register in that set is a finding.  A spill anywhere else - of values the compiler itself
+    produced, e.g. in an epilogue after the last asm load has been consumed - is harmless and is what the kernels that
+    still spill do.  Returns {kernel: [(line number within the kernel, instruction)]} for kernels with findings, and the
+    number of kernels examined that spill at all."""
+    import re
+    out, spilling = {}, 0
+    for m in re.finditer(r"\n(_Z\w+):[^\n]*\n", asm_text):
+        name = m.group(1)
+        if kernel_filter and not kernel_filter(name):
+            continue
+        end = asm_text.find(".Lfunc_end", m.end())
+        lines = asm_text[m.end():end if end > 0 else len(asm_text)].split("\n")
+        if not any("scratch_store" in l for l in lines):
+            continue
+        spilling += 1
+        labels = {l.split(":")[0].strip(): i for i, l in enumerate(lines) if re.match(r"^\.?\w+:", l)}
+        findings = []
+        inflight = {}  # vgpr -> "vm" | "lgkm"
+
+        def walk(lo, hi, in_asm):
+            for i in range(lo, hi):
+                l = lines[i].split(";")[0].strip() if not lines[i].lstrip().startswith(";;#") else lines[i].strip()
+                if l.startswith(";;#ASMSTART"):
+                    in_asm = True
+                    continue
+                if l.startswith(";;#ASMEND"):
+                    in_asm = False
+                    continue
+                if not l or l.endswith(":") or l.startswith("."):
+                    continue
+                parts = l.replace(",", " ").split()
+                op, args = parts[0], parts[1:]
+                if op == "s_waitcnt":
+                    if "vmcnt(0)" in l:
+                        for r in [r for r, k in inflight.items() if k == "vm"]:
+                            del inflight[r]
+                    if "lgkmcnt(0)" in l:
+                        for r in [r for r, k in inflight.items() if k == "lgkm"]:
+                            del inflight[r]
+                    continue
+                if op.startswith("scratch_store"):
+                    hit = set().union(*[_regs(a) for a in args]) & set(inflight)
+                    if hit and (i, lines[i].strip()) not in findings:
+                        findings.append((i, lines[i].strip()))
+                    continue
+                is_load = op.startswith(("global_load", "ds_read", "buffer_load", "flat_load", "scratch_load"))
+                dst = _regs(args[0]) if args and (is_load or op.startswith("v_")) else set()
+                srcs = set().union(*[_regs(a) for a in (args[1:] if dst else args)]) if args else set()
+                for r in srcs:      # a read: the hand-written wait in front of the first use has passed
+                    inflight.pop(r, None)
+                if in_asm and is_load and not op.startswith("scratch"):
+                    kind = "lgkm" if op.startswith("ds_") else "vm"
+                    for r in dst:
+                        inflight[r] = kind
+                else:
+                    for r in dst:   # overwritten by something the compiler tracks
+                        inflight.pop(r, None)
+            return in_asm
+
+        walk(0, len(lines), False)
+        # loops: every backward branch re-walks its body once with the state of the fall-through
+        for i, l in enumerate(lines):
+            t = l.split(";")[0].split()
+            if len(t) == 2 and t[0].startswith(("s_cbranch", "s_branch")) and t[1] in labels and labels[t[1]] < i:
+                inflight.clear()
+                walk(labels[t[1]], i, False)
+                walk(labels[t[1]], i, False)
+        if findings:
+            out[name] = findings
+    return out, spilling
+
+
+def isa_of(src, extra_flags=()):
+    """hipcc -S (device only) of one translation unit, as text"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        o = os.path.join(d, "tu.s")
+        r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", *extra_flags, "-x", "hip",
+                            "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", o], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr)
+            raise RuntimeError(f"hipcc -S failed on {src}")
+        with open(o) as f:
+            return f.read()
+
+
 def build_variant(out, cxxflags):
     """Kernel experiments: the library once more with extra -D switches, as `out` (loaded through VITSMI_LIB); the product
     library and its record are left alone."""
@@ -122,11 +226,29 @@ def build_variant(out, cxxflags):
 
 
 def build(force=False, verbose=False):
+    # one builder at a time per tree: N ranks that find the library stale would otherwise compile the same objects into the
+    # same files side by side (_ffi.load() calls this from every process); the others wait, then find it fresh
+    import fcntl
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    with open(os.path.join(HERE, "build", ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     sha = source_sha()
     if not force and not stale():
-        info = write_build_info(False, sha)
-        print(f"phoonnx_amd.build: reused libvitsmi.so (source_sha {sha} matches the record; built from "
-              f"{info.get('commit', '?')}{'+dirty' if info.get('dirty') else ''})", file=sys.stderr)
+        if read_build_info().get("source_sha") == sha:
+            info = write_build_info(False, sha)
+            print(f"phoonnx_amd.build: reused libvitsmi.so (source_sha {sha} matches the record; built from "
+                  f"{info.get('commit', '?')}{'+dirty' if info.get('dirty') else ''})", file=sys.stderr)
+        else:
+            # fresh by file times only (a library without a record): usable, but its content was never checked against these
+            # sources, so no hash is recorded for it - the next call falls back to the file times again
+            print("phoonnx_amd.build: reused libvitsmi.so (no build record: newer than every source by mtime only)", file=sys.stderr)
         return LIB
     # one hipcc process per translation unit, side by side, then one link (the HIP files dominate: minutes each)
     from concurrent.futures import ThreadPoolExecutor
@@ -143,32 +265,53 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         results = list(ex.map(compile_one, SOURCES))
-    spilled = {}
+    spilled, spilled_src = {}, {}
     for src, _, r in results:
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError(f"hipcc failed compiling {src}")
         if verbose:
             sys.stderr.write(r.stderr)
-        spilled.update(spilling_kernels(r.stderr))
+        for k, v in spilling_kernels(r.stderr).items():
+            spilled[k] = v
+            spilled_src[k] = src
     # The conv engines feed their MFMA loops through ASYNCHRONOUS inline-asm loads (global_load / ds_read whose results are
     # only valid behind a counted s_waitcnt): if the compiler spills such a register between the load and the wait it saves
     # the OLD contents and later restores them - silently wrong results (seen: conv_sx_pair16_kernel<64, 2, 256>, 41 spilled
-    # registers, inf in the generator).  A spilling instantiation of those kernels is therefore a build error.
-    # (enforced for the split-operand engine's kernels - the generator, flow and encoder of every full-size voice; the
-    # 32x32x16 pair kernel, now reached through test hooks only, and the f32 engine's small tiles spill 3-34 registers - none
-    # of them an asynchronous destination so far, every parity test green - and are reported, not refused)
+    # registers, inf in the generator).  Two rules, both build ERRORS:
+    #  1. the kernels whose whole life is such a pipeline (the 16x16x32 / short-launch conv engines, the fused pair16 kernel,
+    #     the 16-bit attention) must not spill at all;
+    #  2. every OTHER kernel that spills (today: conv_sx_pair_kernel's 64-channel and fused-chain instantiations - on the
+    #     default f16x3 path - the f32 engine's small tiles, the fp32 attention) is checked on its ISA: no spill store may
+    #     hit a register that is the destination of an asm load not yet consumed (spill_hazards).  Their spills sit in the
+    #     epilogues, behind the last asm load's use; a compiler that moves one into the pipeline fails the build here.
     no_spill = ("conv_sx_kernel", "conv_sx_pair16", "conv_sx_small_kernel", "attention_relpos16_kernel")
     bad = {k: v for k, v in spilled.items() if any(n in k for n in no_spill)}
     if bad:
         raise RuntimeError("kernels with asynchronous inline-asm loads must not spill registers: " + ", ".join(f"{k} ({v})" for k, v in bad.items()))
     if spilled:
-        print("phoonnx_amd.build: note: " + ", ".join(f"{k.split('vitsmi')[-1][:40]} spills {v}" for k, v in spilled.items()), file=sys.stderr)
-    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [o for _, o, _ in results],
+        units = sorted(set(spilled_src.values()))
+        with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as ex:
+            isas = dict(zip(units, ex.map(lambda u: isa_of(u, os.environ.get("VITSMI_CXXFLAGS", "").split()), units)))
+        hazards, checked = {}, 0
+        for u in units:
+            f, n = spill_hazards(isas[u])
+            hazards.update(f)
+            checked += n
+        if checked < len(set(spilled)):
+            raise RuntimeError(f"spill check: the remarks name {len(set(spilled))} spilling kernels, the ISA of {units} shows {checked}")
+        if hazards:
+            raise RuntimeError("a spilled register is the destination of an asynchronous inline-asm load still in flight: " +
+                               "; ".join(f"{k}: {v[0][1]} (+{len(v) - 1} more)" for k, v in hazards.items()))
+        print(f"phoonnx_amd.build: {len(spilled)} kernels spill registers ({', '.join(sorted(set(k.split('vitsmi')[-1][:28] for k in spilled)))}); "
+              f"ISA-checked ({', '.join(units)}): no spill store hits an asynchronous load's destination", file=sys.stderr)
+    tmp_lib = LIB + f".tmp{os.getpid()}"
+    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + [o for _, o, _ in results],
                        capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("hipcc failed linking libvitsmi.so")
+    os.replace(tmp_lib, LIB)  # (a process that has the old library mapped keeps its inode)
     write_build_info(True, sha)
     print(f"phoonnx_amd.build: compiled libvitsmi.so (source_sha {sha})", file=sys.stderr)
     return LIB

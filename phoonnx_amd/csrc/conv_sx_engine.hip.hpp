@@ -84,6 +84,23 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 enum : int { SX_NO_RAW_STORE = 256 };  // out_raw is only the EPI_ACC operand, not a destination
 
+// Ragged batches (the generator: models.py:348-368 has no mask, so the reference graph renders every utterance of a padded
+// batch to the longest one's length).  Utterance b's tensors END at min(T, (len[b] + add) * mul) columns: a workgroup whose
+// tile starts behind that end exits at once, columns behind it are zero padding for the loads and are not stored.  `add` is
+// the generator's receptive field in frames (Model::gen_rf_frames), so every VALID sample (frame < len[b]) still sees exactly
+// the values the padded rendering computes - the chunked renderer (vitsmi.hip render_chunks) relies on the same argument.
+// len == nullptr: every utterance spans T (the padded rendering).
+struct SxRagged {
+    const int *len;       // valid frames per utterance (device), or nullptr
+    int add, mul;         // frames of margin; columns per frame at this layer's input
+};
+__device__ __forceinline__ int sx_valid_cols(const SxRagged &r, int b, int T) {
+    if (!r.len) return T;
+    const int n = r.len[b];
+    const long long v = n > 0 ? (long long)(n + r.add) * r.mul : 0;
+    return v < T ? (int)v : T;
+}
+
 struct SxArgs {
     const u32x4 *xp;      // input planes, cells of 8 bf16
     int64_t x_bstride;    // cells between batch items (= 3 * Cin/8 * T)
@@ -131,6 +148,7 @@ struct SxArgs {
     // A peak above 65504 (or inf) means split2h_pair clamped: the run is then reported as out of range instead of
     // returning plausible-looking audio (vits_stats::f16_peak_max / f16_saturated, VITS_E_RANGE).
     unsigned *peak;
+    SxRagged rag;         // per-utterance tensor ends (generator convs of a padded batch), see SxRagged
 };
 
 
@@ -281,6 +299,9 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
     if (tile_nb >= a.NT * a.B) return;                 // padding workgroups of the last round (uniform exit)
     const int b = tile_nb / a.NT, t0 = (tile_nb - b * a.NT) * BN;
     const int T = a.T, LW = a.LW, K = a.K, CG = a.Cin >> 3;
+    // TV: where this utterance's tensor ends (SxRagged; = T for a padded rendering).  T stays the row pitch of every tensor.
+    const int TV = __builtin_amdgcn_readfirstlane(sx_valid_cols(a.rag, b, T));
+    if (t0 >= TV) return;                              // (uniform exit) the whole tile lies behind the utterance's end
     const int RS = S16 ? a.RS : a.LW;          // cells between the rows of an x stage (16x16x32: rounded up, see launch_conv_sx)
     constexpr int XG = S16 ? 4 : 2;            // channel groups of 8 per chunk: rows of a stage = planes x XG
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_sx;
@@ -317,11 +338,11 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
                 const int row = (int)__umulhi((unsigned)i, a.magic);  // (magic = ceil(2^32 / RS))
                 const int col = i - row * RS;
                 const int t = t0 - a.padL + col;
-                xok[it] = it < nit && row < XG * NPL && col < LW && t >= 0 && t < T;
+                xok[it] = it < nit && row < XG * NPL && col < LW && t >= 0 && t < TV;
                 xoffs[it] = (uint32_t)(((int64_t)(row / XG) * pstride + (int64_t)(row % XG) * T + t) * 16);
                 nx_issued += __builtin_amdgcn_ballot_w64(xok[it]) != 0 ? 1 : 0;
             }
-            if (t0 - a.padL < 0 || t0 - a.padL + LW > T) {  // (uniform) only edge tiles have padding columns
+            if (t0 - a.padL < 0 || t0 - a.padL + LW > TV) {  // (uniform) only edge tiles have padding columns
                 const u32x4 z = {0u, 0u, 0u, 0u};
                 for (uint32_t o = (uint32_t)tid * 16u; o < a.lds_bytes; o += 4096u) ds_write128(lds0 + o, z);
                 __syncthreads();  // the zeros are in place before the first DMA can land on a neighbouring cell
@@ -350,7 +371,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
             const int row = (int)__umulhi((unsigned)i, a.magic);
             const int col = i - row * LW;
             const int t = t0 - a.padL + col;
-            const bool ok = row < 2 * NPL && t >= 0 && t < T;  // (rows of planes this mode does not read stay unloaded)
+            const bool ok = row < 2 * NPL && t >= 0 && t < TV;  // (rows of planes this mode does not read stay unloaded)
             const u32x4 *src = ok ? xb + ((row >> 1) * pstride + (int64_t)(2 * chunk + (row & 1)) * T + t)
                                   : reinterpret_cast<const u32x4 *>(a.zeros) + lane;
             lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + xoff + base * 16));
@@ -378,7 +399,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
             int kh, col;
             xcell(it, kh, col);
             const int t = t0 - a.padL + col;
-            xrok[it] = it < nxc && kh < 2 && t >= 0 && t < T;
+            xrok[it] = it < nxc && kh < 2 && t >= 0 && t < TV;
             xroff[it] = xrok[it] ? (uint32_t)(((int64_t)kh * T + t) * 32) : 0u;
         }
     }
@@ -1185,7 +1206,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
             const int n = n0 + j;
             int co0, r, t;
             geom(m, n, co0, r, t);
-            if (t >= T) continue;
+            if (t >= TV) continue;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int64_t cell = cell_at(co0, r, t, q);

@@ -67,6 +67,7 @@ struct SxPairArgs {
     unsigned a_ring;          // (32-channel variant) byte offset of the shared weight ring in LDS: 3 groups x 2 steps x 2 KiB
     unsigned bias_off;        // (one chain) byte offset of the two bias vectors in LDS (one 1 KiB DMA slot behind the tile)
     unsigned long long *prof;  // (SX_PAIR_PROF builds) 8 counters of this launch: six phase sums in shader cycles, -, workgroups
+    SxRagged rag;             // per-utterance tensor ends of a padded batch (conv_sx_engine.hip.hpp)
 };
 
 // (the 32-channel variant needs ~165 registers and <= 40 KiB of LDS: three workgroups per CU hide more of each
@@ -129,6 +130,8 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
     const int b = tile_nb / a.NT, t0 = (tile_nb - b * a.NT) * a.BNo;  // first kept output column
     const int t1 = t0 - a.pad2;                                        // first column phase 1 computes
     const int T = a.T, LW = a.LW1;
+    const int TV = __builtin_amdgcn_readfirstlane(sx_valid_cols(a.rag, b, T));  // this utterance's tensor end (SxRagged); T = row pitch
+    if (t0 >= TV) return;                                                        // (uniform exit) no kept column lies inside it
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_sx;
     const uint32_t XB = a.x_bytes;
     const char *wbase1 = reinterpret_cast<const char *>(a.wp1) + wm * (MW * NPW * 1024);
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
             const int t = t1 - a.pad1 + col;
             xkh[it] = kh;
             xcol[it] = col;
-            xrok[it] = it < nxc && kh < 2 && t >= 0 && t < T;
+            xrok[it] = it < nxc && kh < 2 && t >= 0 && t < TV;
             xroff[it] = xrok[it] ? (uint32_t)(((int64_t)kh * T + t) * 32) : 0u;
         }
         static_for<MAXCH>([&](auto CH) {
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
         for (int n = 0; n < NW; n++) {
             const int col = (wn * NW + n) * 32 + l31;
             const int t = t1 + col;
-            const bool live = t >= 0 && t < T;  // outside the tensor c2 sees zero padding, not c1 evaluated there
+            const bool live = t >= 0 && t < TV;  // outside the tensor c2 sees zero padding, not c1 evaluated there
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float o[4];
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
                 const int n = rr * 2 + j;
                 const int col = (wn * NW + n) * 32 + l31;
                 const int t = t1 + col;
-                const bool kept = !(col < a.pad2 || col >= a.pad2 + a.BNo || t >= T);  // overlap columns belong to the neighbours
+                const bool kept = !(col < a.pad2 || col >= a.pad2 + a.BNo || t >= TV);  // overlap columns belong to the neighbours
                 if constexpr (NCH == 1) {
                     if (!kept) continue;
                 }

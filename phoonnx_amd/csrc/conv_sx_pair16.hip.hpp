@@ -59,6 +59,7 @@ struct SxPair16Args {
     float div;
     unsigned *peak;
     unsigned long long *prof;  // (P16_PROF builds) 8 counters: x landed, converted + barrier, phase 1, hand-over, phase 2, epilogue, stores drained, workgroups
+    SxRagged rag;             // per-utterance tensor ends of a padded batch (conv_sx_engine.hip.hpp)
 };
 
 // C channels (32 | 64), NPL planes, BN columns per tile (128 | 256), OVL: Y overlays the x tile
@@ -87,6 +88,8 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
     const int b = tile_nb / a.NT, t0 = (tile_nb - b * a.NT) * a.BNo;  // first kept output column
     const int t1 = t0 - a.pad2;                                        // first column phase 1 computes
     const int T = a.T, LW1 = a.LW1, RS1 = a.RS1, RS2 = a.RS2;
+    const int TV = __builtin_amdgcn_readfirstlane(sx_valid_cols(a.rag, b, T));  // this utterance's tensor end (SxRagged); T = row pitch
+    if (t0 >= TV) return;                                                        // (uniform exit) no kept column lies inside it
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_sx;
     const uint32_t ylds = lds0 + a.y_off;
     const uint32_t XPB = (uint32_t)(CG * RS1) * 16u, YPB = (uint32_t)(CG * RS2) * 16u;  // bytes per plane
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
             const int row = (int)__umulhi((unsigned)i, a.magic1);
             const int col = i - row * RS1;
             const int t = t1 - a.pad1 + col;
-            const bool ok = row < NPL * CG && col < LW1 && t >= 0 && t < T;
+            const bool ok = row < NPL * CG && col < LW1 && t >= 0 && t < TV;
             const void *src = ok ? static_cast<const void *>(xb + ((int64_t)row * T + t) * 8)
                                  : static_cast<const void *>(reinterpret_cast<const char *>(a.zeros) + lane * 16);
             // (lanes past the tile's last cell are masked off: nothing is written behind the allocation)
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
         for (int n = 0; n < NQ; n++) {
             const int j = wn * BNW + n * 32 + l31;
             const int t = t1 + j;
-            const bool live = t >= 0 && t < T;  // outside the tensor c2 sees zero padding, not c1 evaluated there
+            const bool live = t >= 0 && t < TV;  // outside the tensor c2 sees zero padding, not c1 evaluated there
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float o[4];
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
         for (int n = 0; n < NQ; n++) {
             const int j = wn * BNW + n * 32 + l31;
             const int t = t1 + j;
-            const bool kept = j >= k_pad2 && j < k_pad2 + k_BNo && t < T;  // overlap columns belong to the neighbours
+            const bool kept = j >= k_pad2 && j < k_pad2 + k_BNo && t < TV;  // overlap columns belong to the neighbours
             const int tl = t < 0 ? 0 : (t < T ? t : T - 1);
             f32x4 adl[4], xres[4];
             if constexpr (!KEEP) read_x16(j, xres);

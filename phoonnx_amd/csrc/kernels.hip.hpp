@@ -1084,12 +1084,20 @@ __global__ void wn_update_kernel(float *x, float *skip, const float *rs, const i
 
 // ---- a12 tail: leaky_relu(0.01) -> conv_post (C -> 1, k taps, no bias) -> tanh ---------------------
 // The one genuinely HBM-bound kernel: C*4 bytes read + 4 written per sample.
+// vlen / hop (optional): samples at and behind vlen[b] * hop - the padding of a shorter utterance in a batch - are written as
+// zeros (and, with the ragged generator, were never rendered: nothing behind them is read for a sample that is kept).
 __global__ __launch_bounds__(256) void post_conv_tanh_kernel(const float *x, const float *w, float *out, int C,
-                                                             int K, int T, float slope) {
+                                                             int K, int T, float slope, const int *vlen = nullptr, int hop = 1) {
     extern __shared__ float sm[];  // [C][256 + K - 1] staged tile, then weights [C*K]
     const int LW = 256 + K - 1;
     float *ws = sm + (size_t)C * LW;
     int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+    const long long nv_ = vlen ? (long long)vlen[b] * hop : (long long)T;
+    const int NV = nv_ < T ? (int)nv_ : T;
+    if (t0 >= NV) {  // (uniform) the whole tile is padding
+        if (t0 + tid < T) out[(int64_t)b * T + t0 + tid] = 0.f;
+        return;
+    }
     const float *xb = x + (int64_t)b * C * T;
     for (int i = tid; i < C * K; i += 256) ws[i] = w[i];
     const int pad = (K - 1) / 2;
@@ -1105,7 +1113,7 @@ __global__ __launch_bounds__(256) void post_conv_tanh_kernel(const float *x, con
     float acc = 0.f;
     for (int c = 0; c < C; c++)
         for (int k = 0; k < K; k++) acc += ws[c * K + k] * sm[c * LW + tid + k];
-    out[(int64_t)b * T + t] = tanhf(acc);
+    out[(int64_t)b * T + t] = t < NV ? tanhf(acc) : 0.f;
 }
 
 // Same tail for the split-exact generator: x is the fp32 raw layout [C/8][T][8] (conv_sx_engine.hip.hpp).
@@ -1114,10 +1122,18 @@ __global__ __launch_bounds__(256) void post_conv_tanh_kernel(const float *x, con
 // 32 x 7 LDS reads of a thread are issued and awaited one by one.
 template <int KT>
 __global__ __launch_bounds__(256) void post_conv_tanh_blocked_kernel(const float *x, const float *__restrict__ w, float *out,
-                                                                     int C, int K, int T, float slope) {
+                                                                     int C, int K, int T, float slope, const int *vlen = nullptr,
+                                                                     int hop = 1) {
     extern __shared__ float sm[];  // [C][256 + K - 1] staged tile (the weights are uniform: scalar loads, no LDS)
     const int LW = 256 + K - 1;
     int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+    // (vlen / hop: see post_conv_tanh_kernel - zeros at and behind the utterance's end, whose tiles are not even read)
+    const long long nv_ = vlen ? (long long)vlen[b] * hop : (long long)T;
+    const int NV = nv_ < T ? (int)nv_ : T;
+    if (t0 >= NV) {  // (uniform) the whole tile is padding
+        if (t0 + tid < T) out[(int64_t)b * T + t0 + tid] = 0.f;
+        return;
+    }
     const float *xb = x + (int64_t)b * C * T;
     const int pad = (K - 1) / 2;
     // one thread moves a whole cell (8 channels of one time step, 32 contiguous bytes) per round: a wave reads
@@ -1171,7 +1187,7 @@ __global__ __launch_bounds__(256) void post_conv_tanh_blocked_kernel(const float
         for (int c = 0; c < C; c++)
             for (int k = 0; k < K; k++) acc += w[c * K + k] * sm[c * LW + tid + k];
     }
-    out[(int64_t)b * T + t] = tanhf(acc);
+    out[(int64_t)b * T + t] = t < NV ? tanhf(acc) : 0.f;
 }
 
 // ---- noise: Philox4x32-10 counter RNG + Box-Muller (production path; parity uses injected noise) ---

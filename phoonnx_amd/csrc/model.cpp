@@ -34,6 +34,7 @@ struct Resolver {
     std::map<std::string, TRef> t;
     std::map<std::string, int64_t> ints;
     std::vector<std::vector<float>> owned;
+    std::string name_warnings;  // resolve(): every node whose name and structural position disagree, one per line
 
     void put(const std::string &name, const OnnxTensor *ot) {
         if (!ot || !ot->data() || t.count(name)) return;
@@ -414,8 +415,12 @@ void resolve(const OnnxModel &om, Resolver &R) {
             if (sp[i] != n.name) {
                 const std::string msg = "node '" + n.name + "' sits where the graph's structure expects '" + sp[i] + "'";
                 if (strict) throw std::runtime_error(msg);
-                fprintf(stderr, "vitsmi: warning: %s (names win; VITSMI_STRICT_NAMES=1 rejects such files)\n", msg.c_str());
-                break;
+                // every disagreement is kept for the caller (vits_meta "vitsmi.name_warnings", one per line); stderr names the
+                // first and says how many there are
+                if (R.name_warnings.empty())
+                    fprintf(stderr, "vitsmi: warning: %s (names win; VITSMI_STRICT_NAMES=1 rejects such files; the full list: "
+                                    "vits_meta \"vitsmi.name_warnings\")\n", msg.c_str());
+                R.name_warnings += msg + "\n";
             }
         }
     }
@@ -1125,6 +1130,8 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
         zeros_off = P.alloc(1024);  // zero page: padding source of the conv engine's LDS-DMA
         input_names = om.inputs;
         meta = om.meta;
+        // (not from the file: what the loader has to report about it; absent when there is nothing to report)
+        if (!R.name_warnings.empty()) meta["vitsmi.name_warnings"] = R.name_warnings;
         // Graph inputs (voice.py:347-373 filters its feed by these names).  "langid" appears in third-party
         // multi-lingual exports (voice.py:369): it is accepted when nothing in the graph consumes a language table
         // this engine would have to apply; anything else is not a graph this engine understands.

@@ -79,6 +79,12 @@ struct vits_handle {
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int cur_stage = 0;  // 0 enc, 1 dp, 2 flow, 3 dec
     uint64_t run_counter = 0;
+    // Padded batches (B > 1, unequal frame counts).  The reference graph does not mask its generator (models.py:348-368, 720):
+    // it renders every utterance to the longest one's length and the samples behind an utterance's end are the generator's
+    // response to zeros.  tails_reference = false (default; VITSMI_TAILS=reference or vits_set_tails(h, 1) for the other):
+    // those samples are NOT rendered - every generator launch ends utterance b's tensors gen_rf_frames behind y_len[b]
+    // (SxRagged), so each valid sample is bit-identical to the padded rendering - and the output holds zeros there.
+    bool tails_reference = false;
     int gen_nprod = 2;  // generator arithmetic (VITSMI_GEN_PRECISION): 2 = two fp16 planes / three products (default), 6 = six
                         // exact bf16 plane products, 1 = one fp16 plane / one product with fp16 activations (config 4)
     // f16 range guard: every launch that splits values into fp16 planes publishes the largest magnitude it saw into its
@@ -226,7 +232,20 @@ struct Ctx {
     const float *A;  // device arena
     int B;
     hipError_t err = hipSuccess;
+    // ragged generator (run_generator*): device frame counts + margin, the frame count F the launches' T are multiples of, and
+    // the share of B * F frames that lies inside the utterances' (margin-extended) ends - what the FLOP / byte accounting of a
+    // generator launch is scaled by (host copy of the frame counts: h_len)
+    SxRagged rag{nullptr, 0, 0};
+    int rag_F = 0;
+    double rag_frac = 1.0;
+    const int *h_len = nullptr;
     const float *P(int64_t off) const { return off >= 0 ? A + off : nullptr; }
+    // the SxRagged of a generator launch whose input tensors have T columns per utterance
+    SxRagged rag_at(int T) const {
+        if (!rag.len || rag_F <= 0 || T % rag_F) return SxRagged{nullptr, 0, 0};
+        return SxRagged{rag.len, rag.add, T / rag_F};
+    }
+    double work_frac() const { return rag.len ? rag_frac : 1.0; }
     void note(hipError_t e) {
         if (err == hipSuccess && e != hipSuccess) err = e;
     }
@@ -235,8 +254,9 @@ struct Ctx {
 // algorithmic FLOPs / layer-granular bytes of one conv launch, per pipeline stage
 void conv_account(Ctx &c, const ConvDesc &d, int T) {
     vits_handle *h = c.h;
-    double fl = 2.0 * d.macs_per_t * (double)T * c.B;
-    double by = (d.h1 ? 2.0 : 4.0) * c.B * ((double)d.Cin * T + (double)d.Cout * T);  // (stored dtype: SURVEY 8d)
+    // (ragged generator launches: only the columns inside the utterances' ends are worked on)
+    double fl = 2.0 * d.macs_per_t * (double)T * c.B * c.work_frac();
+    double by = (d.h1 ? 2.0 : 4.0) * c.B * ((double)d.Cin * T + (double)d.Cout * T) * c.work_frac();  // (stored dtype: SURVEY 8d)
     h->stats.conv_flops += fl;
     h->stats.conv_bytes += by;
     h->stats.conv_launches++;
@@ -413,6 +433,7 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.wscale = d.wscale;
     a.s16 = d.s16 ? 1 : 0;
     vits_handle *h = c.h;
+    if (h->cur_stage == 3) a.rag = c.rag_at(T);
     a.peak = range_slots(h, (d.f16 || d.h1) && (d.rawin || out_pl));  // launches that turn values into fp16 planes
     const bool ev = conv_event_begin(c);
     // Short grids (a single utterance, a streaming chunk): the 128-row packing is read by the 64- or 32-row kernel -
@@ -453,17 +474,19 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     // covers.  VITSMI_SX_SMALL_GEN=1 lifts that for single-shot latency: 1.31 -> 1.27 ms on `medium`, 3.34 -> 3.24 on `high`.)
     static const bool small_gen = [] { const char *e = std::getenv("VITSMI_SX_SMALL_GEN"); return e && e[0] == '1'; }();
     const bool small_kind = (a.flags & (SX_WN_RMW | SX_GATE)) != 0 || small_gen;
-    if (small_max > 0 && small_kind && conv_sx_small_ok(a, d.rawin, nprod) && conv_sx_small_wgs(a, c.B) <= small_max)
+    if (small_max > 0 && small_kind && !a.rag.len && conv_sx_small_ok(a, d.rawin, nprod) && conv_sx_small_wgs(a, c.B) <= small_max)
         c.note(launch_conv_sx_small(a, c.B, d.cfg, c.st));
     else
         c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, nprod, d.cfg));
     // layer-granular bytes in the STORED dtype ("bf16 storage halves these"): 2 bytes per element in the
     // single-plane mode, 4 otherwise
     const double ebytes = d.h1 ? 2.0 : 4.0;
-    if (ev) conv_event_end(c, true, 2.0 * d.macs_per_t * (double)T * c.B, ebytes * c.B * ((double)d.Cin * T + (double)d.Cout * T), d, T);
+    const double wf = a.rag.len ? c.rag_frac : 1.0;
+    const double fl = 2.0 * d.macs_per_t * (double)T * c.B * wf, by = ebytes * c.B * ((double)d.Cin * T + (double)d.Cout * T) * wf;
+    if (ev) conv_event_end(c, true, fl, by, d, T);
     conv_account(c, d, T);
-    h->stats.sx_flops += 2.0 * d.macs_per_t * (double)T * c.B;
-    h->stats.sx_bytes += ebytes * c.B * ((double)d.Cin * T + (double)d.Cout * T);
+    h->stats.sx_flops += fl;
+    h->stats.sx_bytes += by;
     h->stats.sx_launches++;
 }
 
@@ -589,6 +612,7 @@ void conv_sx_pair(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const float *x
     a.flags = flags & (EPI_ACC | EPI_DIV);
     a.div = div;
     vits_handle *h = c.h;
+    a.rag = c.rag_at(T);
     a.peak = range_slots(h, true);
 #if SX_PAIR_PROF
     {
@@ -617,15 +641,16 @@ void conv_sx_pair(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const float *x
 #endif
     const bool ev = conv_event_begin(c);
     c.note(launch_conv_sx_pair(a, c1.cfg, c.B, c.st, chain));
-    if (ev)
-        conv_event_end(c, true, 2.0 * (c1.macs_per_t + c2.macs_per_t) * (double)T * c.B,
-                       4.0 * c.B * ((double)(c1.Cin + c1.Cout) * T + (double)(c2.Cin + c2.Cout) * T), c1, T);
+    const double wf = c.work_frac();
+    const double fl = 2.0 * (c1.macs_per_t + c2.macs_per_t) * (double)T * c.B * wf;
+    const double by = 4.0 * c.B * ((double)(c1.Cin + c1.Cout) * T + (double)(c2.Cin + c2.Cout) * T) * wf;
+    if (ev) conv_event_end(c, true, fl, by, c1, T);
     conv_account(c, c1, T);
     conv_account(c, c2, T);
     h->stats.conv_launches--;  // (two convs, one launch)
     h->stats.total_launches--;
-    h->stats.sx_flops += 2.0 * (c1.macs_per_t + c2.macs_per_t) * (double)T * c.B;
-    h->stats.sx_bytes += 4.0 * c.B * ((double)(c1.Cin + c1.Cout) * T + (double)(c2.Cin + c2.Cout) * T);
+    h->stats.sx_flops += fl;
+    h->stats.sx_bytes += by;
     h->stats.sx_launches++;
 }
 
@@ -673,12 +698,13 @@ void conv_sx_pair16(Ctx &c, const ConvDesc &c1, const ConvDesc &c2, const uint16
     a.flags = flags;
     a.div = div;
     vits_handle *h = c.h;
+    a.rag = c.rag_at(T);
     a.peak = range_slots(h, true);
     const double ebytes = h1 ? 2.0 : 4.0;
     const bool ev = conv_event_begin(c);
     c.note(launch_conv_sx_pair16(a, C, h1 ? 1 : 2, c.B, c.st, chain));
-    const double fl = 2.0 * (c1.macs_per_t + c2.macs_per_t) * (double)T * c.B;
-    const double by = ebytes * c.B * ((double)(c1.Cin + c1.Cout) * T + (double)(c2.Cin + c2.Cout) * T);
+    const double fl = 2.0 * (c1.macs_per_t + c2.macs_per_t) * (double)T * c.B * c.work_frac();
+    const double by = ebytes * c.B * ((double)(c1.Cin + c1.Cout) * T + (double)(c2.Cin + c2.Cout) * T) * c.work_frac();
     if (ev) conv_event_end(c, true, fl, by, c1, T);
     conv_account(c, c1, T);
     conv_account(c, c2, T);
@@ -741,7 +767,10 @@ void conv_sx_mrf(Ctx &c, const UpStageDesc &stg, const float *x, int T, float *o
         bytes += 4.0 * ((double)(c1.Cin + c1.Cout) + (double)(c2.Cin + c2.Cout));  // (layer-granular, as the separate launches)
     }
     vits_handle *h = c.h;
+    a.rag = c.rag_at(T);
     a.peak = range_slots(h, true);
+    macs *= c.work_frac();
+    bytes *= c.work_frac();
     const bool ev = conv_event_begin(c);
     c.note(launch_conv_sx_mrf(a, c.B, c.st));
     if (ev) conv_event_end(c, true, 2.0 * macs * (double)T * c.B, bytes * T * c.B, stg.rbs[n - 1].c1[0], T);
@@ -1200,6 +1229,26 @@ size_t gen_ws_bytes(const Model &m, int B, int F) {
     return (size_t)(m.gen_sx ? kGenRegionsSx : kGenRegions) * al(gen_region_floats(m, B, F));
 }
 
+// Ragged rendering of a padded batch (vits_handle::tails_reference == false): from here on every generator launch ends
+// utterance b's tensors gen_rf_frames behind ylen[b] (Ctx::rag_at), and the tail kernel writes zeros behind ylen[b] * hop.
+// Needs the host copy of the frame counts (Ctx::h_len) for the FLOP / byte accounting; B = 1 has no padding.
+void rag_begin(vits_handle *h, Ctx &c, const int *ylen, int B, int F) {
+    c.rag = SxRagged{nullptr, 0, 0};
+    c.rag_F = F;
+    c.rag_frac = 1.0;
+    if (!ylen || !c.h_len || B < 2 || h->tails_reference) return;
+    const int rf = h->model.gen_rf_frames;
+    double cols = 0;
+    for (int b = 0; b < B; b++) {
+        const int n = c.h_len[b];
+        cols += n > 0 ? (n + rf < F ? n + rf : F) : 0;
+    }
+    c.rag = SxRagged{ylen, rf, 1};
+    c.rag_frac = cols / ((double)B * F);
+}
+// the frame counts the tail kernel zeroes behind (nullptr: the reference's padded rendering is kept as it is)
+const int *tail_len(const vits_handle *h, const int *ylen) { return h->tails_reference ? nullptr : ylen; }
+
 // The PLANE-STREAM generator of the two fp16 arithmetics: f16x3 (the default: two fp16 planes per operand, three MFMA
 // products per fp32 product) and f16 (VITSMI_GEN_PRECISION=f16, BASELINE config 4's reduced-precision vocoder: one plane, one
 // product).  Every tensor between two convs exists ONCE, as the operand planes of the consumer's leaky_relu
@@ -1219,6 +1268,7 @@ int run_generator_planes(vits_handle *h, Ctx &c, const float *z, int64_t z_bstri
     float *xs_raw = slab_take<float>(s, R);
     h->cur_stage = 3;
     stage_mark(h, 3);
+    rag_begin(h, c, ylen, B, F);
     const float S = 0.1f;  // Generator.LRELU_SLOPE / ResBlock LRELU_SLOPE
     const int nst = (int)m.ups.size();
     // z * y_mask (models.py:349) as conv_pre's operand plane (no activation in front of conv_pre)
@@ -1303,18 +1353,21 @@ int run_generator_planes(vits_handle *h, Ctx &c, const float *z, int64_t z_bstri
         const size_t lds = (size_t)m.post_cin * (256 + m.post_k - 1) * sizeof(float);
         if (m.post_k == 7)
             post_conv_tanh_blocked_kernel<7><<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out,
-                                                                                        m.post_cin, m.post_k, T, 0.01f);
+                                                                                        m.post_cin, m.post_k, T, 0.01f,
+                                                                                        tail_len(h, ylen), T / F);
         else
             post_conv_tanh_blocked_kernel<0><<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out,
-                                                                                        m.post_cin, m.post_k, T, 0.01f);
+                                                                                        m.post_cin, m.post_k, T, 0.01f,
+                                                                                        tail_len(h, ylen), T / F);
     }
     c.note(hipGetLastError());
     h->stats.total_launches++;
     {
-        double fl = 2.0 * m.post_cin * m.post_k * (double)T * B, by = 4.0 * B * ((double)m.post_cin * T + T);
+        double fl = 2.0 * m.post_cin * m.post_k * (double)T * B * c.work_frac(), by = 4.0 * B * ((double)m.post_cin * T + T) * c.work_frac();
         h->stats.dec_flops += fl;
         h->stats.dec_bytes += by;
     }
+    c.rag = SxRagged{nullptr, 0, 0};
     stage_mark(h, 4);
     return 0;
 }
@@ -1336,6 +1389,7 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
     float *tmp_raw = reinterpret_cast<float *>(tmp_pl), *xin_raw = reinterpret_cast<float *>(stage_in[0]);
     h->cur_stage = 3;
     stage_mark(h, 3);
+    rag_begin(h, c, ylen, B, F);
     const float S = 0.1f;  // Generator.LRELU_SLOPE / ResBlock LRELU_SLOPE
     const int nst = (int)m.ups.size();
     // Tensor formats (model.hpp sx_raw_format): > 64 channels: 16-bit planes that already carry the consumer's
@@ -1445,18 +1499,21 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
         const size_t lds = (size_t)m.post_cin * (256 + m.post_k - 1) * sizeof(float);
         if (m.post_k == 7)
             post_conv_tanh_blocked_kernel<7><<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out,
-                                                                                        m.post_cin, m.post_k, T, 0.01f);
+                                                                                        m.post_cin, m.post_k, T, 0.01f,
+                                                                                        tail_len(h, ylen), T / F);
         else
             post_conv_tanh_blocked_kernel<0><<<dim3((T + 255) / 256, B), 256, lds, st>>>(xs_raw, c.P(m.post_w), h->d_out,
-                                                                                        m.post_cin, m.post_k, T, 0.01f);
+                                                                                        m.post_cin, m.post_k, T, 0.01f,
+                                                                                        tail_len(h, ylen), T / F);
     }
     c.note(hipGetLastError());
     h->stats.total_launches++;
     {
-        double fl = 2.0 * m.post_cin * m.post_k * (double)T * B, by = 4.0 * B * ((double)m.post_cin * T + T);
+        double fl = 2.0 * m.post_cin * m.post_k * (double)T * B * c.work_frac(), by = 4.0 * B * ((double)m.post_cin * T + T) * c.work_frac();
         h->stats.dec_flops += fl;
         h->stats.dec_bytes += by;
     }
+    c.rag = SxRagged{nullptr, 0, 0};
     stage_mark(h, 4);
     (void)xa_is_raw;
     return 0;
@@ -1535,14 +1592,15 @@ int run_generator(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int
     size_t lds = ((size_t)m.post_cin * (256 + m.post_k - 1) + (size_t)m.post_cin * m.post_k) * sizeof(float);
     // (the leaky_relu(0.01) of models.py:364 was applied by the last stage's epilogue)
     post_conv_tanh_kernel<<<dim3((T + 255) / 256, B), 256, lds, st>>>(x, c.P(m.post_w), h->d_out, m.post_cin, m.post_k,
-                                                                      T, 1.0f);
+                                                                      T, 1.0f, tail_len(h, ylen), T / F);
     c.note(hipGetLastError());
     h->stats.total_launches++;
     {
-        double fl = 2.0 * m.post_cin * m.post_k * (double)T * B, by = 4.0 * B * ((double)m.post_cin * T + T);
+        double fl = 2.0 * m.post_cin * m.post_k * (double)T * B * c.work_frac(), by = 4.0 * B * ((double)m.post_cin * T + T) * c.work_frac();
         h->stats.dec_flops += fl;
         h->stats.dec_bytes += by;
     }
+    c.rag = SxRagged{nullptr, 0, 0};
     stage_mark(h, 4);
     return 0;
 }
@@ -1583,6 +1641,7 @@ int render_chunks(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int
     // length mask makes the conv engines bound their reads by the chunk instead of by the row pitch
     int *yl = slab_take<int>(s, B);
     const size_t mark = s.used;
+    const int *const whole_len = c.h_len;  // host copy of ylen (or nullptr)
     const int64_t total = (int64_t)F * hop;
     int64_t pend_first = 0, pend_n = 0;
     int pend = -1, k = 0, stop = 0;
@@ -1598,7 +1657,14 @@ int render_chunks(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int
         const int lo = f0 - ov > 0 ? f0 - ov : 0, hi = f1 + ov < F ? f1 + ov : F, n = hi - lo;
         s.used = mark;  // the previous chunk's workspace (its copy-out precedes this chunk on the stream)
         chunk_len_kernel<<<(B + 63) / 64, 64, 0, st>>>(ylen, yl, B, lo, n);
-        if (int rc = run_generator(h, c, z + lo, z_bstride, z_cstride, yl, B, n, dec_cond, s)) return rc;
+        // (host mirror of chunk_len_kernel for the ragged accounting; without frame counts every frame is valid)
+        std::vector<int> hyl((size_t)B, n);
+        if (ylen && whole_len)
+            for (int b = 0; b < B; b++) hyl[b] = whole_len[b] - lo < 0 ? 0 : (whole_len[b] - lo > n ? n : whole_len[b] - lo);
+        c.h_len = ylen && !whole_len ? nullptr : hyl.data();
+        const int rc_gen = run_generator(h, c, z + lo, z_bstride, z_cstride, yl, B, n, dec_cond, s);
+        c.h_len = whole_len;
+        if (rc_gen) return rc_gen;
         if (c.err != hipSuccess) return fail(h, VITS_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(c.err));
         const int64_t ns = (int64_t)(f1 - f0) * hop;
         // interior of this chunk: samples [(f0 - lo) * hop, (f1 - lo) * hop) of every row -> ring[k] as [B, ns]
@@ -1640,6 +1706,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     Slab &s = h->frm;
     s.used = 0;
     Ctx c{h, m, h->stream, h->arena_dev, B};
+    if ((int)h->h_ylen.size() == B) c.h_len = h->h_ylen.data();
     hipStream_t st = h->stream;
     const int *len = h->d_len, *ylen = h->d_ylen;
     float *zp = slab_take<float>(s, nCF), *z = slab_take<float>(s, nCF);
@@ -1823,6 +1890,10 @@ static int open_common(const char *path, vits_handle **out, bool host_only, int 
     }
     h->host_only = host_only;
     {
+        const char *te = std::getenv("VITSMI_TAILS");  // "reference": the graph's padded rendering (see vits_set_tails)
+        h->tails_reference = te && std::string(te) == "reference";
+    }
+    {
         // Arithmetic of the generator's convs on the split-exact engine (fp32 operands and results in every mode):
         //   f16x3  (default) two fp16 planes per operand, three MFMA products: each product within ~3 * 2^-24
         //   bf16x6 three bf16 planes, six products: each product exact to 2^-24
@@ -1992,6 +2063,13 @@ void *vits_stream(vits_handle *h) { return h ? (void *)h->stream : nullptr; }
 int vits_set_timing(vits_handle *h, int enable) {
     if (!h) return VITS_E_ARG;
     h->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
+    return VITS_OK;
+}
+
+int vits_set_tails(vits_handle *h, int reference) {
+    if (!h) return VITS_E_ARG;
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->tails_reference = reference != 0;
     return VITS_OK;
 }
 

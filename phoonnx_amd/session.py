@@ -70,6 +70,22 @@ class _PinnedPool:
                 release.append(ptr)
         return release
 
+    def drain(self, keep_bytes=None):
+        """Sort the blocks whose arrays have died into the free lists NOW and release what exceeds `keep_bytes` (default: the
+        pool's cap; 0 releases every idle block).  array() does this as it goes; a process that rendered one large batch and
+        then goes idle, streams, or asks for pageable results calls it through MiSession.close() / _fetch so that the host
+        memory does not stay page-locked until the next pooled allocation."""
+        with self._mu:
+            release = self._drain()
+            if keep_bytes is not None:
+                for c in sorted(self._free, reverse=True):
+                    while self._free[c] and self._idle > keep_bytes:
+                        release.append(self._free[c].pop())
+                        self._idle -= c
+        for q in release:
+            _ffi.load().vits_host_free(q)
+        return len(release)
+
     def array(self, shape, dtype=np.float32):
         import weakref
         count = int(np.prod(shape))
@@ -128,8 +144,13 @@ class MiSession:
     def __init__(self, path_or_bytes, sess_options=None, providers=None, provider_options=None, device_id: int = 0,
                  arena_device_ptr: Optional[int] = None, arena_bytes: int = 0, host_only: bool = False,
                  gen_precision: Optional[str] = None, range_fallback: bool = True, layout_only: bool = False,
-                 pinned_results: bool = True, **kwargs):
-        """gen_precision: arithmetic of the generator's convs - None (VITSMI_GEN_PRECISION or the default "f16x3"),
+                 pinned_results: bool = True, tails: Optional[str] = None, **kwargs):
+        """tails: what a padded batch (B > 1, unequal frame counts) holds behind each utterance's end - None (VITSMI_TAILS or
+        the default "zero"), "zero" (those samples are not rendered at all and read 0.0; every valid sample is bit-identical to
+        the padded rendering), "reference" (the exported graph's own padded rendering: its generator is not masked,
+        models.py:348-368, so the tails are its response to zeros - what onnxruntime returns).  The reference calls the
+        model with B = 1 only (voice.py:350-351), where the two are the same thing.
+        gen_precision: arithmetic of the generator's convs - None (VITSMI_GEN_PRECISION or the default "f16x3"),
         "f16x3", "bf16x6" (exact products), "f16" (the reduced-precision vocoder of BASELINE config 4: fp16 storage, one
         fp16 product per fp32 product, fp32 accumulation).  range_fallback: on a RangeError of an fp16 arithmetic, reopen
         with "bf16x6" and repeat the call (never silently clamped audio).
@@ -154,6 +175,9 @@ class MiSession:
         self.range_fallback = bool(range_fallback) and arena_device_ptr is None
         self._open_args = dict(arena_device_ptr=arena_device_ptr, arena_bytes=arena_bytes, host_only=self.host_only,
                                layout_only=layout_only)
+        if tails not in (None, "zero", "reference"):
+            raise SessionError(f"tails must be None, 'zero' or 'reference' (got {tails!r})")
+        self.tails = tails
         self._seed = 0
         self.range_fallbacks = 0  # times this session reopened itself with bf16x6 after a RangeError (stats())
         self._open(gen_precision)
@@ -173,6 +197,8 @@ class MiSession:
             raise SessionError(f"vits_open({self.path!r}) failed [{rc}]: {_ffi.last_error(None)}")
         self._h = h
         self.gen_precision = gen_precision
+        if self.tails is not None:
+            self._lib.vits_set_tails(self._h, 1 if self.tails == "reference" else 0)
         n = self._lib.vits_num_inputs(self._h)
         self._input_names = [self._lib.vits_input_name(self._h, i).decode() for i in range(n)]
 
@@ -196,6 +222,10 @@ class MiSession:
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.vits_close(self._h)
             self._h = C.c_void_p()
+            try:
+                _POOL.drain()   # dead result arrays of this session: back to the pool, the excess over its cap released
+            except Exception:
+                pass
 
     def __del__(self):
         try:
@@ -309,6 +339,8 @@ class MiSession:
         rc = self._lib.vits_fetch_output(self._h, C.c_void_p(dst), S_out, rows * S_out)
         if rc != 0:
             self._raise("vits_run", rc)
+        if not self.pinned_results:
+            _POOL.drain()   # (no pooled allocation will come along to do it)
 
     def vocoder(self, z, sid=None):
         z = np.ascontiguousarray(z, np.float32)
@@ -358,9 +390,14 @@ class MiSession:
             return 1 if stop.is_set() else 0
 
         def work():
+            # the session lock is held for the whole chunked run (taken on THIS thread: an RLock belongs to the thread that
+            # acquired it): a batch call from another thread then waits instead of running between this run's chunks on the
+            # same workspace - and returning this run's frame counts and audio as its own
             try:
-                rc = start(on_chunk)
-                put(None if rc == 0 or stop.is_set() else (rc, self._err()))
+                with self._mu:
+                    rc = start(on_chunk)
+                    err = None if rc == 0 or stop.is_set() else (rc, self._err())
+                put(err)
             except BaseException as e:  # noqa: BLE001 - re-raised on the consumer's thread
                 put(e)
 
@@ -420,16 +457,17 @@ class MiSession:
                                                                           int(chunk_frames), cb, None))
 
     def tap(self, name):
-        dims = (C.c_int64 * 4)()
-        nd = self._lib.vits_tap(self._h, name.encode(), None, 0, dims)
-        if nd < 0:
-            raise SessionError(f"vits_tap({name}) failed: {self._err()}")
-        shape = tuple(dims[i] for i in range(nd))
-        buf = np.empty(shape, np.float32)
-        nd = self._lib.vits_tap(self._h, name.encode(), _ffi.ptr(buf), buf.size, dims)
-        if nd < 0:
-            raise SessionError(f"vits_tap({name}) failed: {self._err()}")
-        return buf
+        with self._mu:  # (two C calls on the last run's workspace)
+            dims = (C.c_int64 * 4)()
+            nd = self._lib.vits_tap(self._h, name.encode(), None, 0, dims)
+            if nd < 0:
+                raise SessionError(f"vits_tap({name}) failed: {self._err()}")
+            shape = tuple(dims[i] for i in range(nd))
+            buf = np.empty(shape, np.float32)
+            nd = self._lib.vits_tap(self._h, name.encode(), _ffi.ptr(buf), buf.size, dims)
+            if nd < 0:
+                raise SessionError(f"vits_tap({name}) failed: {self._err()}")
+            return buf
 
     def meta(self, key):
         buf = C.create_string_buffer(1 << 16)
@@ -442,13 +480,22 @@ class MiSession:
             raise SessionError(self._err())
         return v.value
 
+    def set_tails(self, tails: str):
+        """"zero" / "reference": see the constructor (applies to the following runs)."""
+        if tails not in ("zero", "reference"):
+            raise SessionError(f"tails must be 'zero' or 'reference' (got {tails!r})")
+        with self._mu:
+            self.tails = tails
+            self._lib.vits_set_tails(self._h, 1 if tails == "reference" else 0)
+
     def set_timing(self, on=True):
         """True / 1: stage marks + events around every conv launch; 2: stage marks only; False / 0: off."""
         self._lib.vits_set_timing(self._h, 2 if on == 2 else (1 if on else 0))
 
     def stats(self):
         s = _ffi.VitsStats()
-        self._lib.vits_get_stats(self._h, C.byref(s))
+        with self._mu:
+            self._lib.vits_get_stats(self._h, C.byref(s))
         d = {k: getattr(s, k) for k, _ in _ffi.VitsStats._fields_}
         d["range_fallbacks"] = self.range_fallbacks
         return d
@@ -499,11 +546,12 @@ class MiSession:
                 "y_lengths_ptr": C.cast(out.y_lengths, C.c_void_p).value}
 
     def last_y_lengths(self) -> np.ndarray:
-        n = self._lib.vits_last_y_lengths(self._h, None, 0)
-        buf = np.zeros(max(n, 0), np.int64)
-        if n > 0:
-            self._lib.vits_last_y_lengths(self._h, buf.ctypes.data_as(C.POINTER(C.c_int64)), n)
-        return buf
+        with self._mu:  # (size, then contents: both of the same run)
+            n = self._lib.vits_last_y_lengths(self._h, None, 0)
+            buf = np.zeros(max(n, 0), np.int64)
+            if n > 0:
+                self._lib.vits_last_y_lengths(self._h, buf.ctypes.data_as(C.POINTER(C.c_int64)), n)
+            return buf
 
     def last_pcm16(self, normalize: bool = True, volume: float = 1.0, shape=None) -> np.ndarray:
         """int16 PCM of the last run, post-processed on the GPU exactly as TTSVoice.synthesize + AudioChunk do
@@ -540,9 +588,10 @@ class MiSession:
             return self.last_pcm16(normalize, volume, shape=(B, S)), ylen
 
     def sync(self):
-        rc = self._lib.vits_sync(self._h)
-        if rc != 0:
-            self._raise("vits_sync", rc)
+        with self._mu:
+            rc = self._lib.vits_sync(self._h)
+            if rc != 0:
+                self._raise("vits_sync", rc)
 
 
 class PipelinedSession:
@@ -578,7 +627,7 @@ class PipelinedSession:
         precision = first.gen_precision
         for _ in range(self._n_parts - 1):
             self.parts.append(MiSession(first.path, device_id=first.device_id, arena_device_ptr=first.arena_device(),
-                                        arena_bytes=first.arena_bytes(), gen_precision=precision))
+                                        arena_bytes=first.arena_bytes(), gen_precision=precision, tails=first.tails))
 
     def _fall_back(self, exc):
         """After a RangeError on any part: every borrower is synchronised and closed, THEN the owner reopens with the
@@ -615,6 +664,12 @@ class PipelinedSession:
     def set_seed(self, seed: int):
         for i, s in enumerate(self.parts):
             s.set_seed(int(seed) + i)
+
+    def set_tails(self, tails: str):
+        """"zero" / "reference" on every handle (MiSession.set_tails)."""
+        with self._mu:
+            for s in self.parts:
+                s.set_tails(tails)
 
     def hparam(self, key):
         return self.parts[0].hparam(key)

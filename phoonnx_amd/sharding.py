@@ -115,6 +115,28 @@ def open_sharded(path: str, device_id: int, dist=None, src: int = 0, force_broad
     return sess, arena
 
 
+class _DeviceArray:
+    """A device buffer the engine owns, described to torch through the CUDA array interface (zero copy)."""
+
+    def __init__(self, ptr: int, shape, typestr: str = "<f4"):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def report_rank_failure(exc: BaseException, rank: int, what: str = "") -> str:
+    """One machine-readable line for a rank that cannot go on (a peer died inside a collective, a device error, ...):
+    {"error": ..., "rank": ..., "what": ..., "stderr_tail": traceback}.  Printed to stdout and returned; the caller exits
+    non-zero.  A front end (bench.py launch_ranks, a serving supervisor) relays it instead of waiting for a result."""
+    import json
+    import sys
+    import traceback
+    tb = "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))
+    line = json.dumps({"error": f"{type(exc).__name__}: {exc}", "rank": int(rank), "what": what, "stderr_tail": tb[-1500:]})
+    print(line, flush=True)
+    sys.stderr.write(tb)
+    return line
+
+
 class ShardedSynthesizer:
     """Batched-utterance front: `synthesize(utterances)` runs this rank's shard and (optionally)
     gathers the waveforms of all ranks on the host in the original order."""
@@ -144,11 +166,15 @@ class ShardedSynthesizer:
         when the backend is nccl, on the host with gloo."""
         shards, inv = partition([len(u) for u in utterances], self.world)
         mine = shards[self.rank]
+        scales = np.asarray(scales, np.float32)
+        use_dev = bool(gather) and self.dist is not None and self.dist.get_backend() == "nccl" and hasattr(self.session, "run_device")
+        if use_dev:
+            return self._gather_device(utterances, shards, mine, scales, sids, gather, dst)
         local = []
         if len(mine):
             ids, lens = pad_batch([utterances[i] for i in mine])
             sid = None if sids is None else np.asarray([sids[i] for i in mine], np.int64)
-            r = self.session.synthesize_batch(ids, lens, np.asarray(scales, np.float32), sid)
+            r = self.session.synthesize_batch(ids, lens, scales, sid)
             for b in range(len(mine)):
                 n = int(r["y_lengths"][b]) * self.hop
                 local.append(r["output"][b, 0, 0, :n])
@@ -156,7 +182,7 @@ class ShardedSynthesizer:
             return [(int(i), w.copy()) for i, w in zip(mine, local)]
         import torch
         dist = self.dist
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        dev = torch.device("cpu")
         # 1. sample counts of every utterance of every rank (shards differ by at most one utterance: pad with zeros)
         rows = max(len(sh) for sh in shards)
         cnt = torch.zeros(rows, dtype=torch.int64)
@@ -169,7 +195,45 @@ class ShardedSynthesizer:
         flat = torch.zeros(max(width, 1), dtype=torch.float32)
         if local:
             flat[:int(cnt.sum())] = torch.from_numpy(np.concatenate(local))
-        flat = flat.to(dev)
+        return self._collect(flat, allcnt, shards, len(utterances), gather, dst)
+
+    def _gather_device(self, utterances, shards, mine, scales, sids, gather, dst):
+        """nccl backend: the shard is rendered device to device (vits_run_device), its valid samples are packed back to back
+        on the GPU straight out of the engine's output buffer, and that buffer goes into the collective - the waveform crosses
+        PCIe once, on its way to whoever asked for it (the host path costs a D2H, an H2D and another D2H per rank)."""
+        import torch
+        dist = self.dist
+        dev = torch.device("cuda", torch.cuda.current_device())
+        rows = max(len(sh) for sh in shards)
+        cnt = torch.zeros(rows, dtype=torch.int64, device=dev)
+        out = ylen = None
+        if len(mine):
+            ids, lens = pad_batch([utterances[i] for i in mine])
+            d_ids, d_lens = torch.from_numpy(ids).to(dev), torch.from_numpy(lens).to(dev)
+            d_sid = None if sids is None else torch.from_numpy(np.asarray([sids[i] for i in mine], np.int64)).to(dev)
+            torch.cuda.synchronize(dev)   # (the engine runs on its own stream: the inputs are in place before it starts)
+            r = self.session.run_device(d_ids.data_ptr(), d_lens.data_ptr(), len(mine), ids.shape[1], scales,
+                                        None if d_sid is None else d_sid.data_ptr())
+            self.session.sync()           # ... and its output is complete before torch's stream reads it
+            B, S = int(r["dims"][0]), int(r["dims"][3])
+            out = torch.as_tensor(_DeviceArray(r["data_ptr"], (B, S)), device=dev)
+            ylen = torch.as_tensor(_DeviceArray(r["y_lengths_ptr"], (B,), "<i8"), device=dev)
+            cnt[:B] = ylen * self.hop
+        allcnt = torch.zeros(self.world * rows, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allcnt, cnt)
+        allcnt = allcnt.cpu().view(self.world, rows)
+        width = int(allcnt.sum(1).max())
+        flat = torch.zeros(max(width, 1), dtype=torch.float32, device=dev)
+        if out is not None:
+            mask = torch.arange(out.shape[1], device=dev)[None, :] < cnt[:out.shape[0], None]
+            flat[:int(allcnt[self.rank].sum())] = out[mask]   # row-major: every row's valid prefix, rows in shard order
+        return self._collect(flat, allcnt, shards, len(utterances), gather, dst)
+
+    def _collect(self, flat, allcnt, shards, n_utts, gather, dst):
+        """ONE collective over the ranks' flat buffers (device tensors over RCCL, host tensors over gloo), then the rows are
+        cut apart on the host and put back into the request's order."""
+        import torch
+        dist = self.dist
         root_only = gather == "root"
         if root_only:
             parts = [torch.empty_like(flat) for _ in range(self.world)] if self.rank == dst else None
@@ -178,11 +242,11 @@ class ShardedSynthesizer:
                 return None
             everything = torch.stack(parts).cpu().numpy()
         else:
-            out = torch.empty(self.world * flat.numel(), dtype=torch.float32, device=dev)
+            out = torch.empty(self.world * flat.numel(), dtype=torch.float32, device=flat.device)
             dist.all_gather_into_tensor(out, flat)
             everything = out.cpu().numpy().reshape(self.world, flat.numel())
         # 3. cut the rows apart and restore the request's order
-        res = [None] * len(utterances)
+        res = [None] * n_utts
         for rk, sh in enumerate(shards):
             off = 0
             for j, i in enumerate(sh):

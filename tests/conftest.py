@@ -31,3 +31,14 @@ def golden_cases(npz):
 def case_get(npz, case, key):
     k = f"{case}/{key}"
     return npz[k] if k in npz.files else None
+
+
+def zero_tails(ref, y_lengths, hop):
+    """The reference's padded rendering [B,1,1,S] with every sample behind an utterance's end (y_lengths[b] * hop) set to
+    zero: what the engine returns by default (MiSession(tails="zero"): those samples are not rendered; the exported graph
+    fills them with its unmasked generator's response to zeros, models.py:348-368 / SURVEY 0.9)."""
+    import numpy as np
+    out = np.array(ref, copy=True)
+    for b in range(out.shape[0]):
+        out[b, ..., int(y_lengths[b]) * hop:] = 0
+    return out

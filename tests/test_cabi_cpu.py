@@ -348,3 +348,166 @@ def test_exporter_variants_resolve_or_are_refused_with_a_reason(variant):
     s.close()
     base.close()
 
+
+
+# ------------------------------------------------------------------ the build's ISA rule for spilled registers
+_ASM_HEAD = "\n_ZN6vitsmi4demoEv: ; @demo\n"
+_ASM_TAIL = "\ts_endpgm\n.Lfunc_end0:\n"
+
+
+def _kernel(body):
+    return _ASM_HEAD + "\n".join("\t" + ln if not ln.startswith((";;#", ".L")) else ln for ln in body) + "\n" + _ASM_TAIL
+
+
+def test_spill_hazard_check_finds_a_spilled_destination_of_an_asynchronous_load():
+    """phoonnx_amd.build.spill_hazards (DESIGN 5.1g hazard 1) on hand-written ISA: a scratch_store of a register that an
+    inline-asm load has been issued to, before anything read it or a full drain passed, is a finding; the same spill behind
+    the drain, behind the first use, or of a register the compiler itself loaded, is not."""
+    from phoonnx_amd.build import spill_hazards
+    load = [";;#ASMSTART", "global_load_dwordx4 v[10:13], v2, s[4:5] offset:1024", ";;#ASMEND"]
+    spill = ["scratch_store_dwordx4 off, v[10:13], off offset:16 ; 16-byte Folded Spill"]
+    # 1. spilled while in flight
+    f, n = spill_hazards(_kernel(load + ["v_add_u32_e32 v1, v2, v3"] + spill))
+    assert n == 1 and list(f) == ["_ZN6vitsmi4demoEv"] and "scratch_store_dwordx4" in f["_ZN6vitsmi4demoEv"][0][1]
+    # 2. one register of the quad is enough; a counted wait (vmcnt(2)) proves nothing
+    f, _ = spill_hazards(_kernel(load + [";;#ASMSTART", "s_waitcnt vmcnt(2)", ";;#ASMEND", "scratch_store_dword off, v12, off"]))
+    assert f
+    # 3. behind a full drain of the counter: fine
+    f, n = spill_hazards(_kernel(load + [";;#ASMSTART", "s_waitcnt vmcnt(0)", ";;#ASMEND"] + spill))
+    assert n == 1 and not f
+    # 4. behind its first use (the hand-written wait sits in front of that use): fine
+    f, _ = spill_hazards(_kernel(load + ["v_mfma_f32_32x32x16_f16 v[50:65], v[10:13], v[86:89], v[50:65]"] + spill))
+    assert not f
+    # 5. a load the COMPILER issued (outside an asm block) is tracked by the compiler itself: fine
+    f, _ = spill_hazards(_kernel(["global_load_dwordx4 v[10:13], v[2:3], off"] + spill))
+    assert not f
+    # 6. LDS reads count under lgkmcnt: vmcnt(0) does not cover them, lgkmcnt(0) does
+    lds = [";;#ASMSTART", "ds_read_b128 v[20:23], v5 offset:512", ";;#ASMEND"]
+    f, _ = spill_hazards(_kernel(lds + ["s_waitcnt vmcnt(0)", "scratch_store_dwordx4 off, v[20:23], off"]))
+    assert f
+    f, _ = spill_hazards(_kernel(lds + ["s_waitcnt lgkmcnt(0)", "scratch_store_dwordx4 off, v[20:23], off"]))
+    assert not f
+    # 7. a loop: the load sits at the bottom of the body, the spill at its top - they meet across the back edge
+    loop = [".LBB0_1:", "scratch_store_dwordx4 off, v[10:13], off offset:16"] + load + ["s_cbranch_scc1 .LBB0_1"]
+    f, _ = spill_hazards(_kernel(loop))
+    assert f
+    # 8. kernels that do not spill are not examined
+    f, n = spill_hazards(_kernel(load + ["v_add_f32_e32 v1, v10, v11"]))
+    assert n == 0 and not f
+
+
+def test_name_and_structure_disagreements_are_all_reported_through_the_abi(tmp_path):
+    """A graph whose node NAMES put two convs in each other's module (the names win: the file loads, weights bound by name)
+    reports every such node through vits_meta("vitsmi.name_warnings") - a C-ABI caller cannot read stderr - and a clean
+    file has no such key."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rename_nodes as rn
+    src = open(os.path.join(GOLDEN, "tiny_rb1.onnx"), "rb").read()
+    A, B = b"/enc_p/encoder/ffn_layers.0/conv_1/Conv", b"/enc_p/encoder/ffn_layers.1/conv_1/Conv"
+    out, seen = bytearray(), 0
+    for fn, wt, f0, a, b in rn._fields(src, 0, len(src)):
+        if fn != 7 or wt != 2:
+            out += src[f0:b]
+            continue
+        g = bytearray()
+        for gfn, gwt, g0, ga, gb in rn._fields(src, a, b):
+            if gfn != 1 or gwt != 2:
+                g += src[g0:gb]
+                continue
+            node = bytearray()
+            for nfn, nwt, n0, na, nb in rn._fields(src, ga, gb):
+                nm = bytes(src[na:nb])
+                if nfn == 3 and nwt == 2 and nm in (A, B):
+                    node += rn._ld(3, B if nm == A else A)
+                    seen += 1
+                else:
+                    node += src[n0:nb]
+            g += rn._ld(1, bytes(node))
+        out += rn._ld(7, bytes(g))
+    assert seen == 2
+    bad = tmp_path / "swapped.onnx"
+    bad.write_bytes(bytes(out))
+    s = MiSession(str(bad), host_only=True)
+    w = s.meta("vitsmi.name_warnings")
+    assert w is not None and len(w.strip().splitlines()) == 2 and A.decode() in w and B.decode() in w
+    s.close()
+    clean = MiSession(os.path.join(GOLDEN, "tiny_rb1.onnx"), host_only=True)
+    assert clean.meta("vitsmi.name_warnings") is None
+    clean.close()
+
+
+def test_a_stream_holds_the_session_lock_against_calls_from_other_threads():
+    """A chunked run (synthesize_stream / vocoder_stream) owns the handle's workspace until it ends: a call from another
+    thread (here: last_y_lengths, the middle one of a batch call's three C calls) must wait for it instead of running between
+    its chunks.  Stub library, no GPU: the worker thread of _stream takes MiSession's RLock around the C call."""
+    import ctypes as C
+    import threading
+    import time
+
+    log = []
+
+    class FakeLib:
+        def vits_last_y_lengths(self, h, buf, n):
+            log.append("Y")
+            return 0
+
+    s = object.__new__(MiSession)
+    s._mu = threading.RLock()
+    s._lib = FakeLib()
+    s._h = None
+
+    def start(cb):  # stands for vits_run_chunked: blocks, hands three chunks to the callback
+        log.append("S0")
+        buf = (C.c_float * 4)(1, 2, 3, 4)
+        for i in range(3):
+            time.sleep(0.05)
+            cb(None, C.cast(buf, C.POINTER(C.c_float)), 1, 4 * i, 4, 12)
+        log.append("S1")
+        return 0
+
+    got = []
+    t = threading.Thread(target=lambda: got.extend(c for c in s._stream(start)))
+    t.start()
+    time.sleep(0.06)          # the stream is between its chunks now
+    s.last_y_lengths()        # ... and this call has to wait for its end
+    t.join()
+    assert log == ["S0", "S1", "Y"], log
+    assert [c[0] for c in got] == [0, 4, 8] and all(np.array_equal(c[1], [[1, 2, 3, 4]]) for c in got)
+
+
+def test_pinned_pool_drain_releases_idle_blocks_without_waiting_for_the_next_allocation(monkeypatch):
+    """_PinnedPool.drain(): blocks whose arrays have died go back to the free lists at once and the excess over the cap is
+    released - MiSession.close() and the pageable-result path call it, so an idle process does not keep a large batch's
+    result page-locked.  Host allocator stubbed (no GPU here)."""
+    import ctypes as C
+    import gc
+    from phoonnx_amd import session as ses
+
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.free.argtypes = [C.c_void_p]
+    freed = []
+
+    class Stub:
+        def vits_host_alloc(self, n):
+            return libc.malloc(n)
+
+        def vits_host_free(self, p):
+            freed.append(p)
+            libc.free(p)
+
+    monkeypatch.setattr(ses._ffi, "load", lambda: Stub())
+    pool = ses._PinnedPool(keep_bytes=3 << 20)
+    a = pool.array((1 << 20,), np.float32)      # 4 MiB block
+    b = pool.array((1 << 18,), np.float32)      # 1 MiB block
+    a[:] = 1.0
+    b[:] = 2.0
+    del a, b
+    gc.collect()
+    assert pool.drain() == 1 and len(freed) == 1            # the 4 MiB block exceeds the cap next to nothing: released
+    assert pool._idle == 1 << 20                            # the 1 MiB one is kept for reuse
+    c = pool.array((1 << 18,), np.float32)
+    assert len(freed) == 1                                  # ... and reused
+    del c
+    gc.collect()
+    assert pool.drain(keep_bytes=0) == 1 and pool._idle == 0 and len(freed) == 2

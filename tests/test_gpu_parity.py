@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ALL_PRESETS, GOLDEN, ROOT, SX_PRESETS, TINY_PRESETS, case_get, golden_cases
+from conftest import ALL_PRESETS, GOLDEN, ROOT, SX_PRESETS, TINY_PRESETS, case_get, golden_cases, zero_tails
 
 pytestmark = pytest.mark.gpu
 
@@ -17,9 +17,16 @@ WAVE_TOL = 1e-3   # BASELINE.json north_star: max-abs on the final fp32 waveform
 STAGE_TOL = 2e-4
 
 
-def _session(preset):
+def _session(preset, tails=None):
     from phoonnx_amd import MiSession
-    return MiSession(os.path.join(GOLDEN, preset + ".onnx"))
+    return MiSession(os.path.join(GOLDEN, preset + ".onnx"), tails=tails)
+
+
+def _ref_wave(g, c, s, tails):
+    """The reference fixture's waveform as the session's tails mode returns it: the graph's padded rendering
+    ("reference") or that with the samples behind each utterance's end zeroed ("zero", the default)."""
+    ref = case_get(g, c, "out_output")
+    return ref if tails == "reference" else zero_tails(ref, case_get(g, c, "out_y_lengths"), s.hparam("hop"))
 
 
 # ------------------------------------------------------------------ kernel level: conv engine
@@ -659,9 +666,10 @@ def test_attention16_window_2_and_sharp_softmax():
 TAPS = ("x", "m_p", "logs_p", "logw", "w_ceil", "z_p", "z")
 
 
+@pytest.mark.parametrize("tails", ["zero", "reference"])
 @pytest.mark.parametrize("preset", TINY_PRESETS)
-def test_pipeline_matches_reference_goldens(preset):
-    s = _session(preset)
+def test_pipeline_matches_reference_goldens(preset, tails):
+    s = _session(preset, tails)
     g = np.load(os.path.join(GOLDEN, preset + ".npz"))
     for c in golden_cases(g):
         r = s.synthesize_batch(case_get(g, c, "ids"), case_get(g, c, "lens"), case_get(g, c, "scales"),
@@ -675,22 +683,24 @@ def test_pipeline_matches_reference_goldens(preset):
             ref = case_get(g, c, "out_" + k)
             assert r[k].shape == ref.shape, (preset, c, k, r[k].shape, ref.shape)
             np.testing.assert_allclose(r[k], ref, atol=STAGE_TOL, rtol=0, err_msg=f"{preset}/{c}/{k}")
-        ref = case_get(g, c, "out_output")
+        # tails="reference": the graph's whole padded output; "zero": its valid samples, exact zeros behind them
+        ref = _ref_wave(g, c, s, tails)
         assert r["output"].shape == ref.shape and r["output"].dtype == np.float32
         np.testing.assert_allclose(r["output"], ref, atol=WAVE_TOL, rtol=0, err_msg=f"{preset}/{c}/output")
         assert np.abs(r["output"] - ref).max() < 5e-5, "fp32 path should sit far inside the 1e-3 budget"
     s.close()
 
 
+@pytest.mark.parametrize("tails", ["zero", "reference"])
 @pytest.mark.parametrize("precision,nprod", [("f16x3", 2), ("bf16x6", 6)])
 @pytest.mark.parametrize("preset", SX_PRESETS)
-def test_sx_generator_matches_reference_goldens(monkeypatch, preset, precision, nprod):
+def test_sx_generator_matches_reference_goldens(monkeypatch, preset, precision, nprod, tails):
     """The headline kernel pinned to the reference: these fixtures come from the reference's own PyTorch graph
     (oracle/gen_golden.py) and their generators (256 -> 128 -> 64 -> 32 channels) run on conv_sx_kernel - plane-format
     ResBlock pairs at 128 channels, raw-format stages below, pixel-shuffled upsamplers, the speaker bias - in BOTH
     arithmetics.  A break in conv_sx_kernel or pack_conv_sx fails here against numbers the reference produced."""
     monkeypatch.setenv("VITSMI_GEN_PRECISION", precision)
-    s = _session(preset)
+    s = _session(preset, tails)
     assert s.hparam("gen_sx") == 1 and s.hparam("gen_nprod") == nprod
     g = np.load(os.path.join(GOLDEN, preset + ".npz"))
     worst = 0.0
@@ -701,7 +711,7 @@ def test_sx_generator_matches_reference_goldens(monkeypatch, preset, precision, 
         assert np.array_equal(r["y_lengths"], case_get(g, c, "out_y_lengths")), (preset, c)
         for k in ("x", "m_p", "logs_p", "logw", "z_p", "z"):
             np.testing.assert_allclose(r[k], case_get(g, c, "out_" + k), atol=STAGE_TOL, rtol=0, err_msg=f"{preset}/{c}/{k}")
-        ref = case_get(g, c, "out_output")
+        ref = _ref_wave(g, c, s, tails)
         assert r["output"].shape == ref.shape and r["output"].dtype == np.float32
         assert np.abs(ref).max() > 0.05                       # the comparison is not vacuous
         err = float(np.abs(r["output"] - ref).max())
@@ -713,9 +723,10 @@ def test_sx_generator_matches_reference_goldens(monkeypatch, preset, precision, 
     s.close()
 
 
+@pytest.mark.parametrize("tails", ["zero", "reference"])
 @pytest.mark.parametrize("precision,tol", [("f16x3", 5e-5), ("f16", 1e-2)])
 @pytest.mark.parametrize("preset", SX_PRESETS)
-def test_plane_stream_generator_matches_reference_goldens(monkeypatch, preset, precision, tol):
+def test_plane_stream_generator_matches_reference_goldens(monkeypatch, preset, precision, tol, tails):
     """The PLANE-STREAM generator (vitsmi.hip run_generator_planes: every inter-conv tensor stored once, as the operand
     planes of its consumer's leaky_relu; residuals recovered from them; fused ResBlock steps on conv_sx_pair16_kernel)
     against the reference fixtures - in the single-plane arithmetic, whose only generator it is (declared tolerance 1e-2 /
@@ -723,7 +734,7 @@ def test_plane_stream_generator_matches_reference_goldens(monkeypatch, preset, p
     raw-stream generator, which measures 3-5 % faster) and must be as accurate as the default."""
     monkeypatch.setenv("VITSMI_GEN_PRECISION", precision)
     monkeypatch.setenv("VITSMI_F16X3_STREAM", "planes")
-    s = _session(preset)
+    s = _session(preset, tails)
     assert s.hparam("gen_sx") == 1 and s.hparam("gen_nprod") == (2 if precision == "f16x3" else 1)
     g = np.load(os.path.join(GOLDEN, preset + ".npz"))
     worst, snr = 0.0, 1e9
@@ -732,7 +743,7 @@ def test_plane_stream_generator_matches_reference_goldens(monkeypatch, preset, p
                                case_get(g, c, "sid"), case_get(g, c, "noise_dp"), case_get(g, c, "noise_z"), taps=("z",))
         assert np.array_equal(r["y_lengths"], case_get(g, c, "out_y_lengths")), (preset, c)
         np.testing.assert_allclose(r["z"], case_get(g, c, "out_z"), atol=STAGE_TOL, rtol=0)
-        ref = case_get(g, c, "out_output")
+        ref = _ref_wave(g, c, s, tails)
         worst = max(worst, float(np.abs(r["output"] - ref).max()))
         d = (r["output"] - ref).astype(np.float64)
         snr = min(snr, 10 * np.log10((ref.astype(np.float64) ** 2).sum() / max((d ** 2).sum(), 1e-30)))

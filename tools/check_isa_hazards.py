@@ -6,6 +6,9 @@ scalar load in flight counts in lgkmcnt and returns out of order, so a counted w
 The engines drain the counter once at that boundary; this script compiles each instantiation unit to assembly and verifies
 that EVERY s_load between a kernel's first and last MFMA is followed by `s_waitcnt lgkmcnt(0)` before any counted wait.
 
+Second check (the build's own rule, phoonnx_amd.build.spill_hazards): no spill store of any kernel may hit a register that
+is the destination of an asynchronous inline-asm load not yet consumed (hazard 1).
+
     python tools/check_isa_hazards.py        (needs hipcc; ~1 min per unit; exit code 1 on a finding)
 """
 import os
@@ -15,8 +18,10 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from phoonnx_amd.build import spill_hazards  # noqa: E402
 CSRC = os.path.join(ROOT, "phoonnx_amd", "csrc")
-UNITS = ["tu_sx_h1", "tu_sx_s16p", "tu_sx_s16", "tu_sx_s32", "tu_sx_bf16", "tu_pair16", "tu_pair", "vitsmi"]
+UNITS = ["tu_sx_h1", "tu_sx_s16p", "tu_sx_s16", "tu_sx_s32", "tu_sx_bf16", "tu_pair16", "tu_pair", "tu_conv_f32", "vitsmi"]
 # kernels with counted lgkmcnt waits: the conv engines, and the 16x16x32 attention kernel (attention16.hip.hpp, in vitsmi.hip)
 KERNELS = r"_ZN6vitsmi[0-9]+(?:conv_sx|attention_relpos16)\w*"
 
@@ -42,18 +47,21 @@ def check(unit):
             if "s_load_dword" in l and mf[0] < k < mf[-1]:
                 nxt = next((m for m in lines[k + 1:] if "lgkmcnt" in m), "")
                 if "lgkmcnt(0)" not in nxt:
-                    bad.append((name, k, nxt.strip()))
+                    bad.append((name, k, "s_load followed by '" + nxt.strip() + "'"))
                     break
-    return n, bad
+    hz, nspill = spill_hazards(txt)
+    for name, f in hz.items():
+        bad.append((name, f[0][0], "spill of an asynchronous load's destination: " + f[0][1]))
+    return n, bad, nspill
 
 
 def main():
     total = 0
     for u in UNITS:
-        n, bad = check(u)
-        print(f"{u}: {n} kernels, unsafe: {len(bad)}")
-        for name, k, nxt in bad:
-            print(f"   {name}: s_load at line {k} followed by '{nxt}'")
+        n, bad, nspill = check(u)
+        print(f"{u}: {n} conv / attention kernels, {nspill} kernels that spill, unsafe: {len(bad)}")
+        for name, k, what in bad:
+            print(f"   {name}: line {k}: {what}")
         total += len(bad)
     sys.exit(1 if total else 0)
 

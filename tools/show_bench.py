@@ -1,4 +1,8 @@
-import json,sys
-d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-r=d["roofline"]
-print(sys.argv[1], round(d["value"]/1e6,1), "Msamples/s", round(d["ms_per_step"],2), "ms; sx avg launch ms", round(r["avg_launch_ms"],4), "stages", {k:round(v,2) for k,v in r.get("stages",{}).items() if k.endswith("_ms")})
+"""Print the summary block of a bench.py JSON line (file argument, or stdin)."""
+import json
+import sys
+
+txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
+d = json.loads([ln for ln in txt.strip().splitlines() if ln.startswith("{")][-1])
+for k, v in d.get("summary", {"value": d.get("value"), "ms_per_step": d.get("ms_per_step")}).items():
+    print(f"{k:32s} {v}")

@@ -8,6 +8,8 @@ import torch
 from phoonnx_amd import MiSession, _ffi
 from phoonnx_amd.synth import write_voice
 lib = _ffi.load()
+default_limit = lib.vits_test_set_sx_small_max(0)   # (returns the previous value: restored after every voice)
+lib.vits_test_set_sx_small_max(default_limit)
 for preset in ("medium", "high"):
     path = f"/tmp/vitsmi_bench/synth_{preset}.onnx"
     os.makedirs("/tmp/vitsmi_bench", exist_ok=True)
@@ -29,5 +31,5 @@ for preset in ("medium", "high"):
                 t0 = time.perf_counter(); s.synthesize_batch(ids, lens, sc); per.append((time.perf_counter() - t0) * 1e3)
             row.append("%d:%.2f" % (lim, np.median(per)))
         print(preset, "B=%d" % B, " ".join(row), flush=True)
-    lib.vits_test_set_sx_small_max(768)
+    lib.vits_test_set_sx_small_max(default_limit)
     s.close()
