@@ -48,6 +48,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <utility>
 
 #include "conv_engine.hip.hpp"
@@ -1010,7 +1011,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
                 for (int q = 0; q < 4; q++) {
                     const f32x4 other = __builtin_bit_cast(f32x4, got[k][q]);
                     const f32x4 own = wm == 0 ? mine[k][q] : mine[NW / 2 + k][q];
-                    if (t < T) {
+                    if (t < TV) {
                         if (a.out_pl) {
                             // acts as the fp16 operand planes of the res_skip conv on this engine (|acts| < 1: no range issue)
                             unsigned wa[2], wb[2];
@@ -1070,7 +1071,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
 #pragma unroll
                         for (int r = 0; r < 16; r++) old[r] = 0.f;
                     }
-                    if (t >= T) continue;
+                    if (t >= TV) continue;
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         float o[4];
@@ -1525,9 +1526,30 @@ inline hipError_t launch_conv_sx_h1_epi(const SxArgs &a, int epi, dim3 grid, siz
         default: return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, 1, 16>(a, grid, lds, stream);
     }
 }
+// (2 x 2 waves of 64 x 128: the compile-time epilogues only - the generic one spills there, which this engine's kernels must not)
+inline hipError_t launch_conv_sx_h1_epi22(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+    switch (epi) {
+        case kSxEpiPlanes: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiPlanes, false, false, 1, 16>(a, grid, lds, stream);
+        case kSxEpiInnerPl: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiInnerPl, false, false, 1, 16>(a, grid, lds, stream);
+        case kSxEpiFirst: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiFirst, false, false, 1, 16>(a, grid, lds, stream);
+        case kSxEpiAccum: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiAccum, false, false, 1, 16>(a, grid, lds, stream);
+        case kSxEpiAccum | EPI_DIV: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiAccum | EPI_DIV, false, false, 1, 16>(a, grid, lds, stream);
+        case kSxEpiStageOut: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiStageOut, false, false, 1, 16>(a, grid, lds, stream);
+        default: return launch_conv_sx_h1_epi<1, 8, 4, 1>(a, epi, grid, lds, stream);
+    }
+}
 hipError_t launch_conv_sx_h1_s16(const SxArgs &a, int cfg, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+    // 128 x 256 tile of the single-plane mode: four waves of 32 x 256 (each streams its own weight rows: what f16x3 runs,
+    // SX16_WIDE) or 2 x 2 waves of 64 x 128 - a B fragment then feeds two 32-row blocks, i.e. half the LDS reads per MFMA,
+    // which is what this mode (one product per fragment pair: 3x the operand bytes per MFMA of f16x3) is short of.
+    // VITSMI_H1_TILE=2x2 | 4x1 selects (A/B); default below.
+    static const bool t2x2 = [] {
+        const char *e = std::getenv("VITSMI_H1_TILE");
+        return e ? std::string(e) == "2x2" : false;
+    }();
     switch (cfg) {
-        case 0: return launch_conv_sx_h1_epi<1, 8, 4, 1>(a, epi, grid, lds, stream);
+        case 0: return t2x2 ? launch_conv_sx_h1_epi22(a, epi, grid, lds, stream)
+                            : launch_conv_sx_h1_epi<1, 8, 4, 1>(a, epi, grid, lds, stream);
         case 1: return launch_conv_sx_h1_epi<1, 4, 2, 2>(a, epi, grid, lds, stream);
         case 3: return launch_conv_sx_h1_epi<1, 2, 2, 2>(a, epi, grid, lds, stream);
         default: return launch_conv_sx_h1_epi<1, 2, 1, 4>(a, epi, grid, lds, stream);

@@ -41,6 +41,9 @@ __global__ __launch_bounds__(256) void conv_sx_small_kernel(SxArgs a, int MBP) {
         b = id / a.NT;
     }
     const int t0 = nt * (16 * NCT);
+    // TV: where this utterance's tensors end (SxRagged: the masked frame domain of a padded batch; = T otherwise).  T = row pitch.
+    const int TV = __builtin_amdgcn_readfirstlane(sx_valid_cols(a.rag, b, T));
+    if (t0 >= TV) return;  // (uniform exit) the whole tile lies behind the utterance's end
     // weights: step s of 32-row block mbi starts at ((mbi / MBP) * S * MBP + s * MBP + mbi % MBP) * 4 KiB
     const char *wb[NBLK];
 #pragma unroll
@@ -71,8 +74,8 @@ __global__ __launch_bounds__(256) void conv_sx_small_kernel(SxArgs a, int MBP) {
         static_for<NCT>([&](auto Nn) {
             constexpr int n = decltype(Nn)::value;
             const int tt = tcol[n] + tap * dil;
-            const u32x4 *p0 = (unsigned)tt < (unsigned)T ? xb + (int64_t)chunk * 4 * T + tt : zero16;
-            const u32x4 *p1 = (unsigned)tt < (unsigned)T ? xb + plane_cells + (int64_t)chunk * 4 * T + tt : zero16;
+            const u32x4 *p0 = (unsigned)tt < (unsigned)TV ? xb + (int64_t)chunk * 4 * T + tt : zero16;
+            const u32x4 *p1 = (unsigned)tt < (unsigned)TV ? xb + plane_cells + (int64_t)chunk * 4 * T + tt : zero16;
             rb[j][n * 2 + 0] = global_read128_v<0>(p0);
             rb[j][n * 2 + 1] = global_read128_v<0>(p1);
         });
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_sx_small_kernel(SxArgs a, int MBP) {
             const f32x4 bs = *reinterpret_cast<const f32x4 *>(biasp + (mt * 64 + 32 + rbk) * b_on) +
                              *reinterpret_cast<const f32x4 *>(bbp + (H + ch0 + rbk) * bb_on);
             const int t = t0 + c;
-            if (t < T) {
+            if (t < TV) {
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++)
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_sx_small_kernel(SxArgs a, int MBP) {
             // then fp32 raw cells [Cr/8][T][8] with leaky_relu(oslope) and / or operand planes with leaky_relu(oslope2)
             const int row0 = mt * 32 + 8 * (2 * sub + (g & 1)) + 4 * (g >> 1);
             const int t = t0 + n * 16 + c;
-            if (t < T) {
+            if (t < TV) {
                 const int64_t cell = ((int64_t)(row0 >> 3) * T + t) * 8 + (row0 & 4);
                 float *rawb = a.out_raw ? a.out_raw + (int64_t)b * a.raw_bstride : nullptr;
                 f32x4 v;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_sx_small_kernel(SxArgs a, int MBP) {
         const bool planes = plb && (a.pl_of2 ? !to_x : to_x) && r0 < a.pl_rows;
         const f32x4 bq = *reinterpret_cast<const f32x4 *>(biasp + row0 * b_on);
         const int t = t0 + n * 16 + c;
-        if (t < T) {
+        if (t < TV) {
             const float mk = t < Lb ? 1.f : 0.f;
             float o[4];
 #pragma unroll

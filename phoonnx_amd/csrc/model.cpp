@@ -1566,9 +1566,10 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
         {
             double r = double(conv_pre.K - 1 - conv_pre.padL > conv_pre.padL ? conv_pre.K - 1 - conv_pre.padL : conv_pre.padL);
             double rate = 1;
+            std::vector<double> part;  // reach of each stage (its transposed conv + its widest ResBlock), in frames
             for (auto &st : ups) {
                 const int right = st.up.K - 1 - st.up.padL;  // dense-conv form of the transposed conv: taps -padL .. right
-                r += double(right > st.up.padL ? right : st.up.padL) / rate;
+                double p = double(right > st.up.padL ? right : st.up.padL) / rate;
                 rate *= st.u;
                 double widest = 0;
                 for (auto &rb : st.rbs) {
@@ -1580,10 +1581,21 @@ std::string Model::build(const OnnxModel &om, bool layout_only) {
                     }
                     widest = w > widest ? w : widest;
                 }
-                r += widest / rate;
+                p += widest / rate;
+                part.push_back(p);
+                r += p;
             }
-            r += double(post_k / 2) / rate;
+            const double tail = double(post_k / 2) / rate;
+            r += tail;
             gen_rf_frames = int(std::ceil(r)) + 1;
+            // ... and what is left of it from the input of stage s on (ragged rendering: the launches of stage s end an
+            // utterance's tensors this many frames behind its end - every launch of a stage the same, they share the running sum)
+            gen_rf_stage.assign(ups.size(), 0);
+            double rest = tail;
+            for (int si = int(ups.size()) - 1; si >= 0; si--) {
+                rest += part[size_t(si)];
+                gen_rf_stage[size_t(si)] = int(std::ceil(rest)) + 1;
+            }
         }
         if (input_names.empty()) {
             input_names = {"input", "input_lengths", "scales"};

@@ -154,6 +154,7 @@ struct Model {
     int64_t post_w = -1;  // [Cin, K] conv_post weight (Cout = 1, no bias)
     int post_cin = 0, post_k = 7;
     int gen_rf_frames = 0;  // one-sided receptive field of the whole generator, in input frames (rounded up, + 1)
+    std::vector<int> gen_rf_stage;  // ... of what follows the INPUT of upsampling stage s (its transposed conv included)
 
     // ---- packed arena (host copy; empty after a layout-only build)
     std::vector<float> arena;

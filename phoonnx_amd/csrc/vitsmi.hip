@@ -246,6 +246,10 @@ struct Ctx {
         return SxRagged{rag.len, rag.add, T / rag_F};
     }
     double work_frac() const { return rag.len ? rag_frac : 1.0; }
+    // the flow's convs on a padded batch (conv_sx): frames behind y_len[b] are neither read nor written (device frame counts;
+    // the share of B * F frames inside the utterances, for the accounting)
+    const int *flow_len = nullptr;
+    double flow_frac = 1.0;
     void note(hipError_t e) {
         if (err == hipSuccess && e != hipSuccess) err = e;
     }
@@ -255,8 +259,9 @@ struct Ctx {
 void conv_account(Ctx &c, const ConvDesc &d, int T) {
     vits_handle *h = c.h;
     // (ragged generator launches: only the columns inside the utterances' ends are worked on)
-    double fl = 2.0 * d.macs_per_t * (double)T * c.B * c.work_frac();
-    double by = (d.h1 ? 2.0 : 4.0) * c.B * ((double)d.Cin * T + (double)d.Cout * T) * c.work_frac();  // (stored dtype: SURVEY 8d)
+    const double wf = c.h->cur_stage == 2 && c.flow_len ? c.flow_frac : c.work_frac();
+    double fl = 2.0 * d.macs_per_t * (double)T * c.B * wf;
+    double by = (d.h1 ? 2.0 : 4.0) * c.B * ((double)d.Cin * T + (double)d.Cout * T) * wf;  // (stored dtype: SURVEY 8d)
     h->stats.conv_flops += fl;
     h->stats.conv_bytes += by;
     h->stats.conv_launches++;
@@ -434,6 +439,10 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.s16 = d.s16 ? 1 : 0;
     vits_handle *h = c.h;
     if (h->cur_stage == 3) a.rag = c.rag_at(T);
+    // the flow's tensors are masked by y_len (modules.py:447-466: every conv's input is x * mask, every result * mask): a
+    // padded batch's frames behind an utterance's end are zeros the reference computes and this engine neither reads nor
+    // writes (run_frames: Ctx::flow_len, when every launch of the flow is one of these)
+    else if (h->cur_stage == 2 && c.flow_len) a.rag = SxRagged{c.flow_len, 0, 1};
     a.peak = range_slots(h, (d.f16 || d.h1) && (d.rawin || out_pl));  // launches that turn values into fp16 planes
     const bool ev = conv_event_begin(c);
     // Short grids (a single utterance, a streaming chunk): the 128-row packing is read by the 64- or 32-row kernel -
@@ -474,14 +483,14 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     // covers.  VITSMI_SX_SMALL_GEN=1 lifts that for single-shot latency: 1.31 -> 1.27 ms on `medium`, 3.34 -> 3.24 on `high`.)
     static const bool small_gen = [] { const char *e = std::getenv("VITSMI_SX_SMALL_GEN"); return e && e[0] == '1'; }();
     const bool small_kind = (a.flags & (SX_WN_RMW | SX_GATE)) != 0 || small_gen;
-    if (small_max > 0 && small_kind && !a.rag.len && conv_sx_small_ok(a, d.rawin, nprod) && conv_sx_small_wgs(a, c.B) <= small_max)
+    if (small_max > 0 && small_kind && conv_sx_small_ok(a, d.rawin, nprod) && conv_sx_small_wgs(a, c.B) <= small_max)
         c.note(launch_conv_sx_small(a, c.B, d.cfg, c.st));
     else
         c.note(launch_conv_sx(a, run_cfg, c.B, c.st, d.rawin, nprod, d.cfg));
     // layer-granular bytes in the STORED dtype ("bf16 storage halves these"): 2 bytes per element in the
     // single-plane mode, 4 otherwise
     const double ebytes = d.h1 ? 2.0 : 4.0;
-    const double wf = a.rag.len ? c.rag_frac : 1.0;
+    const double wf = !a.rag.len ? 1.0 : (h->cur_stage == 2 ? c.flow_frac : c.rag_frac);
     const double fl = 2.0 * d.macs_per_t * (double)T * c.B * wf, by = ebytes * c.B * ((double)d.Cin * T + (double)d.Cout * T) * wf;
     if (ev) conv_event_end(c, true, fl, by, d, T);
     conv_account(c, d, T);
@@ -1232,19 +1241,26 @@ size_t gen_ws_bytes(const Model &m, int B, int F) {
 // Ragged rendering of a padded batch (vits_handle::tails_reference == false): from here on every generator launch ends
 // utterance b's tensors gen_rf_frames behind ylen[b] (Ctx::rag_at), and the tail kernel writes zeros behind ylen[b] * hop.
 // Needs the host copy of the frame counts (Ctx::h_len) for the FLOP / byte accounting; B = 1 has no padding.
+// the margin of the following launches (frames behind an utterance's end that its tensors still cover), and with it the
+// share of B * F frames they work on
+void rag_margin(Ctx &c, int add) {
+    if (!c.rag.len) return;
+    const int B = c.B, F = c.rag_F;
+    double cols = 0;
+    for (int b = 0; b < B; b++) {
+        const int n = c.h_len[b];
+        cols += n > 0 ? (n + add < F ? n + add : F) : 0;
+    }
+    c.rag.add = add;
+    c.rag_frac = cols / ((double)B * F);
+}
 void rag_begin(vits_handle *h, Ctx &c, const int *ylen, int B, int F) {
     c.rag = SxRagged{nullptr, 0, 0};
     c.rag_F = F;
     c.rag_frac = 1.0;
-    if (!ylen || !c.h_len || B < 2 || h->tails_reference) return;
-    const int rf = h->model.gen_rf_frames;
-    double cols = 0;
-    for (int b = 0; b < B; b++) {
-        const int n = c.h_len[b];
-        cols += n > 0 ? (n + rf < F ? n + rf : F) : 0;
-    }
-    c.rag = SxRagged{ylen, rf, 1};
-    c.rag_frac = cols / ((double)B * F);
+    if (!ylen || !c.h_len || B < 2 || B != c.B || h->tails_reference) return;
+    c.rag = SxRagged{ylen, 0, 1};
+    rag_margin(c, h->model.gen_rf_frames);  // (conv_pre: the whole receptive field; the stages set their own, smaller ones)
 }
 // the frame counts the tail kernel zeroes behind (nullptr: the reference's padded rendering is kept as it is)
 const int *tail_len(const vits_handle *h, const int *ylen) { return h->tails_reference ? nullptr : ylen; }
@@ -1282,6 +1298,7 @@ int run_generator_planes(vits_handle *h, Ctx &c, const float *z, int64_t z_bstri
     int T = F;
     for (int si = 0; si < nst; si++) {
         const auto &stg = m.ups[si];
+        rag_margin(c, m.gen_rf_stage[si]);  // (what is left of the receptive field from this stage's input on)
         // y = up(xa), stored as leaky_relu(y, 0.1): the resblocks' first operand and, un-activated, their residual
         conv_sx(c, stg.up, xa, T, nullptr, y_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
         T *= stg.u;
@@ -1421,6 +1438,7 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
     int T = F;
     for (int si = 0; si < nst; si++) {
         const auto &stg = m.ups[si];
+        rag_margin(c, m.gen_rf_stage[si]);  // (what is left of the receptive field from this stage's input on)
         const bool fr = sx_raw_format(stg.C);  // format of this stage's tensors
         // y = up(leaky_relu(xa)): pixel-shuffled dense conv; raw (residual / raw-format input) [+ planes]
         conv_sx(c, stg.up, xa, T, y_raw, fr ? nullptr : y_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S, S);
@@ -1714,6 +1732,24 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     h->d_z = z;
     h->cur_stage = 2;
     stage_mark(h, 2);
+    {
+        // Ragged flow: only when EVERY launch of the flow is a conv_sx() launch (pre / gated in-layer / res_skip / post on the
+        // split-operand engine: every f16x3 voice) - a kernel without the per-utterance end would read what its predecessor
+        // did not write.  Masked either way, so results are those of the padded form, bit for bit.
+        static const bool off = std::getenv("VITSMI_NO_RAGGED_FLOW") != nullptr;  // A/B timing
+        bool all_sx = !off && B > 1 && c.h_len && (C / 2) % 32 == 0 && Hf % 32 == 0;
+        for (const auto &cd : m.flow) {
+            all_sx = all_sx && cd.pre_sx.sx && cd.post_sx.sx && cd.n_wn > 0;
+            for (int i = 0; i < cd.n_wn && all_sx; i++)
+                all_sx = cd.wn[i].in.sx && cd.wn[i].in.f16 && cd.wn[i].in.gate && cd.wn[i].rs_sx.sx;
+        }
+        if (all_sx) {
+            double fr = 0;
+            for (int b = 0; b < B; b++) fr += c.h_len[b] < F ? c.h_len[b] : F;
+            c.flow_len = ylen;
+            c.flow_frac = fr / ((double)B * F);
+        }
+    }
     const float noise_scale = scales[0];
     const float *nz = nullptr;
     int64_t nzs = F;

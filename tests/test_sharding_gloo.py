@@ -210,6 +210,9 @@ def test_bench_gpus_flag_launches_that_many_ranks():
                            capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode != 0
         assert '"metric"' not in r.stdout
+        # ... and the launcher says so in ONE machine-readable line instead of printing nothing
+        errs = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"error"' in ln]
+        assert len(errs) == 1 and "stderr_tail" in errs[0], r.stdout[-800:]
         if r.stderr.count("bench.py needs an MI355X") >= 2:
             break
     assert r.stderr.count("bench.py needs an MI355X") >= 2, r.stderr[-1500:]      # both ranks got as far as the device check
@@ -217,3 +220,60 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
                        timeout=120, env=env2)
     assert r.returncode != 0 and "--gpus 4 but the launcher started 1 rank" in (r.stderr + r.stdout)
+
+
+_KILL_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "tests"))
+import datetime
+import numpy as np
+import torch.distributed as dist
+from phoonnx_amd.sharding import ShardedSynthesizer, report_rank_failure
+from test_sharding_gloo import _StubSession, _request
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2, timeout=datetime.timedelta(seconds=20))
+sh = ShardedSynthesizer("unused.onnx", 0, dist, session=_StubSession())
+utts, sids = _request()
+scales = np.array([0.667, 1.5, 0.8], np.float32)
+sh.synthesize(utts, scales, sids, gather=True)      # one healthy request
+if rank == 1:
+    os._exit(7)                                     # ... then this rank dies, mid-service, without a word
+try:
+    sh.synthesize(utts, scales, sids, gather=True)  # the survivor's next gather cannot complete
+    print("UNEXPECTED: the gather returned", flush=True)
+    os._exit(0)
+except BaseException as e:
+    report_rank_failure(e, rank, "synthesize(gather=True)")
+    os._exit(3)
+'''
+
+
+def test_a_rank_that_dies_mid_request_makes_the_survivor_exit_with_an_error_line(tmp_path):
+    """VERDICT r4 item 7: two gloo ranks serve one gathered request, then rank 1 is gone (os._exit) while rank 0 enters the
+    next gather.  Rank 0 must neither hang nor return garbage: the collective fails (connection closed, or the process
+    group's timeout), phoonnx_amd.sharding.report_rank_failure prints ONE {"error", "rank", "stderr_tail"} line on stdout
+    and the process exits non-zero - what bench.py's launcher relays and a serving supervisor acts on."""
+    import json
+    import subprocess
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "kill_worker.py"
+    script.write_text(_KILL_WORKER.format(root=ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    t0 = time.time()
+    out0, err0 = procs[0].communicate(timeout=240)
+    procs[1].communicate(timeout=60)
+    assert procs[1].returncode == 7
+    assert procs[0].returncode == 3, (procs[0].returncode, out0[-500:], err0[-1500:])
+    assert time.time() - t0 < 200
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "UNEXPECTED" not in out0
+    rec = json.loads(lines[0])
+    assert rec["rank"] == 0 and rec["error"] and rec["what"] == "synthesize(gather=True)" and "Traceback" in rec["stderr_tail"]
