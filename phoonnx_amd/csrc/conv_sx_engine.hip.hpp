@@ -1526,30 +1526,12 @@ inline hipError_t launch_conv_sx_h1_epi(const SxArgs &a, int epi, dim3 grid, siz
         default: return launch_conv_sx_k<MW, NW, WM, WN, -1, false, false, 1, 16>(a, grid, lds, stream);
     }
 }
-// (2 x 2 waves of 64 x 128: the compile-time epilogues only - the generic one spills there, which this engine's kernels must not)
-inline hipError_t launch_conv_sx_h1_epi22(const SxArgs &a, int epi, dim3 grid, size_t lds, hipStream_t stream) {
-    switch (epi) {
-        case kSxEpiPlanes: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiPlanes, false, false, 1, 16>(a, grid, lds, stream);
-        case kSxEpiInnerPl: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiInnerPl, false, false, 1, 16>(a, grid, lds, stream);
-        case kSxEpiFirst: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiFirst, false, false, 1, 16>(a, grid, lds, stream);
-        case kSxEpiAccum: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiAccum, false, false, 1, 16>(a, grid, lds, stream);
-        case kSxEpiAccum | EPI_DIV: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiAccum | EPI_DIV, false, false, 1, 16>(a, grid, lds, stream);
-        case kSxEpiStageOut: return launch_conv_sx_k<2, 4, 2, 2, kSxEpiStageOut, false, false, 1, 16>(a, grid, lds, stream);
-        default: return launch_conv_sx_h1_epi<1, 8, 4, 1>(a, epi, grid, lds, stream);
-    }
-}
 hipError_t launch_conv_sx_h1_s16(const SxArgs &a, int cfg, int epi, dim3 grid, size_t lds, hipStream_t stream) {
-    // 128 x 256 tile of the single-plane mode: four waves of 32 x 256 (each streams its own weight rows: what f16x3 runs,
-    // SX16_WIDE) or 2 x 2 waves of 64 x 128 - a B fragment then feeds two 32-row blocks, i.e. half the LDS reads per MFMA,
-    // which is what this mode (one product per fragment pair: 3x the operand bytes per MFMA of f16x3) is short of.
-    // VITSMI_H1_TILE=2x2 | 4x1 selects (A/B); default below.
-    static const bool t2x2 = [] {
-        const char *e = std::getenv("VITSMI_H1_TILE");
-        return e ? std::string(e) == "2x2" : false;
-    }();
+    // (round 5, measured and not kept: the 128 x 256 tile as 2 x 2 waves of 64 x 128 - a B fragment then feeds two 32-row
+    // blocks, half the LDS reads per MFMA, what this one-product mode looked short of - is SLOWER than the four 32 x 256 waves
+    // f16x3 runs: headline batch 264.3 vs 277.5 M samples/s, default voice 1039 vs 1059 M; gpurun_out r05c)
     switch (cfg) {
-        case 0: return t2x2 ? launch_conv_sx_h1_epi22(a, epi, grid, lds, stream)
-                            : launch_conv_sx_h1_epi<1, 8, 4, 1>(a, epi, grid, lds, stream);
+        case 0: return launch_conv_sx_h1_epi<1, 8, 4, 1>(a, epi, grid, lds, stream);
         case 1: return launch_conv_sx_h1_epi<1, 4, 2, 2>(a, epi, grid, lds, stream);
         case 3: return launch_conv_sx_h1_epi<1, 2, 2, 2>(a, epi, grid, lds, stream);
         default: return launch_conv_sx_h1_epi<1, 2, 1, 4>(a, epi, grid, lds, stream);

@@ -988,6 +988,14 @@ __global__ void ylen_to_i64(const int *in, int64_t *out, int B) {
 }
 
 // ---- f2: synthesize()'s post-processing on the device (voice.py:271-282 + AudioChunk, :88-91) ----------
+// out[b][c][t] = t < len[b] ? in[b][c][t] : 0 over [B][C][T] tensors (run_frames: z = z_p * y_mask for the ragged flow)
+__global__ __launch_bounds__(256) void masked_copy_kernel(const float *in, float *out, const int *len, int C, int T) {
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t >= T) return;
+    const int64_t i = ((int64_t)b * C + c) * T + t;
+    out[i] = t < len[b] ? in[i] : 0.f;
+}
+
 // per utterance: peak = max|x| over its valid samples; x = peak < 1e-8 ? 0 : x / peak; x *= volume;
 // clip to [-1,1]; int16 = trunc(clip(x * 32767, -32767, 32767)).  Same float32 operations in the same
 // order as the NumPy code, so the PCM is bit-identical.

@@ -1389,6 +1389,12 @@ int run_generator_planes(vits_handle *h, Ctx &c, const float *z, int64_t z_bstri
     return 0;
 }
 
+// f16x3, plane-format stages: residual stream as operand planes only (run_generator_sx); VITSMI_F16X3_RES=raw|planes
+bool res_planes_on() {  // (read per run: tests switch it inside one process)
+    const char *e = std::getenv("VITSMI_F16X3_RES");
+    return e ? std::string(e) == "planes" : false;
+}
+
 // The generator on the split-operand engine.  Same dataflow as run_generator below; tensors that feed a conv
 // are stored as 16-bit planes (already leaky-ReLU'd by their producer), the residual stream as fp32 raw cells.
 int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int z_cstride, const int *ylen, int B,
@@ -1440,8 +1446,16 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
         const auto &stg = m.ups[si];
         rag_margin(c, m.gen_rf_stage[si]);  // (what is left of the receptive field from this stage's input on)
         const bool fr = sx_raw_format(stg.C);  // format of this stage's tensors
+        // Plane-format stages (> 64 channels) in f16x3: the residual stream as operand planes ONLY (SX_RES_PL: a residual is
+        // recovered from the planes of leaky_relu(x), 22 bits, as in run_generator_planes) - no fp32 copy of y and of the
+        // blocks' intermediate x is written or read: 12 instead of 16 bytes per element on the residual convs, which at 128
+        // channels and k = 3 are HBM-bound (launch table r05c: 0.65 ms = 4.9 TB/s of real traffic).  Needs every conv of the
+        // stage on the 16x16x32 loop (the SX_RES_PL instantiations); VITSMI_F16X3_RES=raw keeps the fp32 residual stream (A/B).
+        bool rpl = !fr && h->gen_nprod == 2 && res_planes_on() && stg.up.s16;
+        for (const auto &rbk : stg.rbs)
+            for (int q = 0; q < rbk.n && rpl; q++) rpl = rbk.c1[q].s16 && rbk.c1[q].f16 && (!rbk.type1 || (rbk.c2[q].s16 && rbk.c2[q].f16));
         // y = up(leaky_relu(xa)): pixel-shuffled dense conv; raw (residual / raw-format input) [+ planes]
-        conv_sx(c, stg.up, xa, T, y_raw, fr ? nullptr : y_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S, S);
+        conv_sx(c, stg.up, xa, T, rpl ? nullptr : y_raw, fr ? nullptr : y_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S, S);
         T *= stg.u;
         uint16_t *xs_pl = stage_in[(si + 1) & 1];
         const int nk = (int)stg.rbs.size();
@@ -1476,6 +1490,19 @@ int run_generator_sx(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, 
                     }
                 }
                 const void *in = fr ? static_cast<const void *>(cur) : static_cast<const void *>(cura);
+                if (rpl) {
+                    // (the block's stream exists as planes only: an inner step writes no raw tensor, every step takes its
+                    // residual from the planes of its own input)
+                    if (!last) dst = nullptr;
+                    if (rbk.type1) {
+                        conv_sx(c, rbk.c1[q], in, T, nullptr, tmp_pl, 0, nullptr, nullptr, 0, 1.f, 1.f, S);
+                        conv_sx(c, rbk.c2[q], tmp_pl, T, dst, dsta, fl, nullptr, nullptr, 0, (float)nk, 1.f, S, 1.f, nullptr, cura, S);
+                    } else
+                        conv_sx(c, rbk.c1[q], in, T, dst, dsta, fl, nullptr, nullptr, 0, (float)nk, 1.f, S, 1.f, nullptr, cura, S);
+                    cur = dst;
+                    cura = dsta;
+                    continue;
+                }
                 if (rbk.type1) {  // modules.py:301-314: x = c2(lrelu(c1(lrelu(x)))) + x
                     if (fr && sx_pair_ok(h, rbk.c1[q], rbk.c2[q])) {
                         // both convs in one launch: the intermediate stays in LDS, x is read once
@@ -1769,7 +1796,14 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
                                                                        len, ylen, nz, nzs, noise_scale, zp, C, T, F,
                                                                        nz == d_noise_z ? Freal : F);
     h->stats.total_launches++;
-    HIPCHECK(h, hipMemcpyAsync(z, zp, nCF * 4, hipMemcpyDeviceToDevice, st));
+    if (c.flow_len) {
+        // z = z_p * y_mask: the ragged flow leaves the frames behind an utterance's end alone, where the reference's couplings
+        // zero them one half at a time ((x1 - m) * mask, modules.py:464) - same z wherever it is valid, and the zeros the
+        // reference ends up with behind
+        masked_copy_kernel<<<dim3((F + 255) / 256, C, B), 256, 0, st>>>(zp, z, ylen, C, F);
+        h->stats.total_launches++;
+    } else
+        HIPCHECK(h, hipMemcpyAsync(z, zp, nCF * 4, hipMemcpyDeviceToDevice, st));
 
     // ---- inverse coupling flow (models.py:247-254, modules.py:447-466); Flips folded at pack time
     float *hx = slab_take<float>(s, nHF), *skip = slab_take<float>(s, nHF), *acts = slab_take<float>(s, nHF);

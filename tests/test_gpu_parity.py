@@ -723,6 +723,26 @@ def test_sx_generator_matches_reference_goldens(monkeypatch, preset, precision, 
     s.close()
 
 
+@pytest.mark.parametrize("preset", SX_PRESETS)
+def test_plane_residual_stream_of_the_wide_stages_matches_reference_goldens(monkeypatch, preset):
+    """VITSMI_F16X3_RES=planes: the > 64-channel stages of the default (raw-stream) f16x3 generator keep their residual
+    stream as operand planes only (SX_RES_PL: 12 instead of 16 bytes per element on the residual convs); the <= 64-channel
+    stages stay on the fused raw-format kernels.  Same fixtures, same bar as the default."""
+    monkeypatch.setenv("VITSMI_F16X3_RES", "planes")
+    s = _session(preset, "reference")
+    assert s.hparam("gen_sx") == 1 and s.hparam("gen_nprod") == 2
+    g = np.load(os.path.join(GOLDEN, preset + ".npz"))
+    worst = 0.0
+    for c in golden_cases(g):
+        r = s.synthesize_batch(case_get(g, c, "ids"), case_get(g, c, "lens"), case_get(g, c, "scales"),
+                               case_get(g, c, "sid"), case_get(g, c, "noise_dp"), case_get(g, c, "noise_z"))
+        assert np.array_equal(r["y_lengths"], case_get(g, c, "out_y_lengths")), (preset, c)
+        worst = max(worst, float(np.abs(r["output"] - case_get(g, c, "out_output")).max()))
+    print(f"{preset} plane residual stream: worst waveform error vs the reference fixture {worst:.3g}")
+    assert worst < 5e-5
+    s.close()
+
+
 @pytest.mark.parametrize("tails", ["zero", "reference"])
 @pytest.mark.parametrize("precision,tol", [("f16x3", 5e-5), ("f16", 1e-2)])
 @pytest.mark.parametrize("preset", SX_PRESETS)
