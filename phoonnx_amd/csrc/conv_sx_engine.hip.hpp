@@ -150,6 +150,11 @@ struct SxArgs {
     // returning plausible-looking audio (vits_stats::f16_peak_max / f16_saturated, VITS_E_RANGE).
     unsigned *peak;
     SxRagged rag;         // per-utterance tensor ends (generator convs of a padded batch), see SxRagged
+    // Transposed convs (ups > 1) of kernel 2 * ups in their dense 3-tap form: every output phase uses TWO of the three taps -
+    // tap 2 is all zeros for the phases r with (r + zt_p) / ups == 0, tap 0 for the others (model.cpp pack_convT_sx).  zt_p >= 0:
+    // the 16x16x32 loop's four-wave tile (a wave = one 32-row block = one phase) skips the MFMAs of its block's zero tap (a
+    // third of the launch's matrix work; adding x * 0 changes no accumulator).  -1: no such structure.
+    int zt_p = -1;
 };
 
 
@@ -512,6 +517,15 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
 #pragma unroll
                 for (int bb = 0; bb < 2; bb++) c16[m][aa][n][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int S = a.nchunks * K, H = S * HPS;
+    // this wave's all-zero tap of a transposed conv (SxArgs::zt_p), or -1
+    int ztap = -1;
+    if constexpr (MW == 1 && WN == 1) {
+        if (a.zt_p >= 0 && a.ups > 1) {
+            const int blk = (mt * BM + wm * 32) >> 5;  // 32-row block = (channel block, phase)
+            ztap = __builtin_amdgcn_readfirstlane(((blk % a.ups) + a.zt_p) / a.ups == 0 ? 2 : 0);
+        }
+    }
+    bool zskip = false;  // (per half-step, wave-uniform)
     const uint32_t voff0 = (uint32_t)lane * 16u;
     auto load_ah = [&](AHalf &f, int hs) __attribute__((always_inline)) {  // half-step hs = (step, 32-row block m)
         const int st = hs / HPS, m = hs - st * HPS;
@@ -549,6 +563,9 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
         constexpr int m = decltype(M)::value, bf = decltype(BUF)::value, q = decltype(Q)::value;
         // products in the order of the 32x32x16 loop: g1*h0, g0'*h1', g0*h0; consecutive MFMAs hit different accumulators
         if constexpr ((SX16_ABL & 1) != 0) return;
+        if constexpr (MW == 1 && WN == 1) {
+            if (zskip) return;  // (uniform) this block's weights of this tap are all zeros
+        }
         if constexpr (SX16_PRIO) __builtin_amdgcn_s_setprio(1);
         if constexpr (H1) {
 #pragma unroll
@@ -621,6 +638,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
         // ... unless this half-step opens a chunk whose x tile was issued by the previous one (K = 1 and one half-step per
         // step): the barrier below publishes that tile, so this wave's share of it must have landed
         const bool chunk_start = m == 0 && tap == 0;
+        zskip = tap == ztap;
         // A(hs) was the FIRST request of the half-step NA - 1 back: in flight behind it may stay that half-step's x DMAs and
         // everything the half-steps since have issued.  A half-step that opens a chunk also needs that chunk's x tile (the
         // barrier below publishes it): behind its DMAs only the weight requests made since may stay.

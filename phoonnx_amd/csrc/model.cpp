@@ -909,6 +909,16 @@ ConvDesc pack_convT_sx(Packer &P, const Resolver &R, const std::string &name) {
     ConvDesc d = pack_conv_sx(P, g.Cin, g.Cout * g.u, Kv, 1, -g.o_min, wf, b ? bv.data() : nullptr);
     d.ups = g.u;
     d.macs_per_t = double(g.Cin) * g.Cout * g.K;
+    // K = 2 u, three dense taps starting at -1: phase r reads taps {e, e + 1} with e = (r + p) / u in {0, 1} - the third is zero
+    if (g.K == 2 * g.u && Kv == 3 && g.o_min == -1 && d.K == 3) {
+        bool ok = true;  // (checked against the packed function itself, tap by tap)
+        for (int cov = 0; cov < g.Cout * g.u && ok; cov += 32) {
+            const int r = (cov / 32) % g.u, zt = (r + g.p) / g.u == 0 ? 2 : 0;
+            for (int ci = 0; ci < g.Cin && ok; ci++)
+                for (int k = 0; k < 32 && ok; k++) ok = wf(cov + k, ci, zt) == 0.f;
+        }
+        if (ok) d.zt_p = g.p;
+    }
     return d;
 }
 

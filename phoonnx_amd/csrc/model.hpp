@@ -47,6 +47,9 @@ struct ConvDesc {
     // sx only (flow WN in-layers): rows packed as [32 tanh | 32 sigmoid] per 64-row tile, the conv's epilogue applies
     // the gate and writes planar acts (conv_sx_engine.hip.hpp SX_GATE)
     bool gate = false;
+    // sx transposed convs of kernel 2 * ups (dense 3-tap form): the padding of the transposed conv - which of the three taps
+    // is all zeros follows from it per output phase (SxArgs::zt_p); -1: not such a conv
+    int zt_p = -1;
     double macs_per_t = 0;   // algorithmic MACs per input time step (reference definition)
     bool valid() const { return w_off >= 0; }
 };

@@ -437,6 +437,10 @@ void conv_sx(Ctx &c, const ConvDesc &d, const void *x, int T, float *out_raw, ui
     a.oslope2 = oslope2;
     a.wscale = d.wscale;
     a.s16 = d.s16 ? 1 : 0;
+    {
+        static const bool zt_off = std::getenv("VITSMI_NO_ZERO_TAP_SKIP") != nullptr;  // A/B timing
+        a.zt_p = zt_off ? -1 : d.zt_p;
+    }
     vits_handle *h = c.h;
     if (h->cur_stage == 3) a.rag = c.rag_at(T);
     // the flow's tensors are masked by y_len (modules.py:447-466: every conv's input is x * mask, every result * mask): a
@@ -1389,10 +1393,12 @@ int run_generator_planes(vits_handle *h, Ctx &c, const float *z, int64_t z_bstri
     return 0;
 }
 
-// f16x3, plane-format stages: residual stream as operand planes only (run_generator_sx); VITSMI_F16X3_RES=raw|planes
+// f16x3, plane-format stages: residual stream as operand planes only (run_generator_sx); VITSMI_F16X3_RES=raw for the fp32 one
 bool res_planes_on() {  // (read per run: tests switch it inside one process)
+    // default ON (r05e, same box, two runs each: 138.9 / 137.4 M samples/s against 136.3 / 136.3 with the fp32 residual stream;
+    // 128-channel k = 3 residual conv 652 -> 588-600 us, stride-8 upsampler 983 -> 830 us, k = 11 residual convs +2-3 %)
     const char *e = std::getenv("VITSMI_F16X3_RES");
-    return e ? std::string(e) == "planes" : false;
+    return e ? std::string(e) != "raw" : true;
 }
 
 // The generator on the split-operand engine.  Same dataflow as run_generator below; tensors that feed a conv
@@ -2742,6 +2748,7 @@ static void fill_sx_args(SxArgs &a, const ConvDesc &d, const float *dA, int T) {
     a.nchunks = d.nchunks; a.ups = d.ups;
     a.div = 1.f;
     a.s16 = d.s16 ? 1 : 0;
+    a.zt_p = std::getenv("VITSMI_NO_ZERO_TAP_SKIP") ? -1 : d.zt_p;
 }
 
 static int run_test_conv_sx(const ConvDesc &d, const std::vector<float> &arena, const float *x, int B, int T, int flags,

@@ -691,12 +691,17 @@ class PipelinedSession:
             out.append((b0, nb, r))
         return out
 
-    def run_device_steps(self, ids_ptr, lens_ptr, B, T, scales, steps, sid_ptr=None):
+    def run_device_steps(self, ids_ptr, lens_ptr, B, T, scales, steps, sid_ptr=None, alternate=False):
         """`steps` back-to-back passes over the same device-resident batch with one host thread per part, as two
         serving workers would run: a part goes on to its next pass without waiting for the other one, and part i
         starts once part i-1 has handed its first generator to the GPU, so that the small-grid stages of one part
         keep falling under the generator of the other.  Returns the frame count of every utterance of every pass,
-        int64 [steps, B]; all work has completed on return."""
+        int64 [steps, B]; all work has completed on return.
+        alternate=False: every pass is split over the parts (rows [b0, b1) each) - a pass's latency is that of a sub-batch.
+        alternate=True: WHOLE passes are dealt to the parts in turn (pass k on part k mod n: request-level pipelining, each
+        worker renders complete batches) - the generator keeps the full batch's grids (a sub-batch of 11 leaves the default
+        voice's 128-channel stage at 283 workgroups on 512 slots), while pass k + 1's token and frame stages still fall
+        under pass k's generator on the other handle."""
         import threading
         bnd = self.bounds(B)
         n = len(bnd) - 1
@@ -708,6 +713,13 @@ class PipelinedSession:
             try:
                 if i > 0:
                     started[i - 1].wait()
+                if alternate:
+                    for k in range(i, steps, n):
+                        self.parts[i].run_device(ids_ptr, lens_ptr, B, T, scales, sid_ptr)
+                        started[i].set()
+                        out[k, :] = self.parts[i].last_y_lengths()
+                    self.parts[i].sync()
+                    return
                 b0, nb = bnd[i], bnd[i + 1] - bnd[i]
                 for k in range(steps):
                     self.parts[i].run_device(ids_ptr + b0 * T * 8, lens_ptr + b0 * 8, nb, T, scales,

@@ -707,8 +707,13 @@ assert np.array_equal(a["y_lengths"], b["y_lengths"]) and np.array_equal(a["outp
 s.close(); plain.close()
 sh = ShardedSynthesizer(path, 0, dist, force_broadcast=True)
 utts = [list(map(int, ids[i, :lens[i]])) for i in range(3)]
+# (nccl backend: the shard is rendered device to device, its valid samples are packed on the GPU out of the engine's own
+# output buffer, and that tensor goes into the collective - sharding.ShardedSynthesizer._gather_device)
 out = sh.synthesize(utts, sc, sids=[0, 3, 1], gather=True)
 assert len(out) == 3 and all(len(w) == int(b["y_lengths"][i]) * sh.hop for i, w in enumerate(out))
+assert all(np.array_equal(w, b["output"][i, 0, 0, :len(w)]) for i, w in enumerate(out))      # every sample of a plain run
+root = sh.synthesize(utts, sc, sids=[0, 3, 1], gather="root")
+assert all(np.array_equal(w, v) for w, v in zip(out, root))
 sh.close()
 dist.destroy_process_group()
 print("SHARDED_OK")

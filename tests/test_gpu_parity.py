@@ -723,12 +723,14 @@ def test_sx_generator_matches_reference_goldens(monkeypatch, preset, precision, 
     s.close()
 
 
+@pytest.mark.parametrize("res", ["planes", "raw"])
 @pytest.mark.parametrize("preset", SX_PRESETS)
-def test_plane_residual_stream_of_the_wide_stages_matches_reference_goldens(monkeypatch, preset):
-    """VITSMI_F16X3_RES=planes: the > 64-channel stages of the default (raw-stream) f16x3 generator keep their residual
-    stream as operand planes only (SX_RES_PL: 12 instead of 16 bytes per element on the residual convs); the <= 64-channel
-    stages stay on the fused raw-format kernels.  Same fixtures, same bar as the default."""
-    monkeypatch.setenv("VITSMI_F16X3_RES", "planes")
+def test_residual_stream_of_the_wide_stages_matches_reference_goldens_in_both_forms(monkeypatch, preset, res):
+    """The > 64-channel stages of the f16x3 generator keep their residual stream as operand planes only (the default:
+    SX_RES_PL, a residual is recovered from the planes of leaky_relu(x); 12 instead of 16 bytes per element on the residual
+    convs) or as fp32 raw tensors next to the planes (VITSMI_F16X3_RES=raw: rounds 1-4); the <= 64-channel stages stay on
+    the fused raw-format kernels either way.  Same fixtures, same bar."""
+    monkeypatch.setenv("VITSMI_F16X3_RES", res)
     s = _session(preset, "reference")
     assert s.hparam("gen_sx") == 1 and s.hparam("gen_nprod") == 2
     g = np.load(os.path.join(GOLDEN, preset + ".npz"))
@@ -738,7 +740,7 @@ def test_plane_residual_stream_of_the_wide_stages_matches_reference_goldens(monk
                                case_get(g, c, "sid"), case_get(g, c, "noise_dp"), case_get(g, c, "noise_z"))
         assert np.array_equal(r["y_lengths"], case_get(g, c, "out_y_lengths")), (preset, c)
         worst = max(worst, float(np.abs(r["output"] - case_get(g, c, "out_output")).max()))
-    print(f"{preset} plane residual stream: worst waveform error vs the reference fixture {worst:.3g}")
+    print(f"{preset} residual stream as {res}: worst waveform error vs the reference fixture {worst:.3g}")
     assert worst < 5e-5
     s.close()
 
