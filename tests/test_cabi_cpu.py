@@ -511,3 +511,39 @@ def test_pinned_pool_drain_releases_idle_blocks_without_waiting_for_the_next_all
     del c
     gc.collect()
     assert pool.drain(keep_bytes=0) == 1 and pool._idle == 0 and len(freed) == 2
+
+
+def test_alternate_schedule_deals_whole_passes_to_the_handles_in_turn():
+    """PipelinedSession.run_device_steps(alternate=True), stubbed handles (no GPU): pass k runs on part k mod n with the WHOLE
+    batch (request-level pipelining); the split schedule gives every part its rows of every pass."""
+    from phoonnx_amd.session import PipelinedSession
+
+    class Part:
+        def __init__(self, i):
+            self.i, self.calls, self.last = i, [], None
+
+        def run_device(self, ids_ptr, lens_ptr, B, T, scales, sid_ptr=None):
+            self.calls.append((ids_ptr, lens_ptr, B))
+            self.last = np.full(B, 100 * self.i + len(self.calls), np.int64)
+
+        def last_y_lengths(self):
+            return self.last
+
+        def sync(self):
+            pass
+
+    import threading
+    p = object.__new__(PipelinedSession)
+    p.parts = [Part(0), Part(1), Part(2)]
+    p._mu = threading.RLock()
+    B, T = 8, 16
+    out = p.run_device_steps(1000, 2000, B, T, None, 7, alternate=True)
+    assert [len(q.calls) for q in p.parts] == [3, 2, 2]
+    assert all(c == (1000, 2000, B) for q in p.parts for c in q.calls)                 # whole batch, same pointers
+    assert [int(out[k, 0]) // 100 for k in range(7)] == [0, 1, 2, 0, 1, 2, 0]          # pass k on part k mod 3
+    for q in p.parts:
+        q.calls.clear()
+    out = p.run_device_steps(1000, 2000, B, T, None, 2)
+    bnd = p.bounds(B)
+    assert [len(q.calls) for q in p.parts] == [2, 2, 2]
+    assert [q.calls[0] for q in p.parts] == [(1000 + bnd[i] * T * 8, 2000 + bnd[i] * 8, bnd[i + 1] - bnd[i]) for i in range(3)]

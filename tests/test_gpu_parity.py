@@ -1082,6 +1082,12 @@ def test_pipelined_session_free_running_steps():
     assert got.shape == (4, B)
     for k in range(4):
         assert np.array_equal(got[k], ref)
+    # request-level pipelining: whole passes dealt to the handles in turn (pass k on part k mod 2), odd pass count
+    got = p.run_device_steps(dptr[0].value, dptr[1].value, B, T, sc, steps=5, alternate=True)
+    assert got.shape == (5, B)
+    for k in range(5):
+        assert np.array_equal(got[k], ref)
+    assert all(pp.last_y_lengths().shape == (B,) for pp in p.parts)      # each handle rendered the WHOLE batch
     p.close()
     for d in dptr:
         hip.hipFree(d)
