@@ -186,6 +186,55 @@ def spill_hazards(asm_text, kernel_filter=None):
     return out, spilling
 
 
+def sgpr_vmem_hazards(asm_text):
+    """Hazard 5 of the hand-scheduled kernels, checked on the ISA: a vector-memory instruction needs five wait
+    states after a VALU instruction (v_readlane / v_readfirstlane) wrote the scalar register it takes its base from.  hipcc's
+    hazard recogniser inserts them for the memory instructions it emits itself - not for those inside inline asm, and under
+    scalar-register pressure it parks uniform values in VGPR lanes and fetches them with v_readlane right in front of their
+    use.  Returns {kernel: [(line, wait states found, the VALU write, the memory instruction)]} for every inline-asm memory
+    instruction that follows such a write of one of its scalar operands too closely (s_nop N counts N + 1)."""
+    import re
+    out = {}
+    for m in re.finditer(r"\n(_Z\w+):[^\n]*\n", asm_text):
+        name = m.group(1)
+        end = asm_text.find(".Lfunc_end", m.end())
+        ins, in_asm = [], False
+        for i, l in enumerate(asm_text[m.end():end if end > 0 else len(asm_text)].split("\n")):
+            st = l.strip()
+            if st.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if st.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            ls = l.split(";")[0].strip()
+            if ls and not ls.endswith(":") and not ls.startswith("."):
+                ins.append((i, ls, in_asm))
+        bad = []
+        for n, (i, ls, ia) in enumerate(ins):
+            if not ia or not re.match(r"(global_|buffer_|flat_|scratch_)", ls):
+                continue
+            sg = set()
+            for a, b in re.findall(r"s\[(\d+):(\d+)\]", ls):
+                sg |= set(range(int(a), int(b) + 1))
+            for a in re.findall(r"(?<![\w\[])s(\d+)\b", ls):
+                sg.add(int(a))
+            ws = 0
+            for back in range(1, 8):
+                if n - back < 0 or ws >= 5:
+                    break
+                _, pl, _ = ins[n - back]
+                mm = re.match(r"(v_readlane_b32|v_readfirstlane_b32) s(\d+)", pl)
+                if mm and int(mm.group(2)) in sg:
+                    bad.append((i, ws, pl, ls))
+                    break
+                mn = re.match(r"s_nop (\d+)", pl)
+                ws += (int(mn.group(1)) + 1) if mn else 1
+        if bad:
+            out[name] = bad
+    return out
+
+
 def isa_of(src, extra_flags=()):
     """hipcc -S (device only) of one translation unit, as text"""
     import tempfile
@@ -289,10 +338,19 @@ def _build_locked(force, verbose):
     bad = {k: v for k, v in spilled.items() if any(n in k for n in no_spill)}
     if bad:
         raise RuntimeError("kernels with asynchronous inline-asm loads must not spill registers: " + ", ".join(f"{k} ({v})" for k, v in bad.items()))
+    # the ISA of every HIP unit (device only, side by side): hazards 1 and 5 are properties of the generated code
+    hip_units = [u for u in SOURCES if u.endswith(".hip")]
+    with ThreadPoolExecutor(max_workers=min(len(hip_units), os.cpu_count() or 4)) as ex:
+        isas = dict(zip(hip_units, ex.map(lambda u: isa_of(u, os.environ.get("VITSMI_CXXFLAGS", "").split()), hip_units)))
+    h5 = {}
+    for u in hip_units:
+        h5.update(sgpr_vmem_hazards(isas[u]))
+    if h5:
+        raise RuntimeError("an inline-asm memory instruction reads a scalar base a VALU instruction wrote fewer than five wait states "
+                           "before (stale base: wild addresses): " +
+                           "; ".join(f"{k}: '{v[0][3]}' {v[0][1]} wait states after '{v[0][2]}' (+{len(v) - 1} more)" for k, v in h5.items()))
     if spilled:
         units = sorted(set(spilled_src.values()))
-        with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as ex:
-            isas = dict(zip(units, ex.map(lambda u: isa_of(u, os.environ.get("VITSMI_CXXFLAGS", "").split()), units)))
         hazards, checked = {}, 0
         for u in units:
             f, n = spill_hazards(isas[u])

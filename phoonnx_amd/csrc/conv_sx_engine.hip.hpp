@@ -174,6 +174,26 @@ __device__ __forceinline__ u32x4 global_read128(uint32_t voff, const void *sbase
     return r;
 }
 
+// Four (two) 16-byte loads per lane from ONE scalar base, 1 KiB apart, in one statement that opens with the five wait states
+// a vector-memory instruction needs after a VALU instruction wrote its scalar base.  Under scalar-register pressure hipcc
+// keeps uniform values in VGPR lanes and fetches them with v_readlane right in front of their use; its hazard recogniser
+// inserts the wait states for the memory instructions IT emits, not for those inside inline asm: the load then goes out with
+// a stale base (seen: conv_sx_pair16_kernel<.., PERSIST>, memory faults at wild addresses from its tile loop; DESIGN 5.1g
+// hazard 5; phoonnx_amd.build.sgpr_vmem_hazards checks every kernel's ISA for it).
+__device__ __forceinline__ void global_read128_x4(uint32_t voff, const void *sbase, u32x4 &r0, u32x4 &r1, u32x4 &r2, u32x4 &r3) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %4, %5 offset:0\n\tglobal_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                 "global_load_dwordx4 %2, %4, %5 offset:2048\n\tglobal_load_dwordx4 %3, %4, %5 offset:3072"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(voff), "s"(sbase)
+                 : "memory");
+}
+__device__ __forceinline__ void global_read128_x2(uint32_t voff, const void *sbase, u32x4 &r0, u32x4 &r1) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %2, %3 offset:0\n\tglobal_load_dwordx4 %1, %2, %3 offset:1024"
+                 : "=&v"(r0), "=&v"(r1)
+                 : "v"(voff), "s"(sbase)
+                 : "memory");
+}
+
 // ... at a per-lane address
 template <int OFF>
 __device__ __forceinline__ u32x4 global_read128_v(const void *p) {

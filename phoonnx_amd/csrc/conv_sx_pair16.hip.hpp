@@ -29,7 +29,8 @@
 
 namespace vitsmi {
 
-enum : int { P16_HAS_RAW = 1 << 9, P16_HAS_PL = 1 << 10 };  // (EPI_ACC / EPI_DIV as everywhere)
+enum : int { P16_HAS_RAW = 1 << 9, P16_HAS_PL = 1 << 10,  // (EPI_ACC / EPI_DIV as everywhere)
+             P16_NO_OVERLAP = 1 << 11 };  // (A/B, VITSMI_P16_DEBUG=nooverlap) persistent form: the next x tile requested behind phase 2, not under it
 #ifndef P16_PROF
 #define P16_PROF 0  // diagnostic build: s_memtime stamps at the phase boundaries, summed per launch into SxPair16Args::prof
 #endif
@@ -63,8 +64,16 @@ struct SxPair16Args {
 };
 
 // C channels (32 | 64), NPL planes, BN columns per tile (128 | 256), OVL: Y overlays the x tile
-template <int C, int NPL, int BN, bool CHAIN, bool OVL, int WPS>
+// PERSIST (round 5): a workgroup renders tiles blockIdx.x, blockIdx.x + gridDim.x, .. (the grid is WPS workgroups per CU) and
+// brings tile i + 1's x tile into LDS WHILE tile i's second conv runs: the DMA rounds of the next tile are dealt to phase 2's
+// steps, right behind each step's weight request, with exact vector-memory accounting in the counted waits (vector-memory
+// operations retire in order: behind the weights of step s sit min(left, D - 1) younger weight sets and the DMA rounds issued
+// since - per wave: a wave issues a round only if its 64 cells lie inside the tile).  The x buffer is free by then: Y sits
+// beside it (no overlay) and the residual waits in registers from the hand-over on.  What a tile of the one-shot form spends
+// waiting for its x tile (4.5-5 k cycles of 16-32 k) passes under the MFMAs of its predecessor.
+template <int C, int NPL, int BN, bool CHAIN, bool OVL, int WPS, bool PERSIST = false>
 __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a) {
+    static_assert(!(PERSIST && OVL), "persistent form: Y beside x (x is refilled under phase 2)");
     constexpr bool H1 = NPL == 1;
     constexpr int WM = C / 32, WN = 4 / WM, BNW = BN / WN, NCB = BNW / 16, NQ = NCB / 2, NCH = C / 32, CG = C / 8;
     static_assert((C == 32 || C == 64) && (NPL == 1 || NPL == 2) && (BN == 128 || BN == 256) && NQ >= 1, "shape");
@@ -79,17 +88,38 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
     constexpr int BLKBYTES = 2 * NPL * 1024, STEPBYTES = WM * BLKBYTES;
     static_assert(NU % 2 == 0 && (RPU == 1 || RPU == 2 || RPU == 4), "");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_sx[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;  // (PERSIST: re-derived at the top of every tile behind an opaque asm, see the tile loop)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int tile_nb = (int)blockIdx.x;
-    if (tile_nb >= a.NT * a.B) return;
-    const int b = tile_nb / a.NT, t0 = (tile_nb - b * a.NT) * a.BNo;  // first kept output column
-    const int t1 = t0 - a.pad2;                                        // first column phase 1 computes
+    int l31 = lane & 31, hi = lane >> 5;
     const int T = a.T, LW1 = a.LW1, RS1 = a.RS1, RS2 = a.RS2;
-    const int TV = __builtin_amdgcn_readfirstlane(sx_valid_cols(a.rag, b, T));  // this utterance's tensor end (SxRagged); T = row pitch
-    if (t0 >= TV) return;                                                        // (uniform exit) no kept column lies inside it
+    const int NTOT = a.NT * a.B, G = (int)gridDim.x;
+    // (utterance, first kept output column, the utterance's tensor end (SxRagged; T = row pitch)) of tile tn
+    auto tile_geom = [&](int tn, int &gb, int &gt0, int &gTV) __attribute__((always_inline)) {
+        gb = tn / a.NT;
+        gt0 = (tn - gb * a.NT) * a.BNo;
+        gTV = __builtin_amdgcn_readfirstlane(sx_valid_cols(a.rag, gb, T));
+    };
+    // the first tile tn, tn + G, .. with a kept column inside its utterance (NTOT: none)
+    auto next_valid = [&](int tn, int &gb, int &gt0, int &gTV) __attribute__((always_inline)) {
+        while (tn < NTOT) {
+            tile_geom(tn, gb, gt0, gTV);
+            if (gt0 < gTV) break;
+            tn += G;
+        }
+        return tn;
+    };
+    int tile_nb = (int)blockIdx.x, b = 0, t0 = 0, TV = 0;  // the current tile
+    if constexpr (PERSIST) {
+        tile_nb = next_valid(tile_nb, b, t0, TV);
+        if (tile_nb >= NTOT) return;                       // (uniform exit)
+    } else {
+        if (tile_nb >= NTOT) return;
+        tile_geom(tile_nb, b, t0, TV);
+        if (t0 >= TV) return;                              // (uniform exit) no kept column lies inside the utterance
+    }
+    int t1 = t0 - a.pad2;                                  // first column phase 1 computes
     const uint32_t lds0 = (uint32_t)(uintptr_t)lds_sx;
     const uint32_t ylds = lds0 + a.y_off;
     const uint32_t XPB = (uint32_t)(CG * RS1) * 16u, YPB = (uint32_t)(CG * RS2) * 16u;  // bytes per plane
@@ -111,24 +141,25 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
     asm volatile("" ::"s"(k_raw_bs), "s"(k_pl_bs), "s"(__float_as_uint(k_ws1)), "s"(__float_as_uint(k_ws2)), "s"(__float_as_uint(k_msl)),
                  "s"(__float_as_uint(k_osl)), "s"(__float_as_uint(k_div)), "s"(__float_as_uint(k_unisl)), "s"(k_peak), "s"(wbase2));
     asm volatile("" ::"s"(a.y_off), "s"(a.pad1), "s"(a.K1), "s"(a.dil1), "s"(a.bias1), "s"(a.bias2), "s"(a.zeros));
+    const uint16_t *const k_xpl = a.xpl;
+    const int64_t k_x_bs = a.x_bstride;
+    const unsigned k_magic1 = a.magic1;
+    const int k_pad1 = a.pad1;
+    const float *const k_zeros = a.zeros;
+    asm volatile("" ::"s"(k_xpl), "s"(k_x_bs), "s"(k_magic1), "s"(k_pad1), "s"(k_zeros));
 
     struct ASet {
         u32x4 f[2][NPL];
     };
-    const uint32_t voff0 = (uint32_t)lane * 16u;
     auto load_a = [&](ASet &f, const char *wb, int step) __attribute__((always_inline)) {
+        const uint32_t voff0 = (uint32_t)lane * 16u;  // (from the tile's own lane id: see the tile loop)
         const uint64_t pa = reinterpret_cast<uint64_t>(wb) + (uint64_t)((int64_t)step * STEPBYTES);
         const char *sb = reinterpret_cast<const char *>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(pa >> 32)) << 32) |
                                                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((unsigned)pa));
-        if constexpr (H1) {
-            f.f[0][0] = global_read128<0>(voff0, sb);
-            f.f[1][0] = global_read128<1024>(voff0, sb);
-        } else {
-            f.f[0][0] = global_read128<0>(voff0, sb);
-            f.f[0][1] = global_read128<1024>(voff0, sb);
-            f.f[1][0] = global_read128<2048>(voff0, sb);
-            f.f[1][1] = global_read128<3072>(voff0, sb);
-        }
+        // (one statement per set, behind the wait states its scalar base needs: this kernel's tile loop keeps scalars in VGPR
+        // lanes, and a v_readlane directly in front of an inline-asm load is a hazard the compiler does not see)
+        if constexpr (H1) global_read128_x2(voff0, sb, f.f[0][0], f.f[1][0]);
+        else global_read128_x4(voff0, sb, f.f[0][0], f.f[0][1], f.f[1][0], f.f[1][1]);
     };
     ASet fs[NS];
     auto prefetch_a = [&](const char *wb, int S) __attribute__((always_inline)) {  // the first D sets of a conv
@@ -155,24 +186,28 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
     // =================================================================== prologue: the whole x tile -> LDS
     // x tile column 0 = time t1 - pad1; cells outside the tensor are zero (the convs' zero padding)
     const int S1 = NCH * a.K1, S2 = NCH * k_K2;
+    // one DMA round = 256 cells (16 bytes per lane) of the flattened [plane][row][RS1] cell space of the x tile of utterance
+    // gb whose phase-1 columns start at gt1; a wave issues it iff its 64 cells lie inside the tile (ncell % 64 == 0)
+    const int ncell = NPL * CG * RS1, nit = (ncell + 255) >> 8;
+    const int my_rounds = (ncell - wave * 64 + 255) >> 8;  // rounds THIS wave takes part in (wave-uniform)
+    auto dma_round = [&](int it, int gb, int gt1, int gTV) __attribute__((always_inline)) {
+        const uint16_t *xb = k_xpl + (int64_t)gb * k_x_bs;
+        const int base = it * 256 + wave * 64;
+        const int i = base + lane;
+        const int row = (int)__umulhi((unsigned)i, k_magic1);
+        const int col = i - row * RS1;
+        const int t = gt1 - k_pad1 + col;
+        const bool ok = row < NPL * CG && col < LW1 && t >= 0 && t < gTV;
+        const void *src = ok ? static_cast<const void *>(xb + ((int64_t)row * T + t) * 8)
+                             : static_cast<const void *>(reinterpret_cast<const char *>(k_zeros) + lane * 16);
+        // (a wave whose cells lie past the tile's last one skips the round: nothing is written behind the allocation)
+        if (base < ncell) lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + (size_t)base * 16));
+    };
     {
         // LDS-DMA, 16 bytes per lane: the flattened [plane][row][RS1] cell space in rounds of 256 cells; a lane whose cell is
         // padding (column past LW1, row past the tile, time outside the tensor) reads the zero page.  (Plane p, group g of
         // the tensor is row p * C/8 + g of [NPL][C/8][T] cells: the same index as in the tile.)
-        const uint16_t *xb = a.xpl + (int64_t)b * a.x_bstride;
-        const int ncell = NPL * CG * RS1, nit = (ncell + 255) >> 8;
-        for (int it = 0; it < nit; it++) {
-            const int base = it * 256 + wave * 64;
-            const int i = base + lane;
-            const int row = (int)__umulhi((unsigned)i, a.magic1);
-            const int col = i - row * RS1;
-            const int t = t1 - a.pad1 + col;
-            const bool ok = row < NPL * CG && col < LW1 && t >= 0 && t < TV;
-            const void *src = ok ? static_cast<const void *>(xb + ((int64_t)row * T + t) * 8)
-                                 : static_cast<const void *>(reinterpret_cast<const char *>(a.zeros) + lane * 16);
-            // (lanes past the tile's last cell are masked off: nothing is written behind the allocation)
-            if (i < ncell) lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + (size_t)base * 16));
-        }
+        for (int it = 0; it < nit; it++) dma_round(it, b, t1, TV);
         // both bias vectors ride along (one DMA of wave 0): read from LDS in the hand-over / the epilogue - as dependent global
         // loads at those points each cost an exposed L2 round trip per tile (r04f stamps: ~1.5 k cycles, twice)
         if (wave == 0) {
@@ -256,18 +291,61 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
             default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         }
     };
+    // (PERSIST, phase 2) at most n vector-memory operations in flight, n = the weight loads AND the next tile's DMA rounds
+    // this wave has issued behind the set it waits for; n <= (D - 1) NAL + D * rounds per step (<= 16 for every shape that
+    // fits: a larger count waits for more than it must, which is safe)
+    auto wait_vm_n = [&](int n) __attribute__((always_inline)) {
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+            case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+            case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        }
+    };
+    // the NEXT tile of this workgroup (PERSIST): set at the top of a tile, its x tile is requested during phase 2
+    int nx_tile = NTOT, nx_b = 0, nx_t0 = 0, nx_TV = 0;
+    int dma_R = 0;  // DMA rounds per step of phase 2 (0: no next tile)
     const std::integral_constant<int, 0> I0{};
     // rows0: this lane's cell of (plane 0, chunk 0, tap 0, unit 0): row = lane >> 4, column = the wave's first + (lane & 15).
     // The first D weight sets must have been requested (prefetch_a).
-    auto run_conv = [&](const char *wb, int K, int dil, uint32_t rows0, uint32_t row_bytes, uint32_t pstride) __attribute__((always_inline)) {
+    auto run_conv = [&](auto WITH_DMA, const char *wb, int K, int dil, uint32_t rows0, uint32_t row_bytes, uint32_t pstride) __attribute__((always_inline)) {
+        constexpr bool dma = decltype(WITH_DMA)::value;
         const int S = NCH * K;
         int chunk = 0, tap = 0;
         load_b(I0, I0, rows0, pstride);
+        // DMA rounds this wave has issued before step s of this conv
+        auto dsum = [&](int s) __attribute__((always_inline)) { const int v = s * dma_R; return v < my_rounds ? v : my_rounds; };
         auto step = [&](ASet &fc, ASet &fload, int s) __attribute__((always_inline)) {
             const int left = S - 1 - s;
-            wait_a(left < D - 1 ? left : D - 1);
+            const int younger = left < D - 1 ? left : D - 1;
+            if constexpr (dma) {
+                // behind A(s) (requested first thing in step s - D, or by the prefetch): the younger weight sets and every
+                // DMA round of the steps since
+                const int s0 = s > D ? s - D : 0;
+                wait_vm_n(younger * NAL + (dma_R ? dsum(s) - dsum(s0) : 0));
+            } else
+                wait_a(younger);
             __builtin_amdgcn_sched_barrier(0);
             if (s + D < S) load_a(fload, wb, s + D);
+            if constexpr (dma) {
+                if (dma_R) {
+                    for (int r = s * dma_R; r < (s + 1) * dma_R; r++)
+                        if (r < nit) dma_round(r, nx_b, nx_t0 - k_pad2, nx_TV);
+                }
+            }
             int ntap = tap + 1, nchunk = chunk;
             if (ntap == K) {
                 ntap = 0;
@@ -362,9 +440,30 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
         }
     };
 
+#if P16_PROF
+    unsigned long long tsum[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned ntiles_done = 0;
+#endif
+    for (;;) {  // (PERSIST: one iteration per tile of this workgroup; else exactly one)
+    if constexpr (PERSIST) {
+        // Everything a tile derives from the lane id (LDS addresses of the fragments, of Y, of the residual, the epilogue's
+        // cell offsets) is loop-invariant: hipcc hoists it all out of the tile loop and keeps it live across the whole body -
+        // tens of registers, spills in every instantiation.  Re-deriving the lane id behind an opaque statement makes each tile
+        // compute what it needs where it needs it, as the one-shot form does.
+        lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        l31 = lane & 31;
+        hi = lane >> 5;
+        // the tile after this one: found NOW - the scalar loads of the search (SxRagged::len) must not be in flight inside the
+        // phases, whose counted lgkmcnt waits assume LDS reads only - and requested during phase 2
+        nx_tile = next_valid(tile_nb + G, nx_b, nx_t0, nx_TV);
+        dma_R = nx_tile < NTOT && !(k_flags & P16_NO_OVERLAP) ? (nit + S2 - 1) / S2 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // =================================================================== phase 1: c1 over columns [t1, t1 + BN)
     zero_acc();
-    run_conv(wbase1, a.K1, a.dil1, lds0 + (uint32_t)((lane >> 4) * RS1 + wn * BNW + (lane & 15)) * 16u, (uint32_t)RS1 * 16u, XPB);
+    run_conv(std::false_type{}, wbase1, a.K1, a.dil1, lds0 + (uint32_t)((lane >> 4) * RS1 + wn * BNW + (lane & 15)) * 16u, (uint32_t)RS1 * 16u, XPB);
     P16_STAMP(3);
     prefetch_a(wbase2, S2);  // c2's first weights travel during the hand-over
     gather_acc();
@@ -372,7 +471,7 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
     // =================================================================== hand-over: c1's output -> Y (operand planes in LDS)
     // pre: the residual in the accumulator layout - CHAIN: x1 = c1(..) + x (phase 2's residual); PAIR with OVL: x, saved
     // before Y overwrites the tile.  (PAIR without OVL reads x from LDS in the epilogue: no registers.)
-    constexpr bool KEEP = CHAIN || OVL;
+    constexpr bool KEEP = CHAIN || OVL || PERSIST;  // (PERSIST: the x buffer is refilled under phase 2)
     f32x4 pre[KEEP ? NQ : 1][4];
     if constexpr (KEEP) {
 #pragma unroll
@@ -435,8 +534,18 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
     P16_STAMP(4);
 
     // =================================================================== phase 2: c2 over Y (stored pad2 columns to the right)
-    run_conv(wbase2, k_K2, k_dil2, ylds + (uint32_t)((lane >> 4) * RS2 + wn * BNW + (lane & 15)) * 16u, (uint32_t)RS2 * 16u, YPB);
+    // (PERSIST: every wave is behind the barrier above, i.e. done with the x tile - phase 1 and the residual read - so the
+    // next tile's DMA rounds may land in it while c2 runs over Y)
+    run_conv(std::integral_constant<bool, PERSIST>{}, wbase2, k_K2, k_dil2,
+             ylds + (uint32_t)((lane >> 4) * RS2 + wn * BNW + (lane & 15)) * 16u, (uint32_t)RS2 * 16u, YPB);
     P16_STAMP(5);
+    if constexpr (PERSIST) {
+        if (nx_tile < NTOT) {
+            // (with the overlap on, S2 * dma_R >= nit: nothing is left; off (debug): the whole tile is requested here)
+            for (int r = S2 * dma_R; r < nit; r++) dma_round(r, nx_b, nx_t0 - k_pad2, nx_TV);
+            prefetch_a(wbase1, S1);  // the next tile's first weights travel under this tile's epilogue
+        }
+    }
     gather_acc();
 
     // =================================================================== epilogue: bias2 + residual [+ xs] [/ n] -> raw / plane
@@ -502,14 +611,36 @@ __global__ __launch_bounds__(256, WPS) void conv_sx_pair16_kernel(SxPair16Args a
             }
         }
     }
-#undef ACC
 #if P16_PROF
     P16_STAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     P16_STAMP(7);
+    for (int i = 0; i < 7; i++) tsum[i] += tp[i + 1] - tp[i];
+    ntiles_done++;
+#endif
+    if constexpr (!PERSIST) break;
+    else {
+        if (nx_tile >= NTOT) break;
+        tile_nb = nx_tile;
+        b = nx_b;
+        t0 = nx_t0;
+        TV = nx_TV;
+        t1 = t0 - k_pad2;
+        // the x tile requested under phase 2, the weights requested before the epilogue and the epilogue's own stores: all behind
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        P16_STAMP(0);
+        P16_STAMP(1);
+        __builtin_amdgcn_s_barrier();  // the x tile is complete; every wave has left phase 2 (Y may be rewritten)
+        __builtin_amdgcn_sched_barrier(0);
+        P16_STAMP(2);
+    }
+    }  // tiles
+#undef ACC
+#if P16_PROF
     if (a.prof && tid == 0) {  // (a row per workgroup, plain stores: atomics on eight shared words distorted what they measured)
-        for (int i = 0; i < 7; i++) a.prof[(size_t)blockIdx.x * 8 + i] = tp[i + 1] - tp[i];
-        a.prof[(size_t)blockIdx.x * 8 + 7] = tp[0];
+        // phase sums over this workgroup's tiles (one tile in the one-shot form); [7] = tiles
+        for (int i = 0; i < 7; i++) a.prof[(size_t)blockIdx.x * 8 + i] = tsum[i];
+        a.prof[(size_t)blockIdx.x * 8 + 7] = ntiles_done;
     }
 #endif
     if (k_peak) sx_publish_peak(k_peak, (int)blockIdx.x, pk);  // (uniform branch; every thread arrives)
@@ -548,20 +679,47 @@ hipError_t launch_conv_sx_pair16(SxPair16Args a, int C, int npl, int B, hipStrea
 int sx_pair16_plan(int C, int npl, int K1, int dil1, int K2, int dil2, bool *ovl);
 
 #ifdef VITSMI_IMPL_PAIR16
-template <int C, int NPL, int BN, bool CHAIN, bool OVL, int WPS>
+template <int C, int NPL, int BN, bool CHAIN, bool OVL, int WPS, bool PERSIST = false>
 inline hipError_t launch_conv_sx_pair16_k(const SxPair16Args &a, dim3 grid, size_t lds, hipStream_t stream) {
     static std::atomic<uint64_t> attr_done{0};
-    auto kern = conv_sx_pair16_kernel<C, NPL, BN, CHAIN, OVL, WPS>;
+    auto kern = conv_sx_pair16_kernel<C, NPL, BN, CHAIN, OVL, WPS, PERSIST>;
     if (hipError_t e = sx_allow_big_lds(reinterpret_cast<const void *>(kern), attr_done); e != hipSuccess) return e;
     if (g_launch_name_on)
-        snprintf(g_launch_name, sizeof g_launch_name, "conv_sx_pair16_kernel<%d, %d, %d, %s, %s, %d>", C, NPL, BN, CHAIN ? "true" : "false",
-                 OVL ? "true" : "false", WPS);
+        snprintf(g_launch_name, sizeof g_launch_name, "conv_sx_pair16_kernel<%d, %d, %d, %s, %s, %d, %s>", C, NPL, BN, CHAIN ? "true" : "false",
+                 OVL ? "true" : "false", WPS, PERSIST ? "true" : "false");
+    if constexpr (PERSIST) {
+        // WPS workgroups per CU, each walking the tiles blockIdx.x, blockIdx.x + gridDim.x, ..
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+            return n;
+        }();
+        const unsigned g = (unsigned)(WPS * cus);
+        if (grid.x > g) grid.x = g;
+    }
     kern<<<grid, 256, lds, stream>>>(a);
     return hipGetLastError();
 }
 
 // Tile choice per (channels, arithmetic): the widest tile that still leaves >= 3 workgroups per CU (LDS) - measured choices
 // are recorded in DESIGN.md 5.1e; VITSMI_PAIR16_BN forces 128 / 256 for A/B runs.
+// The persistent form (Y beside x at the same tile width must fit the same 80 KiB).  OPT-IN, VITSMI_PAIR16_PERSIST=1: built,
+// parity-green on multi-tile shapes, measured SLOWER (r05l / r05m, B = 32, ms per launch, persistent vs one-shot: f16x3 32 ch
+// k 3 0.670 vs 0.608, k 11 1.297 vs 1.206, 64 ch k 3 0.945 vs 0.875; f16 32 ch k 3 0.455 vs 0.344).  Per-tile stamps
+// (profiles/r05_runs/pair16_stamps_r05m.log, 32 ch f16x3 k 3): the wait for the x tile falls from 4 935 to 189 cycles - the HBM
+// round trip IS hidden - but phase 2 grows from 2 669 to 6 587 (k 11: 8 505 -> 16 826): vector-memory operations retire in
+// order per wave, so every weight set requested behind a DMA round waits out that round's HBM latency (2-5 k cycles against
+// a step of ~800), and the rounds' own issue costs the MFMA loop ~150 cycles each; phase 1, the hand-over and the epilogue
+// run ~35 % longer (the tile loop's scalar state lives in VGPR lanes).  The measurement confirms what DESIGN 5.1f inferred:
+// the next tile's loads need a wave of their OWN (its own vmcnt), which costs the fifth wave's registers.
+bool sx_pair16_persist_ok(int C, int npl, int BN, int K1, int dil1, int K2, int dil2) {
+    static const bool on = [] {
+        const char *e = std::getenv("VITSMI_PAIR16_PERSIST");
+        return e && e[0] == '1';
+    }();
+    SxPair16Geom g;
+    return on && sx_pair16_geom(C, npl, BN, false, K1, dil1, K2, dil2, &g) && g.lds <= (size_t)80 * 1024 - 256;
+}
 int sx_pair16_plan(int C, int npl, int K1, int dil1, int K2, int dil2, bool *ovl) {
     static const int force = [] {
         const char *e = std::getenv("VITSMI_PAIR16_BN");
@@ -592,6 +750,9 @@ int sx_pair16_plan(int C, int npl, int K1, int dil1, int K2, int dil2, bool *ovl
 hipError_t launch_conv_sx_pair16(SxPair16Args a, int C, int npl, int B, hipStream_t stream, bool chain) {
     bool ovl = false;
     const int BN = sx_pair16_plan(C, npl, a.K1, a.dil1, a.K2, a.dil2, &ovl);
+    // the persistent form where x and Y fit side by side (it cannot overlay: the x buffer is refilled under phase 2)
+    const bool persist = BN && sx_pair16_persist_ok(C, npl, BN, a.K1, a.dil1, a.K2, a.dil2);
+    if (persist) ovl = false;
     SxPair16Geom g;
     if (!BN || !sx_pair16_geom(C, npl, BN, ovl, a.K1, a.dil1, a.K2, a.dil2, &g)) return hipErrorInvalidValue;
     if (a.pad1 * 2 != (a.K1 - 1) * a.dil1 || a.pad2 * 2 != (a.K2 - 1) * a.dil2) return hipErrorInvalidValue;  // "same" padding
@@ -604,6 +765,13 @@ hipError_t launch_conv_sx_pair16(SxPair16Args a, int C, int npl, int B, hipStrea
     a.magic1 = (unsigned)((0x100000000ull + a.RS1 - 1) / a.RS1);
     a.NT = (a.T + a.BNo - 1) / a.BNo;
     a.B = B;
+    {
+        static const bool no_overlap = [] {
+            const char *e = std::getenv("VITSMI_P16_DEBUG");
+            return e && std::string(e) == "nooverlap";
+        }();
+        if (no_overlap) a.flags |= P16_NO_OVERLAP;
+    }
     if (a.islope == 0.f) a.islope = 1.f;
     if (a.mslope == 0.f) a.mslope = 1.f;
     if (a.oslope == 0.f) a.oslope = 1.f;
@@ -619,6 +787,19 @@ hipError_t launch_conv_sx_pair16(SxPair16Args a, int C, int npl, int B, hipStrea
     if (nb == 0) return hipSuccess;
     if (nb >= (1ll << 31)) return hipErrorInvalidValue;
     dim3 grid((unsigned)nb, 1, 1);
+#define P16_PCASE(CC, NP, BNN, W)                                                                                \
+    if (persist && C == CC && npl == NP && BN == BNN)                                                             \
+        return chain ? launch_conv_sx_pair16_k<CC, NP, BNN, true, false, W, true>(a, grid, g.lds, stream)         \
+                     : launch_conv_sx_pair16_k<CC, NP, BNN, false, false, W, true>(a, grid, g.lds, stream);
+    // (two workgroups per CU throughout: with the residual in registers and the tile loop's state the single-plane variants
+    // do not fit the 168 registers of three - and a kernel of this family must not spill)
+    P16_PCASE(32, 1, 256, 2)
+    P16_PCASE(32, 1, 128, 2)
+    P16_PCASE(64, 1, 128, 2)
+    P16_PCASE(32, 2, 128, 2)
+    P16_PCASE(32, 2, 256, 2)
+    P16_PCASE(64, 2, 128, 2)
+#undef P16_PCASE
 #define P16_CASE(CC, NP, BNN, OV, W)                                                                              \
     if (C == CC && npl == NP && BN == BNN && ovl == OV)                                                           \
         return chain ? launch_conv_sx_pair16_k<CC, NP, BNN, true, OV, W>(a, grid, g.lds, stream)                  \

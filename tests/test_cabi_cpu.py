@@ -547,3 +547,38 @@ def test_alternate_schedule_deals_whole_passes_to_the_handles_in_turn():
     bnd = p.bounds(B)
     assert [len(q.calls) for q in p.parts] == [2, 2, 2]
     assert [q.calls[0] for q in p.parts] == [(1000 + bnd[i] * T * 8, 2000 + bnd[i] * 8, bnd[i + 1] - bnd[i]) for i in range(3)]
+
+
+def test_f16_request_on_a_voice_whose_generator_cannot_run_it_is_refused_with_the_reason():
+    """gen_precision="f16" (the reduced-precision vocoder) exists on the split-operand engine only: a voice whose generator
+    runs on the f32 engine (a channel count that is not a multiple of 32: the tiny fixtures) refuses the request at open -
+    it used to load and silently render with the exact arithmetic.  The fp32-grade requests still load there."""
+    path = os.path.join(GOLDEN, "tiny_rb1.onnx")
+    with pytest.raises(SessionError, match="f16"):
+        MiSession(path, host_only=True, gen_precision="f16")
+    for ok in ("f16x3", "bf16x6"):
+        s = MiSession(path, host_only=True, gen_precision=ok)
+        assert s.hparam("gen_sx") == 0
+        s.close()
+    s = MiSession(os.path.join(GOLDEN, "sx_rb1.onnx"), host_only=True, gen_precision="f16")
+    assert s.hparam("gen_sx") == 1 and s.hparam("gen_nprod") == 1
+    s.close()
+
+
+def test_sgpr_vmem_hazard_check_on_hand_written_isa():
+    """phoonnx_amd.build.sgpr_vmem_hazards (DESIGN 5.1g hazard 5): an inline-asm memory instruction whose scalar base was
+    written by v_readlane / v_readfirstlane fewer than five wait states earlier is a finding (the compiler inserts the wait
+    states only for memory instructions it emits itself); with the wait states, with a scalar-ALU producer, or outside inline
+    asm it is not."""
+    from phoonnx_amd.build import sgpr_vmem_hazards
+    load = [";;#ASMSTART", "global_load_dwordx4 v[2:5], v34, s[4:5] offset:0", ";;#ASMEND"]
+    f = sgpr_vmem_hazards(_kernel(["v_readlane_b32 s4, v236, 6", "v_lshlrev_b32_e32 v34, 4, v182", "v_readlane_b32 s5, v236, 7"] + load))
+    assert list(f) == ["_ZN6vitsmi4demoEv"] and f["_ZN6vitsmi4demoEv"][0][1] == 0
+    f = sgpr_vmem_hazards(_kernel(["v_readfirstlane_b32 s5, v3", "s_nop 1", "v_mov_b32_e32 v1, v2"] + load))
+    assert f and f["_ZN6vitsmi4demoEv"][0][1] == 3
+    assert not sgpr_vmem_hazards(_kernel(["v_readlane_b32 s5, v236, 7", "s_nop 4"] + load))
+    assert not sgpr_vmem_hazards(_kernel(["v_readlane_b32 s5, v236, 7", ";;#ASMSTART", "s_nop 4",
+                                          "global_load_dwordx4 v[2:5], v34, s[4:5] offset:0", ";;#ASMEND"]))
+    assert not sgpr_vmem_hazards(_kernel(["s_add_u32 s4, s8, s30", "s_addc_u32 s5, s9, 0"] + load))        # scalar-ALU producer
+    assert not sgpr_vmem_hazards(_kernel(["v_readlane_b32 s5, v236, 7", "global_load_dwordx4 v[2:5], v34, s[4:5]"]))  # the compiler's own
+    assert not sgpr_vmem_hazards(_kernel(["v_readlane_b32 s9, v236, 7"] + load))                             # another register

@@ -1243,3 +1243,35 @@ def test_renamed_graph_renders_the_same_waveform(tmp_path, preset):
     rb = b.synthesize_batch(*args)
     b.close()
     assert np.array_equal(ra["y_lengths"], rb["y_lengths"]) and np.array_equal(ra["output"], rb["output"])
+
+
+def test_persistent_pair16_form_on_multi_tile_launches():
+    """conv_sx_pair16_kernel<.., PERSIST> (opt-in, VITSMI_PAIR16_PERSIST=1: a workgroup walks several tiles and requests tile
+    i + 1's x tile under tile i's second conv, with exact vmcnt accounting; measured slower) on launches of more
+    tiles than the persistent grid has workgroups - ragged ends, PAIR and CHAIN, both arithmetics - against the 32x32x16 pair
+    kernel.  This is the code that exposed hazard 5 (a v_readlane in front of an inline-asm load): wrong addresses, not wrong
+    numbers, so the test's first duty is to finish.  In a child process: the switch is read once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from phoonnx_amd.session import test_conv_pair_sx
+rng = np.random.default_rng(3)
+for kern, C, K, d1, d2, chain, B, T, tol in (("pair16", 32, 3, 1, 1, False, 2, 150001, 2e-5), ("pair16", 64, 7, 3, 1, False, 3, 50003, 2e-5),
+                                             ("pair16", 32, 5, 2, 6, True, 2, 140000, 2e-5), ("pair16_f16", 32, 3, 1, 1, False, 2, 150001, 2e-2),
+                                             ("pair16_f16", 64, 3, 1, 2, True, 2, 80000, 2e-2), ("pair16", 32, 11, 5, 1, False, 1, 140009, 2e-5)):
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    w1 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    w2 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    ref = test_conv_pair_sx(x, w1, b, w2, b, dil1=d1, dil2=d2, chain=chain, kernel="pair")
+    got = test_conv_pair_sx(x, w1, b, w2, b, dil1=d1, dil2=d2, chain=chain, kernel=kern)
+    err = float(np.abs(got - ref).max())
+    assert err < tol, (kern, C, K, chain, err)
+print("PERSIST_OK")
+'''
+    env = dict(os.environ, VITSMI_PAIR16_PERSIST="1")
+    r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "PERSIST_OK" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-1500:])

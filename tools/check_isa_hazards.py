@@ -7,7 +7,9 @@ The engines drain the counter once at that boundary; this script compiles each i
 that EVERY s_load between a kernel's first and last MFMA is followed by `s_waitcnt lgkmcnt(0)` before any counted wait.
 
 Second check (the build's own rule, phoonnx_amd.build.spill_hazards): no spill store of any kernel may hit a register that
-is the destination of an asynchronous inline-asm load not yet consumed (hazard 1).
+is the destination of an asynchronous inline-asm load not yet consumed (hazard 1).  Third (sgpr_vmem_hazards): no inline-asm
+memory instruction may read a scalar base that a v_readlane / v_readfirstlane wrote fewer than five wait states before
+(hazard 5: the compiler's hazard recogniser does not look into inline asm).
 
     python tools/check_isa_hazards.py        (needs hipcc; ~1 min per unit; exit code 1 on a finding)
 """
@@ -19,9 +21,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from phoonnx_amd.build import spill_hazards  # noqa: E402
+from phoonnx_amd.build import sgpr_vmem_hazards, spill_hazards  # noqa: E402
 CSRC = os.path.join(ROOT, "phoonnx_amd", "csrc")
-UNITS = ["tu_sx_h1", "tu_sx_s16p", "tu_sx_s16", "tu_sx_s32", "tu_sx_bf16", "tu_pair16", "tu_pair", "tu_conv_f32", "vitsmi"]
+UNITS = ["tu_sx_h1", "tu_sx_s16p", "tu_sx_s16", "tu_sx_s32", "tu_sx_bf16", "tu_pair16", "tu_pair", "tu_conv_f32", "vitsmi", "g2p"]
 # kernels with counted lgkmcnt waits: the conv engines, and the 16x16x32 attention kernel (attention16.hip.hpp, in vitsmi.hip)
 KERNELS = r"_ZN6vitsmi[0-9]+(?:conv_sx|attention_relpos16)\w*"
 
@@ -52,6 +54,8 @@ def check(unit):
     hz, nspill = spill_hazards(txt)
     for name, f in hz.items():
         bad.append((name, f[0][0], "spill of an asynchronous load's destination: " + f[0][1]))
+    for name, f in sgpr_vmem_hazards(txt).items():
+        bad.append((name, f[0][0], f"'{f[0][3]}' only {f[0][1]} wait states after '{f[0][2]}' (hazard 5)"))
     return n, bad, nspill
 
 
