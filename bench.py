@@ -105,7 +105,8 @@ def pmc_traffic(preset, family):
             n += c["launches"]
     if not n:
         return None
-    return {"bytes_per_launch": tot / n, "source": fname, "commit": doc.get("commit"), "length_scale": doc.get("length_scale")}
+    return {"bytes_per_launch": tot / n, "source": fname, "commit": doc.get("commit"), "source_sha": doc.get("source_sha"),
+            "length_scale": doc.get("length_scale")}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -600,6 +601,7 @@ def main():
                 "algorithmic_gbytes_per_launch": kby / max(kn, 1) / 1e9,
                 "traffic": (tr or {}).get("bytes_per_launch"),
                 "traffic_source": (tr or {}).get("source"), "traffic_commit": (tr or {}).get("commit"),
+                "traffic_source_sha": (tr or {}).get("source_sha"),  # (== config.source_sha: the profile is of the code that ran)
                 "traffic_note": "launch-weighted mean over every conv_sx_kernel and conv_sx_pair_kernel instantiation",
                 "kernels": rows, "kernels_pmc_source": pfile,
                 "launches_per_step": kn // n_t, "avg_launch_ms": kms / max(kn, 1),

@@ -90,7 +90,14 @@ def main():
         commit = info["commit"] + ("+dirty" if info.get("dirty") else "")
     except Exception:
         pass
-    out = {"preset": a.preset, "commit": commit, "length_scale": a.length_scale,
+    source_sha = None
+    try:  # (what identifies the code that ran: a hash over the sources the library is built from; bench.py config.source_sha)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from phoonnx_amd import build as _b
+        source_sha = _b.source_sha()
+    except Exception:
+        pass
+    out = {"preset": a.preset, "commit": commit, "source_sha": source_sha, "length_scale": a.length_scale,
            "source": "rocprofv3 --kernel-trace --pmc <set>, one counter set per run (tools/profile_gpu.sh); sums over all "
                      "dispatches of the run unless a key says per_launch",
            "kernels": {}}
