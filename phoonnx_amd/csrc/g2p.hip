@@ -63,15 +63,15 @@ __global__ __launch_bounds__(256) void g2p_rmsnorm_kernel(const float *x, const 
 // [NB][C] vectors (1, C).  bucket_lut: bucket of (j - i) at index (j - i) + lut_zero, or nullptr (cross attention).
 // Keys / values are channel-major (time contiguous): lanes run along time, and every loop over channels issues its
 // loads eight at a time (one dependent load per channel made a decoder step's eight attention calls 30 us each).
-__global__ __launch_bounds__(256) void g2p_attention_kernel(const float *__restrict__ q, int q_cs, int q_ts,
-                                                            const float *__restrict__ k, const float *__restrict__ v, int kp,
-                                                            int64_t kv_bs, const float *__restrict__ bias,
-                                                            const int *__restrict__ bucket_lut, int lut_zero,
-                                                            float *__restrict__ out, int heads, int dk, int seg,
-                                                            const int *__restrict__ lens, int Tk, int q_off, int causal) {
-    extern __shared__ float sc[];  // [Tk] scores, then [dk] the query
-    __shared__ float red[256];
-    const int c = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void g2p_attention_body(const float *__restrict__ q, int q_cs, int q_ts,
+                                                   const float *__restrict__ k, const float *__restrict__ v, int kp,
+                                                   int64_t kv_bs, const float *__restrict__ bias,
+                                                   const int *__restrict__ bucket_lut, int lut_zero,
+                                                   float *__restrict__ out, int heads, int dk, int seg,
+                                                   const int *__restrict__ lens, int Tk, int q_off, int causal, int c, int h,
+                                                   float *sc, float *red) {
+    // sc: [Tk] scores, then [dk] the query; red: 256 floats (both workgroup-shared)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = c / seg, i = c - b * seg;
     const int ipos = i + q_off;
     const int nk = lens ? lens[b] : Tk;
@@ -137,6 +137,18 @@ __global__ __launch_bounds__(256) void g2p_attention_kernel(const float *__restr
             if (lane == 0 && d0 + e < dk) out[((int64_t)h * dk + d0 + e) * q_cs + (int64_t)c * q_ts] = acc[e] * inv;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void g2p_attention_kernel(const float *__restrict__ q, int q_cs, int q_ts,
+                                                            const float *__restrict__ k, const float *__restrict__ v, int kp,
+                                                            int64_t kv_bs, const float *__restrict__ bias,
+                                                            const int *__restrict__ bucket_lut, int lut_zero,
+                                                            float *__restrict__ out, int heads, int dk, int seg,
+                                                            const int *__restrict__ lens, int Tk, int q_off, int causal) {
+    extern __shared__ float sc[];
+    __shared__ float red[256];
+    g2p_attention_body(q, q_cs, q_ts, k, v, kp, kv_bs, bias, bucket_lut, lut_zero, out, heads, dk, seg, lens, Tk, q_off, causal,
+                       (int)blockIdx.x, (int)blockIdx.y, sc, red);
 }
 
 // T5DenseGatedActDense: h = act(a) * b;  T5DenseActDense: h = act(a)     act: 0 gelu_new, 1 relu, 2 gelu (erf)
@@ -268,6 +280,7 @@ struct G2PStepJob {
     float *y;
     const float *res;
     int ys, yb, out, blocks;  // row stride, sequence stride; blocks = ceil(out / 4)
+    int yt;                   // (persistent step) y is a cache row: the step's position t is added to it
 };
 struct G2PStepArgs {
     G2PStepJob job[3];
@@ -283,8 +296,8 @@ __device__ __forceinline__ float g2p_activation(float x, int act) {
 }
 
 template <int NB>
-__global__ __launch_bounds__(256) void g2p_step_kernel(G2PStepArgs a) {
-    int blk = blockIdx.x, j = 0;
+__device__ __forceinline__ void g2p_step_body(const G2PStepArgs &a, int blk, int t) {
+    int j = 0;
     while (j + 1 < a.njobs && blk >= a.job[j].blocks) blk -= a.job[j++].blocks;
     const G2PStepJob &J = a.job[j];
     const int lane = threadIdx.x & 63, row = blk * 4 + (threadIdx.x >> 6);
@@ -343,9 +356,13 @@ __global__ __launch_bounds__(256) void g2p_step_kernel(G2PStepArgs a) {
         float y = s[b] * rs;
         if (v4) y = g2p_activation(y, a.act) * (s2[b] * rs);
         else if (a.act >= 0) y = g2p_activation(y, a.act);
-        const int64_t o = (int64_t)b * J.yb + (int64_t)row * J.ys;
+        const int64_t o = (int64_t)b * J.yb + (int64_t)row * J.ys + (int64_t)J.yt * t;
         J.y[o] = J.res ? y + J.res[o] : y;
     }
+}
+template <int NB>
+__global__ __launch_bounds__(256) void g2p_step_kernel(G2PStepArgs a) {
+    g2p_step_body<NB>(a, (int)blockIdx.x, 0);
 }
 
 // x[b][c] = table[ids[b * id_stride]][c]: the embeddings of the tokens the NB sequences decode next
@@ -365,11 +382,9 @@ __global__ void g2p_scale_kernel(float *x, int64_t n, float s) {
 // argmax over the vocabulary (first maximum, as np.argmax), one workgroup per sequence b = blockIdx.x:
 // logits element v of sequence b at b * lb + v * pitch + t  ->  ids[b * ib + slot] (int64) and, if given, the same
 // place of the pinned host copy
-__global__ __launch_bounds__(256) void g2p_argmax_kernel(const float *logits, int V, int pitch, int t, int64_t lb, int64_t *ids,
-                                                         int64_t ib, int slot, int64_t *host_copy) {
-    __shared__ float bv[256];
-    __shared__ int bi[256];
-    const int tid = threadIdx.x, b = blockIdx.x;
+__device__ __forceinline__ void g2p_argmax_body(const float *logits, int V, int pitch, int t, int64_t lb, int64_t *ids, int64_t ib,
+                                                int slot, int64_t *host_copy, int b, float *bv, int *bi) {
+    const int tid = threadIdx.x;
     logits += (int64_t)b * lb;
     float best = -__builtin_inff();
     int idx = 0x7fffffff;
@@ -393,6 +408,117 @@ __global__ __launch_bounds__(256) void g2p_argmax_kernel(const float *logits, in
     if (tid == 0) {
         ids[(int64_t)b * ib + slot] = bi[0];
         if (host_copy) host_copy[(int64_t)b * ib + slot] = bi[0];  // (pinned, mapped: visible once the step's event has fired)
+    }
+}
+__global__ __launch_bounds__(256) void g2p_argmax_kernel(const float *logits, int V, int pitch, int t, int64_t lb, int64_t *ids,
+                                                         int64_t ib, int slot, int64_t *host_copy) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    g2p_argmax_body(logits, V, pitch, t, lb, ids, ib, slot, host_copy, (int)blockIdx.x, bv, bi);
+}
+
+// ---- the decoder step as ONE launch ------------------------------------------------------------------------------------
+// A step of the narrow path is 3 + 8 * layers launches of 5-30 us of work each, so the step's time is mostly the gaps
+// between them.  The persistent form runs the same bodies, in the same order, from a phase table in device memory:
+// every workgroup walks the table, takes the virtual blocks `vb = blockIdx.x, + gridDim.x, ...` of each phase, and meets
+// the others at a grid barrier between phases.  The arithmetic (and so every generated token) is the launch-per-phase
+// path's, bit for bit: the bodies are shared and a virtual block computes exactly what the real block did.
+//
+// Grid barrier: one counter that only grows.  Launch t, phase p waits for (t * nph + p + 1) * gridDim.x arrivals (every
+// launch makes exactly nph * gridDim.x, so no reset between launches).  Thread 0 of a workgroup: release fence (L2
+// write-back: the XCDs' L2s are not coherent with each other), atomic add, spin with s_sleep on a device-scope load,
+// acquire fence.  The grid is clamped to what the occupancy calculator says is co-resident; a barrier that has not
+// completed after ~2 s of the constant 100 MHz clock raises `bar[1]` and every workgroup leaves - a wrong launch can
+// fail a call but never hang the device.
+enum { G2P_PH_EMBED = 0, G2P_PH_STEP = 1, G2P_PH_ATT = 2, G2P_PH_ARGMAX = 3 };
+struct G2PPhase {
+    int kind, nblocks;
+    G2PStepArgs step;  // STEP (job.yt set where the output is a cache column of the step's position)
+    // ATT: the arguments of g2p_attention_kernel; self_att: Tk = t + 1 and q_off = t
+    const float *q, *k, *v, *bias;
+    const int *lut, *lens;
+    float *out;
+    int q_cs, q_ts, kp, lut_zero, seg, Tk, causal, self_att, heads, dk, cols;
+    int64_t kv_bs;
+    // EMBED: x[b][c] = table[ids[b * ib + t]][c];  ARGMAX: logits [b][V] -> ids[b * ib + t + 1]
+    int64_t *ids, *host_copy;
+    const float *table;
+    float *x;
+    int C, vocab;
+    int64_t ib;
+};
+
+// `ep`: the barrier's index since the counters were cleared (launch t, phase p: t * nph + p).  Two levels: a workgroup
+// arrives on its group's counter (groups of `gs` workgroups, a cache line each), the group's last arrival on the top
+// counter - same-address device-scope atomics serialise at ~0.1 us each, and a flat counter cost 26 us per barrier at
+// 256 workgroups.
+__device__ __forceinline__ bool g2p_grid_barrier(unsigned *bar, unsigned ep, int gs, bool wait) {
+    __shared__ int ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned grp = blockIdx.x / gs, ngrp = (gridDim.x + gs - 1) / gs;
+        const unsigned gsize = grp + 1 < ngrp ? gs : gridDim.x - grp * gs;
+        __threadfence();  // release: this workgroup's stores are in L2 (the __syncthreads above); write them back
+        const unsigned old = __hip_atomic_fetch_add(bar + 32 * (grp + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == (ep + 1) * gsize) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int good = 1;
+        if (wait) {
+            const unsigned target = (ep + 1) * ngrp;
+            const uint64_t w0 = wall_clock64();
+            while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                    wall_clock64() - w0 > 200000000ull) {  // 2 s at 100 MHz
+                    __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    good = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __threadfence();  // acquire: drop this CU's L1 and the L2's lines of other XCDs' data
+        }
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+
+template <int NB>
+__global__ __launch_bounds__(256) void g2p_decode_step_kernel(const G2PPhase *__restrict__ ph, int nph, unsigned *bar, int t,
+                                                              int64_t *gave_up, int gs) {
+    extern __shared__ float sc[];
+    __shared__ float red[256];
+    __shared__ int redi[256];
+    if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {  // (an earlier step gave up)
+        if (blockIdx.x == 0 && threadIdx.x == 0) *gave_up = 1;
+        return;
+    }
+    for (int p = 0; p < nph; p++) {
+        const G2PPhase &P = ph[p];
+        const int kind = P.kind, nblocks = P.nblocks;
+        for (int vb = blockIdx.x; vb < nblocks; vb += gridDim.x) {
+            if (kind == G2P_PH_STEP) {
+                g2p_step_body<NB>(P.step, vb, t);
+            } else if (kind == G2P_PH_ATT) {
+                __syncthreads();  // (sc / red of the previous virtual block)
+                g2p_attention_body(P.q, P.q_cs, P.q_ts, P.k, P.v, P.kp, P.kv_bs, P.bias, P.lut, P.lut_zero, P.out, P.heads, P.dk,
+                                   P.seg, P.lens, P.self_att ? t + 1 : P.Tk, P.self_att ? t : 0, P.causal, vb % P.cols, vb / P.cols,
+                                   sc, red);
+            } else if (kind == G2P_PH_EMBED) {
+                const int per = (P.C + 255) / 256, b = vb / per, c = (vb - b * per) * 256 + (int)threadIdx.x;
+                if (c < P.C) {
+                    int64_t id = P.ids[(int64_t)b * P.ib + t];
+                    id = id < 0 ? 0 : (id >= P.vocab ? P.vocab - 1 : id);
+                    P.x[(int64_t)b * P.C + c] = P.table[id * P.C + c];
+                }
+            } else {
+                __syncthreads();
+                g2p_argmax_body(P.step.x, P.vocab, 1, 0, P.vocab, P.ids, P.ib, t + 1, P.host_copy, vb, red, redi);
+            }
+        }
+        if (!g2p_grid_barrier(bar, (unsigned)t * (unsigned)nph + (unsigned)p, gs, p + 1 < nph)) {
+            if (threadIdx.x == 0) *gave_up = 1;  // (pinned: the host reads it after the step's event)
+            return;
+        }
     }
 }
 
@@ -548,6 +674,16 @@ void ffn(Run &r, const T5FfnDesc &f, const float *hn, float *x, int T, float *a,
     linear(r, f.wo, a, T, T, x, T, x);  // x += wo(h)
 }
 
+// OPT-IN (VITSMI_G2P_PERSIST=1).  Measured on the ByT5-small shape, one sequence, ms per token: a launch per phase 0.307;
+// persistent, 256 workgroups: flat barrier 0.92, two-level 0.70, two-level without the fences (wrong tokens - the XCDs'
+// L2s need them) 0.45; 512 workgroups 0.91 / 0.39.  A barrier costs more than the command processor's gap between two
+// dependent launches (~6 us, which already includes the same L2 write-back and invalidate), so the default stays a
+// launch per phase; the persistent form is kept for the measurement and is token-identical.
+bool g2p_persist_on() {
+    const char *e = std::getenv("VITSMI_G2P_PERSIST");
+    return e && e[0] == '1';
+}
+
 int ws_reserve(g2p_handle *h, size_t bytes) {
     if (bytes <= h->ws_cap) return 0;
     if (h->ws) {
@@ -625,7 +761,7 @@ int g2p_open(const char *path, int device, g2p_handle **out) {
             hipMalloc((void **)&h->d_bucket_enc, lut) != hipSuccess || hipMalloc((void **)&h->d_bucket_dec, lut) != hipSuccess ||
             hipMemcpy(h->d_bucket_enc, h->model.bucket_enc.data(), lut, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(h->d_bucket_dec, h->model.bucket_dec.data(), lut, hipMemcpyHostToDevice) != hipSuccess ||
-            hipHostMalloc((void **)&h->tok_host, (size_t)G2P_MAX_BATCH * G2PModel::kMaxPos * sizeof(int64_t), hipHostMallocMapped) != hipSuccess ||
+            hipHostMalloc((void **)&h->tok_host, ((size_t)G2P_MAX_BATCH * G2PModel::kMaxPos + 8) * sizeof(int64_t), hipHostMallocMapped) != hipSuccess ||
             hipHostGetDevicePointer((void **)&h->tok_dev, h->tok_host, 0) != hipSuccess ||
             hipEventCreateWithFlags(&h->step_done[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->step_done[1], hipEventDisableTiming) != hipSuccess) {
@@ -788,7 +924,7 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
     const size_t need = 8 * (nA * 4 + 512) + 2 * ((size_t)m.d_ff * T * 4 + 512) +
                         (size_t)nd * 2 * ((size_t)NB * m.inner * TM * 4 + 512) + (size_t)nd * 2 * ((size_t)m.inner * T * 4 + 512) +
                         (size_t)(T + (size_t)NB * TM) * 8 + (size_t)NB * (m.vocab + 2 * m.d_model + 2 * m.inner + 2 * m.d_ff + 64) * 4 +
-                        (1 << 16);
+                        (size_t)(3 + 8 * nd) * sizeof(G2PPhase) + (1 << 18);
     if (int rc = ws_reserve(h, need)) return rc;
     Run r{h, h->stream, h->arena_dev};
     r.ws = h->ws;
@@ -808,6 +944,100 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
     float *x1 = r.take<float>((size_t)NB * m.d_model), *q1 = r.take<float>((size_t)NB * m.inner);
     float *a1 = r.take<float>((size_t)NB * m.inner), *f1 = r.take<float>((size_t)NB * m.d_ff), *lg = r.take<float>((size_t)NB * m.vocab);
     float *h1 = r.take<float>((size_t)NB * m.d_model), *f2 = r.take<float>((size_t)NB * m.d_ff);  // (wide step only)
+    // The narrow step as one persistent launch (see g2p_decode_step_kernel), opt-in: VITSMI_G2P_PERSIST=1.
+    const float post = m.scale_out ? 1.0f / std::sqrt((float)m.d_model) : 1.0f;
+    const int D = m.d_model, I = m.inner;
+    const int64_t cache_bs = (int64_t)I * TM;
+    const bool persist = !wide && g2p_persist_on();
+    const int nph = 3 + 8 * nd;
+    G2PPhase *d_ph = persist ? r.take<G2PPhase>(nph) : nullptr;
+    const size_t nbar = 32 * (1 + 4096 / 4);  // top counter + give-up flag, then a line per group
+    unsigned *d_bar = persist ? r.take<unsigned>(nbar) : nullptr;
+    int persist_gs = 32;
+    if (const char *e = std::getenv("VITSMI_G2P_PERSIST_GROUP")) persist_gs = std::atoi(e) >= 4 ? std::atoi(e) : persist_gs;
+    int64_t *gave_up_host = h->tok_host + (size_t)G2P_MAX_BATCH * G2PModel::kMaxPos, *gave_up_dev = h->tok_dev + (size_t)G2P_MAX_BATCH * G2PModel::kMaxPos;
+    std::vector<G2PPhase> phases;
+    int persist_grid = 0;
+    const size_t persist_lds = (size_t)((S > TM ? S : TM) + m.d_kv) * sizeof(float);
+    if (persist) {
+        auto step_phase = [&](std::initializer_list<StepJob> jobs, const float *x, int64_t g, int act, float pst, int yt_from) {
+            G2PPhase P{};
+            P.kind = G2P_PH_STEP;
+            G2PStepArgs &a = P.step;
+            int jn = 0;
+            for (const StepJob &j : jobs) {
+                G2PStepJob &d = a.job[a.njobs++];
+                d.W = r.P(j.L->rowmajor);
+                d.W2 = j.gate ? r.P(j.gate->rowmajor) : nullptr;
+                d.y = j.y;
+                d.ys = j.ys;
+                d.yb = j.yb;
+                d.res = j.res;
+                d.out = j.L->out;
+                d.blocks = (j.L->out + 3) / 4;
+                d.yt = jn >= yt_from ? 1 : 0;  // (k | v of the step's position: column t of the cache)
+                P.nblocks += d.blocks;
+                a.in = j.L->in;
+                jn++;
+            }
+            a.x = x;
+            a.g = g >= 0 ? r.P(g) : nullptr;
+            a.act = act;
+            a.eps = m.eps;
+            a.post = pst;
+            phases.push_back(P);
+        };
+        auto att_phase = [&](const float *k_, const float *v_, int kp, int64_t kv_bs, int64_t bias, const int *lut, const int *ln,
+                             int Tk, bool self_att) {
+            G2PPhase P{};
+            P.kind = G2P_PH_ATT;
+            P.q = q1, P.k = k_, P.v = v_, P.bias = bias >= 0 ? r.P(bias) : nullptr, P.lut = lut, P.lens = ln, P.out = a1;
+            P.q_cs = 1, P.q_ts = I, P.kp = kp, P.kv_bs = kv_bs, P.lut_zero = G2PModel::kMaxPos - 1, P.seg = 1, P.Tk = Tk;
+            P.causal = self_att ? 1 : 0, P.self_att = self_att ? 1 : 0, P.heads = m.heads, P.dk = m.d_kv, P.cols = NB;
+            P.nblocks = NB * m.heads;
+            phases.push_back(P);
+        };
+        {
+            G2PPhase P{};
+            P.kind = G2P_PH_EMBED;
+            P.ids = d_gen, P.ib = TM, P.table = r.P(m.shared), P.x = x1, P.C = D, P.vocab = m.vocab;
+            P.nblocks = (D + 255) / 256 * NB;
+            phases.push_back(P);
+        }
+        for (int l = 0; l < nd; l++) {
+            const auto &b = m.dec[l];
+            step_phase({{&b.self.q, nullptr, q1, 1, I, nullptr}, {&b.self.k, nullptr, ks[l], TM, (int)cache_bs, nullptr},
+                        {&b.self.v, nullptr, vs[l], TM, (int)cache_bs, nullptr}}, x1, b.ln_self, -1, 1.f, 1);
+            att_phase(ks[l], vs[l], TM, cache_bs, m.dec_bias, h->d_bucket_dec, nullptr, 0, true);
+            step_phase({{&b.self.o, nullptr, x1, 1, D, x1}}, a1, -1, -1, 1.f, 9);
+            step_phase({{&b.cross.q, nullptr, q1, 1, I, nullptr}}, x1, b.ln_cross, -1, 1.f, 9);
+            att_phase(kc[l], vc[l], T, S, -1, nullptr, d_lens, S, false);
+            step_phase({{&b.cross.o, nullptr, x1, 1, D, x1}}, a1, -1, -1, 1.f, 9);
+            step_phase({{&b.ffn.wi0, b.ffn.gated ? &b.ffn.wi1 : nullptr, f1, 1, m.d_ff, nullptr}}, x1, b.ln_ffn, m.act, 1.f, 9);
+            step_phase({{&b.ffn.wo, nullptr, x1, 1, D, x1}}, f1, -1, -1, 1.f, 9);
+        }
+        step_phase({{&m.lm_head, nullptr, lg, 1, m.vocab, nullptr}}, x1, m.dec_final_ln, -1, post, 9);
+        {
+            G2PPhase P{};
+            P.kind = G2P_PH_ARGMAX;
+            P.step.x = lg, P.vocab = m.vocab, P.ids = d_gen, P.ib = TM, P.host_copy = h->tok_dev;
+            P.nblocks = NB;
+            phases.push_back(P);
+        }
+        // every workgroup has to be resident at once: the grid is what the occupancy calculator allows, at most
+        // VITSMI_G2P_PERSIST_WGS per CU (default 1: a barrier's cost grows with the number of workgroups)
+        const void *fn = NB == 1 ? (const void *)g2p_decode_step_kernel<1> : NB == 2 ? (const void *)g2p_decode_step_kernel<2>
+                                                                                    : (const void *)g2p_decode_step_kernel<4>;
+        int per_cu = 0, cus = 0;
+        r.note(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, persist_lds));
+        r.note(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        int want = 1;
+        if (const char *e = std::getenv("VITSMI_G2P_PERSIST_WGS")) want = std::atoi(e) > 0 ? std::atoi(e) : want;
+        per_cu = per_cu < want ? per_cu : want;
+        persist_grid = per_cu * cus;
+        if (persist_grid <= 0) return gfail(h, VITS_E_DEVICE, "g2p: the persistent decoder step does not fit the device");
+        *gave_up_host = 0;
+    }
     {   // padded ids [NB][S], lengths, start tokens: one staging buffer each (pageable -> the copies are staged at once)
         std::vector<int64_t> ids((size_t)T, 0), gen((size_t)NB * TM, 0);
         std::vector<int> ln(NB, 1);
@@ -819,6 +1049,10 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
         r.note(hipMemcpyAsync(d_in, ids.data(), (size_t)T * 8, hipMemcpyHostToDevice, st));
         r.note(hipMemcpyAsync(d_gen, gen.data(), (size_t)NB * TM * 8, hipMemcpyHostToDevice, st));
         r.note(hipMemcpyAsync(d_lens, ln.data(), (size_t)NB * 4, hipMemcpyHostToDevice, st));
+        if (persist) {
+            r.note(hipMemcpyAsync(d_ph, phases.data(), phases.size() * sizeof(G2PPhase), hipMemcpyHostToDevice, st));
+            r.note(hipMemsetAsync(d_bar, 0, nbar * sizeof(unsigned), st));
+        }
         r.note(hipStreamSynchronize(st));  // (the staging vectors go out of scope)
     }
     run_encoder(r, d_in, S, NB, d_lens, xe, hn, q, k, v, att, fa, fb);
@@ -827,9 +1061,6 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
     // One decoder step for position t of every sequence (inputs d_gen[b][t]; the argmax lands in d_gen[b][t + 1] and in
     // the pinned copy); keys / values of position t join the caches.  8 launches per layer: norm + q|k|v, attention,
     // o (+x), norm + q, cross attention, o (+x), norm + gated input projections, wo (+x).
-    const float post = m.scale_out ? 1.0f / std::sqrt((float)m.d_model) : 1.0f;
-    const int D = m.d_model, I = m.inner;
-    const int64_t cache_bs = (int64_t)I * TM;
     auto enqueue_wide = [&](int t) {  // activations [C][NB]: column b = sequence b at position t
         g2p_embed_kernel<<<dim3((D + 255) / 256, NB), 256, 0, st>>>(d_gen + t, TM, r.P(m.shared), x1, D, NB, NB, m.vocab);
         for (int l = 0; l < nd; l++) {
@@ -855,6 +1086,16 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
     };
     auto enqueue_step = [&](int t) {
         if (wide) return enqueue_wide(t);
+        if (persist) {
+            switch (NB) {
+                case 1: g2p_decode_step_kernel<1><<<persist_grid, 256, persist_lds, st>>>(d_ph, nph, d_bar, t, gave_up_dev, persist_gs); break;
+                case 2: g2p_decode_step_kernel<2><<<persist_grid, 256, persist_lds, st>>>(d_ph, nph, d_bar, t, gave_up_dev, persist_gs); break;
+                default: g2p_decode_step_kernel<4><<<persist_grid, 256, persist_lds, st>>>(d_ph, nph, d_bar, t, gave_up_dev, persist_gs); break;
+            }
+            r.note(hipGetLastError());
+            r.note(hipEventRecord(h->step_done[t & 1], st));
+            return;
+        }
         g2p_embed_rows_kernel<<<dim3((D + 255) / 256, NB), 256, 0, st>>>(d_gen + t, TM, r.P(m.shared), x1, D, m.vocab);
         for (int l = 0; l < nd; l++) {
             const auto &b = m.dec[l];
@@ -887,6 +1128,11 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
         if (r.err != hipSuccess) {
             hipStreamSynchronize(st);
             return gfail(h, VITS_E_DEVICE, "g2p_generate failed: %s", hipGetErrorString(r.err));
+        }
+        if (persist && *gave_up_host) {
+            hipStreamSynchronize(st);
+            return gfail(h, VITS_E_DEVICE, "g2p_generate: the persistent decoder step's grid barrier timed out at step %d "
+                         "(unset VITSMI_G2P_PERSIST: a launch per phase)", t);
         }
         for (int b = 0; b < B; b++) {
             if (done[b]) continue;

@@ -50,6 +50,22 @@ def test_g2p_generate_matches_reference_greedy_loop(sess):
     assert gen == want
 
 
+def test_persistent_decoder_step_generates_the_same_ids(sess, monkeypatch):
+    """The opt-in one-launch decoder step (g2p.hip g2p_decode_step_kernel: the phases' bodies behind grid barriers) is the
+    launch-per-phase path's arithmetic: same ids for one sequence and for batches of 2 and 3 (NB 2 and 4)."""
+    G = np.load(os.path.join(GOLDEN, "byt5_tiny.npz"))
+    monkeypatch.setenv("VITSMI_G2P_PERSIST", "1")
+    for c in range(4):
+        ids, want = G[f"c{c}/input_ids"], G[f"c{c}/greedy"].tolist()
+        assert sess.generate(ids[0], max_length=len(want)) == want
+    many = [G[f"c{c}/input_ids"][0] for c in range(3)]
+    for nb in (2, 3):
+        got = sess.generate_batch(many[:nb], max_length=24)
+        monkeypatch.setenv("VITSMI_G2P_PERSIST", "0")
+        assert got == sess.generate_batch(many[:nb], max_length=24)
+        monkeypatch.setenv("VITSMI_G2P_PERSIST", "1")
+
+
 def test_g2p_matches_oracle_on_fresh_inputs(sess):
     from t5_oracle import T5Oracle
     o = T5Oracle(os.path.join(GOLDEN, "byt5_tiny.onnx"))
