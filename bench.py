@@ -459,6 +459,7 @@ def main():
         return torch.randint(0, int(first.hparam("n_speakers")), (Bn,), generator=g, dtype=torch.int64)
 
     prewarmed = {}
+    reserved = {}
 
     def measure(first, preset, steps, warmup, parts, lockstep, seed, inputs_h=None, pipe=None):
         """K timed passes of the whole path on `parts` handles sharing `first`'s arena -> (dt, samples, pipe).
@@ -492,6 +493,19 @@ def main():
         # a fresh process' first passes are slow (first touch of ~60 GB of workspace, clock ramp: the first bench run on a fresh
         # box measured 567 M samples/s where every later one measured 740-750 M): pre-warm for --prewarm-s seconds (untimed,
         # like the model load), THEN the W warm-up steps and the K timed ones of the contract
+        # A batch's frame count depends on the predicted durations, i.e. on each pass' noise: the headline batch needs 13.6-15.4
+        # GB of frame-domain workspace per handle from pass to pass, and a pass that needs more than any before it frees and
+        # reallocates the slab (device-wide sync + hipMalloc of 15-45 GB: 0.3 ms to 5 s, measured) - inside the timed region
+        # that read as 69 instead of 139 M samples/s (r05t) and 88 instead of 1022 M on config 4.  As a serving process would
+        # at start-up, size the workspaces once for the largest request admitted: this workload + 25 % more frames than the
+        # probe pass rendered (MiSession.reserve -> vits_reserve).
+        if not reserved.get(id(pipe)):
+            reserved[id(pipe)] = True
+            pipe.run_device(ids.data_ptr(), lens.data_ptr(), B, T, scales, sid_ptr)
+            f_probe = int(pipe.last_y_lengths(B).max())
+            pipe.sync()
+            pipe.reserve(B, T, int(f_probe * 1.25) + 64,
+                         whole_batch=a.schedule == "alternate" and not (lockstep or len(pipe.parts) == 1))
         if a.prewarm_s > 0 and not prewarmed.get(id(first)):
             prewarmed[id(first)] = True
             t_pw = time.perf_counter()
@@ -512,6 +526,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if os.environ.get("BENCH_TRACE"):  # (diagnostics: when each timed pass' call returned on its worker, ms from the start)
+            st = getattr(pipe, "last_pass_stamps", None) or []
+            sys.stderr.write(f"bench trace: {preset} parts={len(pipe.parts)} steps={steps} dt={dt * 1e3:.1f} ms; pass returns at "
+                             f"{[round((x - t0) * 1e3, 1) for x in st]}\n")
         return dt, samples, pipe, (ids, lens, ids_h, lens_h, scales, sid, sid_h)
 
     def roofline_of(s, preset, inputs, n_t):

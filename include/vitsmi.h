@@ -105,6 +105,7 @@ int vits_meta(vits_handle *h, const char *key, char *buf, size_t n);
  * "gen_sx" (1: the generator runs on the split-operand matrix-core engine, 0: on the f32-MFMA engine),
  * "enc_sx" (1: the text encoder's convs run on the split-operand engine too - f16x3 voices; VITSMI_ENC_ENGINE=f32 keeps
  *   the f32-MFMA engine),
+ * "workspace_bytes" (device memory the handle's workspaces hold right now: grows with the largest request, vits_reserve),
  * "gen_rf_frames" (one-sided receptive field of the generator in frames: the context chunked rendering adds),
  * "gen_nprod" (the generator's arithmetic, chosen by VITSMI_GEN_PRECISION in the environment at open time:
  *   2 = "f16x3", the default: fp32 operands as two fp16 planes, three MFMA products per fp32 product, fp32
@@ -259,6 +260,15 @@ int vits_set_timing(vits_handle *h, int enable);
  *       included - what onnxruntime returns for the same padded feed.
  * Applies to the following runs of this handle (whole and chunked). */
 int vits_set_tails(vits_handle *h, int reference);
+
+/* Size the handle's device workspaces NOW for requests of up to B utterances x T tokens that render up to F frames each
+ * (the batch's longest utterance; T = 0 or F = 0 leaves that domain alone).  A run grows a workspace when a request
+ * needs more than any before it - hipFree + hipMalloc of tens of GB at batch 32, a device-wide synchronisation that was
+ * measured at 0.3 ms to 5 s - so a serving process calls this once at start-up with the largest request it admits (the
+ * frame count of a batch depends on the durations the model predicts, i.e. on the noise as well: leave headroom), and no
+ * request up to that size allocates device memory afterwards.  onnxruntime has no counterpart (its arena grows the same
+ * way, voice.py:167-171 passes default SessionOptions); nothing in the reference needs to call it. */
+int vits_reserve(vits_handle *h, int B, int T, int F);
 int vits_get_stats(vits_handle *h, vits_stats *out);
 
 /* One record per conv-engine launch of the last run made with timing enabled, in launch order (call after

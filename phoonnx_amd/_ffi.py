@@ -52,7 +52,7 @@ EXPORTS = [
     "vits_input_name", "vits_meta", "vits_hparam", "vits_arena_bytes", "vits_arena_host", "vits_arena_device",
     "vits_run", "vits_free_output", "vits_run_device", "vits_sync", "vits_last_y_lengths", "vits_last_pcm16", "vits_run_vocoder",
     "vits_tap",
-    "vits_set_timing", "vits_set_tails", "vits_get_stats", "vits_stream", "vits_test_conv1d", "vits_test_conv_transpose1d",
+    "vits_set_timing", "vits_set_tails", "vits_reserve", "vits_get_stats", "vits_stream", "vits_test_conv1d", "vits_test_conv_transpose1d",
     "vits_test_attention", "vits_test_attention16", "vits_bench_conv1d", "vits_test_conv1d_sx", "vits_test_conv1d_sx_planar", "vits_test_conv1d_sx_gate", "vits_test_set_sx_small_max",
     "vits_test_conv_transpose1d_sx",
     "vits_bench_conv1d_sx", "vits_test_conv_pair_sx", "vits_fetch_output", "vits_run_async", "vits_host_alloc", "vits_host_free",
@@ -122,6 +122,7 @@ def load():
     lib.vits_tap.argtypes = [vp, C.c_char_p, vp, C.c_size_t, i64p]
     lib.vits_set_timing.argtypes = [vp, C.c_int]
     lib.vits_set_tails.argtypes = [vp, C.c_int]
+    lib.vits_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.vits_get_stats.argtypes = [vp, C.POINTER(VitsStats)]
     lib.vits_stream.argtypes = [vp]
     lib.vits_stream.restype = vp

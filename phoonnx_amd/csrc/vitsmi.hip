@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -201,7 +202,10 @@ int range_check(vits_handle *h) {
                         __FILE__, __LINE__);                                                    \
     } while (0)
 
-int slab_reserve(vits_handle *h, Slab &s, size_t bytes) {
+// (slack: a request that needs more than any before it gets a quarter on top - the frame count of the SAME batch moves by
+// +-7 % with the noise of a pass - so that growth stops after the first requests; vits_reserve asks for exactly what its
+// caller said)
+int slab_reserve(vits_handle *h, Slab &s, size_t bytes, bool slack = true) {
     if (bytes <= s.cap) return 0;
     if (s.base) {
         HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -209,9 +213,17 @@ int slab_reserve(vits_handle *h, Slab &s, size_t bytes) {
         s.base = nullptr;
         s.cap = 0;
     }
-    size_t want = bytes + bytes / 8 + (1 << 20);
+    size_t want = bytes + (slack ? bytes / 4 : 0) + (1 << 20);
+    static const bool trace = std::getenv("VITSMI_TRACE_ALLOC") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc((void **)&s.base, want);
-    if (e != hipSuccess) return fail(h, VITS_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    if (trace)
+        fprintf(stderr, "vitsmi: handle %p slab %p grows to %.1f MB (hipMalloc %.1f ms)\n", (void *)h, (void *)&s, want / 1e6,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // (the error is reported HERE: the next launch check must not find it)
+        return fail(h, VITS_E_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
     s.cap = want;
     return 0;
 }
@@ -1003,12 +1015,9 @@ void stage_mark(vits_handle *h, int idx) {
     if (h->timing) hipEventRecord(h->ev[idx], h->stream);
 }
 
-// ---- token-domain part: encoder + duration predictor + durations.  Leaves y_len on the host.
-int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int B, int T, const float *scales,
-               const int64_t *d_sid, const float *d_noise_dp, uint64_t seed) {
-    const Model &m = h->model;
+// bytes of the token-domain slab for B utterances of T tokens (run_tokens' plan)
+size_t tokens_ws_bytes(const Model &m, int B, int T) {
     const int H = m.H, C = m.C;
-    // workspace plan (floats)
     const size_t nHT = (size_t)B * H * T;
     const int Cdp = m.use_sdp ? m.dp_pre.Cout : m.dpp_F;
     size_t need = 0;
@@ -1025,6 +1034,21 @@ int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int 
     need += al((size_t)B * pr_rows * T) + al((size_t)B * 2 * T) * 2 + al((size_t)B * T) * 4;
     need += al((size_t)B * (m.gin + m.dp_cond_rows + m.C0 + 16)) + (1 << 16);
     for (auto &cd : m.flow) need += al((size_t)B * 2 * m.flow_H * cd.n_wn);
+    return need;
+}
+
+// ---- token-domain part: encoder + duration predictor + durations.  Leaves y_len on the host.
+int run_tokens(vits_handle *h, const int64_t *d_ids, const int64_t *d_lens, int B, int T, const float *scales,
+               const int64_t *d_sid, const float *d_noise_dp, uint64_t seed) {
+    const Model &m = h->model;
+    const int H = m.H, C = m.C;
+    // workspace plan (floats)
+    const size_t nHT = (size_t)B * H * T;
+    const int Cdp = m.use_sdp ? m.dp_pre.Cout : m.dpp_F;
+    const size_t need = tokens_ws_bytes(m, B, T);
+    int pr_rows = 32;  // spline parameters per position: 3 * bins - 1 (29 for the reference's 10 bins, up to 47)
+    if (m.use_sdp)
+        for (const auto &cfd : m.cf) pr_rows = cfd.proj.Cout > pr_rows ? cfd.proj.Cout : pr_rows;
     if (int rc = slab_reserve(h, h->tok, need)) return rc;
     Slab &s = h->tok;
     s.used = 0;
@@ -1734,6 +1758,17 @@ int render_chunks(vits_handle *h, Ctx &c, const float *z, int64_t z_bstride, int
     return 0;
 }
 
+// bytes of the frame-domain slab (flow + generator) for B utterances of F frames (a multiple of 4), the generator rendering
+// Fgen frames at a time (run_frames' plan)
+size_t frames_ws_bytes(const Model &m, int B, int F, int Fgen) {
+    const size_t nCF = (size_t)B * m.C * F, nHF = (size_t)B * m.flow_H * F;
+    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + al(nHF * 2) + gen_ws_bytes(m, B, Fgen) + (1 << 16);
+    for (auto &cd : m.flow) need += al((size_t)B * 2 * m.flow_H * cd.n_wn);
+    need += al((size_t)B * m.C0);
+    need += al(nCF) + al(nHF * 2);  // operand planes of a coupling's x0 and of its skip sum (pre / post on the split-operand engine)
+    return need;
+}
+
 int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t *d_sid, const float *d_noise_z,
                int64_t noise_z_stride, uint64_t seed, const ChunkSink *sink = nullptr) {
     const Model &m = h->model;
@@ -1749,11 +1784,7 @@ int run_frames(vits_handle *h, int B, int T, const float *scales, const int64_t 
     const size_t nCF = (size_t)B * C * F, nHF = (size_t)B * Hf * F;
     // frames the generator renders at a time: everything, or one chunk with its context
     const int Fgen = sink && sink->chunk_frames + 2 * m.gen_rf_frames < F ? sink->chunk_frames + 2 * m.gen_rf_frames : F;
-    size_t need = al(nCF) * 3 + al(nHF) * 3 + al(nHF * 2) * 2 + al(nHF * 2) + gen_ws_bytes(m, B, Fgen) + (1 << 16);
-    for (auto &cd : m.flow) need += al((size_t)B * 2 * Hf * cd.n_wn);
-    need += al((size_t)B * m.C0);
-    need += al(nCF) + al(nHF * 2);  // operand planes of a coupling's x0 and of its skip sum (pre / post on the split-operand engine)
-    if (int rc = slab_reserve(h, h->frm, need)) return rc;
+    if (int rc = slab_reserve(h, h->frm, frames_ws_bytes(m, B, F, Fgen))) return rc;
     Slab &s = h->frm;
     s.used = 0;
     Ctx c{h, m, h->stream, h->arena_dev, B};
@@ -2137,6 +2168,7 @@ int vits_hparam(vits_handle *h, const char *key, int64_t *out) {
     else if (k == "flow_macs_per_frame") *out = (int64_t)m.flow_macs_per_frame;
     else if (k == "enc_macs_per_token") *out = (int64_t)m.enc_macs_per_token;
     else if (k == "dec_bytes_per_frame") *out = (int64_t)(m.dec_elems_per_frame * 4);
+    else if (k == "workspace_bytes") *out = (int64_t)(h->tok.cap + h->frm.cap + h->io.cap);
     else return fail(h, VITS_E_ARG, "unknown hparam %s", key);
     return VITS_OK;
 }
@@ -2164,6 +2196,24 @@ static int check_dev(vits_handle *h) {
     if (h->host_only) return fail(h, VITS_E_DEVICE, "handle was opened host-only");
     if (hipSetDevice(h->device) != hipSuccess) return fail(h, VITS_E_DEVICE, "hipSetDevice(%d) failed", h->device);
     return 0;
+}
+
+int vits_reserve(vits_handle *h, int B, int T, int F) {
+    if (int rc = check_dev(h)) return rc;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const Model &m = h->model;
+    if (B <= 0 || T < 0 || F < 0) return fail(h, VITS_E_ARG, "vits_reserve: B=%d T=%d F=%d", B, T, F);
+    if (T > 0) {
+        if (int rc = slab_reserve(h, h->tok, tokens_ws_bytes(m, B, T), false)) return rc;
+        // the staging slab: ids | lens | sid, and injected noises where a caller passes them (vits_noise)
+        const size_t io = (size_t)B * T * 8 + (size_t)B * 16 + (size_t)B * 2 * T * 4 + (size_t)B * m.C * (size_t)((F + 3) & ~3) * 4 + 4096;
+        if (int rc = slab_reserve(h, h->io, io, false)) return rc;
+    }
+    if (F > 0) {
+        const int Fp = (F + 3) & ~3;
+        if (int rc = slab_reserve(h, h->frm, frames_ws_bytes(m, B, Fp, Fp), false)) return rc;
+    }
+    return VITS_OK;
 }
 
 static int run_device_locked(vits_handle *h, const int64_t *ids, const int64_t *lens, int B, int T,

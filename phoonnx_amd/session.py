@@ -9,6 +9,7 @@ and forwards them over the C ABI (include/vitsmi.h) to the gfx950 engine.  There
 fallback: without libvitsmi.so + an MI355X this raises.
 """
 import ctypes as C
+import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -488,6 +489,14 @@ class MiSession:
             self.tails = tails
             self._lib.vits_set_tails(self._h, 1 if tails == "reference" else 0)
 
+    def reserve(self, batch: int, tokens: int = 0, frames: int = 0):
+        """Size the device workspaces now for requests of up to `batch` utterances x `tokens` ids rendering up to `frames`
+        frames each (vits_reserve): a serving process calls this once at start-up with the largest request it admits, so that
+        no request reallocates tens of GB mid-stream (a device-wide synchronisation measured at up to seconds)."""
+        with self._mu:
+            if self._lib.vits_reserve(self._h, int(batch), int(tokens), int(frames)) != 0:
+                raise SessionError(self._err())
+
     def set_timing(self, on=True):
         """True / 1: stage marks + events around every conv launch; 2: stage marks only; False / 0: off."""
         self._lib.vits_set_timing(self._h, 2 if on == 2 else (1 if on else 0))
@@ -665,6 +674,13 @@ class PipelinedSession:
         for i, s in enumerate(self.parts):
             s.set_seed(int(seed) + i)
 
+    def reserve(self, batch: int, tokens: int = 0, frames: int = 0, whole_batch: bool = True):
+        """MiSession.reserve on every part.  whole_batch=True sizes every part for the WHOLE batch (run_device_steps(...,
+        alternate=True) deals complete requests to the parts); False for its rows only (the split schedule)."""
+        bnd = self.bounds(batch)
+        for i in range(len(self.parts) if whole_batch else len(bnd) - 1):
+            self.parts[i].reserve(batch if whole_batch else bnd[i + 1] - bnd[i], tokens, frames)
+
     def set_tails(self, tails: str):
         """"zero" / "reference" on every handle (MiSession.set_tails)."""
         with self._mu:
@@ -706,6 +722,7 @@ class PipelinedSession:
         bnd = self.bounds(B)
         n = len(bnd) - 1
         out = np.zeros((steps, B), np.int64)
+        stamps = self.last_pass_stamps = [0.0] * steps  # (alternate: when pass k's call returned on its worker; diagnostics)
         started = [threading.Event() for _ in range(n)]
         errors = []
 
@@ -718,6 +735,7 @@ class PipelinedSession:
                         self.parts[i].run_device(ids_ptr, lens_ptr, B, T, scales, sid_ptr)
                         started[i].set()
                         out[k, :] = self.parts[i].last_y_lengths()
+                        stamps[k] = time.perf_counter()
                     self.parts[i].sync()
                     return
                 b0, nb = bnd[i], bnd[i + 1] - bnd[i]

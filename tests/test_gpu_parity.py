@@ -691,6 +691,43 @@ def test_pipeline_matches_reference_goldens(preset, tails):
     s.close()
 
 
+def test_reserved_workspaces_do_not_grow_and_change_no_result():
+    """vits_reserve (MiSession.reserve): a handle sized up front for the largest request renders the fixtures without growing
+    its workspaces (hparam "workspace_bytes" stays put) and bit-identically to a handle that grew on demand; a request
+    beyond the reservation still works (grows); a reservation the device cannot hold fails with the engine's error."""
+    preset = TINY_PRESETS[0]
+    g = np.load(os.path.join(GOLDEN, preset + ".npz"))
+    cases = golden_cases(g)
+    args = lambda c: (case_get(g, c, "ids"), case_get(g, c, "lens"), case_get(g, c, "scales"), case_get(g, c, "sid"),  # noqa: E731
+                      case_get(g, c, "noise_dp"), case_get(g, c, "noise_z"))
+    grown, fixed = _session(preset), _session(preset)
+    Bm = max(case_get(g, c, "ids").shape[0] for c in cases)
+    Tm = max(case_get(g, c, "ids").shape[1] for c in cases)
+    Fm = max(int(case_get(g, c, "out_y_lengths").max()) for c in cases)
+    before = fixed.hparam("workspace_bytes")
+    fixed.reserve(Bm, Tm, Fm)
+    cap = fixed.hparam("workspace_bytes")
+    assert cap > before
+    for c in cases:
+        a, b = grown.synthesize_batch(*args(c)), fixed.synthesize_batch(*args(c))
+        assert np.array_equal(a["output"], b["output"]) and np.array_equal(a["y_lengths"], b["y_lengths"]), c
+        assert fixed.hparam("workspace_bytes") == cap, (c, "a reserved handle allocated")
+    fixed.reserve(Bm, Tm, Fm)            # (idempotent)
+    fixed.reserve(1, 0, 0)               # (smaller: nothing shrinks)
+    assert fixed.hparam("workspace_bytes") == cap
+    small = _session(preset)
+    small.reserve(1, 4, 4)
+    c = cases[-1]
+    assert np.array_equal(small.synthesize_batch(*args(c))["output"], grown.synthesize_batch(*args(c))["output"])
+    with pytest.raises(Exception, match="hipMalloc"):
+        small.reserve(4096, 4096, 1 << 20)
+    assert np.array_equal(small.synthesize_batch(*args(c))["output"], grown.synthesize_batch(*args(c))["output"])
+    with pytest.raises(Exception):
+        small.reserve(0, 1, 1)
+    for s in (grown, fixed, small):
+        s.close()
+
+
 @pytest.mark.parametrize("tails", ["zero", "reference"])
 @pytest.mark.parametrize("precision,nprod", [("f16x3", 2), ("bf16x6", 6)])
 @pytest.mark.parametrize("preset", SX_PRESETS)
