@@ -68,10 +68,13 @@ def write_build_info(compiled, sha):
         info["time"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())
     try:
         head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5)
-        if head.returncode == 0 and head.stdout.strip() and compiled:
-            info["commit"] = head.stdout.strip()
-            info["dirty"] = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"],
-                                           capture_output=True, text=True, timeout=10).stdout.strip() != ""
+        if head.returncode == 0 and head.stdout.strip():
+            dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"],
+                                   capture_output=True, text=True, timeout=10).stdout.strip() != ""
+            # (a reused library whose sources hash as recorded, in a clean tree: HEAD holds exactly these sources - name it)
+            if compiled or not dirty:
+                info["commit"] = head.stdout.strip()
+                info["dirty"] = dirty
     except Exception:
         pass
     try:
