@@ -1,6 +1,11 @@
 import os
 import sys
 
+# The C oracle (oracle/libvits_oracle.so) is OpenMP code: on the GPU box's 256 hardware threads its default team turns the
+# tiny fixtures' loops into barrier traffic (one tiny_rb1 rendering: 34 s there, 0.03 s with 8 threads) - and the GPU suite's
+# time was mostly that.  Set before anything loads libgomp; an explicit OMP_NUM_THREADS in the environment wins.
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, os.cpu_count() or 1))))
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
