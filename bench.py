@@ -461,10 +461,11 @@ def main():
     prewarmed = {}
     reserved = {}
 
-    def measure(first, preset, steps, warmup, parts, lockstep, seed, inputs_h=None, pipe=None):
+    def measure(first, preset, steps, warmup, parts, lockstep, seed, inputs_h=None, pipe=None, schedule=None):
         """K timed passes of the whole path on `parts` handles sharing `first`'s arena -> (dt, samples, pipe).
         inputs_h: (ids, lens, sid) host tensors of another workload than the command line's (the config-4 block).
         pipe: an existing pipeline of `first` to run on instead of a new one."""
+        schedule = schedule or a.schedule
         if pipe is None:
             pipe = PipelinedSession(first, max(1, parts))
         pipe.set_seed(1234 + rank * 16)
@@ -488,7 +489,7 @@ def main():
                     n += int(pipe.last_y_lengths(B).sum()) * hop
                 return n
             return int(pipe.run_device_steps(ids.data_ptr(), lens.data_ptr(), B, T, scales, k, sid_ptr,
-                                             alternate=a.schedule == "alternate").sum()) * hop
+                                             alternate=schedule == "alternate").sum()) * hop
 
         # a fresh process' first passes are slow (first touch of ~60 GB of workspace, clock ramp: the first bench run on a fresh
         # box measured 567 M samples/s where every later one measured 740-750 M): pre-warm for --prewarm-s seconds (untimed,
@@ -505,7 +506,7 @@ def main():
             f_probe = int(pipe.last_y_lengths(B).max())
             pipe.sync()
             pipe.reserve(B, T, int(f_probe * 1.25) + 64,
-                         whole_batch=a.schedule == "alternate" and not (lockstep or len(pipe.parts) == 1))
+                         whole_batch=(schedule == "alternate" or a.schedule == "alternate") and not (lockstep or len(pipe.parts) == 1))
         if a.prewarm_s > 0 and not prewarmed.get(id(first)):
             prewarmed[id(first)] = True
             t_pw = time.perf_counter()
@@ -726,6 +727,15 @@ def main():
         one_handle = {"value": n1 / dt1, "unit": "samples/s", "steps": k1, "ms_per_step": dt1 / k1 * 1e3,
                       "note": "the same batch on ONE engine handle / stream: the schedule of the `roofline` and `stages` blocks"}
 
+    # The round-4 schedule of the same handles (every pass split over them, rows each), so that rounds can be compared like
+    # for like: under it a request's latency is one step; under `alternate` n whole requests are in flight on n handles.
+    split_sched = None
+    if extras and len(pipe.parts) > 1 and a.schedule == "alternate" and not a.lockstep:
+        ks = max(3, a.steps // 2)
+        dts, ns, _ps, _ = measure(sess, a.preset, ks, 2, a.parts, a.lockstep, 1234 + rank, pipe=pipe, schedule="split")
+        split_sched = {"value": ns / dts, "unit": "samples/s", "steps": ks, "ms_per_step": dts / ks * 1e3,
+                       "note": "--schedule split: every pass divided over the handles (the bench default up to round 4)"}
+
     # The same batch as the exported graph itself renders it (tails="reference"): its generator is not masked, so every
     # utterance is rendered to the longest one's length.  `value` does not render those tails (the default: each generator
     # launch ends an utterance's tensors gen_rf_frames behind its end; every valid sample is bit-identical, tests/
@@ -875,6 +885,9 @@ def main():
         except Exception as e:  # noqa: BLE001 - the baseline is a report, never the product
             cpu = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
+    def g_ms(d):
+        return d.get("ms_per_step") if isinstance(d, dict) else None
+
     if rank == 0:
         value = samples_all / dt_max
         line = {
@@ -912,7 +925,14 @@ def main():
                        "weights": weights, "commit": git_head(), "source_sha": source_sha()},
             "roofline": roofline, "cpu_baseline": cpu, "step_ms": step_pct, "host_io": host_io, "one_handle": one_handle,
             "exact_arithmetic": exact, "padded_rendering": padded, "also": also, "stages": stage, "f16_range": f16_range,
-            "b1": b1, "config4": config4,
+            "b1": b1, "config4": config4, "split_schedule": split_sched,
+            "request_latency_ms": {
+                "saturated": dt_max / a.steps * 1e3 * (n_parts if (a.schedule == "alternate" and not a.lockstep and n_parts > 1) else 1),
+                "unloaded": g_ms(one_handle) if one_handle else dt_max / a.steps * 1e3,
+                "note": "ms_per_step is the interval between finished requests.  Under the default schedule (whole requests dealt "
+                        "to the handles in turn) n = pipeline_parts requests are in flight at any time, so a request submitted to "
+                        "the saturated pipeline takes n x ms_per_step (Little's law); `unloaded` = one request alone on one "
+                        "handle (one_handle.ms_per_step)"},
             "value_is": "device-resident ids in, waveform left on the device (the contract's HBM-resident timed region); the "
                         "figure shaped like the reference's session.run (host ids in, one host fp32 [B,1,1,S] array out) is "
                         "host_io.value",
@@ -929,6 +949,8 @@ def main():
         line["summary"] = {
             "value": value, "ms_per_step": line["ms_per_step"], "n_gpus": world, "preset": a.preset, "dtype": a.gen_precision,
             "padded_rendering.value": g(padded, "value"), "one_handle.value": g(one_handle, "value"), "host_io.value": g(host_io, "value"),
+            "split_schedule.value": g(split_sched, "value"), "request_latency_ms.saturated": g(line, "request_latency_ms", "saturated"),
+            "request_latency_ms.unloaded": g(line, "request_latency_ms", "unloaded"),
             "exact_arithmetic.value": g(exact, "value"), "also.preset": g(also, "preset"), "also.value": g(also, "value"),
             "also.ms_per_step": g(also, "ms_per_step"), "also.roofline.bound": g(also, "roofline", "bound"),
             "also.roofline.frac": g(also, "roofline", "frac"), "also.dec_hbm_frac_marks": g(also, "stages", "stage_marks_only", "dec_hbm_frac"),

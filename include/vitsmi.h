@@ -266,8 +266,13 @@ int vits_set_tails(vits_handle *h, int reference);
  * needs more than any before it - hipFree + hipMalloc of tens of GB at batch 32, a device-wide synchronisation that was
  * measured at 0.3 ms to 5 s - so a serving process calls this once at start-up with the largest request it admits (the
  * frame count of a batch depends on the durations the model predicts, i.e. on the noise as well: leave headroom), and no
- * request up to that size allocates device memory afterwards.  onnxruntime has no counterpart (its arena grows the same
- * way, voice.py:167-171 passes default SessionOptions); nothing in the reference needs to call it. */
+ * request up to that size allocates device memory afterwards (vits_last_pcm16's int16 staging of such a request
+ * included).  onnxruntime has no counterpart (its arena grows the same way, voice.py:167-171 passes default
+ * SessionOptions); nothing in the reference needs to call it.
+ * INVALIDATES THE LAST RUN'S RESULTS when a workspace actually grows: the device waveform, frame counts and taps of the
+ * last run live in those workspaces, so after a growing vits_reserve (or any run that grows one) vits_fetch_output /
+ * vits_last_pcm16 / vits_tap return VITS_E_ARG ("no completed run") until the next run, and an out->data / out->y_lengths
+ * pointer still held from vits_run_device / vits_run_async must not be read any more.  Fetch first, reserve afterwards. */
 int vits_reserve(vits_handle *h, int B, int T, int F);
 int vits_get_stats(vits_handle *h, vits_stats *out);
 

@@ -281,8 +281,16 @@ def build(force=False, verbose=False):
     # one builder at a time per tree: N ranks that find the library stale would otherwise compile the same objects into the
     # same files side by side (_ffi.load() calls this from every process); the others wait, then find it fresh
     import fcntl
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    with open(os.path.join(HERE, "build", ".lock"), "w") as lk:
+    try:
+        os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+        lk = open(os.path.join(HERE, "build", ".lock"), "w")
+    except OSError:
+        # a read-only install (site-packages of another user, a read-only image layer): nothing can be compiled into this tree
+        # anyway - a fresh library is used as it is, a stale one is the error it would have been further down
+        if not force and not stale():
+            return _build_locked(False, verbose)
+        raise
+    with lk:
         fcntl.flock(lk, fcntl.LOCK_EX)
         try:
             return _build_locked(force, verbose)
@@ -310,9 +318,27 @@ def _build_locked(force, verbose):
             "-Rpass-analysis=kernel-resource-usage"]  # (the remarks are parsed below: register spills are an ERROR here)
     base[1:1] = os.environ.get("VITSMI_CXXFLAGS", "").split()  # kernel experiments (-DSX_EXP_...)
 
+    # The ISA checks below read the assembly of THIS compile (-save-temps=obj leaves <unit>-hip-amdgcn-amd-amdhsa-gfx950.s
+    # next to the object; each unit in a directory of its own, removed once read): the code that is checked is the code that
+    # ships, and a stale library costs one compile per unit, not two.
+    isas = {}
+
     def compile_one(src):
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        r = subprocess.run(base + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+        stem = os.path.splitext(src)[0]
+        obj = os.path.join(objdir, stem + ".o")
+        if not src.endswith(".hip"):
+            r = subprocess.run(base + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj], capture_output=True, text=True)
+            return src, obj, r
+        tdir = os.path.join(objdir, "temps_" + stem)
+        shutil.rmtree(tdir, ignore_errors=True)
+        os.makedirs(tdir)
+        tobj = os.path.join(tdir, stem + ".o")
+        r = subprocess.run(base + ["-save-temps=obj", "-x", "hip", "-c", os.path.join(CSRC, src), "-o", tobj], capture_output=True, text=True)
+        if r.returncode == 0:
+            os.replace(tobj, obj)
+            with open(os.path.join(tdir, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")) as f:
+                isas[src] = f.read()
+        shutil.rmtree(tdir, ignore_errors=True)
         return src, obj, r
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
@@ -343,8 +369,9 @@ def _build_locked(force, verbose):
         raise RuntimeError("kernels with asynchronous inline-asm loads must not spill registers: " + ", ".join(f"{k} ({v})" for k, v in bad.items()))
     # the ISA of every HIP unit (device only, side by side): hazards 1 and 5 are properties of the generated code
     hip_units = [u for u in SOURCES if u.endswith(".hip")]
-    with ThreadPoolExecutor(max_workers=min(len(hip_units), os.cpu_count() or 4)) as ex:
-        isas = dict(zip(hip_units, ex.map(lambda u: isa_of(u, os.environ.get("VITSMI_CXXFLAGS", "").split()), hip_units)))
+    missing = [u for u in hip_units if u not in isas]
+    if missing:
+        raise RuntimeError(f"no device assembly was kept for {missing} (-save-temps=obj): the ISA checks cannot run")
     h5 = {}
     for u in hip_units:
         h5.update(sgpr_vmem_hazards(isas[u]))

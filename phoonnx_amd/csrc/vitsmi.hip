@@ -205,10 +205,25 @@ int range_check(vits_handle *h) {
 // (slack: a request that needs more than any before it gets a quarter on top - the frame count of the SAME batch moves by
 // +-7 % with the noise of a pass - so that growth stops after the first requests; vits_reserve asks for exactly what its
 // caller said)
+// A workspace that is about to be freed takes the last run's results with it: everything vits_fetch_output /
+// vits_last_pcm16 / vits_tap (and a caller of vits_run_device / vits_run_async still holding out->data) would read lives
+// in tok or frm.  Those pointers are dropped here, so the next such call fails with "no completed run" instead of reading
+// freed device memory (a run that grows a slab sets them again itself, behind the growth).
+void forget_results_in(vits_handle *h, const Slab &s) {
+    if (&s == &h->tok) {
+        h->d_emb = h->d_x = h->d_mp = h->d_logs = h->d_logw = h->d_wceil = nullptr;
+        h->d_len = h->d_ylen = h->d_cum = nullptr;
+        h->d_ylen64 = nullptr;
+    } else if (&s == &h->frm) {
+        h->d_zp = h->d_z = h->d_out = nullptr;
+    }
+}
+
 int slab_reserve(vits_handle *h, Slab &s, size_t bytes, bool slack = true) {
     if (bytes <= s.cap) return 0;
     if (s.base) {
         HIPCHECK(h, hipStreamSynchronize(h->stream));
+        forget_results_in(h, s);
         HIPCHECK(h, hipFree(s.base));
         s.base = nullptr;
         s.cap = 0;
@@ -2206,7 +2221,10 @@ int vits_reserve(vits_handle *h, int B, int T, int F) {
     if (T > 0) {
         if (int rc = slab_reserve(h, h->tok, tokens_ws_bytes(m, B, T), false)) return rc;
         // the staging slab: ids | lens | sid, and injected noises where a caller passes them (vits_noise)
-        const size_t io = (size_t)B * T * 8 + (size_t)B * 16 + (size_t)B * 2 * T * 4 + (size_t)B * m.C * (size_t)((F + 3) & ~3) * 4 + 4096;
+        // ... or, between runs, vits_last_pcm16's int16 waveform and per-utterance peaks (the larger of the two uses)
+        const size_t io_in = (size_t)B * T * 8 + (size_t)B * 16 + (size_t)B * 2 * T * 4 + (size_t)B * m.C * (size_t)((F + 3) & ~3) * 4 + 4096;
+        const size_t io_pcm = (((size_t)B * F * m.hop * 2 + 255) & ~size_t(255)) + (size_t)B * 4 + 256;
+        const size_t io = io_in > io_pcm ? io_in : io_pcm;
         if (int rc = slab_reserve(h, h->io, io, false)) return rc;
     }
     if (F > 0) {

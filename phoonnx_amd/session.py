@@ -207,6 +207,45 @@ class MiSession:
         cls = RangeError if rc == _ffi.VITS_E_RANGE else SessionError
         raise cls(f"{what} failed [{rc}]: {self._err()}")
 
+    # How long a call from ANOTHER thread waits for a chunked run in progress before it gives up (a generator that was
+    # neither exhausted nor closed keeps its run - and the session lock - until it is garbage-collected).
+    busy_timeout_s = 120.0
+
+    def _locked(self, read_only: bool = False):
+        """The per-session lock, aware of chunked runs.  A chunked run holds the lock on its worker thread from the first
+        chunk to the last, and the engine holds the handle's own mutex with it.  The CONSUMER of that generator must not
+        block on either: its read-only calls (frame counts - valid from the first chunk on - and everything answered from
+        host state) pass, anything that needs the handle raises instead of deadlocking.  Other threads wait for the run
+        to end, for at most busy_timeout_s."""
+        import contextlib
+        import threading
+        import time
+
+        @contextlib.contextmanager
+        def cm():
+            owner = getattr(self, "_stream_owner", None)
+            if owner is not None and owner == threading.get_ident():
+                if read_only:
+                    yield
+                    return
+                raise SessionError("a chunked run is in progress on this session (the synthesize_stream / vocoder_stream "
+                                   "generator this thread is consuming): exhaust or close() it before other calls")
+            deadline = None
+            while not self._mu.acquire(timeout=0.25):
+                if getattr(self, "_stream_owner", None) is None:
+                    deadline = None      # an ordinary batch call of another thread: wait as long as it takes
+                    continue
+                now = time.monotonic()
+                deadline = deadline or now + float(self.busy_timeout_s)
+                if now > deadline:
+                    raise SessionError(f"session busy: a chunked run has been in progress for more than "
+                                       f"{self.busy_timeout_s:g} s (an unclosed synthesize_stream generator?)")
+            try:
+                yield
+            finally:
+                self._mu.release()
+        return cm()
+
     def _fall_back_to_bf16x6(self, exc):
         """After a RangeError: reopen this voice with the exact six-product arithmetic (bf16 planes: fp32 range)."""
         import logging
@@ -309,7 +348,7 @@ class MiSession:
                 raise SessionError(f"noise_z must be [B,inter,F], got {noise_z.shape}")
             noise.noise_z = noise_z.ctypes.data
             noise.noise_z_stride = noise_z.shape[2]
-        with self._mu:  # enqueue -> frame counts -> copy-out -> taps all use this handle's one workspace
+        with self._locked():  # enqueue -> frame counts -> copy-out -> taps all use this handle's one workspace
             try:
                 self._begin(ids, lens, scales, sid, noise)
                 ylen = self.last_y_lengths()
@@ -350,7 +389,7 @@ class MiSession:
             raise SessionError(f"z must have {self.hparam('inter')} channels")
         sid = None if sid is None else np.ascontiguousarray(sid, np.int64)
         out = _ffi.VitsOutput()
-        with self._mu:
+        with self._locked():
             rc = self._lib.vits_run_vocoder(self._h, _ffi.ptr(z), B, F, _ffi.ptr(sid), C.byref(out))
             if rc == _ffi.VITS_E_RANGE:
                 try:
@@ -372,6 +411,9 @@ class MiSession:
         engine hands chunks over: the consumer works on chunk i while chunk i + 1 renders."""
         import queue
         import threading
+        if getattr(self, "_stream_owner", None) == threading.get_ident():
+            raise SessionError("a chunked run is already in progress on this session in this thread: exhaust or close() "
+                               "its generator first")
         q = queue.Queue(maxsize=2)  # the engine renders at most two chunks ahead of the consumer
         stop = threading.Event()
 
@@ -396,12 +438,18 @@ class MiSession:
             # same workspace - and returning this run's frame counts and audio as its own
             try:
                 with self._mu:
-                    rc = start(on_chunk)
-                    err = None if rc == 0 or stop.is_set() else (rc, self._err())
+                    self._stream_owner = consumer
+                    try:
+                        rc = start(on_chunk)
+                        err = None if rc == 0 or stop.is_set() else (rc, self._err())
+                    finally:
+                        self._stream_owner = None
                 put(err)
             except BaseException as e:  # noqa: BLE001 - re-raised on the consumer's thread
                 put(e)
 
+        # (the consumer = the thread that iterates this generator: its frame-count queries pass the lock, see _locked)
+        consumer = threading.get_ident()
         t = threading.Thread(target=work, daemon=True)
         t.start()
         try:
@@ -458,7 +506,7 @@ class MiSession:
                                                                           int(chunk_frames), cb, None))
 
     def tap(self, name):
-        with self._mu:  # (two C calls on the last run's workspace)
+        with self._locked():  # (two C calls on the last run's workspace)
             dims = (C.c_int64 * 4)()
             nd = self._lib.vits_tap(self._h, name.encode(), None, 0, dims)
             if nd < 0:
@@ -485,7 +533,7 @@ class MiSession:
         """"zero" / "reference": see the constructor (applies to the following runs)."""
         if tails not in ("zero", "reference"):
             raise SessionError(f"tails must be 'zero' or 'reference' (got {tails!r})")
-        with self._mu:
+        with self._locked():
             self.tails = tails
             self._lib.vits_set_tails(self._h, 1 if tails == "reference" else 0)
 
@@ -493,7 +541,7 @@ class MiSession:
         """Size the device workspaces now for requests of up to `batch` utterances x `tokens` ids rendering up to `frames`
         frames each (vits_reserve): a serving process calls this once at start-up with the largest request it admits, so that
         no request reallocates tens of GB mid-stream (a device-wide synchronisation measured at up to seconds)."""
-        with self._mu:
+        with self._locked():
             if self._lib.vits_reserve(self._h, int(batch), int(tokens), int(frames)) != 0:
                 raise SessionError(self._err())
 
@@ -503,7 +551,7 @@ class MiSession:
 
     def stats(self):
         s = _ffi.VitsStats()
-        with self._mu:
+        with self._locked():
             self._lib.vits_get_stats(self._h, C.byref(s))
         d = {k: getattr(s, k) for k, _ in _ffi.VitsStats._fields_}
         d["range_fallbacks"] = self.range_fallbacks
@@ -555,7 +603,7 @@ class MiSession:
                 "y_lengths_ptr": C.cast(out.y_lengths, C.c_void_p).value}
 
     def last_y_lengths(self) -> np.ndarray:
-        with self._mu:  # (size, then contents: both of the same run)
+        with self._locked(read_only=True):  # (size, then contents: both of the same run; host state of the handle)
             n = self._lib.vits_last_y_lengths(self._h, None, 0)
             buf = np.zeros(max(n, 0), np.int64)
             if n > 0:
@@ -568,7 +616,8 @@ class MiSession:
         if shape is None:
             raise SessionError("last_pcm16 needs the [B, S] shape of the last output")
         out = np.zeros(shape, np.int16)
-        rc = self._lib.vits_last_pcm16(self._h, 1 if normalize else 0, float(volume), _ffi.ptr(out), out.size)
+        with self._locked():
+            rc = self._lib.vits_last_pcm16(self._h, 1 if normalize else 0, float(volume), _ffi.ptr(out), out.size)
         if rc != 0:
             raise SessionError(f"vits_last_pcm16 failed [{rc}]: {self._err()}")
         return out
@@ -587,7 +636,7 @@ class MiSession:
             sid = np.ascontiguousarray(sid, np.int64)
         noise = _ffi.VitsNoise()
         noise.seed = self._seed
-        with self._mu:
+        with self._locked():
             rc = self._lib.vits_run(self._h, _ffi.ptr(ids), _ffi.ptr(lens), B, T, _ffi.ptr(scales), _ffi.ptr(sid),
                                     C.byref(noise), None)
             if rc != 0:
@@ -597,7 +646,7 @@ class MiSession:
             return self.last_pcm16(normalize, volume, shape=(B, S)), ylen
 
     def sync(self):
-        with self._mu:
+        with self._locked():
             rc = self._lib.vits_sync(self._h)
             if rc != 0:
                 self._raise("vits_sync", rc)

@@ -167,22 +167,31 @@ class ShardedSynthesizer:
         shards, inv = partition([len(u) for u in utterances], self.world)
         mine = shards[self.rank]
         scales = np.asarray(scales, np.float32)
-        use_dev = bool(gather) and self.dist is not None and self.dist.get_backend() == "nccl" and hasattr(self.session, "run_device")
+        # the device path speaks MiSession.run_device's result ({"data_ptr", "dims", "y_lengths_ptr"} of ONE handle): an
+        # injected session (the documented contract is synthesize_batch + hparam only - PipelinedSession.run_device, for one,
+        # returns a list of parts) takes the host path
+        use_dev = bool(gather) and self.dist is not None and self.dist.get_backend() == "nccl" and isinstance(self.session, MiSession)
         if use_dev:
             return self._gather_device(utterances, shards, mine, scales, sids, gather, dst)
-        local = []
-        if len(mine):
-            ids, lens = pad_batch([utterances[i] for i in mine])
-            sid = None if sids is None else np.asarray([sids[i] for i in mine], np.int64)
-            r = self.session.synthesize_batch(ids, lens, scales, sid)
-            for b in range(len(mine)):
-                n = int(r["y_lengths"][b]) * self.hop
-                local.append(r["output"][b, 0, 0, :n])
+        local, failure = [], None
+        try:
+            if len(mine):
+                ids, lens = pad_batch([utterances[i] for i in mine])
+                sid = None if sids is None else np.asarray([sids[i] for i in mine], np.int64)
+                r = self.session.synthesize_batch(ids, lens, scales, sid)
+                for b in range(len(mine)):
+                    n = int(r["y_lengths"][b]) * self.hop
+                    local.append(r["output"][b, 0, 0, :n])
+        except Exception as exc:  # noqa: BLE001 - re-raised below, after the peers have been told
+            if not gather or self.dist is None:
+                raise
+            failure = exc
         if not gather or self.dist is None:
             return [(int(i), w.copy()) for i, w in zip(mine, local)]
         import torch
         dist = self.dist
         dev = torch.device("cpu")
+        self._agree(failure, dev)
         # 1. sample counts of every utterance of every rank (shards differ by at most one utterance: pad with zeros)
         rows = max(len(sh) for sh in shards)
         cnt = torch.zeros(rows, dtype=torch.int64)
@@ -207,18 +216,27 @@ class ShardedSynthesizer:
         rows = max(len(sh) for sh in shards)
         cnt = torch.zeros(rows, dtype=torch.int64, device=dev)
         out = ylen = None
-        if len(mine):
-            ids, lens = pad_batch([utterances[i] for i in mine])
-            d_ids, d_lens = torch.from_numpy(ids).to(dev), torch.from_numpy(lens).to(dev)
-            d_sid = None if sids is None else torch.from_numpy(np.asarray([sids[i] for i in mine], np.int64)).to(dev)
-            torch.cuda.synchronize(dev)   # (the engine runs on its own stream: the inputs are in place before it starts)
-            r = self.session.run_device(d_ids.data_ptr(), d_lens.data_ptr(), len(mine), ids.shape[1], scales,
-                                        None if d_sid is None else d_sid.data_ptr())
-            self.session.sync()           # ... and its output is complete before torch's stream reads it
-            B, S = int(r["dims"][0]), int(r["dims"][3])
-            out = torch.as_tensor(_DeviceArray(r["data_ptr"], (B, S)), device=dev)
-            ylen = torch.as_tensor(_DeviceArray(r["y_lengths_ptr"], (B,), "<i8"), device=dev)
-            cnt[:B] = ylen * self.hop
+        failure = None
+        try:
+            if len(mine):
+                ids, lens = pad_batch([utterances[i] for i in mine])
+                sid = None if sids is None else np.asarray([sids[i] for i in mine], np.int64)
+                # vits_run_device takes device pointers as they are (vits_run's host-side checks do not see them, and the
+                # embedding kernel zeroes an out-of-vocabulary id rather than fault): the request is checked HERE, on the host
+                self._validate(ids, lens, sid)
+                d_ids, d_lens = torch.from_numpy(ids).to(dev), torch.from_numpy(lens).to(dev)
+                d_sid = None if sid is None else torch.from_numpy(sid).to(dev)
+                torch.cuda.synchronize(dev)   # (the engine runs on its own stream: the inputs are in place before it starts)
+                r = self.session.run_device(d_ids.data_ptr(), d_lens.data_ptr(), len(mine), ids.shape[1], scales,
+                                            None if d_sid is None else d_sid.data_ptr())
+                self.session.sync()           # ... and its output is complete before torch's stream reads it
+                B, S = int(r["dims"][0]), int(r["dims"][3])
+                out = torch.as_tensor(_DeviceArray(r["data_ptr"], (B, S)), device=dev)
+                ylen = torch.as_tensor(_DeviceArray(r["y_lengths_ptr"], (B,), "<i8"), device=dev)
+                cnt[:B] = ylen * self.hop
+        except Exception as exc:  # noqa: BLE001 - re-raised by _agree, after the peers have been told
+            failure = exc
+        self._agree(failure, dev)
         allcnt = torch.zeros(self.world * rows, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allcnt, cnt)
         allcnt = allcnt.cpu().view(self.world, rows)
@@ -228,6 +246,34 @@ class ShardedSynthesizer:
             mask = torch.arange(out.shape[1], device=dev)[None, :] < cnt[:out.shape[0], None]
             flat[:int(allcnt[self.rank].sum())] = out[mask]   # row-major: every row's valid prefix, rows in shard order
         return self._collect(flat, allcnt, shards, len(utterances), gather, dst)
+
+    def _validate(self, ids, lens, sid):
+        """The checks vits_run makes on host inputs (vitsmi.hip stage_inputs), for the path that hands the engine device
+        pointers: ids inside the vocabulary, lengths inside the row, speaker ids inside the table."""
+        n_vocab = int(self.session.hparam("n_vocab"))
+        if ids.size and (int(ids.min()) < 0 or int(ids.max()) >= n_vocab):
+            bad = np.argwhere((ids < 0) | (ids >= n_vocab))[0]
+            raise ValueError(f"phoneme id {int(ids[tuple(bad)])} at [{int(bad[0])},{int(bad[1])}] is out of range [0,{n_vocab})")
+        if lens.size and (int(lens.min()) < 0 or int(lens.max()) > ids.shape[1]):
+            raise ValueError(f"input_lengths outside [0,{ids.shape[1]}]")
+        if int(self.session.hparam("gin")):
+            if sid is None:
+                raise ValueError("Missing speaker id")
+            n_spk = int(self.session.hparam("n_speakers"))
+            if sid.size and (int(sid.min()) < 0 or int(sid.max()) >= n_spk):
+                raise ValueError(f"sid out of range [0,{n_spk})")
+
+    def _agree(self, failure, dev):
+        """A gathered request ends in a collective every rank must enter.  A rank whose shard failed (a bad id, a device
+        error, a range violation) would leave its peers waiting in it: one 4-byte all_reduce(MIN) of an ok flag first, and
+        EVERY rank raises - the failing one its own exception, the others a RuntimeError naming the cause as 'a peer'."""
+        import torch
+        ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32, device=dev)
+        self.dist.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if failure is not None:
+            raise failure
+        if int(ok.item()) == 0:
+            raise RuntimeError(f"rank {self.rank}: a peer's shard of this request failed; nothing was gathered")
 
     def _collect(self, flat, allcnt, shards, n_utts, gather, dst):
         """ONE collective over the ranks' flat buffers (device tensors over RCCL, host tensors over gloo), then the rows are

@@ -475,6 +475,79 @@ def test_a_stream_holds_the_session_lock_against_calls_from_other_threads():
     assert [c[0] for c in got] == [0, 4, 8] and all(np.array_equal(c[1], [[1, 2, 3, 4]]) for c in got)
 
 
+def test_the_consumer_of_a_stream_can_ask_for_frame_counts_and_nothing_deadlocks():
+    """The consumer of synthesize_stream may call last_y_lengths() between chunks (the counts are valid from the first chunk
+    on): the worker thread holds the session lock for the whole run, so that call must pass the lock instead of waiting
+    for the run it is itself keeping alive.  Calls that need the handle (the engine holds its mutex for the whole chunked
+    run) raise instead of deadlocking; a second stream on the same session from the same thread is refused; another thread
+    gives up after busy_timeout_s when the generator is abandoned unclosed.  Stub library, no GPU."""
+    import ctypes as C
+    import threading
+    import time
+
+    class FakeLib:
+        def vits_last_y_lengths(self, h, buf, n):
+            if buf is not None and n >= 2:
+                buf[0], buf[1] = 7, 9
+            return 2
+
+        def vits_sync(self, h):
+            return 0
+
+    s = object.__new__(MiSession)
+    s._mu = threading.RLock()
+    s._lib = FakeLib()
+    s._h = None
+    release = threading.Event()
+
+    def start(cb):  # stands for vits_run_chunked: blocks, hands chunks to the callback until told to stop
+        buf = (C.c_float * 4)(1, 2, 3, 4)
+        for i in range(6):
+            if cb(None, C.cast(buf, C.POINTER(C.c_float)), 1, 4 * i, 4, 24):
+                break
+        release.wait(5)
+        return 0
+
+    done = []
+
+    def consume():
+        gen = s._stream(start)
+        first = next(gen)
+        assert first[0] == 0
+        assert np.array_equal(s.last_y_lengths(), [7, 9])       # passes the lock the worker holds
+        with pytest.raises(SessionError, match="chunked run is in progress"):
+            s.sync()                                             # would wait on the handle's mutex for ever
+        with pytest.raises(SessionError, match="already in progress"):
+            next(s._stream(start))
+        done.append("mid")
+        # another thread: waits, then gives up (the generator is neither exhausted nor closed)
+        s.busy_timeout_s = 0.4
+        err = []
+        t0 = time.monotonic()
+
+        def other():
+            try:
+                s.sync()
+                err.append("no error")
+            except SessionError as e:
+                err.append(str(e))
+        t = threading.Thread(target=other)
+        t.start()
+        t.join(5)
+        assert not t.is_alive() and "session busy" in err[0] and time.monotonic() - t0 < 4, err
+        release.set()
+        gen.close()
+        done.append("closed")
+        s.sync()                                                 # the lock is free again
+        done.append("after")
+
+    t = threading.Thread(target=consume)
+    t.start()
+    t.join(15)
+    assert not t.is_alive(), "deadlock: " + repr(done)
+    assert done == ["mid", "closed", "after"], done
+
+
 def test_pinned_pool_drain_releases_idle_blocks_without_waiting_for_the_next_allocation(monkeypatch):
     """_PinnedPool.drain(): blocks whose arrays have died go back to the free lists at once and the excess over the cap is
     released - MiSession.close() and the pageable-result path call it, so an idle process does not keep a large batch's

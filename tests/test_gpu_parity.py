@@ -724,6 +724,29 @@ def test_reserved_workspaces_do_not_grow_and_change_no_result():
     assert np.array_equal(small.synthesize_batch(*args(c))["output"], grown.synthesize_batch(*args(c))["output"])
     with pytest.raises(Exception):
         small.reserve(0, 1, 1)
+    # A reservation that GROWS a workspace frees what the last run left there (vitsmi.h: fetch first, reserve afterwards):
+    # the result calls must then refuse ("no completed run") rather than read freed device memory, and the next run is
+    # unaffected.  A reservation that grows nothing leaves the last run's results readable.
+    r0 = grown.synthesize_batch(*args(c))
+    B0, S0 = r0["output"].shape[0], r0["output"].shape[3]
+    pcm0 = grown.last_pcm16(True, 1.0, shape=(B0, S0))
+    grown.reserve(1, 0, 0)                                   # (grows nothing)
+    assert np.array_equal(grown.last_pcm16(True, 1.0, shape=(B0, S0)), pcm0)
+    z0 = grown.tap("z")
+    cap0 = grown.hparam("workspace_bytes")
+    grown.reserve(4 * Bm, 4 * Tm, 8 * Fm)                    # (grows all three)
+    assert grown.hparam("workspace_bytes") > cap0
+    with pytest.raises(Exception, match="no completed run"):
+        grown.last_pcm16(True, 1.0, shape=(B0, S0))
+    with pytest.raises(Exception, match="no completed run"):
+        grown.tap("z")
+    with pytest.raises(Exception, match="no completed run"):
+        grown._fetch(np.empty_like(r0["output"]), 0, B0)
+    cap1 = grown.hparam("workspace_bytes")
+    r1 = grown.synthesize_batch(*args(c))
+    assert np.array_equal(r1["output"], r0["output"]) and np.array_equal(grown.tap("z"), z0)
+    assert np.array_equal(grown.last_pcm16(True, 1.0, shape=(B0, S0)), pcm0)
+    assert grown.hparam("workspace_bytes") == cap1, "last_pcm16 allocated behind a reservation that covers the request"
     for s in (grown, fixed, small):
         s.close()
 

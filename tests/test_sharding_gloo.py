@@ -147,6 +147,25 @@ def _gather_worker(rank, world, port, q):
         assert (at_root is None) == (rank != 1)
         if at_root is not None:
             assert all(a.tobytes() == b.tobytes() for a, b in zip(at_root, everything))
+        # a shard that FAILS on one rank (a bad id, a device error ...): both ranks raise - the failing one its own error,
+        # its peer a RuntimeError - instead of the peer waiting in the gather for a buffer that never comes
+        class Failing(_StubSession):
+            def synthesize_batch(self, ids, lens, scales, sid=None):
+                if rank == 1:
+                    raise ValueError("phoneme id 999 is out of range")
+                return super().synthesize_batch(ids, lens, scales, sid)
+        bad = ShardedSynthesizer("unused.onnx", 0, dist, session=Failing())
+        try:
+            bad.synthesize(utts, scales, sids, gather=True)
+            verdict = "no error"
+        except ValueError as e:
+            verdict = "own:" + str(e)
+        except RuntimeError as e:
+            verdict = "peer:" + str(e)
+        assert verdict.startswith("own:phoneme id 999" if rank == 1 else "peer:rank 0: a peer's shard"), verdict
+        # ... and the group is still usable afterwards
+        again = sh.synthesize(utts, scales, sids, gather=True)
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(again, everything))
         q.put((rank, [i for i, _ in mine], [w.tobytes() for w in everything]))
     finally:
         dist.destroy_process_group()
