@@ -99,10 +99,14 @@ struct ConvArgs {
     unsigned *peak;         // range-guard slots for those planes (SxArgs::peak), may be nullptr
 };
 
-template <int BYTES>
+template <int BYTES, int AUX = 0>
 __device__ __forceinline__ void lds_dma(const void *gsrc, float *ldst) {
-    // the size operand must be a literal (not template-dependent): dispatch with if constexpr
-    if constexpr (BYTES == 16)
+    // the size and cache-policy operands must be literals (not template-dependent): dispatch with if constexpr
+    // (AUX = 2: `nt`, a streamed read that no other workgroup will ask for again)
+    if constexpr (BYTES == 16 && AUX == 2)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                         (__attribute__((address_space(3))) void *)ldst, 16, 0, 2);
+    else if constexpr (BYTES == 16)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
                                          (__attribute__((address_space(3))) void *)ldst, 16, 0, 0);
     else

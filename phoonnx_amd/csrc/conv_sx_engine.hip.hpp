@@ -78,6 +78,11 @@
 #ifndef SX_NOA
 #define SX_NOA 0  // ablation: weights are not re-fetched after the first steps (wrong results, timing only)
 #endif
+#ifndef SX_XCD_GROUP_DEFAULT
+// (same-box A/B, two interleaved rounds, profiles/r06_runs/xcd_group.txt: groups of 1 / 2 / 4 / 8 / 16 tiles - headline voice
+// 140.7 / 140.9 / 141.2 / 140.8 / 140.6 M samples/s, default voice 806.8 / 811.4 / 812.9 / 813.7 / 811.9 M)
+#define SX_XCD_GROUP_DEFAULT 4
+#endif
 namespace vitsmi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -155,7 +160,30 @@ struct SxArgs {
     // the 16x16x32 loop's four-wave tile (a wave = one 32-row block = one phase) skips the MFMAs of its block's zero tap (a
     // third of the launch's matrix work; adding x * 0 changes no accumulator).  -1: no such structure.
     int zt_p = -1;
+    // XCD grouping of the time tiles (sx_xcd_group_shift()): log2 of how many CONSECUTIVE (time tile, utterance) pairs one XCD
+    // takes before the deal moves on to the next XCD.  0 = round robin tile by tile.
+    int xgs = 0;
 };
+
+// Workgroup ids go round-robin over the 8 XCDs (blocks b and b + 8 share one, MI355X_MICROARCH.md "Workgroup dispatch"), each
+// XCD with an L2 of its own.  Dealt tile by tile, two NEIGHBOURING time tiles - which share their halo columns, (K - 1) dil of
+// 256, a fifth of a k = 11 dilation-5 tile - always sit on different XCDs and the halo crosses the fabric twice.  Dealt in
+// groups of 2^xgs consecutive tiles per XCD, neighbours inside a group are consecutive slots of one XCD (running at the same
+// time on CUs of that XCD): the halo's second reader finds the lines in that L2.  The groups stay small so that the deal still
+// balances utterances of unequal length (ragged rendering) over the XCDs.  VITSMI_XCD_GROUP = 1 | 2 | 4 | 8 | 16 (tiles).
+inline int sx_xcd_group_shift() {
+    static const int v = [] {
+        const char *e = std::getenv("VITSMI_XCD_GROUP");
+        int g = e ? std::atoi(e) : SX_XCD_GROUP_DEFAULT, s = 0;
+        while ((2 << s) <= g && s < 4) s++;
+        return s;
+    }();
+    return v;
+}
+// tile index of (slot `tseq` of XCD `xcd`)
+__device__ __forceinline__ int sx_xcd_tile(int tseq, int xcd, int xgs) {
+    return ((tseq >> xgs) << (xgs + 3)) + (xcd << xgs) + (tseq & ((1 << xgs) - 1));
+}
 
 
 
@@ -192,6 +220,23 @@ __device__ __forceinline__ void global_read128_x2(uint32_t voff, const void *sba
                  : "=&v"(r0), "=&v"(r1)
                  : "v"(voff), "s"(sbase)
                  : "memory");
+}
+
+// (experiment switch) SX_X_NT = 1: the activation tiles - x tiles of every sx kernel, by LDS-DMA or through registers - are
+// requested with the `nt` policy; the weight stream, which every workgroup re-reads from L2, never is
+#ifndef SX_X_NT
+#define SX_X_NT 0
+#endif
+constexpr int kSxXAux = SX_X_NT ? 2 : 0;
+template <int OFF>
+__device__ __forceinline__ u32x4 global_read128_x(uint32_t voff, const void *sbase) {
+#if SX_X_NT
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(r) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    return r;
+#else
+    return global_read128<OFF>(voff, sbase);
+#endif
 }
 
 // ... at a per-lane address
@@ -321,7 +366,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
     // read comes from HBM once and from that L2 for the others.
     const int wg_xcd = blockIdx.x & 7, wg_seq = blockIdx.x >> 3;
     const int mt = __builtin_amdgcn_readfirstlane(wg_seq % a.MT);  // (readfirstlane: keep these provably uniform)
-    const int tile_nb = __builtin_amdgcn_readfirstlane((wg_seq / a.MT) * 8 + wg_xcd);  // (time tile, utterance) index
+    const int tile_nb = __builtin_amdgcn_readfirstlane(sx_xcd_tile(wg_seq / a.MT, wg_xcd, a.xgs));  // (time tile, utterance) index
     if (tile_nb >= a.NT * a.B) return;                 // padding workgroups of the last round (uniform exit)
     const int b = tile_nb / a.NT, t0 = (tile_nb - b * a.NT) * BN;
     const int T = a.T, LW = a.LW, K = a.K, CG = a.Cin >> 3;
@@ -384,7 +429,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
                 for (int it = 0; it < MAXIT; it++) {
                     if (it < nit) {  // (uniform) every wave issues the same count, masked-off rounds included
                         const int base = it * 256 + wave * 64;
-                        if (xok[it]) lds_dma<16>(cb + xoffs[it], reinterpret_cast<float *>(lds_sx + xoff + base * 16));
+                        if (xok[it]) lds_dma<16, kSxXAux>(cb + xoffs[it], reinterpret_cast<float *>(lds_sx + xoff + base * 16));
                     }
                 }
                 return;
@@ -400,7 +445,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
             const bool ok = row < 2 * NPL && t >= 0 && t < TV;  // (rows of planes this mode does not read stay unloaded)
             const u32x4 *src = ok ? xb + ((row >> 1) * pstride + (int64_t)(2 * chunk + (row & 1)) * T + t)
                                   : reinterpret_cast<const u32x4 *>(a.zeros) + lane;
-            lds_dma<16>(src, reinterpret_cast<float *>(lds_sx + xoff + base * 16));
+            lds_dma<16, kSxXAux>(src, reinterpret_cast<float *>(lds_sx + xoff + base * 16));
         }
     };
     // ---- RAWIN: x tile through registers.  A thread owns cells i = it*256 + tid of the [2 channel groups][LW]
@@ -434,8 +479,8 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
         static_for<NXC>([&](auto I) {
             constexpr int it = decltype(I)::value;
             if (it < nxc) {
-                xst[it][0] = global_read128<0>(xroff[it], cbase);
-                xst[it][1] = global_read128<16>(xroff[it], cbase);
+                xst[it][0] = global_read128_x<0>(xroff[it], cbase);
+                xst[it][1] = global_read128_x<16>(xroff[it], cbase);
             }
         });
     };
@@ -725,7 +770,7 @@ __global__ __launch_bounds__(256, (MW * NW > 8) ? 1 : ((SH == 16 && MW * NW == 2
 #pragma unroll
                     for (int it = q; it < MAXIT; it += NQ)
                         if (it < nit && xok[it])
-                            lds_dma<16>(cb + xoffs[it], reinterpret_cast<float *>(lds_sx + xoff + (it * 256 + wave * 64) * 16));
+                            lds_dma<16, kSxXAux>(cb + xoffs[it], reinterpret_cast<float *>(lds_sx + xoff + (it * 256 + wave * 64) * 16));
                 }
             }
         });
@@ -1436,9 +1481,11 @@ hipError_t launch_conv_sx(SxArgs a, int cfg, int B, hipStream_t stream, bool raw
     a.NT = (a.T + BN - 1) / BN;
     a.MT = a.Cout / BM;
     a.B = B;
-    const long long nb = (long long)a.NT * B;  // (time tile, utterance) pairs, dealt round-robin to the 8 XCDs
+    const long long nb = (long long)a.NT * B;  // (time tile, utterance) pairs, dealt to the 8 XCDs in groups of 2^xgs (sx_xcd_tile)
     if (nb == 0) return hipSuccess;
-    const long long wgs = (nb + 7) / 8 * 8 * a.MT;
+    a.xgs = a.NT >= (2 << sx_xcd_group_shift()) ? sx_xcd_group_shift() : 0;  // (short tensors: nothing to group)
+    const long long per_round = 8ll << a.xgs;
+    const long long wgs = (nb + per_round - 1) / per_round * per_round * a.MT;
     if (wgs >= (1ll << 31)) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs, 1, 1);
     // epilogue description (see the SX_* bits): derived from the arguments, then matched against the instantiations

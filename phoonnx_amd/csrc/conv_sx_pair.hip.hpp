@@ -68,6 +68,7 @@ struct SxPairArgs {
     unsigned bias_off;        // (one chain) byte offset of the two bias vectors in LDS (one 1 KiB DMA slot behind the tile)
     unsigned long long *prof;  // (SX_PAIR_PROF builds) 8 counters of this launch: six phase sums in shader cycles, -, workgroups
     SxRagged rag;             // per-utterance tensor ends of a padded batch (conv_sx_engine.hip.hpp)
+    int xgs = 0;              // XCD grouping of the time tiles (SxArgs::xgs)
 };
 
 // (the 32-channel variant needs ~165 registers and <= 40 KiB of LDS: three workgroups per CU hide more of each
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wg_xcd = blockIdx.x & 7, wg_seq = blockIdx.x >> 3;
-    const int tile_nb = __builtin_amdgcn_readfirstlane(wg_seq * 8 + wg_xcd);
+    const int tile_nb = __builtin_amdgcn_readfirstlane(sx_xcd_tile(wg_seq, wg_xcd, a.xgs));
     if (tile_nb >= a.NT * a.B) return;
     const int b = tile_nb / a.NT, t0 = (tile_nb - b * a.NT) * a.BNo;  // first kept output column
     const int t1 = t0 - a.pad2;                                        // first column phase 1 computes
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
             static_for<NXC>([&](auto I) {
                 constexpr int it = decltype(I)::value;
                 if (it < nxc) {
-                    xst[ch][it][0] = global_read128<0>(xroff[it], cbase);
-                    xst[ch][it][1] = global_read128<16>(xroff[it], cbase);
+                    xst[ch][it][0] = global_read128_x<0>(xroff[it], cbase);
+                    xst[ch][it][1] = global_read128_x<16>(xroff[it], cbase);
                 }
             });
         });
@@ -776,7 +777,9 @@ hipError_t launch_conv_sx_pair(SxPairArgs a, int cfg, int B, hipStream_t stream,
     lds = a.bias_off + 1024;
     const long long nb = (long long)a.NT * B;
     if (nb == 0) return hipSuccess;
-    const long long wgs = (nb + 7) / 8 * 8;
+    a.xgs = a.NT >= (2 << sx_xcd_group_shift()) ? sx_xcd_group_shift() : 0;
+    const long long per_round = 8ll << a.xgs;
+    const long long wgs = (nb + per_round - 1) / per_round * per_round;
     if (wgs >= (1ll << 31)) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs, 1, 1);
     const int epi = a.flags & (EPI_ACC | EPI_DIV);
@@ -861,7 +864,9 @@ hipError_t launch_conv_sx_mrf(SxPairArgs a, int B, hipStream_t stream) {
     if ((long long)a.T * 64 + 64 >= (1ll << 32)) return hipErrorInvalidValue;
     const long long nb = (long long)a.NT * B;
     if (nb == 0) return hipSuccess;
-    const long long wgs = (nb + 7) / 8 * 8;
+    a.xgs = a.NT >= (2 << sx_xcd_group_shift()) ? sx_xcd_group_shift() : 0;
+    const long long per_round = 8ll << a.xgs;
+    const long long wgs = (nb + per_round - 1) / per_round * per_round;
     if (wgs >= (1ll << 31)) return hipErrorInvalidValue;
     dim3 grid((unsigned)wgs, 1, 1);
     a.flags = EPI_DIV;
