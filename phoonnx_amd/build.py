@@ -114,13 +114,15 @@ def spill_hazards(asm_text, kernel_filter=None):
     ASYNCHRONOUS inline-asm loads (global_load / ds_read inside ';;#ASMSTART' blocks) whose destination registers only
     become valid behind a counted s_waitcnt the compiler knows nothing about.  If the register allocator spills such a
     register between the load and its first use it saves the OLD contents (and restores them later): silently wrong
-    numbers.  For every kernel of `asm_text` (hipcc -S output) this walks the instructions - loop bodies twice, so a load at
-    the bottom of an iteration meets a spill at the top of the next - with the set of VGPRs that are destinations of asm
-    loads not yet READ by any instruction and not yet behind a full drain (s_waitcnt vmcnt(0) / lgkmcnt(0)); a
-    scratch_store (spill) of a register in that set is a finding.  A spill anywhere else - of values the compiler itself
-    produced, e.g. in an epilogue after the last asm load has been consumed - is harmless and is what the kernels that
-    still spill do.  Returns {kernel: [(line number within the kernel, instruction)]} for kernels with findings, and the
-    number of kernels examined that spill at all."""
+    numbers.  For every kernel of `asm_text` (hipcc -S output) that spills at all this is a forward dataflow analysis over
+    the kernel's control-flow graph - basic blocks cut at labels and branches, a block's entry state the UNION of its
+    predecessors' exit states, iterated to the fixed point, so a load at the bottom of a loop body meets a spill at its top
+    and a spill reached through a forward branch into a loop is seen like any other.  The state is the set of VGPRs that are
+    destinations of asm loads not yet READ by any instruction (the hand-written wait sits in front of the first use) and not
+    yet behind a full drain of their counter (s_waitcnt vmcnt(0) / lgkmcnt(0)); a scratch_store (spill) of a register in
+    that set is a finding.  A spill anywhere else - of values the compiler itself produced, e.g. in an epilogue after the
+    last asm load has been consumed - is harmless and is what the kernels that still spill do.  Returns {kernel: [(line
+    number within the kernel, instruction)]} for kernels with findings, and the number of kernels examined that spill."""
     import re
     out, spilling = {}, 0
     for m in re.finditer(r"\n(_Z\w+):[^\n]*\n", asm_text):
@@ -132,33 +134,76 @@ def spill_hazards(asm_text, kernel_filter=None):
         if not any("scratch_store" in l for l in lines):
             continue
         spilling += 1
-        labels = {l.split(":")[0].strip(): i for i, l in enumerate(lines) if re.match(r"^\.?\w+:", l)}
-        findings = []
-        inflight = {}  # vgpr -> "vm" | "lgkm"
+        # instructions (line number, text, inside an asm block) and the labels in front of them
+        ins, label_at, in_asm = [], {}, False
+        for i, raw in enumerate(lines):
+            st = raw.strip()
+            if st.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if st.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            l = raw.split(";")[0].strip()
+            if not l:
+                continue
+            lm = re.match(r"^(\.?[\w$.]+):$", l)
+            if lm:
+                label_at[lm.group(1)] = len(ins)
+                continue
+            if l.startswith("."):
+                continue
+            ins.append((i, l, in_asm))
+        n = len(ins)
+        if n == 0:
+            continue
 
-        def walk(lo, hi, in_asm):
-            for i in range(lo, hi):
-                l = lines[i].split(";")[0].strip() if not lines[i].lstrip().startswith(";;#") else lines[i].strip()
-                if l.startswith(";;#ASMSTART"):
-                    in_asm = True
-                    continue
-                if l.startswith(";;#ASMEND"):
-                    in_asm = False
-                    continue
-                if not l or l.endswith(":") or l.startswith("."):
-                    continue
+        def branch_of(l):
+            t = l.split()
+            if len(t) == 2 and t[0].startswith(("s_cbranch", "s_branch")) and t[1] in label_at:
+                return t[0], label_at[t[1]]
+            return None, None
+
+        leaders = {0}
+        for k, (_, l, _) in enumerate(ins):
+            op, tgt = branch_of(l)
+            if op:
+                leaders.add(tgt)
+                leaders.add(k + 1)
+            elif l.startswith(("s_endpgm", "s_setpc")):
+                leaders.add(k + 1)
+        leaders = sorted(x for x in leaders if x < n)
+        block_of = {b: j for j, b in enumerate(leaders)}
+        bounds = [(b, leaders[j + 1] if j + 1 < len(leaders) else n) for j, b in enumerate(leaders)]
+        succ = []
+        for lo, hi in bounds:
+            _, l, _ = ins[hi - 1]
+            op, tgt = branch_of(l)
+            sset = set()
+            if op and tgt < n:
+                sset.add(block_of[tgt])
+            if not (op and op.startswith("s_branch")) and not l.startswith(("s_endpgm", "s_setpc")) and hi < n:
+                sset.add(block_of[hi])
+            succ.append(sset)
+        findings = []
+
+        def transfer(j, state):
+            state = dict(state)
+            lo, hi = bounds[j]
+            for k in range(lo, hi):
+                i, l, ia = ins[k]
                 parts = l.replace(",", " ").split()
                 op, args = parts[0], parts[1:]
                 if op == "s_waitcnt":
                     if "vmcnt(0)" in l:
-                        for r in [r for r, k in inflight.items() if k == "vm"]:
-                            del inflight[r]
+                        for r in [r for r, kd in state.items() if kd == "vm"]:
+                            del state[r]
                     if "lgkmcnt(0)" in l:
-                        for r in [r for r, k in inflight.items() if k == "lgkm"]:
-                            del inflight[r]
+                        for r in [r for r, kd in state.items() if kd == "lgkm"]:
+                            del state[r]
                     continue
                 if op.startswith("scratch_store"):
-                    hit = set().union(*[_regs(a) for a in args]) & set(inflight)
+                    hit = set().union(*[_regs(a) for a in args]) & set(state)
                     if hit and (i, lines[i].strip()) not in findings:
                         findings.append((i, lines[i].strip()))
                     continue
@@ -166,26 +211,39 @@ def spill_hazards(asm_text, kernel_filter=None):
                 dst = _regs(args[0]) if args and (is_load or op.startswith("v_")) else set()
                 srcs = set().union(*[_regs(a) for a in (args[1:] if dst else args)]) if args else set()
                 for r in srcs:      # a read: the hand-written wait in front of the first use has passed
-                    inflight.pop(r, None)
-                if in_asm and is_load and not op.startswith("scratch"):
+                    state.pop(r, None)
+                if ia and is_load and not op.startswith("scratch"):
                     kind = "lgkm" if op.startswith("ds_") else "vm"
                     for r in dst:
-                        inflight[r] = kind
+                        state[r] = kind
                 else:
                     for r in dst:   # overwritten by something the compiler tracks
-                        inflight.pop(r, None)
-            return in_asm
+                        state.pop(r, None)
+            return state
 
-        walk(0, len(lines), False)
-        # loops: every backward branch re-walks its body once with the state of the fall-through
-        for i, l in enumerate(lines):
-            t = l.split(";")[0].split()
-            if len(t) == 2 and t[0].startswith(("s_cbranch", "s_branch")) and t[1] in labels and labels[t[1]] < i:
-                inflight.clear()
-                walk(labels[t[1]], i, False)
-                walk(labels[t[1]], i, False)
+        entry = [dict() for _ in bounds]
+        work, seen = [0], {0}
+        # (also seed every block: code only reachable through computed jumps is still examined, from an empty state)
+        work += [j for j in range(1, len(bounds))]
+        seen |= set(work)
+        while work:
+            j = work.pop()
+            seen.discard(j)
+            ex = transfer(j, entry[j])
+            for sj in succ[j]:
+                merged = dict(entry[sj])
+                changed = False
+                for r, kd in ex.items():
+                    if r not in merged:
+                        merged[r] = kd
+                        changed = True
+                if changed:
+                    entry[sj] = merged
+                    if sj not in seen:
+                        seen.add(sj)
+                        work.append(sj)
         if findings:
-            out[name] = findings
+            out[name] = sorted(findings)
     return out, spilling
 
 

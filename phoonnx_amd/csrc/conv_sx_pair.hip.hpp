@@ -99,6 +99,9 @@ struct SxPairArgs {
 #ifndef SX_PAIR_EARLY32
 #define SX_PAIR_EARLY32 1
 #endif
+#ifndef SX_PAIR_ST_SC1
+#define SX_PAIR_ST_SC1 0
+#endif
 // NCH > 1: the multi-receptive-field sum of a ResBlock2 stage, xs = (rb_0(x) + rb_1(x) + ..) / n (models.py:356-363), as ONE
 // launch: the x tile (widest halo of the chains) is loaded and split ONCE and stays in LDS (Y no longer overlays it), the
 // chains run one after the other over the same 256 columns - a chain with a shorter reach reads its operands xoff / yoff
@@ -686,7 +689,15 @@ __global__ __launch_bounds__(256, (NW == 2 && !SX_PAIR_EARLY_ACC && NCH == 1) ? 
 #pragma unroll
                         for (int e = 0; e < 4; e++) v[e] = v[e] / rdiv;
                     }
+#if SX_PAIR_ST_SC1  // (experiment) write-through stores that do not stay in the XCD's L2
+                    {
+                        float *sp = rawb + ((int64_t)((row0 >> 3) + q) * T + t) * 8 + 4 * hi;
+                        const f32x4 sv = v;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(sp), "v"(sv) : "memory");
+                    }
+#else
                     *reinterpret_cast<f32x4 *>(rawb + ((int64_t)((row0 >> 3) + q) * T + t) * 8 + 4 * hi) = v;
+#endif
                 }
             }
         });

@@ -394,6 +394,22 @@ def test_spill_hazard_check_finds_a_spilled_destination_of_an_asynchronous_load(
     # 8. kernels that do not spill are not examined
     f, n = spill_hazards(_kernel(load + ["v_add_f32_e32 v1, v10, v11"]))
     assert n == 0 and not f
+    # 9. control flow is followed, not the text order: the load is issued, a FORWARD branch jumps over the block that would
+    # consume it into the middle of a loop whose body spills the register - a finding; with the consuming block on the only
+    # path, none
+    body = [".LBB0_3:", "scratch_store_dwordx4 off, v[10:13], off offset:16", "s_cbranch_scc1 .LBB0_3"]
+    f, _ = spill_hazards(_kernel(load + ["s_cbranch_vccnz .LBB0_3", "v_add_f32_e32 v1, v10, v11", "v_add_f32_e32 v1, v12, v13"] + body))
+    assert f
+    f, _ = spill_hazards(_kernel(load + ["v_mfma_f32_32x32x16_f16 v[50:65], v[10:13], v[86:89], v[50:65]", "s_cbranch_vccnz .LBB0_3",
+                                         "v_add_f32_e32 v1, v2, v3"] + body))
+    assert not f
+    # 10. two paths meet: in flight on ONE of them is in flight at the join
+    f, _ = spill_hazards(_kernel(["s_cbranch_scc0 .LBB0_5"] + load + [".LBB0_5:"] + spill))
+    assert f
+    # 11. an unconditional branch ends its block: the spill behind it is only reached from the label's other predecessor
+    f, _ = spill_hazards(_kernel(load + ["s_branch .LBB0_7", ".LBB0_6:"] + spill + ["s_endpgm", ".LBB0_7:",
+                                         ";;#ASMSTART", "s_waitcnt vmcnt(0)", ";;#ASMEND", "s_branch .LBB0_6"]))
+    assert not f
 
 
 def test_name_and_structure_disagreements_are_all_reported_through_the_abi(tmp_path):
