@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/g2pmi.h"
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void g2p_rmsnorm_kernel(const float *x, const 
 // [NB][C] vectors (1, C).  bucket_lut: bucket of (j - i) at index (j - i) + lut_zero, or nullptr (cross attention).
 // Keys / values are channel-major (time contiguous): lanes run along time, and every loop over channels issues its
 // loads eight at a time (one dependent load per channel made a decoder step's eight attention calls 30 us each).
-__device__ __forceinline__ void g2p_attention_body(const float *__restrict__ q, int q_cs, int q_ts,
+__device__ __forceinline__ void g2p_attention_body_generic(const float *__restrict__ q, int q_cs, int q_ts,
                                                    const float *__restrict__ k, const float *__restrict__ v, int kp,
                                                    int64_t kv_bs, const float *__restrict__ bias,
                                                    const int *__restrict__ bucket_lut, int lut_zero,
@@ -137,6 +138,135 @@ __device__ __forceinline__ void g2p_attention_body(const float *__restrict__ q, 
             if (lane == 0 && d0 + e < dk) out[((int64_t)h * dk + d0 + e) * q_cs + (int64_t)c * q_ts] = acc[e] * inv;
         }
     }
+}
+
+
+// The same attention for a head width known at compile time, restructured for memory-level parallelism.  At a decoder step
+// the generic body above is a chain of dependent round trips to L2 / HBM - eight groups of eight key loads, then six of
+// value loads, ~14 latencies for a few hundred KB - and the eight attention launches of a token were a third of its time
+// (13-16 us each, tools/g2p_decode_prof.py).  Here a thread requests ALL DK channels of its key at once, and the value
+// fragments of the first 256 keys are requested BEFORE the softmax reductions (they do not depend on the scores), so a
+// step's attention pays about one memory latency.  Sums run in the generic body's order (channels ascending per score,
+// keys ascending per output channel): same bits.
+template <int DK>
+__device__ __forceinline__ void g2p_attention_body_t(const float *__restrict__ q, int q_cs, int q_ts,
+                                                     const float *__restrict__ k, const float *__restrict__ v, int kp,
+                                                     int64_t kv_bs, const float *__restrict__ bias,
+                                                     const int *__restrict__ bucket_lut, int lut_zero,
+                                                     float *__restrict__ out, int heads, int seg,
+                                                     const int *__restrict__ lens, int Tk, int q_off, int causal, int c, int h,
+                                                     float *sc, float *red) {
+    static_assert(DK % 32 == 0, "a wave per group of eight channels, four waves");
+    constexpr int VR = 4, NR = DK / 32;  // value prefetch: key rounds of 64 (256 keys), channel rounds of 32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = c / seg, i = c - b * seg;
+    const int ipos = i + q_off;
+    const int nk = lens ? lens[b] : Tk;
+    const int lim = causal ? (ipos + 1 < nk ? ipos + 1 : nk) : nk;
+    float *qs = sc + Tk;
+    const float *kh = k + (int64_t)b * kv_bs + (int64_t)h * DK * kp, *vh = v + (int64_t)b * kv_bs + (int64_t)h * DK * kp;
+    const float qv = q[((int64_t)h * DK + (tid < DK ? tid : 0)) * q_cs + (int64_t)c * q_ts];
+    float kv[DK];
+    // (loads are unconditional - a lane without a key re-reads the last one and ignores it: a conditional load is a branch
+    // with a full wait at its join, which serialises exactly what this body wants in flight together)
+    const int jlast = lim > 0 ? lim - 1 : 0;
+    auto load_k = [&](int j) {
+        const int jc = j < lim ? j : jlast;
+#pragma unroll
+        for (int d = 0; d < DK; d++) kv[d] = kh[(int64_t)d * kp + jc];
+    };
+    load_k(tid);
+    float vpre[NR][VR][8];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++)
+#pragma unroll
+        for (int r = 0; r < VR; r++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int j = lane + 64 * r;
+                vpre[rr][r][e] = vh[(int64_t)(wave * 8 + 32 * rr + e) * kp + (j < lim ? j : jlast)];
+            }
+    if (tid < DK) qs[tid] = qv;
+    __syncthreads();
+    float mx = -__builtin_inff();
+    for (int jb = 0; jb < lim; jb += 256) {
+        const int j = jb + tid;
+        if (jb) load_k(j);
+        if (j < lim) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < DK; d++) s += qs[d] * kv[d];
+            if (bucket_lut) s += bias[bucket_lut[j - ipos + lut_zero] * heads + h];
+            sc[j] = s;
+            mx = fmaxf(mx, s);
+        }
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+        __syncthreads();
+    }
+    mx = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = tid; j < lim; j += 256) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const float inv = 1.0f / red[0];
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+        const int d0 = wave * 8 + 32 * rr;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = 0.f;
+#pragma unroll
+        for (int r = 0; r < VR; r++) {
+            const int j = lane + 64 * r;
+            if (j < lim) {
+                const float pj = sc[j];
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] += pj * vpre[rr][r][e];
+            }
+        }
+        for (int j = lane + 64 * VR; j < lim; j += 64) {  // keys beyond the prefetch
+            const float pj = sc[j];
+            float vv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) vv[e] = vh[(int64_t)(d0 + e) * kp + j];
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += pj * vv[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+            if (lane == 0) out[((int64_t)h * DK + d0 + e) * q_cs + (int64_t)c * q_ts] = acc[e] * inv;
+        }
+    }
+}
+
+__device__ __forceinline__ void g2p_attention_body(const float *__restrict__ q, int q_cs, int q_ts,
+                                                   const float *__restrict__ k, const float *__restrict__ v, int kp,
+                                                   int64_t kv_bs, const float *__restrict__ bias,
+                                                   const int *__restrict__ bucket_lut, int lut_zero,
+                                                   float *__restrict__ out, int heads, int dk, int seg,
+                                                   const int *__restrict__ lens, int Tk, int q_off, int causal, int c, int h,
+                                                   float *sc, float *red) {
+    if (dk == 64)  // (uniform) every ByT5 / mT5 size: d_kv = 64
+        g2p_attention_body_t<64>(q, q_cs, q_ts, k, v, kp, kv_bs, bias, bucket_lut, lut_zero, out, heads, seg, lens, Tk, q_off, causal,
+                                 c, h, sc, red);
+    else
+        g2p_attention_body_generic(q, q_cs, q_ts, k, v, kp, kv_bs, bias, bucket_lut, lut_zero, out, heads, dk, seg, lens, Tk, q_off,
+                                   causal, c, h, sc, red);
 }
 
 __global__ __launch_bounds__(256) void g2p_attention_kernel(const float *__restrict__ q, int q_cs, int q_ts,
@@ -295,6 +425,12 @@ __device__ __forceinline__ float g2p_activation(float x, int act) {
     return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
 }
 
+#ifndef G2P_UN
+#define G2P_UN 6
+#endif
+#ifndef G2P_UN_GATED
+#define G2P_UN_GATED 3
+#endif
 template <int NB>
 __device__ __forceinline__ void g2p_step_body(const G2PStepArgs &a, int blk, int t) {
     int j = 0;
@@ -323,22 +459,56 @@ __device__ __forceinline__ void g2p_step_body(const G2PStepArgs &a, int blk, int
             }
         }
     } else {
+        // A row is a chain of 1 KiB wave loads (6 for d_model 1472, 14 for d_ff 3584): the loads of up to UN of them are
+        // requested before the first FMA, so a row pays one or two memory latencies instead of one per KiB (the 3584-wide
+        // output projection ran at 1.8 TB/s).  The loads are unconditional (a lane past the row's end re-reads the row's
+        // last 16 bytes and its term is not added: a conditional load is a branch with a full wait at its join), and the
+        // launch-uniform options - second matrix, norm weights - select one of four branch-free variants.  Same sums in the
+        // same order (i ascending per lane).
         const int n4 = a.in >> 2;
-        for (int i = lane; i < n4; i += 64) {
-            const float4 w = w4[i];
-            float4 v = float4{0.f, 0.f, 0.f, 0.f}, g = float4{1.f, 1.f, 1.f, 1.f};
-            if (v4) v = v4[i];
-            if (g4) g = g4[i];
-            float4 x[NB];
+        auto rows = [&](auto GATED, auto NORM) __attribute__((always_inline)) {
+            constexpr bool gated = decltype(GATED)::value, norm = decltype(NORM)::value;
+            // (two matrices double the loads and registers per iteration: fewer iterations in flight keep more waves resident)
+            constexpr int UN1 = gated ? G2P_UN_GATED : G2P_UN;
+            constexpr int UN = NB == 1 ? UN1 : (NB == 2 ? (UN1 + 1) / 2 : (UN1 + 3) / 4);
+            for (int i0 = lane; i0 < n4; i0 += 64 * UN) {
+                float4 w[UN], v[gated ? UN : 1], g[norm ? UN : 1], x[UN][NB];
 #pragma unroll
-            for (int b = 0; b < NB; b++) x[b] = x4[(int64_t)b * n4 + i];
+                for (int u = 0; u < UN; u++) {
+                    const int i = i0 + 64 * u, ic = i < n4 ? i : n4 - 1;
+                    w[u] = w4[ic];
+                    if constexpr (gated) v[u] = v4[ic];
+                    if constexpr (norm) g[u] = g4[ic];
 #pragma unroll
-            for (int b = 0; b < NB; b++) {
-                ss[b] += x[b].x * x[b].x + x[b].y * x[b].y + x[b].z * x[b].z + x[b].w * x[b].w;
-                x[b].x *= g.x, x[b].y *= g.y, x[b].z *= g.z, x[b].w *= g.w;
-                s[b] += w.x * x[b].x + w.y * x[b].y + w.z * x[b].z + w.w * x[b].w;
-                s2[b] += v.x * x[b].x + v.y * x[b].y + v.z * x[b].z + v.w * x[b].w;
+                    for (int b = 0; b < NB; b++) x[u][b] = x4[(int64_t)b * n4 + ic];
+                }
+#pragma unroll
+                for (int u = 0; u < UN; u++) {
+                    const bool ok = i0 + 64 * u < n4;
+#pragma unroll
+                    for (int b = 0; b < NB; b++) {
+                        float4 xb = x[u][b];
+                        const float q2 = xb.x * xb.x + xb.y * xb.y + xb.z * xb.z + xb.w * xb.w;
+                        if constexpr (norm) xb.x *= g[u].x, xb.y *= g[u].y, xb.z *= g[u].z, xb.w *= g[u].w;
+                        const float t1 = w[u].x * xb.x + w[u].y * xb.y + w[u].z * xb.z + w[u].w * xb.w;
+                        ss[b] = ok ? ss[b] + q2 : ss[b];
+                        s[b] = ok ? s[b] + t1 : s[b];
+                        if constexpr (gated) {
+                            const float t2 = v[u].x * xb.x + v[u].y * xb.y + v[u].z * xb.z + v[u].w * xb.w;
+                            s2[b] = ok ? s2[b] + t2 : s2[b];
+                        }
+                    }
+                }
             }
+        };
+        const std::true_type yes{};
+        const std::false_type no{};
+        if (v4) {
+            if (g4) rows(yes, yes);
+            else rows(yes, no);
+        } else {
+            if (g4) rows(no, yes);
+            else rows(no, no);
         }
     }
 #pragma unroll
