@@ -775,6 +775,18 @@ __global__ void rqs_inverse_kernel(const float *pr, float *z, const int *len, in
     const float *q = pr + (int64_t)b * P * T + t;
     float mk = t < len[b] ? 1.f : 0.f;
     float *px0 = z + ((int64_t)b * 2 + ch0) * T + t, *px1 = z + ((int64_t)b * 2 + ch1) * T + t;
+    // Every operand is requested up front, unconditionally (indices clamped into the spline's rows): x, then the widths
+    // where the branch opens, then the heights, then the derivatives were four dependent memory round trips on a grid that
+    // is a handful of workgroups at batch 1.  The arithmetic below is unchanged.
+    float qw[NBMAX], qh[NBMAX], qd[NBMAX];
+#pragma unroll
+    for (int i = 0; i < NBMAX; i++) {
+        const int ic = i < nb ? i : nb - 1, id = i < nb - 1 ? i : (nb > 1 ? nb - 2 : 0);
+        qw[i] = q[(int64_t)ic * T];
+        qh[i] = q[(int64_t)(nb + ic) * T];
+        qd[i] = q[(int64_t)(2 * nb + id) * T];
+    }
+    const float x0 = *px0;
     float x = *px1;
     const float tb = 5.0f, minw = 1e-3f, minh = 1e-3f, mind = 1e-3f;
     float y = x;
@@ -784,7 +796,7 @@ __global__ void rqs_inverse_kernel(const float *pr, float *z, const int *len, in
 #pragma unroll
         for (int i = 0; i < NBMAX; i++)
             if (i < nb) {
-                w[i] = q[(int64_t)i * T] / inv_sqrt_c_div;
+                w[i] = qw[i] / inv_sqrt_c_div;
                 mx = fmaxf(mx, w[i]);
             }
         float s = 0.f;
@@ -816,7 +828,7 @@ __global__ void rqs_inverse_kernel(const float *pr, float *z, const int *len, in
 #pragma unroll
         for (int i = 0; i < NBMAX; i++)
             if (i < nb) {
-                h[i] = q[(int64_t)(nb + i) * T] / inv_sqrt_c_div;
+                h[i] = qh[i] / inv_sqrt_c_div;
                 mx = fmaxf(mx, h[i]);
             }
         s = 0.f;
@@ -848,7 +860,7 @@ __global__ void rqs_inverse_kernel(const float *pr, float *z, const int *len, in
         const float dedge = mind + softplus_f(cst);
 #pragma unroll
         for (int i = 0; i <= NBMAX; i++)
-            if (i <= nb) d[i] = (i == 0 || i == nb) ? dedge : mind + softplus_f(q[(int64_t)(2 * nb + i - 1) * T]);
+            if (i <= nb) d[i] = (i == 0 || i == nb) ? dedge : mind + softplus_f(qd[i > 0 ? (i - 1 < NBMAX ? i - 1 : NBMAX - 1) : 0]);
 
         // searchsorted on cumheights (last knot + 1e-6), then gather by select (registers only)
         int bin = -1;
@@ -878,7 +890,7 @@ __global__ void rqs_inverse_kernel(const float *pr, float *z, const int *len, in
         float root = (2.0f * c) / (-bq - sqrtf(disc));
         y = root * ibw + icw;
     }
-    *px0 = *px0 * mk;  // cat([x0, x1]) * x_mask (modules.py:521)
+    *px0 = x0 * mk;  // cat([x0, x1]) * x_mask (modules.py:521)
     *px1 = y * mk;
 }
 
