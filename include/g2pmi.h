@@ -63,6 +63,14 @@ int g2p_generate(g2p_handle *h, const int64_t *input_ids, int S, int max_length,
 int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens, int B, int max_length, int64_t start_id,
                        int64_t eos_id, int64_t *out_ids, int *n_out);
 
+/* Test hook: the decoder-STEP path (the kernels g2p_generate runs per token: matrix-vector products, one-query attention
+ * over the key / value caches) with GIVEN decoder inputs instead of its own argmax fed back, returning the logits of every
+ * step: logits[b][t] = what g2p_run returns at position t for decoder_input_ids[b][0 .. t].  B <= 4 inputs back to back in
+ * input_ids (lens[b] each), decoder_input_ids [B][T] (column 0 = the start token), logits [B][T][vocab].  The greedy ids of a
+ * randomly initialised model are nearly constant sequences; this compares the step path number by number. */
+int g2p_test_forced_steps(g2p_handle *h, const int64_t *input_ids, const int *lens, int B, const int64_t *decoder_input_ids, int T,
+                          float *logits);
+
 #ifdef __cplusplus
 }
 #endif

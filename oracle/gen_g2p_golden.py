@@ -29,10 +29,16 @@ import numpy as np
 REF = "/root/reference"
 
 
-def build(seed=7):
+# second fixture (round 6): heads of width 64 - every ByT5 / mT5 size has d_kv = 64, and the engine's attention has a
+# body of its own for it (g2p.hip g2p_attention_body_t<64>) that the 16-wide tiny model never reaches
+VARIANTS = {"byt5_tiny": dict(d_model=96, d_kv=16, d_ff=160, num_layers=3, num_decoder_layers=2, num_heads=4),
+            "byt5_dk64": dict(d_model=128, d_kv=64, d_ff=192, num_layers=2, num_decoder_layers=2, num_heads=2)}
+
+
+def build(seed=7, name="byt5_tiny"):
     import torch
     from transformers import T5Config, T5ForConditionalGeneration
-    cfg = T5Config(vocab_size=384, d_model=96, d_kv=16, d_ff=160, num_layers=3, num_decoder_layers=2, num_heads=4,
+    cfg = T5Config(vocab_size=384, **VARIANTS[name],
                    relative_attention_num_buckets=32, relative_attention_max_distance=128, dropout_rate=0.0,
                    feed_forward_proj="gated-gelu", tie_word_embeddings=False, decoder_start_token_id=0, pad_token_id=0,
                    eos_token_id=1, layer_norm_epsilon=1e-6)
@@ -47,6 +53,8 @@ def build(seed=7):
                 p.mul_(3.0)
         # make the greedy path end by itself on some inputs: the EOS row (id 1) shadows the row of the token the
         # untouched model emits sixth for the probe input - wherever that token would have won, EOS now wins
+        if name != "byt5_tiny":   # (the second fixture's sequences run to their length limit: long decoder prefixes)
+            return torch, m, cfg
         probe = torch.tensor([[3 + b for b in b"<de-DE>: x"]])
         gen = [0]
         for _ in range(16):
@@ -97,16 +105,21 @@ def reference_text_functions():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--name", default="byt5_tiny", choices=sorted(VARIANTS),
+                    help="byt5_tiny: the round-2 fixture (also writes byt5_frontend.json); byt5_dk64: heads of width 64, one input "
+                         "longer than 256 bytes (cross attention past the engine's 256-key prefetch), model + vectors only")
     a = ap.parse_args()
-    torch, m, cfg = build()
+    torch, m, cfg = build(name=a.name)
     from transformers.models.t5.modeling_t5 import T5Attention
-    path = os.path.join(a.out, "byt5_tiny.onnx")
+    path = os.path.join(a.out, a.name + ".onnx")
     export(torch, m, path)
     print("wrote", path, os.path.getsize(path), "bytes")
     P = reference_text_functions()
     out = {}
     texts = [("hello world", "en-US"), ("olá, tudo bem?", "pt-PT"), ("x", "de-DE"),
              ("The quick brown fox jumps over the lazy dog near the bank of the river.", "en-GB")]
+    if a.name != "byt5_tiny":
+        texts = [texts[0], texts[3], ("Pack my box with five dozen liquor jugs; how vexingly quick daft zebras jump! " * 4, "en-US")]
     for i, (text, lang) in enumerate(texts):
         ids = P._encode_text(text, lang)                              # reference: mul.py:152-170
         out[f"c{i}/input_ids"] = ids
@@ -131,7 +144,14 @@ def main():
     out["bucket/rel"] = rp[0].numpy()
     out["bucket/enc"] = T5Attention._relative_position_bucket(rp, True, 32, 128)[0].numpy()
     out["bucket/dec"] = T5Attention._relative_position_bucket(rp, False, 32, 128)[0].numpy()
-    np.savez_compressed(os.path.join(a.out, "byt5_tiny.npz"), **out)
+    np.savez_compressed(os.path.join(a.out, a.name + ".npz"), **out)
+    with open(os.path.join(a.out, a.name + ".hparams.json"), "w") as f:
+        json.dump({k: getattr(cfg, k) for k in ("vocab_size", "d_model", "d_kv", "d_ff", "num_layers", "num_decoder_layers",
+                                                "num_heads", "relative_attention_num_buckets",
+                                                "relative_attention_max_distance", "feed_forward_proj",
+                                                "tie_word_embeddings", "layer_norm_epsilon")}, f, indent=1)
+    if a.name != "byt5_tiny":
+        return
     # the reference's text <-> id functions
     tok = {"added_tokens_decoder": {str(i): {"content": c} for i, c in ((0, "<pad>"), (1, "</s>"), (2, "<unk>"), (259, "<extra_id_0>"))}}
     dec_obj = P.__new__(P)
@@ -142,11 +162,6 @@ def main():
                         ([107, 104, 111, 1], [3 + b for b in "həˈloʊ".encode()] + [1], [0, 2, 259, 200, 130, 50])]}
     with open(os.path.join(a.out, "byt5_frontend.json"), "w", encoding="utf-8") as f:
         json.dump(front, f, ensure_ascii=False, indent=1)
-    with open(os.path.join(a.out, "byt5_tiny.hparams.json"), "w") as f:
-        json.dump({k: getattr(cfg, k) for k in ("vocab_size", "d_model", "d_kv", "d_ff", "num_layers", "num_decoder_layers",
-                                                "num_heads", "relative_attention_num_buckets",
-                                                "relative_attention_max_distance", "feed_forward_proj",
-                                                "tie_word_embeddings", "layer_norm_epsilon")}, f, indent=1)
 
 
 if __name__ == "__main__":

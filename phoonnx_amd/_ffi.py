@@ -61,7 +61,7 @@ EXPORTS = [
 
 
 G2P_EXPORTS = ["g2p_open", "g2p_close", "g2p_last_error", "g2p_hparam", "g2p_num_outputs", "g2p_output_name", "g2p_bucket",
-               "g2p_run", "g2p_generate", "g2p_generate_batch"]
+               "g2p_run", "g2p_generate", "g2p_generate_batch", "g2p_test_forced_steps"]
 
 
 def lib_path():
@@ -163,6 +163,7 @@ def load():
     lib.g2p_run.argtypes = [vp, vp, C.c_int, vp, vp, C.c_int, vp]
     lib.g2p_generate.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, C.POINTER(C.c_int)]
     lib.g2p_generate_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int64, vp, vp]
+    lib.g2p_test_forced_steps.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, vp]
     _LIB = lib
     return lib
 

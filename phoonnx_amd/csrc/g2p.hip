@@ -1062,12 +1062,17 @@ int g2p_run(g2p_handle *h, const int64_t *input_ids, int S, const int64_t *mask,
     return VITS_OK;
 }
 
-int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens, int B, int max_length, int64_t start_id,
-                       int64_t eos_id, int64_t *out_ids, int *n_out) {
+// forced / step_logits (g2p_test_forced_steps): the decoder inputs are GIVEN - forced[b][t], t < max_length, forced[b][0] the
+// start token - instead of fed back from the argmax, and the logits every step computes, [max_length][NB][vocab], are copied
+// out: the step path (matrix-vector kernels, one-query attention over the caches) as a function that can be compared with
+// g2p_run's logits for the same decoder_input_ids, number by number.  Narrow steps only (B <= 4).
+static int generate_impl(g2p_handle *h, const int64_t *input_ids, const int *lens, int B, int max_length, int64_t start_id,
+                         int64_t eos_id, int64_t *out_ids, int *n_out, const int64_t *forced, float *step_logits) {
     if (int rc = check_dev(h)) return rc;
     std::lock_guard<std::mutex> lk(h->mu);
     const G2PModel &m = h->model;
     if (!input_ids || !lens || !out_ids || !n_out || B <= 0 || max_length <= 0) return gfail(h, VITS_E_ARG, "bad g2p_generate arguments");
+    if (forced && (!step_logits || B > 4)) return gfail(h, VITS_E_ARG, "forced steps: at most 4 sequences, logits required");
     if (B > G2P_MAX_BATCH) return gfail(h, VITS_E_ARG, "at most %d sequences per call", G2P_MAX_BATCH);
     if (max_length >= G2PModel::kMaxPos) return gfail(h, VITS_E_ARG, "sequence longer than %d", G2PModel::kMaxPos - 1);
     if (start_id < 0 || start_id >= m.vocab) return gfail(h, VITS_E_ARG, "start id out of range");
@@ -1094,7 +1099,8 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
     const size_t need = 8 * (nA * 4 + 512) + 2 * ((size_t)m.d_ff * T * 4 + 512) +
                         (size_t)nd * 2 * ((size_t)NB * m.inner * TM * 4 + 512) + (size_t)nd * 2 * ((size_t)m.inner * T * 4 + 512) +
                         (size_t)(T + (size_t)NB * TM) * 8 + (size_t)NB * (m.vocab + 2 * m.d_model + 2 * m.inner + 2 * m.d_ff + 64) * 4 +
-                        (size_t)(3 + 8 * nd) * sizeof(G2PPhase) + (1 << 18);
+                        (size_t)(3 + 8 * nd) * sizeof(G2PPhase) + (1 << 18) +
+                        (forced ? (size_t)NB * TM * 8 + (size_t)max_length * NB * m.vocab * 4 + 1024 : 0);
     if (int rc = ws_reserve(h, need)) return rc;
     Run r{h, h->stream, h->arena_dev};
     r.ws = h->ws;
@@ -1114,6 +1120,9 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
     float *x1 = r.take<float>((size_t)NB * m.d_model), *q1 = r.take<float>((size_t)NB * m.inner);
     float *a1 = r.take<float>((size_t)NB * m.inner), *f1 = r.take<float>((size_t)NB * m.d_ff), *lg = r.take<float>((size_t)NB * m.vocab);
     float *h1 = r.take<float>((size_t)NB * m.d_model), *f2 = r.take<float>((size_t)NB * m.d_ff);  // (wide step only)
+    // forced steps: the argmax lands in a scratch copy of the id table (the given inputs stay), every step's logits are kept
+    int64_t *d_arg = forced ? r.take<int64_t>((size_t)NB * TM) : d_gen;
+    float *d_steplog = forced ? r.take<float>((size_t)max_length * NB * m.vocab) : nullptr;
     // The narrow step as one persistent launch (see g2p_decode_step_kernel), opt-in: VITSMI_G2P_PERSIST=1.
     const float post = m.scale_out ? 1.0f / std::sqrt((float)m.d_model) : 1.0f;
     const int D = m.d_model, I = m.inner;
@@ -1190,7 +1199,7 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
         {
             G2PPhase P{};
             P.kind = G2P_PH_ARGMAX;
-            P.step.x = lg, P.vocab = m.vocab, P.ids = d_gen, P.ib = TM, P.host_copy = h->tok_dev;
+            P.step.x = lg, P.vocab = m.vocab, P.ids = d_arg, P.ib = TM, P.host_copy = h->tok_dev;
             P.nblocks = NB;
             phases.push_back(P);
         }
@@ -1216,6 +1225,9 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
             ln[b] = lens[b];
         }
         for (int b = 0; b < NB; b++) gen[(size_t)b * TM] = start_id;
+        if (forced)
+            for (int b = 0; b < B; b++)
+                for (int t = 0; t < max_length; t++) gen[(size_t)b * TM + t] = forced[(size_t)b * max_length + t];
         r.note(hipMemcpyAsync(d_in, ids.data(), (size_t)T * 8, hipMemcpyHostToDevice, st));
         r.note(hipMemcpyAsync(d_gen, gen.data(), (size_t)NB * TM * 8, hipMemcpyHostToDevice, st));
         r.note(hipMemcpyAsync(d_lens, ln.data(), (size_t)NB * 4, hipMemcpyHostToDevice, st));
@@ -1263,6 +1275,8 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
                 default: g2p_decode_step_kernel<4><<<persist_grid, 256, persist_lds, st>>>(d_ph, nph, d_bar, t, gave_up_dev, persist_gs); break;
             }
             r.note(hipGetLastError());
+            if (forced)
+                r.note(hipMemcpyAsync(d_steplog + (size_t)t * NB * m.vocab, lg, (size_t)NB * m.vocab * 4, hipMemcpyDeviceToDevice, st));
             r.note(hipEventRecord(h->step_done[t & 1], st));
             return;
         }
@@ -1280,8 +1294,10 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
             step(r, NB, {{&b.ffn.wo, nullptr, x1, 1, D, x1}}, f1, -1);
         }
         step(r, NB, {{&m.lm_head, nullptr, lg, 1, m.vocab, nullptr}}, x1, m.dec_final_ln, -1, post);
-        g2p_argmax_kernel<<<NB, 256, 0, st>>>(lg, m.vocab, 1, 0, m.vocab, d_gen, TM, t + 1, h->tok_dev);
+        g2p_argmax_kernel<<<NB, 256, 0, st>>>(lg, m.vocab, 1, 0, m.vocab, d_arg, TM, t + 1, h->tok_dev);
         r.note(hipGetLastError());
+        if (forced)
+            r.note(hipMemcpyAsync(d_steplog + (size_t)t * NB * m.vocab, lg, (size_t)NB * m.vocab * 4, hipMemcpyDeviceToDevice, st));
         r.note(hipEventRecord(h->step_done[t & 1], st));
     };
     // The loop's one data-dependent decision (stop when every sequence has produced EOS) needs the tokens on the host;
@@ -1308,13 +1324,39 @@ int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens,
             if (done[b]) continue;
             const int64_t tok = h->tok_host[(size_t)b * TM + t + 1];
             out_ids[(size_t)b * max_length + n_out[b]++] = tok;
-            if (tok == eos_id) {
+            if (tok == eos_id && !forced) {
                 done[b] = 1;
                 open_seqs--;
             }
         }
     }
+    if (forced) {  // [max_length][NB][vocab] on the device -> [B][max_length][vocab] for the caller
+        std::vector<float> tmp((size_t)max_length * NB * m.vocab);
+        r.note(hipMemcpyAsync(tmp.data(), d_steplog, tmp.size() * 4, hipMemcpyDeviceToHost, st));
+        r.note(hipStreamSynchronize(st));
+        if (r.err != hipSuccess) return gfail(h, VITS_E_DEVICE, "g2p forced steps failed: %s", hipGetErrorString(r.err));
+        for (int b = 0; b < B; b++)
+            for (int t = 0; t < max_length; t++)
+                std::memcpy(step_logits + ((size_t)b * max_length + t) * m.vocab, tmp.data() + ((size_t)t * NB + b) * m.vocab,
+                            (size_t)m.vocab * 4);
+    }
     return VITS_OK;
+}
+
+int g2p_generate_batch(g2p_handle *h, const int64_t *input_ids, const int *lens, int B, int max_length, int64_t start_id,
+                       int64_t eos_id, int64_t *out_ids, int *n_out) {
+    return generate_impl(h, input_ids, lens, B, max_length, start_id, eos_id, out_ids, n_out, nullptr, nullptr);
+}
+
+int g2p_test_forced_steps(g2p_handle *h, const int64_t *input_ids, const int *lens, int B, const int64_t *decoder_input_ids, int T,
+                          float *logits) {
+    if (!h) return VITS_E_ARG;
+    if (!decoder_input_ids || !logits || T <= 0 || B <= 0) return gfail(h, VITS_E_ARG, "bad g2p_test_forced_steps arguments");
+    for (size_t i = 0; i < (size_t)B * T; i++)
+        if (decoder_input_ids[i] < 0 || decoder_input_ids[i] >= h->model.vocab) return gfail(h, VITS_E_ARG, "decoder id out of range");
+    std::vector<int64_t> ids((size_t)B * T);
+    std::vector<int> n(B);
+    return generate_impl(h, input_ids, lens, B, T, decoder_input_ids[0], -1, ids.data(), n.data(), decoder_input_ids, logits);
 }
 
 int g2p_generate(g2p_handle *h, const int64_t *input_ids, int S, int max_length, int64_t start_id, int64_t eos_id,

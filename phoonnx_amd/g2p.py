@@ -225,6 +225,25 @@ class MiG2PSession:
         return res
 
 
+    def forced_step_logits(self, inputs: Sequence[Sequence[int]], decoder_input_ids) -> np.ndarray:
+        """Test hook (g2p_test_forced_steps): the decoder-step kernels of `generate` driven with GIVEN decoder inputs
+        [B, T] (column 0 = the start token) for up to four inputs side by side -> the logits of every step, float32
+        [B, T, vocab]: position t equals what run() returns there for decoder_input_ids[:, :t + 1]."""
+        seqs = [np.ascontiguousarray(np.asarray(x, np.int64).reshape(-1)) for x in inputs]
+        dec = np.ascontiguousarray(np.asarray(decoder_input_ids, np.int64))
+        if dec.ndim != 2 or dec.shape[0] != len(seqs):
+            raise SessionError(f"decoder_input_ids must be [{len(seqs)}, T], got {dec.shape}")
+        flat = np.ascontiguousarray(np.concatenate(seqs))
+        lens = np.array([len(x) for x in seqs], np.int32)
+        V = self.hparam("vocab")
+        out = np.zeros((len(seqs), dec.shape[1], V), np.float32)
+        rc = self._lib.g2p_test_forced_steps(self._h, _ffi.ptr(flat), _ffi.ptr(lens), len(seqs), _ffi.ptr(dec), int(dec.shape[1]),
+                                             _ffi.ptr(out))
+        if rc != 0:
+            raise SessionError(f"g2p_test_forced_steps failed [{rc}]: {self._err()}")
+        return out
+
+
 class ByT5Phonemizer(SimplePhonemizer):
     """Mirror of `phoonnx.phonemizers.mul.ByT5Phonemizer` over `MiG2PSession` (no downloads: the model and tokenizer
     config are files the caller supplies).  `phonemize_string(text, lang)` as mul.py:232-233; `phonemize(text, lang)`

@@ -80,6 +80,77 @@ def test_g2p_matches_oracle_on_fresh_inputs(sess):
     assert sess.generate(ids, max_length=40) == o.greedy(ids, max_length=40)
 
 
+@pytest.fixture(scope="module")
+def sess64():
+    """Heads of width 64 (every ByT5 / mT5 size): the engine's attention has a body of its own for that width
+    (g2p.hip g2p_attention_body_t<64>) which the 16-wide tiny model never reaches.  oracle/gen_g2p_golden.py --name byt5_dk64."""
+    from phoonnx_amd.g2p import MiG2PSession
+    s = MiG2PSession(os.path.join(GOLDEN, "byt5_dk64.onnx"))
+    yield s
+    s.close()
+
+
+def test_g2p_dk64_logits_match_transformers_goldens(sess64):
+    G = np.load(os.path.join(GOLDEN, "byt5_dk64.npz"))
+    assert sess64.hparam("d_kv") == 64
+    for c in range(3):   # (case 2: 321 input bytes - cross attention over more keys than the 256 the kernel prefetches)
+        ids, dec = G[f"c{c}/input_ids"], G[f"c{c}/decoder_input_ids"]
+        out = sess64.run(["logits"], {"input_ids": ids, "attention_mask": np.ones_like(ids), "decoder_input_ids": dec})[0]
+        err = float(np.abs(out - G[f"c{c}/logits"]).max())
+        assert err < LOGIT_TOL, (c, err)
+        assert sess64.generate(ids[0], max_length=len(G[f"c{c}/greedy"]), eos_id=-1) == G[f"c{c}/greedy"].tolist()
+
+
+@pytest.mark.parametrize("which", ["tiny", "dk64"])
+def test_the_decoder_step_path_computes_the_logits_of_the_whole_graph(which, sess, sess64):
+    """The greedy ids of a randomly initialised T5 are nearly constant sequences - equal ids say little about the step
+    path's arithmetic.  g2p_test_forced_steps drives the SAME kernels `generate` runs per token (matrix-vector products with
+    the norm and the gate folded in, one-query attention over the key / value caches) with given decoder inputs and returns
+    every step's logits: they must be the logits of the whole graph for the same prefix - `run` (pinned to the transformers
+    model above) and, on fresh inputs, the NumPy oracle.  Covered: both attention bodies (head width 16 and 64), more than
+    256 cached keys in self attention (300 steps) and in cross attention (321 / 300 input bytes), 1, 2, 3 and 4 sequences side
+    by side (the NB = 1 / 2 / 4 kernels, padded encoder batch with per-sequence key counts), and the one-launch step."""
+    from t5_oracle import T5Oracle
+    s = sess if which == "tiny" else sess64
+    name = "byt5_tiny" if which == "tiny" else "byt5_dk64"
+    G = np.load(os.path.join(GOLDEN, name + ".npz"))
+    rng = np.random.default_rng(11)
+    # 1. the fixture's own cases: the transformers model's logits
+    for c in range(3):
+        ids, dec = G[f"c{c}/input_ids"], G[f"c{c}/decoder_input_ids"]
+        got = s.forced_step_logits([ids[0]], dec)
+        assert got.shape == G[f"c{c}/logits"].shape
+        assert float(np.abs(got - G[f"c{c}/logits"]).max()) < LOGIT_TOL, (which, c)
+    # 2. long random prefixes against run() (the whole graph on the prefill kernels) and the oracle
+    o = T5Oracle(os.path.join(GOLDEN, name + ".onnx"))
+    for S, T in ((5, 1), (300, 40), (64, 300)):
+        ids = rng.integers(3, 259, S).astype(np.int64)
+        dec = np.concatenate(([0], rng.integers(3, 259, T - 1))).astype(np.int64)[None]
+        got = s.forced_step_logits([ids], dec)[0]
+        ref = s.run(None, {"input_ids": ids[None], "decoder_input_ids": dec})[0][0]
+        assert float(np.abs(got - ref).max()) < LOGIT_TOL, (which, S, T, float(np.abs(got - ref).max()))
+        if T <= 40:
+            assert float(np.abs(got - o.logits(ids, dec[0])).max()) < LOGIT_TOL, (which, S, T)
+    # 3. several sequences of different lengths side by side = each one alone
+    seqs = [rng.integers(3, 259, n).astype(np.int64) for n in (7, 130, 33, 270)]
+    decs = np.concatenate((np.zeros((4, 1), np.int64), rng.integers(3, 259, (4, 23))), axis=1)
+    alone = [s.forced_step_logits([x], decs[i:i + 1])[0] for i, x in enumerate(seqs)]
+    for nb in (2, 3, 4):
+        got = s.forced_step_logits(seqs[:nb], decs[:nb])
+        for i in range(nb):
+            assert float(np.abs(got[i] - alone[i]).max()) < 1e-4, (which, nb, i)
+
+
+def test_the_one_launch_decoder_step_computes_the_same_logits(sess64, monkeypatch):
+    rng = np.random.default_rng(12)
+    ids = rng.integers(3, 259, 90).astype(np.int64)
+    dec = np.concatenate(([0], rng.integers(3, 259, 30))).astype(np.int64)[None]
+    want = sess64.forced_step_logits([ids], dec)
+    monkeypatch.setenv("VITSMI_G2P_PERSIST", "1")
+    got = sess64.forced_step_logits([ids], dec)
+    assert np.array_equal(got, want)   # (the same bodies in the same order: bit for bit)
+
+
 def test_g2p_bad_inputs_raise(sess):
     from phoonnx_amd.session import SessionError
     ok = {"input_ids": np.array([[10, 11]], np.int64), "decoder_input_ids": np.array([[0]], np.int64)}
