@@ -553,6 +553,30 @@ __global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
         prm[9][e] = head ? a.head_w[e] : 0.f;
         prm[10][e] = head ? a.head_b[e] : 0.f;
     }
+    // This wave's first row tile of weights and the residual operands of all its tiles depend on nothing: they are requested
+    // right behind stage 1's own operands (vector loads return in order: stage 1 does not wait for them) instead of behind
+    // stage 1, where their round trip to L2 was exposed - at batch 1 a layer is 16 workgroups with nothing else to run.
+    // (All three tiles' weights up front with their MFMA chains interleaved measured SLOWER: 1.39 vs 1.36 ms per call.)
+    const float4 *wp = reinterpret_cast<const float4 *>(a.pw16);
+    float4 wa[2][NS4];
+    auto load_w = [&](int set, int rt) {
+#pragma unroll
+        for (int i = 0; i < NS4; i++) wa[set][i] = wp[((int64_t)(rt * 4 + kq) * 16 + col) * NS4 + i];
+    };
+    const int tc = t0 + col;
+    const bool tcv = tc < T;
+    float resv[MAXR][4];
+    float zres = 0.f;
+    auto request_stage2_operands = [&]() __attribute__((always_inline)) {
+        load_w(0, wave < NRT ? wave : NRT - 1);
+#pragma unroll
+        for (int j = 0; j < MAXR; j++) {
+            const int rt = wave + 4 * j < NRT ? wave + 4 * j : NRT - 1;  // (a wave without a j-th tile re-reads the last one, unused)
+#pragma unroll
+            for (int r = 0; r < 4; r++) resv[j][r] = p[(int64_t)(rt * 16 + 4 * kq + r) * T + (tcv ? tc : 0)];
+        }
+        if (head) zres = a.head_z[(int64_t)b * a.head_zstride + (tcv ? tc : 0)];
+    };
     // ---- stage 1: depthwise conv (k = 3) of x * mask, LayerNorm over channels, GELU -> y1 (thread: channels cg + 16 i)
     {
         float v[CPT];
@@ -575,6 +599,8 @@ __global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
 #pragma unroll
             for (int k = 0; k < 3; k++) zt[k] = a.head_z[(int64_t)b * a.head_zstride + tt[k]];
         }
+        __builtin_amdgcn_sched_barrier(0);
+        request_stage2_operands();
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();  // prm is in LDS
 #pragma unroll
@@ -612,26 +638,6 @@ __global__ __launch_bounds__(256) void dds_layer16_kernel(DdsLayer16Args a) {
             y1[c * 16 + tl] = tv ? gelu_erf((v[i] - mean) * rs * prm[4][c] + prm[5][c]) : 0.f;
         }
     }
-    // this wave's first row tile of weights travels under the barrier; the residual operands of all its tiles too
-    const float4 *wp = reinterpret_cast<const float4 *>(a.pw16);
-    float4 wa[2][NS4];
-    auto load_w = [&](int set, int rt) {
-#pragma unroll
-        for (int i = 0; i < NS4; i++) wa[set][i] = wp[((int64_t)(rt * 4 + kq) * 16 + col) * NS4 + i];
-    };
-    if (wave < NRT) load_w(0, wave);
-    const int tc = t0 + col;
-    const bool tcv = tc < T;
-    float resv[MAXR][4];
-#pragma unroll
-    for (int j = 0; j < MAXR; j++) {
-        const int rt = wave + 4 * j;
-        if (rt < NRT) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) resv[j][r] = p[(int64_t)(rt * 16 + 4 * kq + r) * T + (tcv ? tc : 0)];
-        }
-    }
-    const float zres = head ? a.head_z[(int64_t)b * a.head_zstride + (tcv ? tc : 0)] : 0.f;
     __syncthreads();
     if (head) {  // (prm is visible since stage 1's first barrier)
 #pragma unroll
