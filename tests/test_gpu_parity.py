@@ -1339,3 +1339,42 @@ print("PERSIST_OK")
     env = dict(os.environ, VITSMI_PAIR16_PERSIST="1")
     r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "PERSIST_OK" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-1500:])
+
+
+def test_the_xcd_deal_of_the_time_tiles_changes_no_bit():
+    """Round 6: time tiles are dealt to the 8 XCDs in groups of 2^xgs consecutive tiles (sx_xcd_tile; VITSMI_XCD_GROUP, default
+    4) so that neighbouring tiles - which share their halo columns - meet in one L2.  That is a permutation of which workgroup
+    renders which tile: every group size must give the same bits, on the plane-input engine (several row tiles per time tile),
+    the raw-input engine and the fused pair / chain kernels, for tile counts that are not multiples of a round (8 x group) and
+    for tensors too short to group at all.  In child processes: the switch is read once per process."""
+    import subprocess
+    import sys
+    import hashlib
+    code = r'''
+import os, sys, hashlib
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from phoonnx_amd.session import test_conv1d_sx, test_conv_pair_sx
+rng = np.random.default_rng(21)
+h = hashlib.sha256()
+for Cin, Cout, K, dil, B, T in ((256, 256, 3, 1, 2, 9001), (128, 128, 11, 5, 3, 13999), (64, 64, 7, 3, 2, 30011), (128, 128, 3, 1, 1, 700)):
+    x = rng.standard_normal((B, Cin, T)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    pad = dil * (K - 1) // 2
+    h.update(test_conv1d_sx(x, w, b, dil=dil, pad_l=pad, residual=True, precision="f16x3").tobytes())
+for C, K, d1, d2, chain, B, T in ((32, 3, 1, 1, False, 2, 70001), (64, 7, 3, 1, False, 2, 30003), (32, 5, 2, 6, True, 3, 50000), (32, 3, 1, 2, True, 1, 900)):
+    x = rng.standard_normal((B, C, T)).astype(np.float32)
+    w1 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    w2 = (rng.standard_normal((C, C, K)) / np.sqrt(C * K)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    h.update(test_conv_pair_sx(x, w1, b, w2, b, dil1=d1, dil2=d2, chain=chain, kernel="pair").tobytes())
+print("XCD_DIGEST", h.hexdigest())
+'''
+    digests = {}
+    for g in ("1", "2", "4", "16"):
+        env = dict(os.environ, VITSMI_XCD_GROUP=g)
+        r = subprocess.run([sys.executable, "-c", code, ROOT], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "XCD_DIGEST" in r.stdout, (g, r.returncode, r.stdout[-300:], r.stderr[-1500:])
+        digests[g] = r.stdout.split("XCD_DIGEST")[1].split()[0]
+    assert len(set(digests.values())) == 1, digests
