@@ -201,27 +201,24 @@ __device__ __forceinline__ void g2p_attention_body_t(const float *__restrict__ q
             mx = fmaxf(mx, s);
         }
     }
-    red[tid] = mx;
+    // maximum and sum over the workgroup: butterflies inside a wave, four values through LDS (the generic body's eight-level
+    // tree costs sixteen barriers per launch; the order of the sum differs from it in the last bits)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
-        __syncthreads();
-    }
-    mx = red[0];
-    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
     for (int j = tid; j < lim; j += 256) {
         const float e = expf(sc[j] - mx);
         sc[j] = e;
         sum += e;
     }
-    red[tid] = sum;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
-        __syncthreads();
-    }
-    const float inv = 1.0f / red[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();  // (also: every sc[j] is written before the value phase reads it)
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
 #pragma unroll
     for (int rr = 0; rr < NR; rr++) {
         const int d0 = wave * 8 + 32 * rr;
