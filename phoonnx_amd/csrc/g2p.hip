@@ -312,7 +312,7 @@ struct G2PLinArgs {
 };
 typedef float g2p_f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(512) void g2p_linear_kernel(G2PLinArgs a) {
+__global__ __launch_bounds__(512) void g2p_linear_generic_kernel(G2PLinArgs a) {
     extern __shared__ float part[];  // [8 waves][8 blocks][4][64]
     int blk = blockIdx.x, jb = 0;
     while (jb + 1 < a.njobs && blk >= a.job[jb].tiles) blk -= a.job[jb++].tiles;
@@ -378,6 +378,85 @@ __global__ __launch_bounds__(512) void g2p_linear_kernel(G2PLinArgs a) {
     }
 #pragma unroll
     for (int n = 0; n < 8; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) part[((wave * 8 + n) * 4 + r) * 64 + lane] = acc[n][r];
+    __syncthreads();
+    // element e = (n * 4 + r) * 64 + l: row = row0 + 4 (l / 16) + r, column = t0 + 16 n + l % 16
+    for (int e = tid; e < nb * 256; e += 512) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; w++) v += part[w * 2048 + e];
+        const int l = e & 63, r = (e >> 6) & 3, n = e >> 8;
+        const int row = row0 + 4 * (l >> 4) + r, col = 16 * n + (l & 15);
+        if (row < J.out && col < ncol) {
+            const int64_t o = (int64_t)row * J.y_rs + (int64_t)(t0 + col) * J.y_cs;
+            J.y[o] = J.res ? v + J.res[o] : v;
+        }
+    }
+}
+
+// The same kernel for reductions that are whole 16-k steps (every T5 size: d_model, d_ff and heads x d_kv are multiples of
+// 16), CB = 16-column blocks per workgroup as a compile-time constant - and NO conditional load.  In the generic kernel above
+// every load sits behind a lane-dependent condition (`row_ok && k + 4 <= in ? .. : 0`, `16 n + m < ncol ? x[..] : 0`), which
+// compiles to a branch per load with `s_waitcnt vmcnt(0)` at its join: the "whole share of the weights requested at once"
+// went out one load at a time, and so did the activations (the ISA: `L b b L b b L .. [vmcnt(0)] MFMA`, 31.6 us per launch at
+// 80 columns where the weights stream in 2-8 us).  Here rows, steps and columns past the end are CLAMPED to the last valid one
+// (re-read, harmless: such rows / columns are never stored, such steps never multiplied) and every load of a group is in
+// flight before the group's first MFMA.  Same products in the same order: bit-identical to the generic kernel.
+template <int CB>
+__global__ __launch_bounds__(512) void g2p_linear_kernel(G2PLinArgs a) {
+    extern __shared__ float part[];  // [8 waves][8 blocks][4][64]
+    int blk = blockIdx.x, jb = 0;
+    while (jb + 1 < a.njobs && blk >= a.job[jb].tiles) blk -= a.job[jb++].tiles;
+    const G2PLinJob &J = a.job[jb];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int row0 = blk * 16, t0 = blockIdx.y * (16 * CB);
+    const int ncol = a.T - t0 < 16 * CB ? a.T - t0 : 16 * CB, nb = (ncol + 15) >> 4;
+    const int steps = a.in >> 4;                               // 16 k per step, no tail
+    const int s0 = steps * wave / 8, s1 = steps * (wave + 1) / 8;
+    const float *wrow = J.W + (int64_t)(row0 + m < J.out ? row0 + m : J.out - 1) * a.in + 4 * kq;
+    int coff[CB];                                              // this lane's column of block n, clamped into the tensor
+#pragma unroll
+    for (int n = 0; n < CB; n++) coff[n] = t0 + (16 * n + m < ncol ? 16 * n + m : ncol - 1);
+    g2p_f32x4 acc[CB];
+#pragma unroll
+    for (int n = 0; n < CB; n++) acc[n] = g2p_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g0 = s0; g0 < s1; g0 += 16) {
+        float4 av[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int sc = g0 + u < s1 ? g0 + u : s1 - 1;
+            av[u] = *reinterpret_cast<const float4 *>(wrow + sc * 16);
+        }
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            if (g0 + 4 * q4 >= s1) break;                      // (wave-uniform)
+            float bv[4][4][CB];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int sc = g0 + 4 * q4 + u < s1 ? g0 + 4 * q4 + u : s1 - 1;
+                const float *xr = a.x + (int64_t)(sc * 16 + 4 * kq) * a.xp;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int n = 0; n < CB; n++) bv[u][j][n] = xr[(int64_t)j * a.xp + coff[n]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (g0 + 4 * q4 + u < s1) {                    // (wave-uniform; no load inside)
+                    const float4 w = av[4 * q4 + u];
+                    const float wj[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int n = 0; n < CB; n++) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wj[j], bv[u][j][n], acc[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < CB; n++)
 #pragma unroll
         for (int r = 0; r < 4; r++) part[((wave * 8 + n) * 4 + r) * 64 + lane] = acc[n][r];
     __syncthreads();
@@ -753,8 +832,6 @@ struct LinJob {
 void linear(Run &r, std::initializer_list<LinJob> jobs, const float *x, int xp, int T, int64_t y_rs) {
     // (the attribute belongs to the (function, device) pair: handles on different GPUs each set it, and no flag is
     // shared between their threads; the call is idempotent and costs ~1 us)
-    r.note(hipFuncSetAttribute(reinterpret_cast<const void *>(g2p_linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               64 * 1024));
     G2PLinArgs a{};
     int tiles = 0;
     for (const LinJob &j : jobs) {
@@ -775,7 +852,29 @@ void linear(Run &r, std::initializer_list<LinJob> jobs, const float *x, int xp, 
     // column tile: 128 wide.  (Narrower tiles on short grids - 32 columns at T = 80 - were measured slower: a
     // workgroup's time is the latency of its weight rows, not its matrix work.)
     a.cb = 8;
-    g2p_linear_kernel<<<dim3(tiles, (T + 16 * a.cb - 1) / (16 * a.cb)), 512, 64 * 1024, r.st>>>(a);
+    // The branch-free kernel serves the short column counts - the decoder step of 8 .. 32 sequences side by side: 0.67 -> 0.44 ms
+    // per step at 8 and 16 sequences - and loses to the generic one on wide tiles (encoder over 80 bytes x 4 inputs 4.4 -> 5.8 ms,
+    // x 64 inputs 48 -> 59 ms: at 5-8 column blocks its 190-230 registers and ~150 loads in flight per lane cost more than the
+    // generic kernel's serialised ones; profiles/r06_runs/g2p_linear_ab.txt), so those keep the generic kernel.
+    bool whole = a.in % 16 == 0 && a.in >= 128 && T <= 32;  // (whole steps; every wave has at least one)
+    for (const LinJob &j : jobs) whole = whole && j.L->in == a.in;
+    static const bool generic_only = std::getenv("VITSMI_G2P_LINEAR_GENERIC") != nullptr;  // (A/B)
+    if (!whole || generic_only) {
+        r.note(hipFuncSetAttribute(reinterpret_cast<const void *>(g2p_linear_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   64 * 1024));
+        g2p_linear_generic_kernel<<<dim3(tiles, (T + 16 * a.cb - 1) / (16 * a.cb)), 512, 64 * 1024, r.st>>>(a);
+        return;
+    }
+    const int cb = (T + 15) / 16;  // 1 or 2
+    a.cb = cb;
+    const dim3 grid(tiles, 1);
+    if (cb == 1) {
+        r.note(hipFuncSetAttribute(reinterpret_cast<const void *>(g2p_linear_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        g2p_linear_kernel<1><<<grid, 512, 64 * 1024, r.st>>>(a);
+    } else {
+        r.note(hipFuncSetAttribute(reinterpret_cast<const void *>(g2p_linear_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        g2p_linear_kernel<2><<<grid, 512, 64 * 1024, r.st>>>(a);
+    }
 }
 void linear(Run &r, const T5Linear &L, const float *x, int xp, int T, float *y, int yp, const float *res = nullptr) {
     linear(r, {{&L, y, res}}, x, xp, T, yp);
